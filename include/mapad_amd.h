@@ -1,0 +1,199 @@
+/* mapad_amd.h — C ABI of the MI355X-native mapAD read-mapping hot path (libmapad_amd.so).
+ *
+ * Drop-in boundary for `mapad map` (mpieva/mapAD v0.45.0).  The reference has no FFI today; its internal seam for this
+ * path is the generic call k_mismatch_search::<SDM, MB>() made from run_inner (src/map/mapping.rs:153-271) and from
+ * Worker::run (src/distributed/worker.rs:80-198), i.e. exactly the worker side of its dispatcher/worker split.  Each
+ * entry point below names the reference interface it replaces.  INTEGRATION.md shows the Rust `extern "C"` block a
+ * maintainer would add.
+ *
+ * Conventions: plain pointers and sizes, POD structs, caller-owned inputs, library-owned results released with the
+ * matching *_free.  Every function returns 0 on success or a negative mapad_status_t; no exceptions cross the boundary.
+ * A context is bound to one GPU and is not re-entrant; use one context per GPU / per host thread.
+ * There is NO CPU fallback: without a usable gfx950 device mapad_ctx_create() fails with MAPAD_ERR_NO_DEVICE.
+ */
+#ifndef MAPAD_AMD_H
+#define MAPAD_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum mapad_status {
+    MAPAD_OK = 0,
+    MAPAD_ERR_INVALID = -1,      /* bad argument                                  (errors.rs: Error::InvalidInput) */
+    MAPAD_ERR_IO = -2,           /* file could not be read / written              (errors.rs: Error::Io)           */
+    MAPAD_ERR_INDEX_VERSION = -3,/* on-disk index version != 5                    (versioned_index.rs:31-40)       */
+    MAPAD_ERR_PARSE = -4,        /* malformed index / FASTA                       (errors.rs: Error::ParseError)   */
+    MAPAD_ERR_NO_DEVICE = -5,    /* no gfx950 GPU / HIP runtime failure (there is no CPU path)                     */
+    MAPAD_ERR_DEVICE = -6,       /* a HIP call failed                                                              */
+    MAPAD_ERR_NOMEM = -7,
+    MAPAD_ERR_READ_TOO_LONG = -8 /* read longer than MAPAD_MAX_READ_LEN           (record.rs:144-150: i16::MAX)     */
+} mapad_status_t;
+
+#define MAPAD_MAX_READ_LEN 1024
+
+/* ---- parameters: AlignmentParameters + the two plugin enums (src/map/mod.rs:21-31,
+ *      sequence_difference_models.rs:67-72, mismatch_bounds.rs:26-30) ------------------------------------------------ */
+enum { MAPAD_MODEL_SIMPLE_ADNA = 0, MAPAD_MODEL_VINDIJA_PWM = 1, MAPAD_MODEL_TEST = 2 };
+enum { MAPAD_LIBRARY_SINGLE_STRANDED = 0, MAPAD_LIBRARY_DOUBLE_STRANDED = 1 };
+enum { MAPAD_BOUND_DISCRETE = 0, MAPAD_BOUND_CONTINUOUS = 1, MAPAD_BOUND_TEST = 2 };
+
+typedef struct mapad_params {
+    int32_t model_kind;
+    int32_t library_prep;
+    float five_prime_overhang, three_prime_overhang; /* double_stranded: five_prime_overhang is the overhang */
+    float ds_deamination_rate, ss_deamination_rate;
+    float divergence;                                /* already divided by 3 (main.rs:452)                   */
+    int32_t ignore_base_quality;
+    float deam_score, mm_score, match_score;         /* TestDifferenceModel                                   */
+    int32_t bound_kind;
+    float poisson_threshold, base_error_rate;        /* Discrete                                              */
+    float cutoff, exponent;                          /* Continuous (cutoff already negated, main.rs:467-470)  */
+    float threshold, repr_mm_bound;                  /* TestBound                                             */
+    float penalty_gap_open, penalty_gap_extend;
+    int32_t gap_dist_ends, max_num_gaps_open;
+    int32_t stack_limit_abort;
+    uint32_t stack_limit, edit_tree_limit;           /* 0 = reference constants 2 000 000 / 10 000 000        */
+    uint64_t chunk_size;                             /* --batch_size, default 250 000                         */
+} mapad_params_t;
+
+/* build_alignment_parameters (src/main.rs:418-499): CLI-level values -> derived parameters.
+ * poisson_prob < 0 selects the Continuous bound with (as_cutoff, as_cutoff_exponent). */
+int mapad_params_from_cli(mapad_params_t* out, int library_prep, float five_prime_overhang, float three_prime_overhang,
+                          float ds_deamination_rate, float ss_deamination_rate, float divergence, float poisson_prob,
+                          float as_cutoff, float as_cutoff_exponent, float indel_rate, float gap_extension_penalty,
+                          int gap_dist_ends, int max_num_gaps_open, int ignore_base_quality, int no_search_limit_recovery,
+                          uint64_t chunk_size);
+
+/* trait SequenceDifferenceModel (sequence_difference_models.rs:14-62) */
+float mapad_sdm_get(const mapad_params_t* p, uint64_t i, uint64_t read_length, uint8_t from, uint8_t to, uint8_t base_quality);
+float mapad_sdm_representative_mismatch_penalty(const mapad_params_t* p);
+float mapad_sdm_min_penalty(const mapad_params_t* p, uint64_t i, uint64_t read_length, uint8_t to, uint8_t base_quality, int only_mismatches);
+int32_t mapad_sdm_alignment_start(const mapad_params_t* p, uint64_t pattern_length);
+/* trait MismatchBound (mismatch_bounds.rs:10-20) */
+int mapad_mb_reject(const mapad_params_t* p, float value, uint64_t read_length);
+int mapad_mb_reject_iterative(const mapad_params_t* p, float value, float reference);
+float mapad_mb_remaining_frac_of_repr_mm(const mapad_params_t* p, float value, uint64_t read_length);
+
+/* ---- index: RtFmdIndex + SampledSuffixArray + FastaIdPositions + OriginalSymbols (src/index/mod.rs) ------------------ */
+typedef struct mapad_index mapad_index_t;
+
+/* `mapad index` (src/index/indexing.rs:29-212) on an in-memory FASTA-like input: n_contigs sequences (any case, IUPAC).
+ * Ambiguous bases in runs shorter than 20 are replaced by a random compatible base drawn from splitmix64(seed) (the
+ * reference uses rand::StdRng(seed), whose stream is not reproduced), longer runs become 'X'; originals are kept. */
+int mapad_index_build(const char* const* names, const uint8_t* const* seqs, const uint64_t* lens, uint32_t n_contigs,
+                      uint64_t seed, mapad_index_t** out);
+/* load_index_from_path + load_suffix_array/.tpi/.tos (src/index/mod.rs:212-239): reads the 7 files <prefix>.{tbw,tle,toc,trt,tsa,tpi,tos} */
+int mapad_index_open(const char* prefix, mapad_index_t** out);
+/* writers of indexing.rs:110-208 (snappy frame stream of bincode 1.3, version byte 5) */
+int mapad_index_save(const mapad_index_t* idx, const char* prefix);
+void mapad_index_free(mapad_index_t* idx);
+uint64_t mapad_index_text_len(const mapad_index_t* idx);           /* n = 2|G| + 2 */
+int mapad_index_copy_bwt(const mapad_index_t* idx, uint8_t* out);  /* n rank bytes ($=0 A=1 C=2 G=3 T=4 X=5) */
+uint32_t mapad_index_n_contigs(const mapad_index_t* idx);
+int mapad_index_contig(const mapad_index_t* idx, uint32_t i, const char** name, uint64_t* start, uint64_t* end);
+/* SampledSuffixArray pieces, for cross-checks: sizes then copies */
+uint64_t mapad_index_sa_sample_len(const mapad_index_t* idx);
+uint64_t mapad_index_sa_extra_len(const mapad_index_t* idx);
+int mapad_index_copy_sa(const mapad_index_t* idx, uint64_t* sample, uint64_t* extra_rows, uint64_t* extra_vals);
+
+/* the rank structure as the GPU sees it: 128-byte blocks (16 x u64 per 256 BWT rows; layout in mapad_amd/csrc/fmd_device.hpp),
+ * less[8] (reference ranks) and the two sentinel rows */
+int mapad_index_device_view(const mapad_index_t* idx, const uint64_t** blocks, uint64_t* n_blocks, uint64_t less[8], uint64_t sentinel[2]);
+/* SampledSuffixArray::get (src/index/mod.rs:160-187) */
+int mapad_index_sa_get(const mapad_index_t* idx, uint64_t row, uint64_t* out);
+
+/* ---- mapping context: one GPU, index resident in HBM ---------------------------------------------------------------- */
+typedef struct mapad_ctx mapad_ctx_t;
+
+int mapad_ctx_create(const mapad_index_t* idx, const mapad_params_t* params, int device_id, mapad_ctx_t** out);
+void mapad_ctx_destroy(mapad_ctx_t* ctx);
+/* run every launch on this HIP stream (a hipStream_t; NULL = the default stream) */
+int mapad_ctx_set_stream(mapad_ctx_t* ctx, void* hip_stream);
+
+/* Score tables are built lazily per read length.  mapad_map_batch() does this itself; before mapad_map_batch_device()
+ * (where the host never sees the reads) announce the lengths that will occur. */
+int mapad_ctx_prepare_lengths(mapad_ctx_t* ctx, const uint32_t* lens, uint32_t n);
+
+/* HitInterval (src/map/mod.rs:34-61) with the edit track flattened; 40 bytes. */
+typedef struct mapad_hit {
+    uint64_t lower, lower_rev, size; /* RtBiInterval */
+    float alignment_score;
+    uint32_t n_ops;                  /* EditOperationsTrack length */
+    uint32_t ops_offset;             /* first op in the batch's ops array */
+    uint32_t reserved;
+} mapad_hit_t;
+/* packed EditOperation (src/map/record.rs:225-237): kind<<24 | reference base (ASCII)<<16 | read position;
+ * kind 0 Insertion, 1 Deletion, 2 Match, 3 Mismatch */
+
+typedef struct mapad_read_counters { /* algorithm events per read; identical on the CPU oracle */
+    uint32_t e_search, e_darray, n_push, n_pop, n_node, n_hits;
+} mapad_read_counters_t;
+
+/* Result of one batch == Vec<BinaryHeap<HitInterval>> of run_inner's par_iter (mapping.rs:153-271), order-preserving.
+ * hits of read i are hits[hit_begin[i] .. hit_begin[i+1]) in BinaryHeap array order. */
+typedef struct mapad_batch_result {
+    uint64_t n_reads;
+    uint64_t n_hits, n_ops;
+    const uint64_t* hit_begin;             /* n_reads + 1 */
+    const mapad_hit_t* hits;               /* n_hits */
+    const uint32_t* ops;                   /* n_ops */
+    const uint32_t* status;                /* per read: 0 ok, 2 stopped by --no_search_limit_recovery */
+    const mapad_read_counters_t* counters; /* per read */
+    const float* d_arrays;                 /* concatenated BiDArray::d_composite, same offsets as the reads (debug/parity) */
+    uint64_t n_second_pass;                /* reads that needed the large-arena pass */
+} mapad_batch_result_t;
+
+/* k_mismatch_search over a chunk of reads (host buffers): seqs/quals concatenated, read i = [offsets[i], offsets[i+1]).
+ * quals are raw Phred values (no +33). */
+int mapad_map_batch(mapad_ctx_t* ctx, const uint8_t* seqs, const uint8_t* quals, const uint64_t* offsets, uint64_t n_reads,
+                    mapad_batch_result_t** out);
+void mapad_batch_result_free(mapad_batch_result_t* r);
+
+/* Device-resident variant used by bench.py and the multi-GPU driver: inputs already in HBM (device pointers), results stay
+ * in the context's device buffers until fetched.  Asynchronous on the context's stream. */
+int mapad_map_batch_device(mapad_ctx_t* ctx, const void* d_seqs, const void* d_quals, const void* d_offsets, uint64_t n_reads,
+                           uint32_t max_read_len);
+/* after synchronising the stream: copy the last device batch's results to the host */
+int mapad_fetch_result(mapad_ctx_t* ctx, mapad_batch_result_t** out);
+/* device pointers of the last batch's raw result buffers (for the RCCL gather): per-read hit counts (u32[n_reads]),
+ * per-read first-hit index (u32[n_reads]), hit pool (mapad_hit_t[]), ops pool (u32[]), 2 x u32 cursors {n_hits, n_ops} */
+int mapad_device_result_ptrs(mapad_ctx_t* ctx, void** d_hit_count, void** d_hit_first, void** d_hits, void** d_ops, void** d_cursors);
+/* sums of the per-read counters of the last batch (after a fetch or a stream sync): {e_search, e_darray, n_push, n_pop, n_node, n_hits} */
+int mapad_last_batch_counters(mapad_ctx_t* ctx, uint64_t out[6]);
+/* kernel names + launch geometry of the last batch, for bench.py's report */
+int mapad_last_launch_info(mapad_ctx_t* ctx, uint32_t out[8]);
+
+/* ---- post-search: intervals_to_bam minus BAM byte encoding (mapping.rs:402-718, record.rs:269-449) ------------------- */
+typedef struct mapad_record {
+    uint16_t flags;
+    uint8_t mapq;
+    uint8_t mapped, reverse;
+    int32_t tid;
+    int64_t pos;          /* 0-based leftmost position, -1 if unmapped */
+    float as_score, xs_score;
+    int32_t nm, x0, x1;
+    uint8_t has_xs;
+    char xt;
+    uint32_t cigar_off, cigar_len, md_off, md_len, xa_off, xa_len; /* into the text blob */
+} mapad_record_t;
+typedef struct mapad_records {
+    uint64_t n;
+    const mapad_record_t* recs;
+    const char* text;
+    uint64_t text_len;
+} mapad_records_t;
+/* in_flags: input BAM flags per read (NULL = 0, i.e. FASTQ input, record.rs:207-213); seed: stands in for rand::rng()
+ * (mapping.rs:273,605; only matters for hits with >= 3 SA rows) */
+int mapad_hits_to_records(const mapad_index_t* idx, const mapad_params_t* params, const mapad_batch_result_t* res, const uint8_t* seqs,
+                          const uint8_t* quals, const uint64_t* offsets, const uint16_t* in_flags, uint64_t seed, mapad_records_t** out);
+void mapad_records_free(mapad_records_t* r);
+
+const char* mapad_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MAPAD_AMD_H */

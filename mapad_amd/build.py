@@ -1,0 +1,42 @@
+"""Builds libmapad_amd.so (HIP kernels + C ABI) in-tree for gfx950.  hipcc cross-compiles without a GPU."""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libmapad_amd.so")
+SOURCES = ["mapad_amd.hip"]
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math",
+         # keep libm out of the constant folder / pow->exp10 rewrites: the reference evaluates these at run time with glibc
+         "-fno-builtin-log2f", "-fno-builtin-powf", "-fno-builtin-expf", "-fno-builtin-exp2f", "-fno-builtin-log10f",
+         "-Wall", "-Wno-unused-function", "-Wno-unknown-pragmas"]
+
+
+def _deps():
+    out = [os.path.join(CSRC, f) for f in os.listdir(CSRC)]
+    out.append(os.path.join(os.path.dirname(HERE), "include", "mapad_amd.h"))
+    return out
+
+
+def needs_build():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    return any(os.path.getmtime(p) > t for p in _deps())
+
+
+def build(force=False, verbose=False):
+    if not force and not needs_build():
+        return LIB
+    cmd = [HIPCC] + FLAGS + ["-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv, verbose=True)
+    print(LIB)

@@ -1,0 +1,154 @@
+// fmd_device.hpp — rank queries and FMD extension on the 128-byte-block device layout.
+//
+// Replaces, on the device: FmdExtIterator (src/map/fmd_index.rs:109-182) + Occ::get_small_k / Less / BWT of the
+// rust-bio fork (byte BWT + u64 checkpoints every 128 rows).  occ(r, c) is a mathematically unique number, so the
+// layout is free: here one 128-byte line answers occ(r, A|C|G|T) for 256 rows.
+//
+//   block b (rows 256b .. 256b+255), 16 x u64:
+//     sub-block w = words [4w .. 4w+3] = { count of base w in rows [0, 256b) ; plane0 ; plane1 ; plane2 }  (rows 256b+64w ..+63)
+//   symbol codes: $=0 X=1 A=4 C=5 G=6 T=7  -> "is base k" = plane2 & (plane1 == k>>1) & (plane0 == k&1)
+//
+// One quad (4 adjacent lanes) serves one rank query pair: lane w loads sub-block w (32 contiguous bytes, so the quad
+// reads the whole 128-byte line coalesced), popcounts its 64 rows for all four bases, and a 2-step DPP butterfly
+// inside the quad sums the partial counts.  Lane w ends up with occ(r, base w).
+#pragma once
+#include "common.hpp"
+
+namespace mapad {
+
+MAPAD_HD int popc64(uint64_t x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __popcll(x);
+#else
+    return __builtin_popcountll(x);
+#endif
+}
+
+// rows of sub-block w that are <= r_in (r_in = row index inside the block, 0..255), as a bit mask
+MAPAD_HD uint64_t row_mask(int w, int r_in) {
+    const int wq = r_in >> 6, bit = r_in & 63;
+    if (w < wq) return ~0ull;
+    if (w > wq) return 0ull;
+    return bit == 63 ? ~0ull : ((2ull << bit) - 1ull);
+}
+
+// ---- scalar reference of the same layout (host emulation + device single-lane paths such as SA walks) -------------
+// occurrences of base k (0..3 = ACGT) in bwt[0..=r]
+MAPAD_HD uint64_t occ_scalar(const DevIndex& ix, uint64_t r, int k) {
+    const uint64_t* blk = ix.blocks + (r >> 8) * 16;
+    const int r_in = (int)(r & 255);
+    uint64_t c = blk[4 * k];
+    const uint64_t inv1 = (k & 2) ? 0ull : ~0ull, inv0 = (k & 1) ? 0ull : ~0ull;
+    for (int w = 0; w <= (r_in >> 6); ++w) {
+        const uint64_t p0 = blk[4 * w + 1], p1 = blk[4 * w + 2], p2 = blk[4 * w + 3];
+        c += popc64(p2 & (p1 ^ inv1) & (p0 ^ inv0) & row_mask(w, r_in));
+    }
+    return c;
+}
+// device symbol code of bwt[r] (0 '$', 1 'X', 4..7 ACGT)
+MAPAD_HD int bwt_code(const DevIndex& ix, uint64_t r) {
+    const uint64_t* blk = ix.blocks + (r >> 8) * 16;
+    const int w = (int)((r >> 6) & 3), bit = (int)(r & 63);
+    return (int)((blk[4 * w + 1] >> bit) & 1) | (int)(((blk[4 * w + 2] >> bit) & 1) << 1) | (int)(((blk[4 * w + 3] >> bit) & 1) << 2);
+}
+// number of '$' rows in [0, pos]  -> sentinel_occ() of fmd_index.rs:140-146 is "count of sentinel rows <= pos"
+MAPAD_HD uint64_t sentinel_le(const DevIndex& ix, uint64_t pos) {
+    return (uint64_t)(pos >= ix.sentinel[0]) + (uint64_t)(pos >= ix.sentinel[1]);
+}
+
+// Result of extending a bi-interval by all four bases (iterator order of the reference is T,G,C,A; here indexed by base 0..3).
+struct Ext4 {
+    uint64_t lower[4], size[4], lower_rev[4];
+};
+
+// FmdExtIterator::new + 4 x extend_once_internal (fmd_index.rs:137-181) for input (lower, lower_rev, size), size >= 1.
+MAPAD_HD void finish_ext4(const DevIndex& ix, uint64_t lower, uint64_t lower_rev, uint64_t size, const uint64_t occ_lo[4],
+                          const uint64_t occ_hi[4], Ext4& out) {
+    const uint64_t hi = lower + size - 1;
+    const uint64_t o_s = lower == 0 ? 0 : sentinel_le(ix, lower - 1);
+    uint64_t s = sentinel_le(ix, hi) - o_s;  // '$' rows inside the interval
+    uint64_t l = lower_rev;
+    for (int k = 3; k >= 0; --k) {  // T, G, C, A
+        l += s;
+        s = occ_hi[k] - occ_lo[k];
+        out.lower[k] = ix.less[k + 1] + occ_lo[k];
+        out.lower_rev[k] = l;
+        out.size[k] = s;
+    }
+}
+
+MAPAD_HD void ext4_scalar(const DevIndex& ix, uint64_t lower, uint64_t lower_rev, uint64_t size, Ext4& out) {
+    uint64_t lo[4], hi[4];
+    for (int k = 0; k < 4; ++k) {
+        lo[k] = lower == 0 ? 0 : occ_scalar(ix, lower - 1, k);
+        hi[k] = occ_scalar(ix, lower + size - 1, k);
+    }
+    finish_ext4(ix, lower, lower_rev, size, lo, hi, out);
+}
+
+#if defined(__HIPCC__)
+// ---- quad-cooperative versions (gfx950) ----------------------------------------------------------------------------
+// DPP quad_perm controls: [1,0,3,2] = 0xB1, [2,3,0,1] = 0x4E, broadcast lane k = k*0x55.
+template <int CTRL>
+__device__ __forceinline__ uint32_t dpp_quad(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, CTRL, 0xF, 0xF, true);
+}
+template <int K>
+__device__ __forceinline__ uint64_t quad_bcast64(uint64_t v) {
+    const uint32_t lo = dpp_quad<K * 0x55>((uint32_t)v), hi = dpp_quad<K * 0x55>((uint32_t)(v >> 32));
+    return ((uint64_t)hi << 32) | lo;
+}
+__device__ __forceinline__ uint32_t quad_sum32(uint32_t v) {
+    v += dpp_quad<0xB1>(v);
+    v += dpp_quad<0x4E>(v);
+    return v;
+}
+
+// lane w (= threadIdx & 3) returns occ(r, base w) for the quad-uniform row r.
+__device__ __forceinline__ uint64_t quad_occ(const DevIndex& ix, uint64_t r, int w) {
+    const uint64_t* sb = ix.blocks + (r >> 8) * 16 + 4 * w;
+    const ulonglong2 v0 = *reinterpret_cast<const ulonglong2*>(sb);      // count_w, plane0
+    const ulonglong2 v1 = *reinterpret_cast<const ulonglong2*>(sb + 2);  // plane1, plane2
+    const uint64_t m = row_mask(w, (int)(r & 255));
+    const uint64_t p0 = v0.y, p1 = v1.x, p2 = v1.y & m;
+    const uint64_t hi1 = p2 & p1, lo1 = p2 & ~p1;  // {G,T} / {A,C}
+    uint32_t ac = (uint32_t)popc64(lo1 & ~p0) | ((uint32_t)popc64(lo1 & p0) << 16);
+    uint32_t gt = (uint32_t)popc64(hi1 & ~p0) | ((uint32_t)popc64(hi1 & p0) << 16);
+    ac = quad_sum32(ac);
+    gt = quad_sum32(gt);
+    const uint32_t pair = (w & 2) ? gt : ac;
+    return v0.x + ((w & 1) ? (pair >> 16) : (pair & 0xFFFFu));
+}
+
+// All four lanes of the quad return the complete Ext4 of the (quad-uniform) input interval.
+__device__ __forceinline__ void ext4_quad(const DevIndex& ix, uint64_t lower, uint64_t lower_rev, uint64_t size, int w, Ext4& out) {
+    const uint64_t my_lo = lower == 0 ? 0 : quad_occ(ix, lower - 1, w);
+    const uint64_t my_hi = quad_occ(ix, lower + size - 1, w);
+    uint64_t lo[4], hi[4];
+    lo[0] = quad_bcast64<0>(my_lo); lo[1] = quad_bcast64<1>(my_lo); lo[2] = quad_bcast64<2>(my_lo); lo[3] = quad_bcast64<3>(my_lo);
+    hi[0] = quad_bcast64<0>(my_hi); hi[1] = quad_bcast64<1>(my_hi); hi[2] = quad_bcast64<2>(my_hi); hi[3] = quad_bcast64<3>(my_hi);
+    finish_ext4(ix, lower, lower_rev, size, lo, hi, out);
+}
+
+// Single-base step for the D-array chains: new (lower, size) of the quad-uniform interval extended by base k (0..3).
+__device__ __forceinline__ void ext1_quad(const DevIndex& ix, uint64_t lower, uint64_t size, int k, int w, uint64_t& new_lower, uint64_t& new_size) {
+    const uint64_t my_lo = lower == 0 ? 0 : quad_occ(ix, lower - 1, w);
+    const uint64_t my_hi = quad_occ(ix, lower + size - 1, w);
+    // pick lane k's values (k is quad-uniform but dynamic): 4 broadcasts + selects
+    const uint64_t l0 = quad_bcast64<0>(my_lo), l1 = quad_bcast64<1>(my_lo), l2 = quad_bcast64<2>(my_lo), l3 = quad_bcast64<3>(my_lo);
+    const uint64_t h0 = quad_bcast64<0>(my_hi), h1 = quad_bcast64<1>(my_hi), h2 = quad_bcast64<2>(my_hi), h3 = quad_bcast64<3>(my_hi);
+    const uint64_t lo = k == 0 ? l0 : k == 1 ? l1 : k == 2 ? l2 : l3;
+    const uint64_t hi = k == 0 ? h0 : k == 1 ? h1 : k == 2 ? h2 : h3;
+    new_lower = ix.less[k + 1] + lo;
+    new_size = hi - lo;
+}
+#endif
+
+MAPAD_HD void ext1_scalar(const DevIndex& ix, uint64_t lower, uint64_t size, int k, uint64_t& new_lower, uint64_t& new_size) {
+    const uint64_t lo = lower == 0 ? 0 : occ_scalar(ix, lower - 1, k);
+    const uint64_t hi = occ_scalar(ix, lower + size - 1, k);
+    new_lower = ix.less[k + 1] + lo;
+    new_size = hi - lo;
+}
+
+}  // namespace mapad

@@ -1,0 +1,305 @@
+// host_index.hpp — host representation of a mapAD index and its construction (`mapad index` equivalent).
+//
+// Follows src/index/indexing.rs:43-212 (FASTA -> uppercase -> IUPAC replacement -> text$revcomp$ -> rank transform ->
+// suffix array -> BWT -> SA sample 1/32 + extra rows -> Less) and src/index/mod.rs (SampledSuffixArray, FastaIdPositions,
+// OriginalSymbols).  Instead of rust-bio's Occ (u64 checkpoints every 128 rows, byte BWT) the rank structure is the
+// 128-byte-block layout of fmd_device.hpp, shared by host (SA walks) and device.
+#pragma once
+#include <algorithm>
+#include <cstdint>
+#include <map>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "fmd_device.hpp"
+
+namespace mapad {
+namespace host {
+
+struct Contig { uint64_t start, end; std::string name; };  // FastaIdPosition (src/index/mod.rs:30-35), end inclusive
+
+struct Index {
+    uint64_t n = 0;
+    std::vector<uint8_t> bwt;        // reference ranks $=0 A=1 C=2 G=3 T=4 X=5
+    uint64_t less[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    uint64_t sentinel[2] = {0, 0};
+    std::vector<uint64_t> blocks;    // device layout, 16 u64 per 256 rows
+    std::vector<uint64_t> x_counts;  // per block: X symbols in rows [0, 256b) (only needed for LF steps through 'X')
+    std::vector<uint64_t> sa_sample;
+    uint64_t sa_rate = 32;
+    std::map<uint64_t, uint64_t> extra_rows;
+    std::vector<Contig> contigs;
+    std::map<uint64_t, uint8_t> original_symbols;
+
+    DevIndex view() const {
+        DevIndex v;
+        v.blocks = blocks.data(); v.n = n; v.n_blocks = blocks.size() / 16;
+        for (int i = 0; i < 8; ++i) v.less[i] = less[i];
+        v.sentinel[0] = sentinel[0]; v.sentinel[1] = sentinel[1];
+        return v;
+    }
+    // occurrences of reference rank `a` in bwt[0..=r]
+    uint64_t occ_rank(uint64_t r, int a) const {
+        if (a >= 1 && a <= 4) return occ_scalar(view(), r, a - 1);
+        if (a == 0) return (uint64_t)(r >= sentinel[0]) + (uint64_t)(r >= sentinel[1]);
+        // 'X': code 1 = plane0 only
+        const uint64_t* blk = blocks.data() + (r >> 8) * 16;
+        const int r_in = (int)(r & 255);
+        uint64_t c = x_counts.empty() ? 0 : x_counts[r >> 8];
+        for (int w = 0; w <= (r_in >> 6); ++w)
+            c += popc64(blk[4 * w + 1] & ~blk[4 * w + 2] & ~blk[4 * w + 3] & row_mask(w, r_in));
+        return c;
+    }
+    // SampledSuffixArray::get (src/index/mod.rs:160-187)
+    bool sa_get(uint64_t index, uint64_t& out) const {
+        if (index >= n) return false;
+        uint64_t pos = index, offset = 0;
+        for (;;) {
+            if (pos % sa_rate == 0) { out = sa_sample[pos / sa_rate] + offset; return true; }
+            const uint8_t c = bwt[pos];
+            if (c == 0) { out = extra_rows.at(pos) + offset; return true; }
+            pos = less[c] + occ_rank(pos - 1, c);
+            offset += 1;
+        }
+    }
+    // FastaIdPositions::get_reference_identifier (src/index/mod.rs:55-75)
+    bool contig_of(uint64_t position, uint64_t pattern_length, uint32_t& tid, uint64_t& rel) const {
+        for (size_t i = 0; i < contigs.size(); ++i)
+            if (contigs[i].start <= position && position + pattern_length - 1 <= contigs[i].end) { tid = (uint32_t)i; rel = position - contigs[i].start; return true; }
+        return false;
+    }
+    bool original_symbol(uint64_t pos, uint8_t& out) const {
+        auto it = original_symbols.find(pos);
+        if (it == original_symbols.end()) return false;
+        out = it->second;
+        return true;
+    }
+};
+
+inline uint8_t complement(uint8_t a) {  // bio::alphabets::dna::complement
+    switch (a) {
+        case 'A': return 'T'; case 'T': return 'A'; case 'C': return 'G'; case 'G': return 'C';
+        case 'a': return 't'; case 't': return 'a'; case 'c': return 'g'; case 'g': return 'c';
+        case 'R': return 'Y'; case 'Y': return 'R'; case 'K': return 'M'; case 'M': return 'K';
+        case 'B': return 'V'; case 'V': return 'B'; case 'D': return 'H'; case 'H': return 'D';
+        case 'r': return 'y'; case 'y': return 'r'; case 'k': return 'm'; case 'm': return 'k';
+        case 'b': return 'v'; case 'v': return 'b'; case 'd': return 'h'; case 'h': return 'd';
+        default: return a;
+    }
+}
+
+// ---- suffix array by induced sorting (SA-IS, Nong/Zhang/Chan 2009), implicit sentinel smaller than every symbol ----------
+// Any correct construction reproduces rust-bio's suffix_array(): the order of the suffixes of text$ is unique.
+template <class S, class I>
+void sais(const S* s, I* SA, I n, I K);
+
+namespace detail {
+struct TypeBits {
+    std::vector<uint64_t> b;
+    explicit TypeBits(size_t n) : b((n + 64) / 64, 0) {}
+    bool get(size_t i) const { return (b[i >> 6] >> (i & 63)) & 1; }
+    void set(size_t i) { b[i >> 6] |= 1ull << (i & 63); }
+};
+template <class S, class I>
+void bucket_bounds(const S* s, I n, I K, std::vector<I>& B, bool ends) {
+    std::fill(B.begin(), B.end(), (I)0);
+    for (I i = 0; i < n; ++i) B[s[i]] += 1;
+    I sum = 0;
+    for (I c = 0; c < K; ++c) { const I cnt = B[c]; if (ends) { sum += cnt; B[c] = sum; } else { B[c] = sum; sum += cnt; } }
+}
+template <class S, class I>
+void induce(const S* s, I* SA, I n, I K, const TypeBits& t, std::vector<I>& B) {
+    bucket_bounds(s, n, K, B, false);
+    SA[B[s[n - 1]]++] = n - 1;  // predecessor of the implicit sentinel is L-type
+    for (I i = 0; i < n; ++i) {
+        const I j = SA[i];
+        if (j > 0 && !t.get((size_t)j - 1)) SA[B[s[j - 1]]++] = j - 1;
+    }
+    bucket_bounds(s, n, K, B, true);
+    for (I i = n; i-- > 0;) {
+        const I j = SA[i];
+        if (j > 0 && t.get((size_t)j - 1)) SA[--B[s[j - 1]]] = j - 1;
+    }
+}
+}  // namespace detail
+
+template <class S, class I>
+void sais(const S* s, I* SA, I n, I K) {
+    using namespace detail;
+    if (n == 0) return;
+    if (n == 1) { SA[0] = 0; return; }
+    TypeBits t((size_t)n);  // bit = S-type
+    for (I i = n - 1; i-- > 0;) if (s[i] < s[i + 1] || (s[i] == s[i + 1] && t.get((size_t)i + 1))) t.set((size_t)i);
+    auto is_lms = [&](I i) { return i > 0 && t.get((size_t)i) && !t.get((size_t)i - 1); };
+    std::vector<I> B((size_t)K);
+    const I EMPTY = (I)-1;
+    // stage 1: sort the LMS substrings
+    std::fill(SA, SA + n, EMPTY);
+    bucket_bounds(s, n, K, B, true);
+    for (I i = n - 1; i > 0; --i) if (is_lms(i)) SA[--B[s[i]]] = i;
+    {   // induce with EMPTY-aware scans
+        bucket_bounds(s, n, K, B, false);
+        SA[B[s[n - 1]]++] = n - 1;
+        for (I i = 0; i < n; ++i) { const I j = SA[i]; if (j != EMPTY && j > 0 && !t.get((size_t)j - 1)) SA[B[s[j - 1]]++] = j - 1; }
+        bucket_bounds(s, n, K, B, true);
+        for (I i = n; i-- > 0;) { const I j = SA[i]; if (j != EMPTY && j > 0 && t.get((size_t)j - 1)) SA[--B[s[j - 1]]] = j - 1; }
+    }
+    I n1 = 0;
+    for (I i = 0; i < n; ++i) if (SA[i] != EMPTY && is_lms(SA[i])) SA[n1++] = SA[i];
+    std::fill(SA + n1, SA + n, EMPTY);
+    I name = 0, prev = EMPTY;
+    for (I i = 0; i < n1; ++i) {
+        const I pos = SA[i];
+        bool diff = prev == EMPTY;
+        if (!diff) {
+            for (I d = 0;; ++d) {
+                if (pos + d >= n || prev + d >= n) { diff = true; break; }
+                if (s[pos + d] != s[prev + d] || t.get((size_t)(pos + d)) != t.get((size_t)(prev + d))) { diff = true; break; }
+                if (d > 0 && (is_lms(pos + d) || is_lms(prev + d))) break;
+            }
+        }
+        if (diff) { name += 1; prev = pos; }
+        SA[n1 + pos / 2] = name - 1;
+    }
+    {
+        I j = n - 1;
+        for (I i = n - 1; i >= n1; --i) { if (SA[i] != EMPTY) SA[j--] = SA[i]; if (i == n1) break; }
+    }
+    I* s1 = SA + (n - n1);
+    I* SA1 = SA;
+    if (name < n1) sais<I, I>(s1, SA1, n1, name);
+    else for (I i = 0; i < n1; ++i) SA1[s1[i]] = i;
+    // stage 2: sorted LMS suffixes -> full SA
+    {
+        I j = 0;
+        for (I i = 1; i < n; ++i) if (is_lms(i)) s1[j++] = i;
+    }
+    for (I i = 0; i < n1; ++i) SA1[i] = s1[SA1[i]];
+    std::fill(SA + n1, SA + n, EMPTY);
+    bucket_bounds(s, n, K, B, true);
+    for (I i = n1; i-- > 0;) {
+        const I j = SA[i];
+        SA[i] = EMPTY;
+        SA[--B[s[j]]] = j;
+    }
+    {
+        bucket_bounds(s, n, K, B, false);
+        SA[B[s[n - 1]]++] = n - 1;
+        for (I i = 0; i < n; ++i) { const I j = SA[i]; if (j != EMPTY && j > 0 && !t.get((size_t)j - 1)) SA[B[s[j - 1]]++] = j - 1; }
+        bucket_bounds(s, n, K, B, true);
+        for (I i = n; i-- > 0;) { const I j = SA[i]; if (j != EMPTY && j > 0 && t.get((size_t)j - 1)) SA[--B[s[j - 1]]] = j - 1; }
+    }
+}
+
+// ---- device block layout from a rank BWT -----------------------------------------------------------------------------------
+inline void build_blocks(Index& ix) {
+    const uint64_t n = ix.n;
+    const uint64_t n_blocks = (n + kBlockRows - 1) / kBlockRows + 1;  // one spare block keeps hi-row prefetches in bounds
+    ix.blocks.assign(n_blocks * 16, 0);
+    ix.x_counts.clear();
+    static const int CODE[6] = {0, 4, 5, 6, 7, 1};  // rank -> device symbol code
+    uint64_t cnt[4] = {0, 0, 0, 0}, xcnt = 0;
+    bool any_x = false;
+    std::vector<uint64_t> xs(n_blocks, 0);
+    int nsent = 0;
+    for (uint64_t b = 0; b < n_blocks; ++b) {
+        uint64_t* blk = ix.blocks.data() + b * 16;
+        for (int w = 0; w < 4; ++w) blk[4 * w] = cnt[w];
+        xs[b] = xcnt;
+        const uint64_t r0 = b * kBlockRows;
+        for (uint64_t r = r0; r < std::min(n, r0 + kBlockRows); ++r) {
+            const uint8_t a = ix.bwt[r];
+            if (a > 5) throw std::runtime_error("BWT symbol out of range");
+            const int code = CODE[a];
+            const int w = (int)((r - r0) >> 6), bit = (int)((r - r0) & 63);
+            if (code & 1) blk[4 * w + 1] |= 1ull << bit;
+            if (code & 2) blk[4 * w + 2] |= 1ull << bit;
+            if (code & 4) blk[4 * w + 3] |= 1ull << bit;
+            if (a >= 1 && a <= 4) cnt[a - 1] += 1;
+            else if (a == 5) { xcnt += 1; any_x = true; }
+            else { if (nsent < 2) ix.sentinel[nsent] = r; nsent += 1; }
+        }
+    }
+    if (nsent != 2) throw std::runtime_error("BWT must contain exactly two sentinels");
+    if (any_x) ix.x_counts = std::move(xs);
+    // Less: less[c] = number of symbols < c
+    uint64_t per[6] = {2, cnt[0], cnt[1], cnt[2], cnt[3], xcnt};
+    uint64_t acc = 0;
+    for (int c = 0; c < 6; ++c) { ix.less[c] = acc; acc += per[c]; }
+    ix.less[6] = acc; ix.less[7] = acc;
+}
+
+// run_apply (src/index/indexing.rs:215-256): ambiguous runs shorter than min_run_len -> non_run_fun (original kept),
+// longer runs -> run_fun.
+template <class F, class G>
+void run_apply(std::vector<uint8_t>& seq, size_t min_run_len, F non_run_fun, G run_fun, std::map<uint64_t, uint8_t>& original) {
+    size_t i = 0;
+    while (i < seq.size()) {
+        const uint8_t sym = seq[i];
+        size_t run = 1;
+        while (i + run < seq.size() && seq[i + run] == sym) ++run;
+        if (base_index(sym) > 3) {
+            if (run < min_run_len) for (size_t j = 0; j < run; ++j) { original[i + j] = seq[i + j]; seq[i + j] = non_run_fun(seq[i + j]); }
+            else for (size_t j = 0; j < run; ++j) seq[i + j] = run_fun(seq[i + j]);
+        }
+        i += run;
+    }
+}
+
+struct SplitMix64 {
+    uint64_t s;
+    uint64_t next() { uint64_t z = (s += 0x9E3779B97F4A7C15ull); z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; return z ^ (z >> 31); }
+};
+
+inline bool is_iupac(uint8_t c) {
+    switch (c) { case 'A': case 'C': case 'G': case 'T': case 'U': case 'R': case 'Y': case 'K': case 'M': case 'S': case 'W': case 'B': case 'D': case 'H': case 'V': case 'N': return true; default: return false; }
+}
+
+// indexing.rs:43-212.  `fixed_replacement` != 0 forces every short-run replacement to that base (test hook).
+inline Index build_index(const std::vector<std::string>& names, const std::vector<std::vector<uint8_t>>& seqs, uint64_t seed, uint8_t fixed_replacement = 0) {
+    Index ix;
+    std::vector<uint8_t> text;
+    uint64_t end = 0;
+    for (size_t c = 0; c < seqs.size(); ++c) {  // :115-137
+        for (uint8_t ch : seqs[c]) text.push_back((uint8_t)std::toupper(ch));
+        end += seqs[c].size();
+        ix.contigs.push_back({end - seqs[c].size(), end - 1, names[c]});
+    }
+    for (uint8_t ch : text) if (!is_iupac(ch)) throw std::runtime_error("Found non-IUPAC symbol in reference sequence");  // :71
+    SplitMix64 rng{seed};
+    auto pick = [&](const char* set) -> uint8_t { const size_t k = std::char_traits<char>::length(set); return (uint8_t)set[rng.next() % k]; };
+    auto replace = [&](uint8_t b) -> uint8_t {  // :78-92
+        if (b == 'U') return 'T';
+        if (fixed_replacement) return fixed_replacement;
+        switch (b) {
+            case 'R': return pick("AG"); case 'Y': return pick("CT"); case 'K': return pick("GT"); case 'M': return pick("AC");
+            case 'S': return pick("CG"); case 'W': return pick("AT"); case 'B': return pick("CGT"); case 'D': return pick("AGT");
+            case 'H': return pick("ACT"); case 'V': return pick("ACG"); default: return pick("ACGT");
+        }
+    };
+    run_apply(text, 20, replace, [](uint8_t) -> uint8_t { return 'X'; }, ix.original_symbols);  // :98-107
+    // :139-160 text $ revcomp $ -> ranks
+    const size_t g = text.size();
+    std::vector<uint8_t> t(2 * g + 2);
+    auto rank = [](uint8_t c) -> uint8_t { return c == 'A' ? 1 : c == 'C' ? 2 : c == 'G' ? 3 : c == 'T' ? 4 : 5; };
+    for (size_t i = 0; i < g; ++i) { t[i] = rank(text[i]); t[g + 1 + i] = rank(complement(text[g - 1 - i])); }
+    t[g] = 0; t[2 * g + 1] = 0;
+    ix.n = t.size();
+    ix.bwt.resize(ix.n);
+    auto finish = [&](auto* sa) {
+        for (uint64_t i = 0; i < ix.n; ++i) {  // :166, :168-182
+            const uint64_t p = (uint64_t)sa[i];
+            ix.bwt[i] = p > 0 ? t[p - 1] : t[ix.n - 1];
+            if (i % ix.sa_rate == 0) ix.sa_sample.push_back(p);
+            else if (ix.bwt[i] == 0) ix.extra_rows[i] = p;
+        }
+    };
+    if (ix.n < (1ull << 31)) { std::vector<int32_t> sa(ix.n); sais<uint8_t, int32_t>(t.data(), sa.data(), (int32_t)ix.n, 6); finish(sa.data()); }
+    else { std::vector<int64_t> sa(ix.n); sais<uint8_t, int64_t>(t.data(), sa.data(), (int64_t)ix.n, 6); finish(sa.data()); }
+    build_blocks(ix);
+    return ix;
+}
+
+}  // namespace host
+}  // namespace mapad

@@ -1,0 +1,679 @@
+// mapad_amd.hip — gfx950 kernels, device context and the C ABI (include/mapad_amd.h) of the mapAD read-mapping hot path.
+//
+// Two kernels per batch of reads (the data-parallel boundary of run_inner, src/map/mapping.rs:153-156):
+//   darray_kernel : BiDArray::new for every read — one wavefront per read, one quad per offset chain (darray_core.hpp)
+//   search_kernel : k_mismatch_search — persistent wavefronts, one quad per read, reads pulled from an atomic work
+//                   counter (search_core.hpp); reads whose state outgrows the small per-quad arena are re-run by the
+//                   same kernel from a second, large-arena pool that holds the reference's full limits
+//                   (STACK_LIMIT / EDIT_TREE_LIMIT, mapping.rs:52-54).
+// Nothing here falls back to the CPU: without a gfx950 device every mapping entry point returns an error.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+#include <new>
+#include <set>
+#include <string>
+#include <vector>
+
+#include "../../include/mapad_amd.h"
+#include "darray_core.hpp"
+#include "host_index.hpp"
+#include "host_index_io.hpp"
+#include "host_models.hpp"
+#include "host_postproc.hpp"
+#include "search_core.hpp"
+
+using namespace mapad;
+
+// ======================================================================================================================
+// device side
+// ======================================================================================================================
+namespace {
+
+enum : uint32_t { ST_POOL_OVERFLOW = 4, ST_NO_TABLE = 8 };
+enum { CUR_HITS = 0, CUR_OPS = 1, CUR_WORK1 = 2, CUR_POOL_OVF = 3, CUR_WORK2 = 4, CUR_N_OVERFLOW = 5, CUR_ERR = 6, CUR_COUNT = 8 };
+
+struct BatchDev {
+    const uint8_t* seqs;
+    const uint8_t* quals;
+    const uint64_t* offsets;
+    uint32_t n_reads;
+    float* d_arrays;
+    ReadCounters* counters;
+    uint32_t* status;
+    uint32_t* hit_count;
+    uint32_t* hit_first;
+    HitRec* hits_pool;
+    uint32_t* ops_pool;
+    uint32_t hits_cap, ops_cap;
+    uint32_t* cursors;
+    uint32_t* overflow_list;  // read ids that need the large-arena pass
+};
+
+struct ArenaPool {
+    uint8_t* base;
+    uint64_t stride;
+    uint64_t off_nodes, off_hits, off_hit_ops, off_scratch;
+    uint32_t heap_cap, node_cap, hit_ops_cap;
+};
+
+__device__ __forceinline__ Arena carve(const ArenaPool& ap, uint32_t slot) {
+    uint8_t* b = ap.base + (uint64_t)slot * ap.stride;
+    Arena a;
+    a.heap = reinterpret_cast<HeapEntry*>(b);
+    a.nodes = reinterpret_cast<Node*>(b + ap.off_nodes);
+    a.hits = reinterpret_cast<HitRec*>(b + ap.off_hits);
+    a.hit_ops = reinterpret_cast<uint32_t*>(b + ap.off_hit_ops);
+    a.scratch = reinterpret_cast<uint16_t*>(b + ap.off_scratch);
+    a.heap_cap = ap.heap_cap; a.node_cap = ap.node_cap; a.hit_ops_cap = ap.hit_ops_cap;
+    return a;
+}
+
+// ---- D arrays: one wavefront per read, quad q = offset chain q ------------------------------------------------------------
+__global__ void __launch_bounds__(64) darray_kernel(DevIndex ix, DevParams P, BatchDev B, int lmax) {
+    extern __shared__ float lds[];
+    float* pen = lds;            // [lmax]
+    float* chains = lds + lmax;  // [15][lmax]
+    __shared__ uint32_t n_ext_total;
+    const int lane = threadIdx.x & 63, quad = lane >> 2, w = lane & 3;
+    for (uint32_t read = blockIdx.x; read < B.n_reads; read += gridDim.x) {
+        const uint64_t off = B.offsets[read];
+        const int L = (int)(B.offsets[read + 1] - off);
+        const uint8_t* seq = B.seqs + off;
+        const uint8_t* qual = B.quals + off;
+        float* dout = B.d_arrays + off;
+        if (L > lmax || P.table_base[L] < 0) {  // fail loudly: the host did not prepare this read length
+            if (lane == 0) { B.status[read] = ST_NO_TABLE; atomicOr(&B.cursors[CUR_ERR], ST_NO_TABLE); B.counters[read].e_darray = 0; }
+            continue;
+        }
+        const int split = P.start_at_end ? L : L / 2;
+        if (lane == 0) n_ext_total = 0;
+        for (int r = lane; r < L; r += 64) pen[r] = d_penalty(P, seq, qual, L, r);
+        __syncthreads();
+        for (int part = 0; part < 2; ++part) {
+            const bool left = part == 0;
+            const int part_len = left ? split : L - split;
+            if (part_len == 0) continue;
+            if (quad < kMaxOffset) {
+                const uint32_t n_ext = d_chain(ix, seq, L, split, left, quad, pen, chains + quad * lmax, w);
+                if (w == 0) atomicAdd(&n_ext_total, n_ext);
+            }
+            __syncthreads();
+            for (int p = lane; p < part_len; p += 64) {  // fold(0.0, f32::min) over the 15 chains (bi_d_array.rs:56-65)
+                float acc = 0.0f;
+#pragma unroll
+                for (int o = 0; o < kMaxOffset; ++o) acc = f32_min(acc, chains[o * lmax + p]);
+                dout[(left ? 0 : split) + p] = acc;
+            }
+            __syncthreads();
+        }
+        if (lane == 0) B.counters[read].e_darray = n_ext_total;
+        __syncthreads();
+    }
+}
+
+// ---- search: persistent quads -----------------------------------------------------------------------------------------
+__device__ __forceinline__ void finalize_read(const BatchDev& B, const Arena& A, const SearchState& st, uint32_t read, int w, bool second_pass) {
+    if (st.status == ST_ARENA_OVERFLOW && !second_pass) {
+        if (w == 0) {
+            const uint32_t k = atomicAdd(&B.cursors[CUR_N_OVERFLOW], 1u);
+            B.overflow_list[k] = read;
+            B.status[read] = ST_ARENA_OVERFLOW;
+            B.hit_count[read] = 0; B.hit_first[read] = 0;
+        }
+        return;
+    }
+    const uint32_t n = st.status == ST_ARENA_OVERFLOW ? 0u : st.n_hits, n_ops = st.status == ST_ARENA_OVERFLOW ? 0u : st.hit_ops_used;
+    uint32_t hbase = 0, obase = 0;
+    if (w == 0) { hbase = atomicAdd(&B.cursors[CUR_HITS], n); obase = atomicAdd(&B.cursors[CUR_OPS], n_ops); }
+    hbase = dpp_quad<0>(hbase);
+    obase = dpp_quad<0>(obase);
+    uint32_t status = st.status;
+    if ((uint64_t)hbase + n > B.hits_cap || (uint64_t)obase + n_ops > B.ops_cap) {
+        status |= ST_POOL_OVERFLOW;
+        if (w == 0) atomicOr(&B.cursors[CUR_POOL_OVF], 1u);
+    } else {
+        for (uint32_t i = w; i < n; i += 4) { HitRec h = A.hits[i]; h.ops_off += obase; B.hits_pool[hbase + i] = h; }
+        for (uint32_t i = w; i < n_ops; i += 4) B.ops_pool[obase + i] = A.hit_ops[i];
+    }
+    if (w == 0) {
+        B.hit_count[read] = (status & ST_POOL_OVERFLOW) ? 0u : n;
+        B.hit_first[read] = hbase;
+        B.status[read] = status;
+        ReadCounters* c = B.counters + read;
+        c->e_search = st.ctr.e_search; c->n_push = st.ctr.n_push; c->n_pop = st.ctr.n_pop; c->n_node = st.ctr.n_node; c->n_hits = st.ctr.n_hits;
+        if (status == ST_ARENA_OVERFLOW) atomicOr(&B.cursors[CUR_ERR], ST_ARENA_OVERFLOW);  // cannot happen in the large-arena pass
+    }
+}
+
+__global__ void __launch_bounds__(64) search_kernel(DevIndex ix, DevParams P, BatchDev B, ArenaPool AP, int second_pass) {
+    const int lane = threadIdx.x & 63, w = lane & 3;
+    const uint32_t slot = blockIdx.x * 16 + (lane >> 2);
+    const Arena A = carve(AP, slot);
+    const uint32_t n_items = second_pass ? B.cursors[CUR_N_OVERFLOW] : B.n_reads;
+    uint32_t* work = &B.cursors[second_pass ? CUR_WORK2 : CUR_WORK1];
+    bool have = false, done = false;
+    ReadIn rd{nullptr, nullptr, nullptr, 0};
+    SearchState st;
+    uint32_t read = 0;
+    for (;;) {
+        if (!have && !done) {
+            uint32_t item = 0;
+            if (w == 0) item = atomicAdd(work, 1u);
+            item = dpp_quad<0>(item);
+            if (item >= n_items) done = true;
+            else {
+                read = second_pass ? B.overflow_list[item] : item;
+                const uint64_t off = B.offsets[read];
+                rd.L = (int)(B.offsets[read + 1] - off);
+                rd.seq = B.seqs + off; rd.qual = B.quals + off; rd.d = B.d_arrays + off;
+                if (B.status[read] == ST_NO_TABLE && !second_pass) {  // D kernel already flagged it
+                    if (w == 0) { B.hit_count[read] = 0; B.hit_first[read] = 0; }
+                } else {
+                    search_init(ix, P, rd, A, st);
+                    have = true;
+                }
+            }
+        }
+        if (__all(done)) break;
+        if (have) {
+            if (!search_step(ix, P, rd, A, st, w)) {
+                finalize_read(B, A, st, read, w, second_pass != 0);
+                have = false;
+            }
+        }
+    }
+}
+
+}  // namespace
+
+// ======================================================================================================================
+// host side
+// ======================================================================================================================
+struct mapad_index {
+    host::Index ix;
+};
+
+namespace {
+
+#define HIP_TRY(expr)                                                                                       \
+    do {                                                                                                    \
+        hipError_t e_ = (expr);                                                                             \
+        if (e_ != hipSuccess) {                                                                             \
+            std::fprintf(stderr, "mapad_amd: %s failed: %s (%s:%d)\n", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return MAPAD_ERR_DEVICE;                                                                        \
+        }                                                                                                   \
+    } while (0)
+
+template <class T>
+struct DevBuf {
+    T* p = nullptr;
+    size_t cap = 0;
+    int ensure(size_t n) {
+        if (n <= cap) return MAPAD_OK;
+        if (p) (void)hipFree(p);
+        p = nullptr; cap = 0;
+        const size_t want = n + n / 8 + 64;
+        if (hipMalloc((void**)&p, want * sizeof(T)) != hipSuccess) { p = nullptr; return MAPAD_ERR_NOMEM; }
+        cap = want;
+        return MAPAD_OK;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+
+ArenaPool make_pool_layout(uint32_t heap_cap, uint32_t node_cap, uint32_t hit_ops_cap, uint32_t lmax) {
+    ArenaPool ap{};
+    auto align = [](uint64_t x) { return (x + 127) & ~127ull; };
+    ap.heap_cap = heap_cap; ap.node_cap = node_cap; ap.hit_ops_cap = hit_ops_cap;
+    uint64_t o = align((uint64_t)heap_cap * sizeof(HeapEntry));
+    ap.off_nodes = o; o = align(o + (uint64_t)node_cap * sizeof(Node));
+    ap.off_hits = o; o = align(o + (uint64_t)kMaxHits * sizeof(HitRec));
+    ap.off_hit_ops = o; o = align(o + (uint64_t)hit_ops_cap * 4);
+    ap.off_scratch = o; o = align(o + 2ull * (lmax + 1) * 2);
+    ap.stride = o;
+    return ap;
+}
+
+}  // namespace
+
+struct mapad_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    mapad_params_t params{};
+    const mapad_index* index = nullptr;
+    host::HostTables tables;
+    bool tables_dirty = true;
+    // index + tables on the device
+    DevBuf<uint64_t> d_blocks;
+    DevBuf<float> d_sdm, d_thr;
+    DevBuf<int32_t> d_base;
+    DevIndex dix{};
+    DevParams dprm{};
+    // batch buffers
+    DevBuf<uint8_t> d_seqs, d_quals;
+    DevBuf<uint64_t> d_offsets;
+    DevBuf<float> d_darr;
+    DevBuf<ReadCounters> d_counters;
+    DevBuf<uint32_t> d_status, d_hit_count, d_hit_first, d_ops, d_cursors, d_overflow;
+    DevBuf<HitRec> d_hits;
+    DevBuf<uint8_t> d_arena1, d_arena2;
+    ArenaPool pool1{}, pool2{};
+    uint32_t slots1 = 0, slots2 = 0, arena_lmax = 0;
+    int n_cu = 256;
+    // last batch
+    BatchDev last{};
+    uint64_t last_total_bases = 0;
+    uint32_t last_lmax = 0;
+    bool last_owned_inputs = false;
+    uint32_t launch_info[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    uint64_t counter_sums[6] = {0, 0, 0, 0, 0, 0};
+
+    ~mapad_ctx() {
+        (void)hipSetDevice(device);
+        d_blocks.release(); d_sdm.release(); d_thr.release(); d_base.release(); d_seqs.release(); d_quals.release(); d_offsets.release();
+        d_darr.release(); d_counters.release(); d_status.release(); d_hit_count.release(); d_hit_first.release(); d_ops.release();
+        d_cursors.release(); d_overflow.release(); d_hits.release(); d_arena1.release(); d_arena2.release();
+    }
+};
+
+namespace {
+
+int upload_tables(mapad_ctx* c) {
+    if (!c->tables_dirty) return MAPAD_OK;
+    int rc;
+    if ((rc = c->d_sdm.ensure(std::max<size_t>(c->tables.sdm.size(), 4)))) return rc;
+    if ((rc = c->d_base.ensure(c->tables.table_base.size()))) return rc;
+    if ((rc = c->d_thr.ensure(c->tables.reject_thr.size()))) return rc;
+    if (!c->tables.sdm.empty()) HIP_TRY(hipMemcpyAsync(c->d_sdm.p, c->tables.sdm.data(), c->tables.sdm.size() * 4, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->d_base.p, c->tables.table_base.data(), c->tables.table_base.size() * 4, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->d_thr.p, c->tables.reject_thr.data(), c->tables.reject_thr.size() * 4, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));  // host vectors may be re-allocated by the next add_length
+    const mapad_params_t& p = c->params;
+    DevParams& d = c->dprm;
+    d.sdm_table = c->d_sdm.p; d.table_base = c->d_base.p; d.reject_thr = c->d_thr.p;
+    d.nq = c->tables.nq; d.bound_kind = p.bound_kind; d.cutoff = p.cutoff; d.repr_mm = c->tables.repr_mm;
+    d.gap_open = p.penalty_gap_open; d.gap_extend = p.penalty_gap_extend;
+    d.gap_dist_ends = p.gap_dist_ends; d.max_num_gaps_open = p.max_num_gaps_open;
+    d.start_at_end = p.model_kind == MAPAD_MODEL_SIMPLE_ADNA;
+    d.stack_limit_abort = p.stack_limit_abort;
+    d.stack_limit = p.stack_limit ? p.stack_limit : 2000000u;
+    d.edit_tree_limit = p.edit_tree_limit ? p.edit_tree_limit : 10000000u;
+    c->tables_dirty = false;
+    return MAPAD_OK;
+}
+
+int ensure_arenas(mapad_ctx* c, uint32_t lmax) {
+    if (c->d_arena1.p && lmax <= c->arena_lmax) return MAPAD_OK;
+    const uint32_t lm = std::max<uint32_t>(lmax, 128);
+    const uint32_t stack_limit = c->dprm.stack_limit, tree_limit = c->dprm.edit_tree_limit;
+    // pass 1: small arenas, many slots (16 quads per wave)
+    const char* e1 = std::getenv("MAPAD_WAVES_PER_CU");
+    const int waves_per_cu = e1 ? std::max(1, std::atoi(e1)) : 8;
+    const char* e2 = std::getenv("MAPAD_ARENA_NODES");
+    const uint32_t node_cap1 = std::min<uint32_t>(e2 ? (uint32_t)std::atoi(e2) : 4096u, tree_limit + 9);
+    const uint32_t heap_cap1 = std::min<uint32_t>(node_cap1, stack_limit + 9);
+    const uint32_t hit_ops_cap = kMaxHits * (lm + 32);
+    c->pool1 = make_pool_layout(heap_cap1, node_cap1, hit_ops_cap, lm);
+    c->slots1 = (uint32_t)c->n_cu * waves_per_cu * 16;
+    int rc;
+    if ((rc = c->d_arena1.ensure((size_t)c->slots1 * c->pool1.stride))) return rc;
+    c->pool1.base = c->d_arena1.p;
+    // pass 2: the reference's full limits (mapping.rs:52-54, +9 like its with_capacity calls :147-148)
+    const char* e3 = std::getenv("MAPAD_PASS2_WAVES");
+    const int waves2 = e3 ? std::max(1, std::atoi(e3)) : 1;
+    c->pool2 = make_pool_layout(stack_limit + 9 + 1, tree_limit + 9 + 1, hit_ops_cap, lm);
+    c->slots2 = (uint32_t)waves2 * 16;
+    if ((rc = c->d_arena2.ensure((size_t)c->slots2 * c->pool2.stride))) return rc;
+    c->pool2.base = c->d_arena2.p;
+    c->arena_lmax = lm;
+    return MAPAD_OK;
+}
+
+int launch_batch(mapad_ctx* c, const uint8_t* d_seqs, const uint8_t* d_quals, const uint64_t* d_offsets, uint64_t n_reads, uint64_t total_bases,
+                 uint32_t lmax) {
+    int rc;
+    if ((rc = upload_tables(c))) return rc;
+    if ((rc = ensure_arenas(c, lmax))) return rc;
+    const size_t nr = std::max<uint64_t>(n_reads, 1);
+    if ((rc = c->d_darr.ensure(std::max<uint64_t>(total_bases, 1)))) return rc;
+    if ((rc = c->d_counters.ensure(nr))) return rc;
+    if ((rc = c->d_status.ensure(nr))) return rc;
+    if ((rc = c->d_hit_count.ensure(nr))) return rc;
+    if ((rc = c->d_hit_first.ensure(nr))) return rc;
+    if ((rc = c->d_overflow.ensure(nr))) return rc;
+    if ((rc = c->d_cursors.ensure(CUR_COUNT))) return rc;
+    const size_t hits_cap = std::max(c->d_hits.cap, (size_t)(2 * nr + 1024));
+    const size_t ops_cap = std::max(c->d_ops.cap, hits_cap * (size_t)(std::min<uint32_t>(lmax, 256) + 8));
+    if ((rc = c->d_hits.ensure(hits_cap))) return rc;
+    if ((rc = c->d_ops.ensure(ops_cap))) return rc;
+    HIP_TRY(hipMemsetAsync(c->d_cursors.p, 0, CUR_COUNT * 4, c->stream));
+    HIP_TRY(hipMemsetAsync(c->d_status.p, 0, nr * 4, c->stream));
+    BatchDev B{};
+    B.seqs = d_seqs; B.quals = d_quals; B.offsets = d_offsets; B.n_reads = (uint32_t)n_reads;
+    B.d_arrays = c->d_darr.p; B.counters = c->d_counters.p; B.status = c->d_status.p;
+    B.hit_count = c->d_hit_count.p; B.hit_first = c->d_hit_first.p;
+    B.hits_pool = c->d_hits.p; B.ops_pool = c->d_ops.p;
+    B.hits_cap = (uint32_t)std::min<size_t>(c->d_hits.cap, 0xFFFFFFFFu); B.ops_cap = (uint32_t)std::min<size_t>(c->d_ops.cap, 0xFFFFFFFFu);
+    B.cursors = c->d_cursors.p; B.overflow_list = c->d_overflow.p;
+    c->last = B; c->last_total_bases = total_bases; c->last_lmax = lmax;
+    if (n_reads == 0) return MAPAD_OK;
+    const uint32_t lds_lmax = std::max<uint32_t>(lmax, 1);
+    const size_t lds_bytes = (size_t)16 * lds_lmax * sizeof(float);
+    const uint32_t grid_d = (uint32_t)std::min<uint64_t>(n_reads, (uint64_t)c->n_cu * 32);
+    hipLaunchKernelGGL(darray_kernel, dim3(grid_d), dim3(64), lds_bytes, c->stream, c->dix, c->dprm, B, (int)lds_lmax);
+    HIP_TRY(hipGetLastError());
+    const uint32_t grid_s = (uint32_t)std::min<uint64_t>((n_reads + 15) / 16, c->slots1 / 16);
+    hipLaunchKernelGGL(search_kernel, dim3(grid_s), dim3(64), 0, c->stream, c->dix, c->dprm, B, c->pool1, 0);
+    HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(search_kernel, dim3(c->slots2 / 16), dim3(64), 0, c->stream, c->dix, c->dprm, B, c->pool2, 1);
+    HIP_TRY(hipGetLastError());
+    c->launch_info[0] = grid_d; c->launch_info[1] = 64; c->launch_info[2] = (uint32_t)lds_bytes;
+    c->launch_info[3] = grid_s; c->launch_info[4] = 64; c->launch_info[5] = c->slots2 / 16;
+    c->launch_info[6] = c->pool1.node_cap; c->launch_info[7] = (uint32_t)(c->pool1.stride >> 10);
+    return MAPAD_OK;
+}
+
+struct HostResult {
+    mapad_batch_result_t pub{};
+    std::vector<uint64_t> hit_begin;
+    std::vector<mapad_hit_t> hits;
+    std::vector<uint32_t> ops, status;
+    std::vector<mapad_read_counters_t> counters;
+    std::vector<float> d_arrays;
+};
+static_assert(sizeof(mapad_hit_t) == sizeof(HitRec), "public hit record == device hit record");
+static_assert(sizeof(mapad_read_counters_t) == sizeof(ReadCounters), "counter layout");
+
+}  // namespace
+
+extern "C" {
+
+const char* mapad_version(void) { return "mapad_amd 0.1.0 (gfx950; mapAD 0.45.0 hot path)"; }
+
+// ---- parameters / plugin surface ------------------------------------------------------------------------------------------
+int mapad_params_from_cli(mapad_params_t* out, int library_prep, float five_prime_overhang, float three_prime_overhang, float ds_deamination_rate,
+                          float ss_deamination_rate, float divergence, float poisson_prob, float as_cutoff, float as_cutoff_exponent, float indel_rate,
+                          float gap_extension_penalty, int gap_dist_ends, int max_num_gaps_open, int ignore_base_quality, int no_search_limit_recovery,
+                          uint64_t chunk_size) {
+    if (!out) return MAPAD_ERR_INVALID;
+    std::memset(out, 0, sizeof *out);
+    out->model_kind = MAPAD_MODEL_SIMPLE_ADNA;
+    out->library_prep = library_prep;
+    out->five_prime_overhang = five_prime_overhang;
+    out->three_prime_overhang = library_prep == MAPAD_LIBRARY_DOUBLE_STRANDED ? five_prime_overhang : three_prime_overhang;
+    out->ds_deamination_rate = ds_deamination_rate; out->ss_deamination_rate = ss_deamination_rate;
+    out->divergence = divergence / 3.0f;  // main.rs:452
+    out->ignore_base_quality = ignore_base_quality;
+    if (poisson_prob >= 0.0f) { out->bound_kind = MAPAD_BOUND_DISCRETE; out->poisson_threshold = poisson_prob; out->base_error_rate = divergence; }  // :456-462
+    else { out->bound_kind = MAPAD_BOUND_CONTINUOUS; out->cutoff = as_cutoff * -1.0f; out->exponent = as_cutoff_exponent; }                             // :463-475
+    const float repr = host::sdm_repr_mm(*out);
+    out->penalty_gap_open = std::log2(indel_rate);             // :478-481
+    out->penalty_gap_extend = gap_extension_penalty * repr;    // :482-485
+    out->gap_dist_ends = gap_dist_ends; out->max_num_gaps_open = max_num_gaps_open;
+    out->stack_limit_abort = no_search_limit_recovery;
+    out->chunk_size = chunk_size ? chunk_size : 250000;
+    return MAPAD_OK;
+}
+float mapad_sdm_get(const mapad_params_t* p, uint64_t i, uint64_t len, uint8_t from, uint8_t to, uint8_t q) { return host::sdm_get(*p, i, len, from, to, q); }
+float mapad_sdm_representative_mismatch_penalty(const mapad_params_t* p) { return host::sdm_repr_mm(*p); }
+float mapad_sdm_min_penalty(const mapad_params_t* p, uint64_t i, uint64_t len, uint8_t to, uint8_t q, int only_mm) { return host::sdm_min_penalty(*p, i, len, to, q, only_mm != 0); }
+int32_t mapad_sdm_alignment_start(const mapad_params_t* p, uint64_t len) { return host::sdm_alignment_start(*p, len); }
+int mapad_mb_reject(const mapad_params_t* p, float v, uint64_t len) { return host::mb_reject(*p, v, len); }
+int mapad_mb_reject_iterative(const mapad_params_t* p, float v, float ref) { return host::mb_reject_iterative(*p, v, ref); }
+float mapad_mb_remaining_frac_of_repr_mm(const mapad_params_t* p, float v, uint64_t len) { return host::mb_remaining_frac(*p, v, len); }
+
+// ---- index ------------------------------------------------------------------------------------------------------------
+int mapad_index_build(const char* const* names, const uint8_t* const* seqs, const uint64_t* lens, uint32_t n_contigs, uint64_t seed, mapad_index_t** out) {
+    if (!out || !names || !seqs || !lens || n_contigs == 0) return MAPAD_ERR_INVALID;
+    try {
+        std::vector<std::string> nm;
+        std::vector<std::vector<uint8_t>> sq;
+        for (uint32_t i = 0; i < n_contigs; ++i) { nm.emplace_back(names[i]); sq.emplace_back(seqs[i], seqs[i] + lens[i]); }
+        const char* fr = std::getenv("MAPAD_INDEX_FIXED_REPLACEMENT");  // test hook: pin the random IUPAC replacement
+        auto idx = std::make_unique<mapad_index>();
+        idx->ix = host::build_index(nm, sq, seed, fr && fr[0] ? (uint8_t)fr[0] : 0);
+        *out = idx.release();
+        return MAPAD_OK;
+    } catch (const std::bad_alloc&) { return MAPAD_ERR_NOMEM; } catch (const std::exception& e) {
+        std::fprintf(stderr, "mapad_index_build: %s\n", e.what());
+        return MAPAD_ERR_PARSE;
+    }
+}
+int mapad_index_open(const char* prefix, mapad_index_t** out) {
+    if (!prefix || !out) return MAPAD_ERR_INVALID;
+    auto idx = std::make_unique<mapad_index>();
+    const int rc = host::load_index(prefix, idx->ix);
+    if (rc != MAPAD_OK) return rc;
+    *out = idx.release();
+    return MAPAD_OK;
+}
+int mapad_index_save(const mapad_index_t* idx, const char* prefix) {
+    if (!idx || !prefix) return MAPAD_ERR_INVALID;
+    return host::save_index(prefix, idx->ix);
+}
+void mapad_index_free(mapad_index_t* idx) { delete idx; }
+uint64_t mapad_index_text_len(const mapad_index_t* idx) { return idx ? idx->ix.n : 0; }
+int mapad_index_copy_bwt(const mapad_index_t* idx, uint8_t* out) {
+    if (!idx || !out) return MAPAD_ERR_INVALID;
+    std::memcpy(out, idx->ix.bwt.data(), idx->ix.bwt.size());
+    return MAPAD_OK;
+}
+uint32_t mapad_index_n_contigs(const mapad_index_t* idx) { return idx ? (uint32_t)idx->ix.contigs.size() : 0; }
+int mapad_index_contig(const mapad_index_t* idx, uint32_t i, const char** name, uint64_t* start, uint64_t* end) {
+    if (!idx || i >= idx->ix.contigs.size()) return MAPAD_ERR_INVALID;
+    if (name) *name = idx->ix.contigs[i].name.c_str();
+    if (start) *start = idx->ix.contigs[i].start;
+    if (end) *end = idx->ix.contigs[i].end;
+    return MAPAD_OK;
+}
+uint64_t mapad_index_sa_sample_len(const mapad_index_t* idx) { return idx ? idx->ix.sa_sample.size() : 0; }
+uint64_t mapad_index_sa_extra_len(const mapad_index_t* idx) { return idx ? idx->ix.extra_rows.size() : 0; }
+int mapad_index_copy_sa(const mapad_index_t* idx, uint64_t* sample, uint64_t* extra_rows, uint64_t* extra_vals) {
+    if (!idx) return MAPAD_ERR_INVALID;
+    if (sample) std::memcpy(sample, idx->ix.sa_sample.data(), idx->ix.sa_sample.size() * 8);
+    size_t k = 0;
+    for (auto& kv : idx->ix.extra_rows) { if (extra_rows) extra_rows[k] = kv.first; if (extra_vals) extra_vals[k] = kv.second; ++k; }
+    return MAPAD_OK;
+}
+
+int mapad_index_device_view(const mapad_index_t* idx, const uint64_t** blocks, uint64_t* n_blocks, uint64_t less[8], uint64_t sentinel[2]) {
+    if (!idx) return MAPAD_ERR_INVALID;
+    if (blocks) *blocks = idx->ix.blocks.data();
+    if (n_blocks) *n_blocks = idx->ix.blocks.size() / 16;
+    if (less) std::memcpy(less, idx->ix.less, sizeof idx->ix.less);
+    if (sentinel) { sentinel[0] = idx->ix.sentinel[0]; sentinel[1] = idx->ix.sentinel[1]; }
+    return MAPAD_OK;
+}
+int mapad_index_sa_get(const mapad_index_t* idx, uint64_t row, uint64_t* out) {
+    if (!idx || !out) return MAPAD_ERR_INVALID;
+    try { return idx->ix.sa_get(row, *out) ? MAPAD_OK : MAPAD_ERR_INVALID; } catch (const std::exception&) { return MAPAD_ERR_PARSE; }
+}
+
+// ---- context ------------------------------------------------------------------------------------------------------------
+int mapad_ctx_create(const mapad_index_t* idx, const mapad_params_t* params, int device_id, mapad_ctx_t** out) {
+    if (!idx || !params || !out) return MAPAD_ERR_INVALID;
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0 || device_id < 0 || device_id >= n_dev) {
+        std::fprintf(stderr, "mapad_amd: no usable HIP device (there is no CPU fallback)\n");
+        return MAPAD_ERR_NO_DEVICE;
+    }
+    if (hipSetDevice(device_id) != hipSuccess) return MAPAD_ERR_NO_DEVICE;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device_id) != hipSuccess) return MAPAD_ERR_NO_DEVICE;
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        std::fprintf(stderr, "mapad_amd: device %d is %s, this library is built for gfx950 only\n", device_id, prop.gcnArchName);
+        return MAPAD_ERR_NO_DEVICE;
+    }
+    auto c = std::make_unique<mapad_ctx>();
+    c->device = device_id; c->params = *params; c->index = idx; c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    c->tables = host::make_tables(*params);
+    int rc;
+    if ((rc = c->d_blocks.ensure(idx->ix.blocks.size()))) return rc;
+    HIP_TRY(hipMemcpy(c->d_blocks.p, idx->ix.blocks.data(), idx->ix.blocks.size() * 8, hipMemcpyHostToDevice));
+    c->dix = idx->ix.view();
+    c->dix.blocks = c->d_blocks.p;
+    *out = c.release();
+    return MAPAD_OK;
+}
+void mapad_ctx_destroy(mapad_ctx_t* ctx) { delete ctx; }
+int mapad_ctx_set_stream(mapad_ctx_t* ctx, void* s) { if (!ctx) return MAPAD_ERR_INVALID; ctx->stream = (hipStream_t)s; return MAPAD_OK; }
+
+// tables for the read lengths of the coming batches (device-resident inputs: the host cannot see the lengths)
+int mapad_ctx_prepare_lengths(mapad_ctx_t* ctx, const uint32_t* lens, uint32_t n) {
+    if (!ctx || (!lens && n)) return MAPAD_ERR_INVALID;
+    for (uint32_t i = 0; i < n; ++i) {
+        if (lens[i] == 0) continue;
+        if (lens[i] > MAPAD_MAX_READ_LEN) return MAPAD_ERR_READ_TOO_LONG;
+        if (ctx->tables.table_base[lens[i]] < 0) { host::add_length(ctx->params, ctx->tables, (int)lens[i]); ctx->tables_dirty = true; }
+    }
+    return MAPAD_OK;
+}
+
+int mapad_map_batch_device(mapad_ctx_t* ctx, const void* d_seqs, const void* d_quals, const void* d_offsets, uint64_t n_reads, uint32_t max_read_len) {
+    if (!ctx || (n_reads && (!d_seqs || !d_quals || !d_offsets))) return MAPAD_ERR_INVALID;
+    if (max_read_len > MAPAD_MAX_READ_LEN) return MAPAD_ERR_READ_TOO_LONG;
+    if (n_reads >= 0xFFFFFFF0ull) return MAPAD_ERR_INVALID;
+    if (hipSetDevice(ctx->device) != hipSuccess) return MAPAD_ERR_NO_DEVICE;
+    uint64_t total = 0;
+    if (n_reads) HIP_TRY(hipMemcpyAsync(&total, (const uint64_t*)d_offsets + n_reads, 8, hipMemcpyDeviceToHost, ctx->stream));
+    if (n_reads) HIP_TRY(hipStreamSynchronize(ctx->stream));
+    ctx->last_owned_inputs = false;
+    return launch_batch(ctx, (const uint8_t*)d_seqs, (const uint8_t*)d_quals, (const uint64_t*)d_offsets, n_reads, total, max_read_len);
+}
+
+int mapad_fetch_result(mapad_ctx_t* ctx, mapad_batch_result_t** out) {
+    if (!ctx || !out) return MAPAD_ERR_INVALID;
+    if (hipSetDevice(ctx->device) != hipSuccess) return MAPAD_ERR_NO_DEVICE;
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    const BatchDev& B = ctx->last;
+    const uint64_t n = B.n_reads;
+    auto r = std::make_unique<HostResult>();
+    uint32_t cur[CUR_COUNT] = {0};
+    if (n) HIP_TRY(hipMemcpy(cur, B.cursors, sizeof cur, hipMemcpyDeviceToHost));
+    if (cur[CUR_ERR] & ST_NO_TABLE) { std::fprintf(stderr, "mapad_amd: a read length had no score table (call mapad_ctx_prepare_lengths)\n"); return MAPAD_ERR_INVALID; }
+    if (cur[CUR_ERR] & ST_ARENA_OVERFLOW) { std::fprintf(stderr, "mapad_amd: arena overflow in the large-arena pass\n"); return MAPAD_ERR_NOMEM; }
+    if (cur[CUR_POOL_OVF]) return MAPAD_ERR_NOMEM;  // mapad_map_batch retries with larger pools
+    std::vector<uint32_t> cnt(n), first(n);
+    std::vector<HitRec> pool(cur[CUR_HITS]);
+    std::vector<uint32_t> ops_pool(cur[CUR_OPS]);
+    r->status.resize(n); r->counters.resize(n); r->d_arrays.resize(ctx->last_total_bases);
+    if (n) {
+        HIP_TRY(hipMemcpy(cnt.data(), B.hit_count, n * 4, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(first.data(), B.hit_first, n * 4, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(r->status.data(), B.status, n * 4, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(r->counters.data(), B.counters, n * sizeof(ReadCounters), hipMemcpyDeviceToHost));
+        if (!pool.empty()) HIP_TRY(hipMemcpy(pool.data(), B.hits_pool, pool.size() * sizeof(HitRec), hipMemcpyDeviceToHost));
+        if (!ops_pool.empty()) HIP_TRY(hipMemcpy(ops_pool.data(), B.ops_pool, ops_pool.size() * 4, hipMemcpyDeviceToHost));
+        if (ctx->last_total_bases) HIP_TRY(hipMemcpy(r->d_arrays.data(), B.d_arrays, ctx->last_total_bases * 4, hipMemcpyDeviceToHost));
+    }
+    // order-preserving collect (mapping.rs:288): hits in read order, BinaryHeap array order inside a read
+    r->hit_begin.assign(n + 1, 0);
+    for (uint64_t i = 0; i < n; ++i) r->hit_begin[i + 1] = r->hit_begin[i] + cnt[i];
+    r->hits.resize(r->hit_begin[n]);
+    r->ops.reserve(ops_pool.size());
+    uint64_t sums[6] = {0, 0, 0, 0, 0, 0};
+    for (uint64_t i = 0; i < n; ++i) {
+        for (uint32_t k = 0; k < cnt[i]; ++k) {
+            const HitRec& h = pool[first[i] + k];
+            mapad_hit_t o{h.lower, h.lower_rev, h.size, h.score, h.n_ops, (uint32_t)r->ops.size(), 0};
+            r->ops.insert(r->ops.end(), ops_pool.begin() + h.ops_off, ops_pool.begin() + h.ops_off + h.n_ops);
+            r->hits[r->hit_begin[i] + k] = o;
+        }
+        const auto& c = r->counters[i];
+        sums[0] += c.e_search; sums[1] += c.e_darray; sums[2] += c.n_push; sums[3] += c.n_pop; sums[4] += c.n_node; sums[5] += c.n_hits;
+    }
+    std::memcpy(ctx->counter_sums, sums, sizeof sums);
+    r->pub.n_reads = n; r->pub.n_hits = r->hits.size(); r->pub.n_ops = r->ops.size();
+    r->pub.hit_begin = r->hit_begin.data(); r->pub.hits = r->hits.data(); r->pub.ops = r->ops.data();
+    r->pub.status = r->status.data(); r->pub.counters = r->counters.data(); r->pub.d_arrays = r->d_arrays.data();
+    r->pub.n_second_pass = cur[CUR_N_OVERFLOW];
+    *out = &r.release()->pub;
+    return MAPAD_OK;
+}
+void mapad_batch_result_free(mapad_batch_result_t* r) {
+    if (r) delete reinterpret_cast<HostResult*>(r);  // pub is the first member
+}
+
+int mapad_map_batch(mapad_ctx_t* ctx, const uint8_t* seqs, const uint8_t* quals, const uint64_t* offsets, uint64_t n_reads, mapad_batch_result_t** out) {
+    if (!ctx || !out || (n_reads && (!seqs || !quals || !offsets))) return MAPAD_ERR_INVALID;
+    if (hipSetDevice(ctx->device) != hipSuccess) return MAPAD_ERR_NO_DEVICE;
+    const uint64_t total = n_reads ? offsets[n_reads] : 0;
+    std::set<uint32_t> lens;
+    uint32_t lmax = 0;
+    for (uint64_t i = 0; i < n_reads; ++i) {
+        const uint64_t l = offsets[i + 1] - offsets[i];
+        if (l > MAPAD_MAX_READ_LEN) return MAPAD_ERR_READ_TOO_LONG;
+        lens.insert((uint32_t)l); lmax = std::max<uint32_t>(lmax, (uint32_t)l);
+    }
+    std::vector<uint32_t> lv(lens.begin(), lens.end());
+    int rc;
+    if ((rc = mapad_ctx_prepare_lengths(ctx, lv.data(), (uint32_t)lv.size()))) return rc;
+    if ((rc = ctx->d_seqs.ensure(std::max<uint64_t>(total, 1)))) return rc;
+    if ((rc = ctx->d_quals.ensure(std::max<uint64_t>(total, 1)))) return rc;
+    if ((rc = ctx->d_offsets.ensure(n_reads + 1))) return rc;
+    if (n_reads) {
+        HIP_TRY(hipMemcpyAsync(ctx->d_seqs.p, seqs, total, hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(hipMemcpyAsync(ctx->d_quals.p, quals, total, hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(hipMemcpyAsync(ctx->d_offsets.p, offsets, (n_reads + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+    }
+    ctx->last_owned_inputs = true;
+    for (int attempt = 0; attempt < 6; ++attempt) {
+        if ((rc = launch_batch(ctx, ctx->d_seqs.p, ctx->d_quals.p, ctx->d_offsets.p, n_reads, total, lmax))) return rc;
+        rc = mapad_fetch_result(ctx, out);
+        if (rc != MAPAD_ERR_NOMEM) return rc;
+        // pools too small for this batch: quadruple and retry (rare: needs > 2 hits per read on average)
+        uint32_t cur[CUR_COUNT];
+        HIP_TRY(hipMemcpy(cur, ctx->d_cursors.p, sizeof cur, hipMemcpyDeviceToHost));
+        if (!cur[CUR_POOL_OVF]) return rc;
+        if ((rc = ctx->d_hits.ensure((size_t)cur[CUR_HITS] + 1024))) return rc;
+        if ((rc = ctx->d_ops.ensure((size_t)cur[CUR_OPS] + 1024))) return rc;
+    }
+    return MAPAD_ERR_NOMEM;
+}
+
+int mapad_device_result_ptrs(mapad_ctx_t* ctx, void** d_hit_count, void** d_hit_first, void** d_hits, void** d_ops, void** d_cursors) {
+    if (!ctx) return MAPAD_ERR_INVALID;
+    if (d_hit_count) *d_hit_count = ctx->last.hit_count;
+    if (d_hit_first) *d_hit_first = ctx->last.hit_first;
+    if (d_hits) *d_hits = ctx->last.hits_pool;
+    if (d_ops) *d_ops = ctx->last.ops_pool;
+    if (d_cursors) *d_cursors = ctx->last.cursors;
+    return MAPAD_OK;
+}
+int mapad_last_batch_counters(mapad_ctx_t* ctx, uint64_t out[6]) {
+    if (!ctx || !out) return MAPAD_ERR_INVALID;
+    if (hipSetDevice(ctx->device) != hipSuccess) return MAPAD_ERR_NO_DEVICE;
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    const uint64_t n = ctx->last.n_reads;
+    std::vector<ReadCounters> c(n);
+    if (n) HIP_TRY(hipMemcpy(c.data(), ctx->last.counters, n * sizeof(ReadCounters), hipMemcpyDeviceToHost));
+    uint64_t s[6] = {0, 0, 0, 0, 0, 0};
+    for (auto& x : c) { s[0] += x.e_search; s[1] += x.e_darray; s[2] += x.n_push; s[3] += x.n_pop; s[4] += x.n_node; s[5] += x.n_hits; }
+    std::memcpy(out, s, sizeof s);
+    return MAPAD_OK;
+}
+int mapad_last_launch_info(mapad_ctx_t* ctx, uint32_t out[8]) {
+    if (!ctx || !out) return MAPAD_ERR_INVALID;
+    std::memcpy(out, ctx->launch_info, sizeof ctx->launch_info);
+    return MAPAD_OK;
+}
+
+// ---- post-search ----------------------------------------------------------------------------------------------------------
+int mapad_hits_to_records(const mapad_index_t* idx, const mapad_params_t* params, const mapad_batch_result_t* res, const uint8_t* seqs, const uint8_t* quals,
+                          const uint64_t* offsets, const uint16_t* in_flags, uint64_t seed, mapad_records_t** out) {
+    if (!idx || !params || !res || !out || (res->n_reads && (!seqs || !quals || !offsets))) return MAPAD_ERR_INVALID;
+    try {
+        *out = host::hits_to_records(idx->ix, *params, *res, seqs, quals, offsets, in_flags, seed);
+        return MAPAD_OK;
+    } catch (const std::bad_alloc&) { return MAPAD_ERR_NOMEM; } catch (const std::exception& e) {
+        std::fprintf(stderr, "mapad_hits_to_records: %s\n", e.what());
+        return MAPAD_ERR_INVALID;
+    }
+}
+void mapad_records_free(mapad_records_t* r) { host::free_records(r); }
+
+}  // extern "C"

@@ -1,0 +1,97 @@
+// emu.cpp — TEST-ONLY host build of the per-read device logic (search_core.hpp / darray_core.hpp).
+//
+// The kernels' control flow is ordinary C++ on quad-uniform values; only the rank queries are lane-cooperative.  Compiling
+// the same headers with g++ (scalar rank queries on the identical block layout) lets the CPU test-suite (-m "not gpu")
+// check heap / slab / hit-list / D-array logic, the block layout and the score tables against the oracle without a GPU.
+// This library is never loaded by the product (mapad_amd/): it is built into tests/emu/_build by tests/emu_util.py.
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "../../include/mapad_amd.h"
+#include "../../mapad_amd/csrc/darray_core.hpp"
+#include "../../mapad_amd/csrc/host_models.hpp"
+#include "../../mapad_amd/csrc/search_core.hpp"
+
+using namespace mapad;
+
+namespace {
+struct EmuResult {
+    mapad_batch_result_t pub{};
+    std::vector<uint64_t> hit_begin;
+    std::vector<mapad_hit_t> hits;
+    std::vector<uint32_t> ops, status;
+    std::vector<mapad_read_counters_t> counters;
+    std::vector<float> d_arrays;
+};
+}  // namespace
+
+extern "C" {
+
+// node_cap / heap_cap: arena capacity of the first pass; reads that overflow are re-run with the reference limits.
+mapad_batch_result_t* emu_map_batch(const uint64_t* blocks, uint64_t n_blocks, uint64_t n, const uint64_t* less8, const uint64_t* sentinel2,
+                                    const mapad_params_t* p, const uint8_t* seqs, const uint8_t* quals, const uint64_t* offsets, uint64_t n_reads,
+                                    uint32_t node_cap, uint32_t heap_cap) {
+    DevIndex ix;
+    ix.blocks = blocks; ix.n = n; ix.n_blocks = n_blocks;
+    for (int i = 0; i < 8; ++i) ix.less[i] = less8[i];
+    ix.sentinel[0] = sentinel2[0]; ix.sentinel[1] = sentinel2[1];
+    host::HostTables t = host::make_tables(*p);
+    uint32_t lmax = 1;
+    for (uint64_t i = 0; i < n_reads; ++i) { const uint32_t l = (uint32_t)(offsets[i + 1] - offsets[i]); lmax = std::max(lmax, l); if (l) host::add_length(*p, t, (int)l); }
+    DevParams P{};
+    P.sdm_table = t.sdm.data(); P.table_base = t.table_base.data(); P.reject_thr = t.reject_thr.data();
+    P.nq = t.nq; P.bound_kind = p->bound_kind; P.cutoff = p->cutoff; P.repr_mm = t.repr_mm;
+    P.gap_open = p->penalty_gap_open; P.gap_extend = p->penalty_gap_extend; P.gap_dist_ends = p->gap_dist_ends; P.max_num_gaps_open = p->max_num_gaps_open;
+    P.start_at_end = p->model_kind == MAPAD_MODEL_SIMPLE_ADNA; P.stack_limit_abort = p->stack_limit_abort;
+    P.stack_limit = p->stack_limit ? p->stack_limit : 2000000u; P.edit_tree_limit = p->edit_tree_limit ? p->edit_tree_limit : 10000000u;
+
+    auto* r = new EmuResult();
+    r->hit_begin.assign(n_reads + 1, 0); r->status.resize(n_reads); r->counters.resize(n_reads);
+    r->d_arrays.resize(n_reads ? offsets[n_reads] : 0);
+    std::vector<float> pen(lmax + 1), chain(lmax + 1);
+    std::vector<HeapEntry> heap;
+    std::vector<Node> nodes;
+    std::vector<HitRec> hits(kMaxHits);
+    std::vector<uint32_t> hit_ops(kMaxHits * (lmax + 32));
+    std::vector<uint16_t> scratch(2 * (lmax + 2));
+    uint64_t second = 0;
+    for (uint64_t i = 0; i < n_reads; ++i) {
+        const uint64_t off = offsets[i];
+        const int L = (int)(offsets[i + 1] - off);
+        float* d = r->d_arrays.data() + off;
+        ReadCounters ctr{};
+        ctr.e_darray = d_array_scalar(ix, P, seqs + off, quals + off, L, pen.data(), chain.data(), d);
+        SearchState st;
+        for (int pass = 0; pass < 2; ++pass) {
+            const uint32_t hc = pass == 0 ? heap_cap : P.stack_limit + 10, nc = pass == 0 ? node_cap : P.edit_tree_limit + 10;
+            // lazily grown backing stores keep the host emulation cheap even with the reference's 2M / 10M limits
+            Arena A;
+            heap.assign(std::min<uint32_t>(hc, 1u << 22), HeapEntry{});
+            nodes.assign(std::min<uint32_t>(nc, 1u << 22), Node{});
+            A.heap = heap.data(); A.nodes = nodes.data(); A.hits = hits.data(); A.hit_ops = hit_ops.data(); A.scratch = scratch.data();
+            A.heap_cap = (uint32_t)heap.size(); A.node_cap = (uint32_t)nodes.size(); A.hit_ops_cap = (uint32_t)hit_ops.size();
+            ReadIn rd{seqs + off, quals + off, d, L};
+            search_read(ix, P, rd, A, st, 0);
+            if (st.status != ST_ARENA_OVERFLOW) break;
+            if (pass == 0) second += 1;
+        }
+        r->status[i] = st.status;
+        ctr.e_search = st.ctr.e_search; ctr.n_push = st.ctr.n_push; ctr.n_pop = st.ctr.n_pop; ctr.n_node = st.ctr.n_node; ctr.n_hits = st.ctr.n_hits;
+        std::memcpy(&r->counters[i], &ctr, sizeof ctr);
+        for (uint32_t k = 0; k < st.n_hits; ++k) {
+            const HitRec& h = hits[k];
+            mapad_hit_t o{h.lower, h.lower_rev, h.size, h.score, h.n_ops, (uint32_t)r->ops.size(), 0};
+            r->ops.insert(r->ops.end(), hit_ops.begin() + h.ops_off, hit_ops.begin() + h.ops_off + h.n_ops);
+            r->hits.push_back(o);
+        }
+        r->hit_begin[i + 1] = r->hits.size();
+    }
+    r->pub.n_reads = n_reads; r->pub.n_hits = r->hits.size(); r->pub.n_ops = r->ops.size();
+    r->pub.hit_begin = r->hit_begin.data(); r->pub.hits = r->hits.data(); r->pub.ops = r->ops.data(); r->pub.status = r->status.data();
+    r->pub.counters = r->counters.data(); r->pub.d_arrays = r->d_arrays.data(); r->pub.n_second_pass = second;
+    return &r->pub;
+}
+void emu_result_free(mapad_batch_result_t* r) { if (r) delete reinterpret_cast<EmuResult*>(r); }
+
+}  // extern "C"

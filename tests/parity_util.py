@@ -1,0 +1,48 @@
+"""Shared comparison helpers: product results (GPU or host emulation of the kernels) vs the CPU oracle."""
+import numpy as np
+
+from oracle import binding as ob
+
+import mapad_amd
+
+NO_DAMAGE = {"model": "simple_adna", "library": "single_stranded", "five_prime_overhang": 0.0, "three_prime_overhang": 0.0,
+             "ds_deamination_rate": 0.0, "ss_deamination_rate": 0.0, "divergence": {"div3": 0.02}, "ignore_base_quality": 0,
+             "bound": "discrete", "poisson_threshold": 0.03, "base_error_rate": 0.02,
+             "penalty_gap_open": {"log2": 0.001}, "penalty_gap_extend": {"repr_mm_times": 1.0}, "gap_dist_ends": 5, "max_num_gaps_open": 2}
+# README example: single-stranded library, 50 % overhang parameters (Readme.md:147-150)
+DAMAGE = dict(NO_DAMAGE, five_prime_overhang=0.5, three_prime_overhang=0.5, ds_deamination_rate=0.02, ss_deamination_rate=1.0)
+
+
+def split_reads(seqs, quals, offsets):
+    n = len(offsets) - 1
+    reads = [seqs[int(offsets[i]):int(offsets[i + 1])].tobytes() for i in range(n)]
+    qs = [quals[int(offsets[i]):int(offsets[i + 1])] for i in range(n)]
+    return reads, qs
+
+
+def assert_same_as_oracle(ores, pres, offsets, check_d=True, check_counters=True):
+    """ores: oracle OracleResult (keep_d=True if check_d); pres: mapad_amd BatchResult.  Bit-exact comparison of every read:
+    hit count, BinaryHeap array order, intervals, f32 score bits, edit tracks, D arrays, event counters."""
+    n = len(offsets) - 1
+    assert pres.n_reads == n == ores.n
+    assert np.array_equal(pres.hit_begin, ores.hit_offsets), "hit counts differ"
+    assert np.array_equal(pres.hits_arr["lower"], ores.intervals[:, 0])
+    assert np.array_equal(pres.hits_arr["lower_rev"], ores.intervals[:, 1])
+    assert np.array_equal(pres.hits_arr["size"], ores.intervals[:, 2])
+    assert np.array_equal(pres.hits_arr["score"].view(np.uint32), ores.scores.view(np.uint32)), "score bits differ"
+    assert np.array_equal(pres.hits_arr["n_ops"].astype(np.uint64), np.diff(ores.op_offsets))
+    assert np.array_equal(pres.ops, ores.ops), "edit tracks differ"
+    if check_d:
+        d = pres.d_arrays(offsets)
+        for i in range(n):
+            assert np.array_equal(d[int(offsets[i]):int(offsets[i + 1])].view(np.uint32), ores.d_array(i).view(np.uint32)), f"D array of read {i}"
+    if check_counters:
+        c = pres.counters
+        got = np.stack([c["e_search"], c["e_darray"], c["n_push"], c["n_pop"], c["n_node"], c["n_hits"]], axis=1).astype(np.uint64)
+        assert np.array_equal(got, ores.counters), "event counters differ"
+
+
+def algorithmic_bytes(counters_sum, total_bases):
+    """256*(E_search + E_darray) + 40*(N_push + N_pop) + 8*N_node + 6*L"""
+    e_search, e_darray, n_push, n_pop, n_node = [int(x) for x in counters_sum[:5]]
+    return 256 * (e_search + e_darray) + 40 * (n_push + n_pop) + 8 * n_node + 6 * int(total_bases)

@@ -1,0 +1,121 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP path through the C ABI vs the CPU oracle and the golden vectors."""
+import numpy as np
+import pytest
+
+import mapad_amd
+from mapad_amd import synth
+from oracle import binding as ob
+
+from kat_util import load, quals_for, resolve_params
+from parity_util import DAMAGE, NO_DAMAGE, assert_same_as_oracle, split_reads
+from test_oracle_kats import KATS, check_search_expectations, integration_reads
+
+pytestmark = pytest.mark.gpu
+
+
+def _gpu_map(index, params, seqs, quals, offsets):
+    ctx = mapad_amd.Context(index, params, 0)
+    try:
+        return ctx.map_batch(seqs, quals, offsets)
+    finally:
+        ctx.close()
+
+
+@pytest.mark.parametrize("case", KATS["cases"], ids=[c["name"] for c in KATS["cases"]])
+def test_search_kat_on_gpu(case):
+    ref = KATS["ref10k"] if case["reference"] == "@ref10k" else case["reference"]
+    rp = resolve_params(case["params"])
+    pidx = mapad_amd.Index.build([("ref", ref.encode())])
+    oidx = ob.OracleIndex.from_text(ref.encode(), "$ACGTX", 128)
+    assert np.array_equal(pidx.bwt(), oidx.bwt())
+    q = quals_for(case["pattern"], case["qual"])
+    seqs = np.frombuffer(case["pattern"].encode(), dtype=np.uint8)
+    offsets = np.array([0, len(seqs)], dtype=np.uint64)
+    res = _gpu_map(pidx, mapad_amd.make_params(rp), seqs, q, offsets)
+    ores = oidx.map_batch(ob.make_params(rp), [case["pattern"].encode()], [q], keep_d=True)
+    assert_same_as_oracle(ores, res, offsets)
+    # and the reference's own expectations, evaluated on the GPU result
+    hits = res.hits(0)
+    for h, oh in zip(hits, ores.hits(0)):
+        h["ops"] = oh["ops"]
+    check_search_expectations(case, hits, oidx.sa(), lambda h, b: ores.bam_fields(0, h, backward=b))
+
+
+@pytest.mark.parametrize("name,prm,kw", [
+    ("no_damage_q40", NO_DAMAGE, dict(qual=40)),
+    ("damage_q20_40", DAMAGE, dict(qual_range=(20, 40), damage=dict(f=0.5, t=0.5, d=0.02, s=1.0))),
+    ("mixed_len_indels", DAMAGE, dict(qual_range=(20, 40), len_range=(35, 100), indel_frac=0.05)),
+])
+def test_synthetic_batch_matches_oracle(name, prm, kw):
+    g = synth.genome(300_000, seed=99)
+    n = 3000 if "len_range" not in kw else 600
+    seqs, quals, offsets = synth.reads(g, n, 50, seed=7 + len(name), **kw)
+    rp = resolve_params(prm)
+    pidx = mapad_amd.Index.build([("chr1", g)])
+    oidx = ob.OracleIndex.from_bwt(pidx.bwt(), "$ACGTX", 128)
+    res = _gpu_map(pidx, mapad_amd.make_params(rp), seqs, quals, offsets)
+    reads, qs = split_reads(seqs, quals, offsets)
+    ores = oidx.map_batch(ob.make_params(rp), reads, qs, n_threads=8, keep_d=True)
+    assert_same_as_oracle(ores, res, offsets)
+
+
+def test_small_arena_second_pass_and_limits(monkeypatch):
+    """Reads that outgrow the first-pass arena are re-run from the large-arena pool; tiny STACK/EDIT_TREE limits
+    exercise the overflow recovery of mapping.rs:1358-1380 on the device."""
+    g = synth.genome(100_000, seed=5)
+    seqs, quals, offsets = synth.reads(g, 400, 50, seed=11)
+    reads, qs = split_reads(seqs, quals, offsets)
+    pidx = mapad_amd.Index.build([("chr1", g)])
+    oidx = ob.OracleIndex.from_bwt(pidx.bwt(), "$ACGTX", 128)
+    monkeypatch.setenv("MAPAD_ARENA_NODES", "64")
+    rp = resolve_params(NO_DAMAGE)
+    res = _gpu_map(pidx, mapad_amd.make_params(rp), seqs, quals, offsets)
+    assert res.n_second_pass > 0
+    ores = oidx.map_batch(ob.make_params(rp), reads, qs, n_threads=8, keep_d=True)
+    assert_same_as_oracle(ores, res, offsets)
+    for limits in ({"stack_limit": 40, "edit_tree_limit": 100000}, {"stack_limit": 100000, "edit_tree_limit": 120},
+                   {"stack_limit": 40, "edit_tree_limit": 100000, "stack_limit_abort": 1}):
+        rp2 = dict(rp, **limits)
+        res = _gpu_map(pidx, mapad_amd.make_params(rp2), seqs, quals, offsets)
+        ores = oidx.map_batch(ob.make_params(rp2), reads, qs, n_threads=8, keep_d=True)
+        assert_same_as_oracle(ores, res, offsets)
+
+
+def test_integration_expectation_on_gpu(monkeypatch):
+    """tests/integration_tests.rs: FASTA -> index -> 17 reads -> record fields, all through the C ABI with the GPU search."""
+    k = load("integration")
+    monkeypatch.setenv("MAPAD_INDEX_FIXED_REPLACEMENT", k["n_replacement"])
+    pidx = mapad_amd.Index.build([(c["name"], c["seq"].encode()) for c in k["contigs"]], seed=1234)
+    rp = resolve_params(k["params"])
+    params = mapad_amd.make_params(rp)
+    reads, quals = integration_reads(k)
+    offsets = np.zeros(len(reads) + 1, dtype=np.uint64)
+    offsets[1:] = np.cumsum([len(r) for r in reads])
+    seqs = np.frombuffer(b"".join(reads), dtype=np.uint8)
+    qs = np.concatenate(quals)
+    ctx = mapad_amd.Context(pidx, params, 0)
+    res = ctx.map_batch(seqs, qs, offsets)
+    recs = mapad_amd.hits_to_records(pidx, params, res, seqs, qs, offsets, in_flags=[r["flags"] for r in k["reads"]])
+    ctx.close()
+    from test_host_logic import check_integration_records
+    check_integration_records(k, recs)
+
+
+def test_empty_and_edge_batches():
+    g = synth.genome(50_000, seed=3)
+    pidx = mapad_amd.Index.build([("chr1", g)])
+    params = mapad_amd.make_params(resolve_params(NO_DAMAGE))
+    ctx = mapad_amd.Context(pidx, params, 0)
+    r = ctx.map_batch(np.zeros(0, np.uint8), np.zeros(0, np.uint8), np.zeros(1, np.uint64))
+    assert r.n_reads == 0 and r.n_hits == 0
+    # ragged: a 1-base read, a read of N's, a read shorter than the 17 bp minimum of the Discrete bound
+    reads = [b"A", b"NNNNNNNNNNNNNNNNNNNNNNNNN", g[1000:1016].tobytes(), g[2000:2050].tobytes()]
+    offsets = np.zeros(len(reads) + 1, dtype=np.uint64)
+    offsets[1:] = np.cumsum([len(r) for r in reads])
+    seqs = np.frombuffer(b"".join(reads), dtype=np.uint8)
+    quals = np.full(len(seqs), 40, np.uint8)
+    res = ctx.map_batch(seqs, quals, offsets)
+    oidx = ob.OracleIndex.from_bwt(pidx.bwt(), "$ACGTX", 128)
+    ores = oidx.map_batch(ob.make_params(resolve_params(NO_DAMAGE)), reads, [quals[int(offsets[i]):int(offsets[i + 1])] for i in range(len(reads))], keep_d=True)
+    assert_same_as_oracle(ores, res, offsets)
+    ctx.close()
