@@ -113,6 +113,8 @@ void mapad_ctx_destroy(mapad_ctx_t* ctx);
 /* run every launch on this HIP stream (a hipStream_t; NULL = the default stream) */
 int mapad_ctx_set_stream(mapad_ctx_t* ctx, void* hip_stream);
 
+/* whether mapad_fetch_result()/mapad_map_batch() also copy the D arrays back (default on; bench.py turns it off) */
+int mapad_ctx_set_fetch_d_arrays(mapad_ctx_t* ctx, int on);
 /* Score tables are built lazily per read length.  mapad_map_batch() does this itself; before mapad_map_batch_device()
  * (where the host never sees the reads) announce the lengths that will occur. */
 int mapad_ctx_prepare_lengths(mapad_ctx_t* ctx, const uint32_t* lens, uint32_t n);
@@ -143,7 +145,8 @@ typedef struct mapad_batch_result {
     const uint32_t* status;                /* per read: 0 ok, 2 stopped by --no_search_limit_recovery */
     const mapad_read_counters_t* counters; /* per read */
     const float* d_arrays;                 /* concatenated BiDArray::d_composite, same offsets as the reads (debug/parity) */
-    uint64_t n_second_pass;                /* reads that needed the large-arena pass */
+    uint64_t n_second_pass;                /* reads that outgrew the small per-quad arena and were re-run in the medium tier */
+    uint64_t n_third_pass;                 /* ... and in the tier that holds the reference's full STACK_LIMIT / EDIT_TREE_LIMIT */
 } mapad_batch_result_t;
 
 /* k_mismatch_search over a chunk of reads (host buffers): seqs/quals concatenated, read i = [offsets[i], offsets[i+1]).
@@ -163,7 +166,11 @@ int mapad_fetch_result(mapad_ctx_t* ctx, mapad_batch_result_t** out);
 int mapad_device_result_ptrs(mapad_ctx_t* ctx, void** d_hit_count, void** d_hit_first, void** d_hits, void** d_ops, void** d_cursors);
 /* sums of the per-read counters of the last batch (after a fetch or a stream sync): {e_search, e_darray, n_push, n_pop, n_node, n_hits} */
 int mapad_last_batch_counters(mapad_ctx_t* ctx, uint64_t out[6]);
-/* kernel names + launch geometry of the last batch, for bench.py's report */
+/* HIP-event durations (ms) of the last batch's launches on the context's stream: {darray_kernel, search_kernel, second-pass
+ * search_kernel}.  Synchronises on the last event. */
+int mapad_last_kernel_ms(mapad_ctx_t* ctx, float out[3]);
+/* launch geometry of the last batch, for bench.py's report: {darray grid, block, LDS bytes, search grid, block, second-pass grid,
+ * first-pass node capacity, first-pass arena KiB per quad} */
 int mapad_last_launch_info(mapad_ctx_t* ctx, uint32_t out[8]);
 
 /* ---- post-search: intervals_to_bam minus BAM byte encoding (mapping.rs:402-718, record.rs:269-449) ------------------- */

@@ -55,7 +55,7 @@ assert HIT_DTYPE.itemsize == C.sizeof(Hit) == 40
 class BatchResultC(C.Structure):
     """mapad_batch_result_t"""
     _fields_ = [("n_reads", C.c_uint64), ("n_hits", C.c_uint64), ("n_ops", C.c_uint64), ("hit_begin", C.c_void_p), ("hits", C.c_void_p),
-                ("ops", C.c_void_p), ("status", C.c_void_p), ("counters", C.c_void_p), ("d_arrays", C.c_void_p), ("n_second_pass", C.c_uint64)]
+                ("ops", C.c_void_p), ("status", C.c_void_p), ("counters", C.c_void_p), ("d_arrays", C.c_void_p), ("n_second_pass", C.c_uint64), ("n_third_pass", C.c_uint64)]
 
 
 class RecordC(C.Structure):
@@ -103,6 +103,7 @@ SYMBOLS = {
     "mapad_ctx_create": (_i32, [_vp, _PP, _i32, C.POINTER(_vp)]),
     "mapad_ctx_destroy": (None, [_vp]),
     "mapad_ctx_set_stream": (_i32, [_vp, _vp]),
+    "mapad_ctx_set_fetch_d_arrays": (_i32, [_vp, _i32]),
     "mapad_ctx_prepare_lengths": (_i32, [_vp, _vp, _u32]),
     "mapad_map_batch": (_i32, [_vp, _vp, _vp, _vp, _u64, C.POINTER(C.POINTER(BatchResultC))]),
     "mapad_batch_result_free": (None, [C.POINTER(BatchResultC)]),
@@ -110,6 +111,7 @@ SYMBOLS = {
     "mapad_fetch_result": (_i32, [_vp, C.POINTER(C.POINTER(BatchResultC))]),
     "mapad_device_result_ptrs": (_i32, [_vp, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp)]),
     "mapad_last_batch_counters": (_i32, [_vp, _vp]),
+    "mapad_last_kernel_ms": (_i32, [_vp, _vp]),
     "mapad_last_launch_info": (_i32, [_vp, _vp]),
     "mapad_hits_to_records": (_i32, [_vp, _PP, C.POINTER(BatchResultC), _vp, _vp, _vp, _vp, _u64, C.POINTER(C.POINTER(RecordsC))]),
     "mapad_records_free": (None, [C.POINTER(RecordsC)]),
@@ -174,7 +176,7 @@ class BatchResult:
     def __init__(self, cptr, free_fn):
         r = cptr.contents
         self.n_reads, self.n_hits, self.n_ops = int(r.n_reads), int(r.n_hits), int(r.n_ops)
-        self.n_second_pass = int(r.n_second_pass)
+        self.n_second_pass, self.n_third_pass = int(r.n_second_pass), int(r.n_third_pass)
 
         def arr(ptr, dtype, n):
             if n == 0 or not ptr:
@@ -305,6 +307,9 @@ class Context:
     def set_stream(self, stream_ptr):
         _check(lib().mapad_ctx_set_stream(self.h, stream_ptr), "mapad_ctx_set_stream")
 
+    def set_fetch_d_arrays(self, on):
+        _check(lib().mapad_ctx_set_fetch_d_arrays(self.h, int(on)), "mapad_ctx_set_fetch_d_arrays")
+
     def prepare_lengths(self, lens):
         a = np.ascontiguousarray(lens, dtype=np.uint32)
         _check(lib().mapad_ctx_prepare_lengths(self.h, _ptr(a), a.size), "mapad_ctx_prepare_lengths")
@@ -333,6 +338,12 @@ class Context:
     def last_counters(self):
         out = np.zeros(6, np.uint64)
         _check(lib().mapad_last_batch_counters(self.h, _ptr(out)), "mapad_last_batch_counters")
+        return out
+
+    def kernel_ms(self):
+        """HIP-event durations (ms) of the last batch: (darray_kernel, search_kernel, second-pass search_kernel)"""
+        out = np.zeros(3, np.float32)
+        _check(lib().mapad_last_kernel_ms(self.h, _ptr(out)), "mapad_last_kernel_ms")
         return out
 
     def launch_info(self):

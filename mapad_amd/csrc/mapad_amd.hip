@@ -35,14 +35,16 @@ using namespace mapad;
 namespace {
 
 enum : uint32_t { ST_POOL_OVERFLOW = 4, ST_NO_TABLE = 8 };
-enum { CUR_HITS = 0, CUR_OPS = 1, CUR_WORK1 = 2, CUR_POOL_OVF = 3, CUR_WORK2 = 4, CUR_N_OVERFLOW = 5, CUR_ERR = 6, CUR_COUNT = 8 };
+constexpr int kTiers = 3;  // arena tiers: small / medium / the reference's full limits
+// cursors: global bump allocators and work counters; per tier t: CUR_WORK + 2t = next work item, CUR_OVF + 2t = reads tier t handed on
+enum { CUR_HITS = 0, CUR_OPS = 1, CUR_POOL_OVF = 2, CUR_ERR = 3, CUR_WORK = 4, CUR_OVF = 5, CUR_COUNT = 4 + 2 * kTiers + 2 };
 
 struct BatchDev {
     const uint8_t* seqs;
     const uint8_t* quals;
     const uint64_t* offsets;
     uint32_t n_reads;
-    float* d_arrays;
+    PosInfo* posinfo;  // per base: scores, read-base class and D value (written by darray_kernel, read by search_kernel)
     ReadCounters* counters;
     uint32_t* status;
     uint32_t* hit_count;
@@ -51,7 +53,7 @@ struct BatchDev {
     uint32_t* ops_pool;
     uint32_t hits_cap, ops_cap;
     uint32_t* cursors;
-    uint32_t* overflow_list;  // read ids that need the large-arena pass
+    uint32_t* overflow_list;  // [kTiers][n_reads]: read ids tier t could not finish in its arena
 };
 
 struct ArenaPool {
@@ -85,14 +87,19 @@ __global__ void __launch_bounds__(64) darray_kernel(DevIndex ix, DevParams P, Ba
         const int L = (int)(B.offsets[read + 1] - off);
         const uint8_t* seq = B.seqs + off;
         const uint8_t* qual = B.quals + off;
-        float* dout = B.d_arrays + off;
+        PosInfo* pout = B.posinfo + off;
         if (L > lmax || P.table_base[L] < 0) {  // fail loudly: the host did not prepare this read length
             if (lane == 0) { B.status[read] = ST_NO_TABLE; atomicOr(&B.cursors[CUR_ERR], ST_NO_TABLE); B.counters[read].e_darray = 0; }
             continue;
         }
         const int split = P.start_at_end ? L : L / 2;
         if (lane == 0) n_ext_total = 0;
-        for (int r = lane; r < L; r += 64) pen[r] = d_penalty(P, seq, qual, L, r);
+        for (int r = lane; r < L; r += 64) {
+            PosInfo pi;
+            pen[r] = position_setup(P, seq, qual, L, r, pi);
+            reinterpret_cast<float4*>(pout + r)[0] = make_float4(pi.delta[0], pi.delta[1], pi.delta[2], pi.delta[3]);
+            pout[r].to_class = pi.to_class;
+        }
         __syncthreads();
         for (int part = 0; part < 2; ++part) {
             const bool left = part == 0;
@@ -107,7 +114,7 @@ __global__ void __launch_bounds__(64) darray_kernel(DevIndex ix, DevParams P, Ba
                 float acc = 0.0f;
 #pragma unroll
                 for (int o = 0; o < kMaxOffset; ++o) acc = f32_min(acc, chains[o * lmax + p]);
-                dout[(left ? 0 : split) + p] = acc;
+                pout[(left ? 0 : split) + p].d = acc;
             }
             __syncthreads();
         }
@@ -117,11 +124,11 @@ __global__ void __launch_bounds__(64) darray_kernel(DevIndex ix, DevParams P, Ba
 }
 
 // ---- search: persistent quads -----------------------------------------------------------------------------------------
-__device__ __forceinline__ void finalize_read(const BatchDev& B, const Arena& A, const SearchState& st, uint32_t read, int w, bool second_pass) {
-    if (st.status == ST_ARENA_OVERFLOW && !second_pass) {
+__device__ __forceinline__ void finalize_read(const BatchDev& B, const Arena& A, const SearchState& st, uint32_t read, int w, int tier) {
+    if (st.status == ST_ARENA_OVERFLOW && tier + 1 < kTiers) {  // hand the read to the next (larger) arena tier
         if (w == 0) {
-            const uint32_t k = atomicAdd(&B.cursors[CUR_N_OVERFLOW], 1u);
-            B.overflow_list[k] = read;
+            const uint32_t k = atomicAdd(&B.cursors[CUR_OVF + 2 * tier], 1u);
+            B.overflow_list[(size_t)tier * B.n_reads + k] = read;
             B.status[read] = ST_ARENA_OVERFLOW;
             B.hit_count[read] = 0; B.hit_first[read] = 0;
         }
@@ -146,18 +153,19 @@ __device__ __forceinline__ void finalize_read(const BatchDev& B, const Arena& A,
         B.status[read] = status;
         ReadCounters* c = B.counters + read;
         c->e_search = st.ctr.e_search; c->n_push = st.ctr.n_push; c->n_pop = st.ctr.n_pop; c->n_node = st.ctr.n_node; c->n_hits = st.ctr.n_hits;
-        if (status == ST_ARENA_OVERFLOW) atomicOr(&B.cursors[CUR_ERR], ST_ARENA_OVERFLOW);  // cannot happen in the large-arena pass
+        if (status == ST_ARENA_OVERFLOW) atomicOr(&B.cursors[CUR_ERR], ST_ARENA_OVERFLOW);  // cannot happen: the last tier holds the reference's limits
     }
 }
 
-__global__ void __launch_bounds__(64) search_kernel(DevIndex ix, DevParams P, BatchDev B, ArenaPool AP, int second_pass) {
+__global__ void __launch_bounds__(64, 4) search_kernel(DevIndex ix, DevParams P, BatchDev B, ArenaPool AP, int tier) {
     const int lane = threadIdx.x & 63, w = lane & 3;
     const uint32_t slot = blockIdx.x * 16 + (lane >> 2);
     const Arena A = carve(AP, slot);
-    const uint32_t n_items = second_pass ? B.cursors[CUR_N_OVERFLOW] : B.n_reads;
-    uint32_t* work = &B.cursors[second_pass ? CUR_WORK2 : CUR_WORK1];
+    const uint32_t n_items = tier == 0 ? B.n_reads : B.cursors[CUR_OVF + 2 * (tier - 1)];
+    uint32_t* work = &B.cursors[CUR_WORK + 2 * tier];
+    const uint32_t* items = B.overflow_list + (size_t)(tier > 0 ? tier - 1 : 0) * B.n_reads;
     bool have = false, done = false;
-    ReadIn rd{nullptr, nullptr, nullptr, 0};
+    ReadIn rd{nullptr, 0};
     SearchState st;
     uint32_t read = 0;
     for (;;) {
@@ -167,11 +175,11 @@ __global__ void __launch_bounds__(64) search_kernel(DevIndex ix, DevParams P, Ba
             item = dpp_quad<0>(item);
             if (item >= n_items) done = true;
             else {
-                read = second_pass ? B.overflow_list[item] : item;
+                read = tier == 0 ? item : items[item];
                 const uint64_t off = B.offsets[read];
                 rd.L = (int)(B.offsets[read + 1] - off);
-                rd.seq = B.seqs + off; rd.qual = B.quals + off; rd.d = B.d_arrays + off;
-                if (B.status[read] == ST_NO_TABLE && !second_pass) {  // D kernel already flagged it
+                rd.pos = B.posinfo + off;
+                if (tier == 0 && B.status[read] == ST_NO_TABLE) {  // the D kernel already flagged it
                     if (w == 0) { B.hit_count[read] = 0; B.hit_first[read] = 0; }
                 } else {
                     search_init(ix, P, rd, A, st);
@@ -182,11 +190,16 @@ __global__ void __launch_bounds__(64) search_kernel(DevIndex ix, DevParams P, Ba
         if (__all(done)) break;
         if (have) {
             if (!search_step(ix, P, rd, A, st, w)) {
-                finalize_read(B, A, st, read, w, second_pass != 0);
+                finalize_read(B, A, st, read, w, tier);
                 have = false;
             }
         }
     }
+}
+
+// D values out of the PosInfo table (parity tests / debugging only)
+__global__ void extract_d_kernel(const PosInfo* pos, float* out, uint64_t n) {
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) out[i] = pos[i].d;
 }
 
 }  // namespace
@@ -256,13 +269,15 @@ struct mapad_ctx {
     // batch buffers
     DevBuf<uint8_t> d_seqs, d_quals;
     DevBuf<uint64_t> d_offsets;
-    DevBuf<float> d_darr;
+    DevBuf<PosInfo> d_pos;
+    DevBuf<float> d_darr;  // only filled on fetch when fetch_d is set
+    bool fetch_d = true;
     DevBuf<ReadCounters> d_counters;
     DevBuf<uint32_t> d_status, d_hit_count, d_hit_first, d_ops, d_cursors, d_overflow;
     DevBuf<HitRec> d_hits;
-    DevBuf<uint8_t> d_arena1, d_arena2;
-    ArenaPool pool1{}, pool2{};
-    uint32_t slots1 = 0, slots2 = 0, arena_lmax = 0;
+    DevBuf<uint8_t> d_arena[kTiers];
+    ArenaPool pool[kTiers] = {};
+    uint32_t slots[kTiers] = {0, 0, 0}, arena_lmax = 0;
     int n_cu = 256;
     // last batch
     BatchDev last{};
@@ -271,12 +286,16 @@ struct mapad_ctx {
     bool last_owned_inputs = false;
     uint32_t launch_info[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     uint64_t counter_sums[6] = {0, 0, 0, 0, 0, 0};
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};  // around darray / search / second-pass launches, on `stream`
+    bool ev_valid = false;
 
     ~mapad_ctx() {
         (void)hipSetDevice(device);
         d_blocks.release(); d_sdm.release(); d_thr.release(); d_base.release(); d_seqs.release(); d_quals.release(); d_offsets.release();
         d_darr.release(); d_counters.release(); d_status.release(); d_hit_count.release(); d_hit_first.release(); d_ops.release();
-        d_cursors.release(); d_overflow.release(); d_hits.release(); d_arena1.release(); d_arena2.release();
+        d_cursors.release(); d_overflow.release(); d_hits.release(); d_pos.release();
+        for (auto& a : d_arena) a.release();
+        for (auto& e : ev) if (e) (void)hipEventDestroy(e);
     }
 };
 
@@ -306,29 +325,31 @@ int upload_tables(mapad_ctx* c) {
     return MAPAD_OK;
 }
 
+uint32_t env_u32(const char* name, uint32_t dflt) {
+    const char* e = std::getenv(name);
+    return e && e[0] ? (uint32_t)std::strtoul(e, nullptr, 10) : dflt;
+}
+
+// Three arena tiers (per quad): tier 0 small and plentiful, tier 1 medium, tier 2 = the reference's full limits
+// (STACK_LIMIT + 9 frames, EDIT_TREE_LIMIT + 9 nodes: mapping.rs:52-54,147-148).  A read that outgrows its tier's arena is
+// re-run from scratch by the next tier; semantic limits (stack_limit / edit_tree_limit) are the same in every tier.
 int ensure_arenas(mapad_ctx* c, uint32_t lmax) {
-    if (c->d_arena1.p && lmax <= c->arena_lmax) return MAPAD_OK;
+    if (c->d_arena[0].p && lmax <= c->arena_lmax) return MAPAD_OK;
     const uint32_t lm = std::max<uint32_t>(lmax, 128);
     const uint32_t stack_limit = c->dprm.stack_limit, tree_limit = c->dprm.edit_tree_limit;
-    // pass 1: small arenas, many slots (16 quads per wave)
-    const char* e1 = std::getenv("MAPAD_WAVES_PER_CU");
-    const int waves_per_cu = e1 ? std::max(1, std::atoi(e1)) : 8;
-    const char* e2 = std::getenv("MAPAD_ARENA_NODES");
-    const uint32_t node_cap1 = std::min<uint32_t>(e2 ? (uint32_t)std::atoi(e2) : 4096u, tree_limit + 9);
-    const uint32_t heap_cap1 = std::min<uint32_t>(node_cap1, stack_limit + 9);
     const uint32_t hit_ops_cap = kMaxHits * (lm + 32);
-    c->pool1 = make_pool_layout(heap_cap1, node_cap1, hit_ops_cap, lm);
-    c->slots1 = (uint32_t)c->n_cu * waves_per_cu * 16;
-    int rc;
-    if ((rc = c->d_arena1.ensure((size_t)c->slots1 * c->pool1.stride))) return rc;
-    c->pool1.base = c->d_arena1.p;
-    // pass 2: the reference's full limits (mapping.rs:52-54, +9 like its with_capacity calls :147-148)
-    const char* e3 = std::getenv("MAPAD_PASS2_WAVES");
-    const int waves2 = e3 ? std::max(1, std::atoi(e3)) : 1;
-    c->pool2 = make_pool_layout(stack_limit + 9 + 1, tree_limit + 9 + 1, hit_ops_cap, lm);
-    c->slots2 = (uint32_t)waves2 * 16;
-    if ((rc = c->d_arena2.ensure((size_t)c->slots2 * c->pool2.stride))) return rc;
-    c->pool2.base = c->d_arena2.p;
+    const uint32_t nodes[kTiers] = {env_u32("MAPAD_TIER0_NODES", 4096), env_u32("MAPAD_TIER1_NODES", 65536), 0xFFFFFFFFu};
+    const uint32_t waves[kTiers] = {env_u32("MAPAD_TIER0_WAVES_PER_CU", 16) * (uint32_t)c->n_cu, env_u32("MAPAD_TIER1_WAVES_PER_CU", 2) * (uint32_t)c->n_cu,
+                                    env_u32("MAPAD_TIER2_WAVES", 4)};
+    for (int t = 0; t < kTiers; ++t) {
+        const uint32_t node_cap = std::min<uint64_t>(nodes[t], (uint64_t)tree_limit + 10);
+        const uint32_t heap_cap = std::min<uint64_t>(nodes[t], (uint64_t)stack_limit + 10);
+        c->pool[t] = make_pool_layout(heap_cap, node_cap, hit_ops_cap, lm);
+        c->slots[t] = std::max<uint32_t>(waves[t], 1) * 16;
+        int rc;
+        if ((rc = c->d_arena[t].ensure((size_t)c->slots[t] * c->pool[t].stride))) return rc;
+        c->pool[t].base = c->d_arena[t].p;
+    }
     c->arena_lmax = lm;
     return MAPAD_OK;
 }
@@ -339,12 +360,12 @@ int launch_batch(mapad_ctx* c, const uint8_t* d_seqs, const uint8_t* d_quals, co
     if ((rc = upload_tables(c))) return rc;
     if ((rc = ensure_arenas(c, lmax))) return rc;
     const size_t nr = std::max<uint64_t>(n_reads, 1);
-    if ((rc = c->d_darr.ensure(std::max<uint64_t>(total_bases, 1)))) return rc;
+    if ((rc = c->d_pos.ensure(std::max<uint64_t>(total_bases, 1)))) return rc;
     if ((rc = c->d_counters.ensure(nr))) return rc;
     if ((rc = c->d_status.ensure(nr))) return rc;
     if ((rc = c->d_hit_count.ensure(nr))) return rc;
     if ((rc = c->d_hit_first.ensure(nr))) return rc;
-    if ((rc = c->d_overflow.ensure(nr))) return rc;
+    if ((rc = c->d_overflow.ensure(nr * kTiers))) return rc;
     if ((rc = c->d_cursors.ensure(CUR_COUNT))) return rc;
     const size_t hits_cap = std::max(c->d_hits.cap, (size_t)(2 * nr + 1024));
     const size_t ops_cap = std::max(c->d_ops.cap, hits_cap * (size_t)(std::min<uint32_t>(lmax, 256) + 8));
@@ -354,7 +375,7 @@ int launch_batch(mapad_ctx* c, const uint8_t* d_seqs, const uint8_t* d_quals, co
     HIP_TRY(hipMemsetAsync(c->d_status.p, 0, nr * 4, c->stream));
     BatchDev B{};
     B.seqs = d_seqs; B.quals = d_quals; B.offsets = d_offsets; B.n_reads = (uint32_t)n_reads;
-    B.d_arrays = c->d_darr.p; B.counters = c->d_counters.p; B.status = c->d_status.p;
+    B.posinfo = c->d_pos.p; B.counters = c->d_counters.p; B.status = c->d_status.p;
     B.hit_count = c->d_hit_count.p; B.hit_first = c->d_hit_first.p;
     B.hits_pool = c->d_hits.p; B.ops_pool = c->d_ops.p;
     B.hits_cap = (uint32_t)std::min<size_t>(c->d_hits.cap, 0xFFFFFFFFu); B.ops_cap = (uint32_t)std::min<size_t>(c->d_ops.cap, 0xFFFFFFFFu);
@@ -364,16 +385,25 @@ int launch_batch(mapad_ctx* c, const uint8_t* d_seqs, const uint8_t* d_quals, co
     const uint32_t lds_lmax = std::max<uint32_t>(lmax, 1);
     const size_t lds_bytes = (size_t)16 * lds_lmax * sizeof(float);
     const uint32_t grid_d = (uint32_t)std::min<uint64_t>(n_reads, (uint64_t)c->n_cu * 32);
+    for (auto& e : c->ev) if (!e) HIP_TRY(hipEventCreate(&e));
+    HIP_TRY(hipEventRecord(c->ev[0], c->stream));
     hipLaunchKernelGGL(darray_kernel, dim3(grid_d), dim3(64), lds_bytes, c->stream, c->dix, c->dprm, B, (int)lds_lmax);
     HIP_TRY(hipGetLastError());
-    const uint32_t grid_s = (uint32_t)std::min<uint64_t>((n_reads + 15) / 16, c->slots1 / 16);
-    hipLaunchKernelGGL(search_kernel, dim3(grid_s), dim3(64), 0, c->stream, c->dix, c->dprm, B, c->pool1, 0);
+    HIP_TRY(hipEventRecord(c->ev[1], c->stream));
+    const uint32_t grid_s = (uint32_t)std::min<uint64_t>((n_reads + 15) / 16, c->slots[0] / 16);
+    hipLaunchKernelGGL(search_kernel, dim3(grid_s), dim3(64), 0, c->stream, c->dix, c->dprm, B, c->pool[0], 0);
     HIP_TRY(hipGetLastError());
-    hipLaunchKernelGGL(search_kernel, dim3(c->slots2 / 16), dim3(64), 0, c->stream, c->dix, c->dprm, B, c->pool2, 1);
-    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(c->ev[2], c->stream));
+    for (int t = 1; t < kTiers; ++t) {
+        const uint32_t grid_t = (uint32_t)std::min<uint64_t>((n_reads + 15) / 16, c->slots[t] / 16);
+        hipLaunchKernelGGL(search_kernel, dim3(grid_t), dim3(64), 0, c->stream, c->dix, c->dprm, B, c->pool[t], t);
+        HIP_TRY(hipGetLastError());
+    }
+    HIP_TRY(hipEventRecord(c->ev[3], c->stream));
+    c->ev_valid = true;
     c->launch_info[0] = grid_d; c->launch_info[1] = 64; c->launch_info[2] = (uint32_t)lds_bytes;
-    c->launch_info[3] = grid_s; c->launch_info[4] = 64; c->launch_info[5] = c->slots2 / 16;
-    c->launch_info[6] = c->pool1.node_cap; c->launch_info[7] = (uint32_t)(c->pool1.stride >> 10);
+    c->launch_info[3] = grid_s; c->launch_info[4] = 64; c->launch_info[5] = c->slots[1] / 16;
+    c->launch_info[6] = c->pool[0].node_cap; c->launch_info[7] = (uint32_t)(c->pool[0].stride >> 10);
     return MAPAD_OK;
 }
 
@@ -508,6 +538,7 @@ int mapad_ctx_create(const mapad_index_t* idx, const mapad_params_t* params, int
         std::fprintf(stderr, "mapad_amd: device %d is %s, this library is built for gfx950 only\n", device_id, prop.gcnArchName);
         return MAPAD_ERR_NO_DEVICE;
     }
+    if (idx->ix.n >= (1ull << 40)) { std::fprintf(stderr, "mapad_amd: text longer than 2^40 symbols is not supported by the packed frame layout\n"); return MAPAD_ERR_INVALID; }
     auto c = std::make_unique<mapad_ctx>();
     c->device = device_id; c->params = *params; c->index = idx; c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     c->tables = host::make_tables(*params);
@@ -520,6 +551,7 @@ int mapad_ctx_create(const mapad_index_t* idx, const mapad_params_t* params, int
     return MAPAD_OK;
 }
 void mapad_ctx_destroy(mapad_ctx_t* ctx) { delete ctx; }
+int mapad_ctx_set_fetch_d_arrays(mapad_ctx_t* ctx, int on) { if (!ctx) return MAPAD_ERR_INVALID; ctx->fetch_d = on != 0; return MAPAD_OK; }
 int mapad_ctx_set_stream(mapad_ctx_t* ctx, void* s) { if (!ctx) return MAPAD_ERR_INVALID; ctx->stream = (hipStream_t)s; return MAPAD_OK; }
 
 // tables for the read lengths of the coming batches (device-resident inputs: the host cannot see the lengths)
@@ -560,7 +592,8 @@ int mapad_fetch_result(mapad_ctx_t* ctx, mapad_batch_result_t** out) {
     std::vector<uint32_t> cnt(n), first(n);
     std::vector<HitRec> pool(cur[CUR_HITS]);
     std::vector<uint32_t> ops_pool(cur[CUR_OPS]);
-    r->status.resize(n); r->counters.resize(n); r->d_arrays.resize(ctx->last_total_bases);
+    r->status.resize(n); r->counters.resize(n);
+    if (ctx->fetch_d) r->d_arrays.resize(ctx->last_total_bases);
     if (n) {
         HIP_TRY(hipMemcpy(cnt.data(), B.hit_count, n * 4, hipMemcpyDeviceToHost));
         HIP_TRY(hipMemcpy(first.data(), B.hit_first, n * 4, hipMemcpyDeviceToHost));
@@ -568,7 +601,14 @@ int mapad_fetch_result(mapad_ctx_t* ctx, mapad_batch_result_t** out) {
         HIP_TRY(hipMemcpy(r->counters.data(), B.counters, n * sizeof(ReadCounters), hipMemcpyDeviceToHost));
         if (!pool.empty()) HIP_TRY(hipMemcpy(pool.data(), B.hits_pool, pool.size() * sizeof(HitRec), hipMemcpyDeviceToHost));
         if (!ops_pool.empty()) HIP_TRY(hipMemcpy(ops_pool.data(), B.ops_pool, ops_pool.size() * 4, hipMemcpyDeviceToHost));
-        if (ctx->last_total_bases) HIP_TRY(hipMemcpy(r->d_arrays.data(), B.d_arrays, ctx->last_total_bases * 4, hipMemcpyDeviceToHost));
+        if (ctx->fetch_d && ctx->last_total_bases) {
+            int rc2;
+            if ((rc2 = ctx->d_darr.ensure(ctx->last_total_bases))) return rc2;
+            hipLaunchKernelGGL(extract_d_kernel, dim3(1024), dim3(256), 0, ctx->stream, B.posinfo, ctx->d_darr.p, ctx->last_total_bases);
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipStreamSynchronize(ctx->stream));
+            HIP_TRY(hipMemcpy(r->d_arrays.data(), ctx->d_darr.p, ctx->last_total_bases * 4, hipMemcpyDeviceToHost));
+        }
     }
     // order-preserving collect (mapping.rs:288): hits in read order, BinaryHeap array order inside a read
     r->hit_begin.assign(n + 1, 0);
@@ -589,8 +629,9 @@ int mapad_fetch_result(mapad_ctx_t* ctx, mapad_batch_result_t** out) {
     std::memcpy(ctx->counter_sums, sums, sizeof sums);
     r->pub.n_reads = n; r->pub.n_hits = r->hits.size(); r->pub.n_ops = r->ops.size();
     r->pub.hit_begin = r->hit_begin.data(); r->pub.hits = r->hits.data(); r->pub.ops = r->ops.data();
-    r->pub.status = r->status.data(); r->pub.counters = r->counters.data(); r->pub.d_arrays = r->d_arrays.data();
-    r->pub.n_second_pass = cur[CUR_N_OVERFLOW];
+    r->pub.status = r->status.data(); r->pub.counters = r->counters.data(); r->pub.d_arrays = ctx->fetch_d ? r->d_arrays.data() : nullptr;
+    r->pub.n_second_pass = cur[CUR_OVF];
+    r->pub.n_third_pass = cur[CUR_OVF + 2];
     *out = &r.release()->pub;
     return MAPAD_OK;
 }
@@ -654,6 +695,14 @@ int mapad_last_batch_counters(mapad_ctx_t* ctx, uint64_t out[6]) {
     uint64_t s[6] = {0, 0, 0, 0, 0, 0};
     for (auto& x : c) { s[0] += x.e_search; s[1] += x.e_darray; s[2] += x.n_push; s[3] += x.n_pop; s[4] += x.n_node; s[5] += x.n_hits; }
     std::memcpy(out, s, sizeof s);
+    return MAPAD_OK;
+}
+int mapad_last_kernel_ms(mapad_ctx_t* ctx, float out[3]) {
+    if (!ctx || !out) return MAPAD_ERR_INVALID;
+    if (!ctx->ev_valid) return MAPAD_ERR_INVALID;
+    if (hipSetDevice(ctx->device) != hipSuccess) return MAPAD_ERR_NO_DEVICE;
+    HIP_TRY(hipEventSynchronize(ctx->ev[3]));
+    for (int i = 0; i < 3; ++i) HIP_TRY(hipEventElapsedTime(&out[i], ctx->ev[i], ctx->ev[i + 1]));
     return MAPAD_OK;
 }
 int mapad_last_launch_info(mapad_ctx_t* ctx, uint32_t out[8]) {

@@ -49,6 +49,7 @@ mapad_batch_result_t* emu_map_batch(const uint64_t* blocks, uint64_t n_blocks, u
     auto* r = new EmuResult();
     r->hit_begin.assign(n_reads + 1, 0); r->status.resize(n_reads); r->counters.resize(n_reads);
     r->d_arrays.resize(n_reads ? offsets[n_reads] : 0);
+    std::vector<PosInfo> pos(lmax + 1);
     std::vector<float> pen(lmax + 1), chain(lmax + 1);
     std::vector<HeapEntry> heap;
     std::vector<Node> nodes;
@@ -61,7 +62,8 @@ mapad_batch_result_t* emu_map_batch(const uint64_t* blocks, uint64_t n_blocks, u
         const int L = (int)(offsets[i + 1] - off);
         float* d = r->d_arrays.data() + off;
         ReadCounters ctr{};
-        ctr.e_darray = d_array_scalar(ix, P, seqs + off, quals + off, L, pen.data(), chain.data(), d);
+        ctr.e_darray = d_array_scalar(ix, P, seqs + off, quals + off, L, pen.data(), chain.data(), pos.data());
+        for (int k = 0; k < L; ++k) d[k] = pos[k].d;
         SearchState st;
         for (int pass = 0; pass < 2; ++pass) {
             const uint32_t hc = pass == 0 ? heap_cap : P.stack_limit + 10, nc = pass == 0 ? node_cap : P.edit_tree_limit + 10;
@@ -71,7 +73,7 @@ mapad_batch_result_t* emu_map_batch(const uint64_t* blocks, uint64_t n_blocks, u
             nodes.assign(std::min<uint32_t>(nc, 1u << 22), Node{});
             A.heap = heap.data(); A.nodes = nodes.data(); A.hits = hits.data(); A.hit_ops = hit_ops.data(); A.scratch = scratch.data();
             A.heap_cap = (uint32_t)heap.size(); A.node_cap = (uint32_t)nodes.size(); A.hit_ops_cap = (uint32_t)hit_ops.size();
-            ReadIn rd{seqs + off, quals + off, d, L};
+            ReadIn rd{pos.data(), L};
             search_read(ix, P, rd, A, st, 0);
             if (st.status != ST_ARENA_OVERFLOW) break;
             if (pass == 0) second += 1;
@@ -89,7 +91,7 @@ mapad_batch_result_t* emu_map_batch(const uint64_t* blocks, uint64_t n_blocks, u
     }
     r->pub.n_reads = n_reads; r->pub.n_hits = r->hits.size(); r->pub.n_ops = r->ops.size();
     r->pub.hit_begin = r->hit_begin.data(); r->pub.hits = r->hits.data(); r->pub.ops = r->ops.data(); r->pub.status = r->status.data();
-    r->pub.counters = r->counters.data(); r->pub.d_arrays = r->d_arrays.data(); r->pub.n_second_pass = second;
+    r->pub.counters = r->counters.data(); r->pub.d_arrays = r->d_arrays.data(); r->pub.n_second_pass = second; r->pub.n_third_pass = 0;
     return &r->pub;
 }
 void emu_result_free(mapad_batch_result_t* r) { if (r) delete reinterpret_cast<EmuResult*>(r); }

@@ -5,12 +5,7 @@ from oracle import binding as ob
 
 import mapad_amd
 
-NO_DAMAGE = {"model": "simple_adna", "library": "single_stranded", "five_prime_overhang": 0.0, "three_prime_overhang": 0.0,
-             "ds_deamination_rate": 0.0, "ss_deamination_rate": 0.0, "divergence": {"div3": 0.02}, "ignore_base_quality": 0,
-             "bound": "discrete", "poisson_threshold": 0.03, "base_error_rate": 0.02,
-             "penalty_gap_open": {"log2": 0.001}, "penalty_gap_extend": {"repr_mm_times": 1.0}, "gap_dist_ends": 5, "max_num_gaps_open": 2}
-# README example: single-stranded library, 50 % overhang parameters (Readme.md:147-150)
-DAMAGE = dict(NO_DAMAGE, five_prime_overhang=0.5, three_prime_overhang=0.5, ds_deamination_rate=0.02, ss_deamination_rate=1.0)
+from mapad_amd.presets import DAMAGE, NO_DAMAGE  # noqa: F401  (benchmark parameter presets)
 
 
 def split_reads(seqs, quals, offsets):

@@ -67,10 +67,11 @@ def test_small_arena_second_pass_and_limits(monkeypatch):
     reads, qs = split_reads(seqs, quals, offsets)
     pidx = mapad_amd.Index.build([("chr1", g)])
     oidx = ob.OracleIndex.from_bwt(pidx.bwt(), "$ACGTX", 128)
-    monkeypatch.setenv("MAPAD_ARENA_NODES", "64")
+    monkeypatch.setenv("MAPAD_TIER0_NODES", "64")
+    monkeypatch.setenv("MAPAD_TIER1_NODES", "512")
     rp = resolve_params(NO_DAMAGE)
     res = _gpu_map(pidx, mapad_amd.make_params(rp), seqs, quals, offsets)
-    assert res.n_second_pass > 0
+    assert res.n_second_pass > 0 and res.n_third_pass > 0
     ores = oidx.map_batch(ob.make_params(rp), reads, qs, n_threads=8, keep_d=True)
     assert_same_as_oracle(ores, res, offsets)
     for limits in ({"stack_limit": 40, "edit_tree_limit": 100000}, {"stack_limit": 100000, "edit_tree_limit": 120},
