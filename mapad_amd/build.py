@@ -30,7 +30,7 @@ def needs_build():
 def build(force=False, verbose=False):
     if not force and not needs_build():
         return LIB
-    cmd = [HIPCC] + FLAGS + ["-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
+    cmd = [HIPCC] + FLAGS + os.environ.get("MAPAD_EXTRA_FLAGS", "").split() + ["-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)

@@ -64,16 +64,17 @@ struct DevParams {
     uint32_t stack_limit, edit_tree_limit;  // src/map/mapping.rs:52-54
 };
 
-MAPAD_HD bool mb_reject(const DevParams& p, float v, int L) {  // mismatch_bounds.rs:85-87,131-134,269-271
-    const float t = p.reject_thr[L];
-    if (p.bound_kind == BOUND_CONTINUOUS) {
+// reject(): `thr` is DevParams::reject_thr[L] of the read.  CONT = the Continuous bound (needs an IEEE division).
+template <bool CONT>
+MAPAD_HD bool mb_reject(float thr, float cutoff, float v) {  // mismatch_bounds.rs:85-87,131-134,269-271
+    if (CONT) {
 #if defined(__HIP_DEVICE_COMPILE__)
-        return __fdiv_rn(v, t) < p.cutoff;
+        return __fdiv_rn(v, thr) < cutoff;
 #else
-        return (v / t) < p.cutoff;
+        return (v / thr) < cutoff;
 #endif
     }
-    return v < t;
+    return v < thr;
 }
 MAPAD_HD bool mb_reject_iterative(const DevParams& p, float v, float ref) {  // :89-91,136-138,273-275
     if (p.bound_kind == BOUND_TEST) return false;

@@ -77,12 +77,25 @@ MAPAD_HD void finish_ext4(const DevIndex& ix, uint64_t lower, uint64_t lower_rev
     }
 }
 
-MAPAD_HD void ext4_scalar(const DevIndex& ix, uint64_t lower, uint64_t lower_rev, uint64_t size, Ext4& out) {
-    uint64_t lo[4], hi[4];
-    for (int k = 0; k < 4; ++k) {
-        lo[k] = lower == 0 ? 0 : occ_scalar(ix, lower - 1, k);
-        hi[k] = occ_scalar(ix, lower + size - 1, k);
+// occ(r, A|C|G|T) by ONE lane: the whole 128-byte block, all four words, branch-free.
+MAPAD_HD void occ4_lane(const DevIndex& ix, uint64_t r, uint64_t out[4]) {
+    const uint64_t* blk = ix.blocks + (r >> 8) * 16;
+    const int r_in = (int)(r & 255);
+    uint32_t a = 0, c = 0, g = 0, t = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        const uint64_t p0 = blk[4 * w + 1], p1 = blk[4 * w + 2], p2 = blk[4 * w + 3] & row_mask(w, r_in);
+        const uint64_t hi1 = p2 & p1, lo1 = p2 & ~p1;
+        a += (uint32_t)popc64(lo1 & ~p0); c += (uint32_t)popc64(lo1 & p0);
+        g += (uint32_t)popc64(hi1 & ~p0); t += (uint32_t)popc64(hi1 & p0);
     }
+    out[0] = blk[0] + a; out[1] = blk[4] + c; out[2] = blk[8] + g; out[3] = blk[12] + t;
+}
+
+MAPAD_HD void ext4_scalar(const DevIndex& ix, uint64_t lower, uint64_t lower_rev, uint64_t size, Ext4& out) {
+    uint64_t lo[4] = {0, 0, 0, 0}, hi[4];
+    if (lower != 0) occ4_lane(ix, lower - 1, lo);
+    occ4_lane(ix, lower + size - 1, hi);
     finish_ext4(ix, lower, lower_rev, size, lo, hi, out);
 }
 

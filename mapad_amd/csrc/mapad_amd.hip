@@ -124,7 +124,11 @@ __global__ void __launch_bounds__(64) darray_kernel(DevIndex ix, DevParams P, Ba
 }
 
 // ---- search: persistent quads -----------------------------------------------------------------------------------------
-__device__ __forceinline__ void finalize_read(const BatchDev& B, const Arena& A, const SearchState& st, uint32_t read, int w, int tier) {
+template <int LPR>
+__device__ __forceinline__ uint32_t group_bcast(uint32_t v) { return LPR == 4 ? dpp_quad<0>(v) : v; }
+
+template <int LPR>
+__device__ __attribute__((noinline)) void finalize_read(const BatchDev B, const Arena A, const SearchState st, uint32_t read, int w, int tier) {
     if (st.status == ST_ARENA_OVERFLOW && tier + 1 < kTiers) {  // hand the read to the next (larger) arena tier
         if (w == 0) {
             const uint32_t k = atomicAdd(&B.cursors[CUR_OVF + 2 * tier], 1u);
@@ -137,15 +141,15 @@ __device__ __forceinline__ void finalize_read(const BatchDev& B, const Arena& A,
     const uint32_t n = st.status == ST_ARENA_OVERFLOW ? 0u : st.n_hits, n_ops = st.status == ST_ARENA_OVERFLOW ? 0u : st.hit_ops_used;
     uint32_t hbase = 0, obase = 0;
     if (w == 0) { hbase = atomicAdd(&B.cursors[CUR_HITS], n); obase = atomicAdd(&B.cursors[CUR_OPS], n_ops); }
-    hbase = dpp_quad<0>(hbase);
-    obase = dpp_quad<0>(obase);
+    hbase = group_bcast<LPR>(hbase);
+    obase = group_bcast<LPR>(obase);
     uint32_t status = st.status;
     if ((uint64_t)hbase + n > B.hits_cap || (uint64_t)obase + n_ops > B.ops_cap) {
         status |= ST_POOL_OVERFLOW;
         if (w == 0) atomicOr(&B.cursors[CUR_POOL_OVF], 1u);
     } else {
-        for (uint32_t i = w; i < n; i += 4) { HitRec h = A.hits[i]; h.ops_off += obase; B.hits_pool[hbase + i] = h; }
-        for (uint32_t i = w; i < n_ops; i += 4) B.ops_pool[obase + i] = A.hit_ops[i];
+        for (uint32_t i = w; i < n; i += LPR) { HitRec h = A.hits[i]; h.ops_off += obase; B.hits_pool[hbase + i] = h; }
+        for (uint32_t i = w; i < n_ops; i += LPR) B.ops_pool[obase + i] = A.hit_ops[i];
     }
     if (w == 0) {
         B.hit_count[read] = (status & ST_POOL_OVERFLOW) ? 0u : n;
@@ -157,40 +161,44 @@ __device__ __forceinline__ void finalize_read(const BatchDev& B, const Arena& A,
     }
 }
 
+template <int LPR, bool CONT>
 __global__ void __launch_bounds__(64, 4) search_kernel(DevIndex ix, DevParams P, BatchDev B, ArenaPool AP, int tier) {
-    const int lane = threadIdx.x & 63, w = lane & 3;
-    const uint32_t slot = blockIdx.x * 16 + (lane >> 2);
+    const int lane = threadIdx.x & 63, w = lane & (LPR - 1);
+    const uint32_t slot = blockIdx.x * (64 / LPR) + (lane / LPR);
     const Arena A = carve(AP, slot);
     const uint32_t n_items = tier == 0 ? B.n_reads : B.cursors[CUR_OVF + 2 * (tier - 1)];
     uint32_t* work = &B.cursors[CUR_WORK + 2 * tier];
     const uint32_t* items = B.overflow_list + (size_t)(tier > 0 ? tier - 1 : 0) * B.n_reads;
     bool have = false, done = false;
-    ReadIn rd{nullptr, 0};
+    ReadIn rd{nullptr, 0, 0.0f};
     SearchState st;
     uint32_t read = 0;
     for (;;) {
         if (!have && !done) {
             uint32_t item = 0;
             if (w == 0) item = atomicAdd(work, 1u);
-            item = dpp_quad<0>(item);
+            item = group_bcast<LPR>(item);
             if (item >= n_items) done = true;
             else {
                 read = tier == 0 ? item : items[item];
                 const uint64_t off = B.offsets[read];
                 rd.L = (int)(B.offsets[read + 1] - off);
                 rd.pos = B.posinfo + off;
+                rd.thr = P.reject_thr[rd.L];
                 if (tier == 0 && B.status[read] == ST_NO_TABLE) {  // the D kernel already flagged it
                     if (w == 0) { B.hit_count[read] = 0; B.hit_first[read] = 0; }
                 } else {
-                    search_init(ix, P, rd, A, st);
+                    SearchState tmp;
+                    search_init(ix.n, alignment_start_of(P, rd.L), A, tmp);
+                    st = tmp;
                     have = true;
                 }
             }
         }
         if (__all(done)) break;
         if (have) {
-            if (!search_step(ix, P, rd, A, st, w)) {
-                finalize_read(B, A, st, read, w, tier);
+            if (!search_step<LPR, CONT>(ix, P, rd, A, st, w)) {
+                finalize_read<LPR>(B, A, st, read, w, tier);
                 have = false;
             }
         }
@@ -278,6 +286,7 @@ struct mapad_ctx {
     DevBuf<uint8_t> d_arena[kTiers];
     ArenaPool pool[kTiers] = {};
     uint32_t slots[kTiers] = {0, 0, 0}, arena_lmax = 0;
+    int lpr = 4;  // lanes per read in the search kernel (MAPAD_LANES_PER_READ = 4 | 1)
     int n_cu = 256;
     // last batch
     BatchDev last{};
@@ -335,17 +344,19 @@ uint32_t env_u32(const char* name, uint32_t dflt) {
 // re-run from scratch by the next tier; semantic limits (stack_limit / edit_tree_limit) are the same in every tier.
 int ensure_arenas(mapad_ctx* c, uint32_t lmax) {
     if (c->d_arena[0].p && lmax <= c->arena_lmax) return MAPAD_OK;
+    c->lpr = env_u32("MAPAD_LANES_PER_READ", 4) == 1 ? 1 : 4;
     const uint32_t lm = std::max<uint32_t>(lmax, 128);
     const uint32_t stack_limit = c->dprm.stack_limit, tree_limit = c->dprm.edit_tree_limit;
     const uint32_t hit_ops_cap = kMaxHits * (lm + 32);
     const uint32_t nodes[kTiers] = {env_u32("MAPAD_TIER0_NODES", 4096), env_u32("MAPAD_TIER1_NODES", 65536), 0xFFFFFFFFu};
-    const uint32_t waves[kTiers] = {env_u32("MAPAD_TIER0_WAVES_PER_CU", 16) * (uint32_t)c->n_cu, env_u32("MAPAD_TIER1_WAVES_PER_CU", 2) * (uint32_t)c->n_cu,
-                                    env_u32("MAPAD_TIER2_WAVES", 4)};
+    // wavefronts per tier: tier 0 fills the chip; tiers 1 and 2 keep the same number of read slots for either lanes-per-read setting
+    const uint32_t waves[kTiers] = {env_u32("MAPAD_TIER0_WAVES_PER_CU", c->lpr == 4 ? 16 : 8) * (uint32_t)c->n_cu,
+                                    env_u32("MAPAD_TIER1_WAVES", (uint32_t)c->n_cu * 4 * c->lpr / 4), env_u32("MAPAD_TIER2_WAVES", c->lpr == 4 ? 4 : 1)};
     for (int t = 0; t < kTiers; ++t) {
         const uint32_t node_cap = std::min<uint64_t>(nodes[t], (uint64_t)tree_limit + 10);
         const uint32_t heap_cap = std::min<uint64_t>(nodes[t], (uint64_t)stack_limit + 10);
         c->pool[t] = make_pool_layout(heap_cap, node_cap, hit_ops_cap, lm);
-        c->slots[t] = std::max<uint32_t>(waves[t], 1) * 16;
+        c->slots[t] = std::max<uint32_t>(waves[t], 1) * (64 / c->lpr);
         int rc;
         if ((rc = c->d_arena[t].ensure((size_t)c->slots[t] * c->pool[t].stride))) return rc;
         c->pool[t].base = c->d_arena[t].p;
@@ -390,19 +401,27 @@ int launch_batch(mapad_ctx* c, const uint8_t* d_seqs, const uint8_t* d_quals, co
     hipLaunchKernelGGL(darray_kernel, dim3(grid_d), dim3(64), lds_bytes, c->stream, c->dix, c->dprm, B, (int)lds_lmax);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(c->ev[1], c->stream));
-    const uint32_t grid_s = (uint32_t)std::min<uint64_t>((n_reads + 15) / 16, c->slots[0] / 16);
-    hipLaunchKernelGGL(search_kernel, dim3(grid_s), dim3(64), 0, c->stream, c->dix, c->dprm, B, c->pool[0], 0);
+    const uint32_t rpw = 64 / c->lpr;  // reads per wavefront
+    auto launch_search = [&](uint32_t grid, const ArenaPool& ap, int tier) {
+        const bool cont = c->dprm.bound_kind == BOUND_CONTINUOUS;
+        if (c->lpr == 4 && !cont) hipLaunchKernelGGL((search_kernel<4, false>), dim3(grid), dim3(64), 0, c->stream, c->dix, c->dprm, B, ap, tier);
+        else if (c->lpr == 4) hipLaunchKernelGGL((search_kernel<4, true>), dim3(grid), dim3(64), 0, c->stream, c->dix, c->dprm, B, ap, tier);
+        else if (!cont) hipLaunchKernelGGL((search_kernel<1, false>), dim3(grid), dim3(64), 0, c->stream, c->dix, c->dprm, B, ap, tier);
+        else hipLaunchKernelGGL((search_kernel<1, true>), dim3(grid), dim3(64), 0, c->stream, c->dix, c->dprm, B, ap, tier);
+    };
+    const uint32_t grid_s = (uint32_t)std::min<uint64_t>((n_reads + rpw - 1) / rpw, c->slots[0] / rpw);
+    launch_search(grid_s, c->pool[0], 0);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(c->ev[2], c->stream));
     for (int t = 1; t < kTiers; ++t) {
-        const uint32_t grid_t = (uint32_t)std::min<uint64_t>((n_reads + 15) / 16, c->slots[t] / 16);
-        hipLaunchKernelGGL(search_kernel, dim3(grid_t), dim3(64), 0, c->stream, c->dix, c->dprm, B, c->pool[t], t);
+        const uint32_t grid_t = (uint32_t)std::min<uint64_t>((n_reads + rpw - 1) / rpw, c->slots[t] / rpw);
+        launch_search(grid_t, c->pool[t], t);
         HIP_TRY(hipGetLastError());
     }
     HIP_TRY(hipEventRecord(c->ev[3], c->stream));
     c->ev_valid = true;
     c->launch_info[0] = grid_d; c->launch_info[1] = 64; c->launch_info[2] = (uint32_t)lds_bytes;
-    c->launch_info[3] = grid_s; c->launch_info[4] = 64; c->launch_info[5] = c->slots[1] / 16;
+    c->launch_info[3] = grid_s; c->launch_info[4] = 64; c->launch_info[5] = c->slots[1] / rpw;
     c->launch_info[6] = c->pool[0].node_cap; c->launch_info[7] = (uint32_t)(c->pool[0].stride >> 10);
     return MAPAD_OK;
 }

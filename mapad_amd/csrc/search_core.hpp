@@ -13,6 +13,16 @@
 #pragma once
 #include "fmd_device.hpp"
 
+// rare paths (a hit is found, limit recovery, read set-up) are kept out of line so they do not inflate the register
+// footprint of the per-pop loop
+#if defined(__HIPCC__) && defined(MAPAD_INLINE_RARE)
+#define MAPAD_RARE __host__ __device__ __forceinline__
+#elif defined(__HIPCC__)
+#define MAPAD_RARE __host__ __device__ __attribute__((noinline))
+#else
+#define MAPAD_RARE inline
+#endif
+
 namespace mapad {
 
 enum : uint32_t { GAP_INS = 0, GAP_DEL = 1, GAP_CLOSED = 2 };  // src/map/mod.rs:93-98
@@ -94,6 +104,7 @@ struct Arena {
 struct ReadIn {
     const PosInfo* pos;  // per-position table of this read (darray_core.hpp)
     int L;
+    float thr;           // DevParams::reject_thr[L]
 };
 
 struct SearchState {
@@ -106,9 +117,13 @@ struct SearchState {
     ReadCounters ctr;
 };
 
+// LPR = lanes per read: 4 = the quad splits every rank query (one coalesced 128-byte line per query);
+//                      1 = every lane owns a read and answers its own rank queries (more reads per instruction issued).
+template <int LPR>
 MAPAD_HD void ext4_any(const DevIndex& ix, uint64_t lower, uint64_t lower_rev, uint64_t size, int w, Ext4& out) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    ext4_quad(ix, lower, lower_rev, size, w, out);
+    if (LPR == 4) ext4_quad(ix, lower, lower_rev, size, w, out);
+    else ext4_scalar(ix, lower, lower_rev, size, out);
 #else
     (void)w;
     ext4_scalar(ix, lower, lower_rev, size, out);
@@ -182,17 +197,9 @@ MAPAD_HD void mm_trickle_down(HeapEntry* v, uint32_t n, uint32_t pos, HeapEntry 
 MAPAD_HD HeapEntry mm_pop_max(HeapEntry* v, uint32_t& n) {
     const uint32_t last_i = n - 1;
     const HeapEntry last = v[last_i];
-    uint32_t idx = 0;
-    HeapEntry item = last;
-    if (n >= 3) {
-        const HeapEntry a = v[1], b = v[2];
-        if (a.score > b.score) { idx = 1; item = a; } else { idx = 2; item = b; }
-    } else if (n == 2) {
-        idx = 1;
-    } else {
-        item = v[0];
-        idx = 0;
-    }
+    const HeapEntry a = v[last_i < 1 ? last_i : 1], b = v[last_i < 2 ? last_i : 2];  // n == 1: both v[0]; n == 2: both v[1]
+    const uint32_t idx = n >= 3 ? (a.score > b.score ? 1u : 2u) : last_i;
+    const HeapEntry item = idx == 2 ? b : a;
     n = last_i;
     if (idx < n) mm_trickle_down<true>(v, n, idx, last);
     return item;
@@ -227,7 +234,7 @@ MAPAD_HD void tree_remove(Node* nodes, SearchState& st, uint32_t key) {  // back
 // ---- extract_edit_operations (src/map/record.rs:465-500) -------------------------------------------------------------
 // Walk leaf -> root (root excluded, stop at a vacant slot), bucket by read position ascending; a bucket keeps walk order
 // if its position is left of the alignment start, else it is reversed.  Counting sort over positions 0..L.
-MAPAD_HD uint32_t extract_ops(const Node* nodes, uint32_t end_node, int alignment_start, int L, uint16_t* scratch, uint32_t* out,
+MAPAD_RARE uint32_t extract_ops(const Node* nodes, uint32_t end_node, int alignment_start, int L, uint16_t* scratch, uint32_t* out,
                               uint32_t out_cap) {
     uint16_t* cnt = scratch;           // [L + 1]
     uint16_t* fill = scratch + L + 1;  // [L + 1]
@@ -284,27 +291,34 @@ MAPAD_HD float d_get(const PosInfo* pos, int L, int split, int backward_index, i
 
 MAPAD_HD int alignment_start_of(const DevParams& P, int L) { return P.start_at_end ? L : (L / 2); }  // find_alignment_start
 
+// The `len == pattern.len()` branch of check_and_push_stack_frame (mapping.rs:973-984): a finished alignment becomes a hit.
+MAPAD_RARE void record_hit(const ReadIn rd, const Arena A, SearchState& st, int alignment_start, uint64_t lower, uint64_t lower_rev, uint64_t size,
+                           float score, uint32_t id) {
+    if (st.n_hits >= (uint32_t)kMaxHits) { st.status = ST_ARENA_OVERFLOW; return; }
+    HitRec h;
+    h.lower = lower; h.lower_rev = lower_rev; h.size = size; h.score = score; h.pad = 0;
+    h.ops_off = st.hit_ops_used;
+    const uint32_t m = extract_ops(A.nodes, id, alignment_start, rd.L, A.scratch, A.hit_ops + st.hit_ops_used, A.hit_ops_cap - st.hit_ops_used);
+    if (m == 0xFFFFFFFFu) { st.status = ST_ARENA_OVERFLOW; return; }
+    h.n_ops = m;
+    st.hit_ops_used += m;
+    hits_push(A.hits, st.n_hits, h);
+    if (st.n_hits == 1 || score > st.best_score) { st.best_score = score; st.best_size = size; }  // new BinaryHeap root
+    st.ctr.n_hits += 1;
+}
+
 // check_and_push_stack_frame (mapping.rs:932-987)
 MAPAD_HD void check_and_push(const DevParams& P, const ReadIn& rd, const Arena& A, SearchState& st, int alignment_start, const Frame& c, float score,
                              uint32_t parent_node, uint32_t op) {
-    if (st.status != ST_OK) return;
     if (st.n_hits > 0 && mb_reject_iterative(P, score, st.best_score)) return;
     if ((int)c.ngaps > P.max_num_gaps_open) return;
     if (st.tree_next == st.tree_entries && st.tree_entries >= A.node_cap) { st.status = ST_ARENA_OVERFLOW; return; }
     const uint32_t id = tree_insert(A.nodes, st, pack_node(op, parent_node, c));
     st.ctr.n_node += 1;
-    if (c.len == rd.L) {
-        if (st.n_hits >= (uint32_t)kMaxHits) { st.status = ST_ARENA_OVERFLOW; return; }
-        HitRec h;
-        h.lower = c.lower; h.lower_rev = c.lower_rev; h.size = c.size; h.score = score; h.pad = 0;
-        h.ops_off = st.hit_ops_used;
-        const uint32_t m = extract_ops(A.nodes, id, alignment_start, rd.L, A.scratch, A.hit_ops + st.hit_ops_used, A.hit_ops_cap - st.hit_ops_used);
-        if (m == 0xFFFFFFFFu) { st.status = ST_ARENA_OVERFLOW; return; }
-        h.n_ops = m;
-        st.hit_ops_used += m;
-        hits_push(A.hits, st.n_hits, h);
-        if (st.n_hits == 1 || score > st.best_score) { st.best_score = score; st.best_size = c.size; }  // new BinaryHeap root
-        st.ctr.n_hits += 1;
+    if (c.len == rd.L) {  // rare: the state takes a round trip through memory only here, so it can live in registers otherwise
+        SearchState tmp = st;
+        record_hit(rd, A, tmp, alignment_start, c.lower, c.lower_rev, c.size, score, id);
+        st = tmp;
         return;
     }
     if (st.heap_len >= A.heap_cap) { st.status = ST_ARENA_OVERFLOW; return; }
@@ -313,15 +327,24 @@ MAPAD_HD void check_and_push(const DevParams& P, const ReadIn& rd, const Arena& 
     st.ctr.n_push += 1;
 }
 
+// Overflow recovery (mapping.rs:1371-1379): evict the worst frames and free their tree nodes.
+MAPAD_RARE void evict_worst(const Arena A, SearchState& st, int64_t cnt) {
+    for (int64_t i = 0; i < cnt; ++i) {
+        if (st.heap_len == 0) break;
+        const HeapEntry m = mm_pop_min(A.heap, st.heap_len);
+        tree_remove(A.nodes, st, m.node);
+    }
+}
+
 // k_mismatch_search (mapping.rs:1012-1383) after the D array has been computed, split into init / step so that a
 // persistent quad can fetch its next read as soon as the current one finishes.  `w` = lane index inside the quad.
-MAPAD_HD void search_init(const DevIndex& ix, const DevParams& P, const ReadIn& rd, const Arena& A, SearchState& st) {
+MAPAD_RARE void search_init(uint64_t n_text, int alignment_start, const Arena A, SearchState& st) {
     st.heap_len = 0; st.tree_entries = 0; st.tree_next = 0; st.tree_len = 0; st.n_hits = 0; st.hit_ops_used = 0; st.status = ST_OK;
     st.best_score = 0.0f; st.best_size = 0;
     st.ctr.e_search = 0; st.ctr.n_push = 0; st.ctr.n_pop = 0; st.ctr.n_node = 0; st.ctr.n_hits = 0;
     Frame root;  // Tree::clear() -> id 0; root frame (mapping.rs:1045-1054)
-    root.lower = 0; root.lower_rev = 0; root.size = ix.n;  // init_interval
-    root.start = alignment_start_of(P, rd.L); root.len = 0; root.gap_f = GAP_CLOSED; root.gap_b = GAP_CLOSED; root.ngaps = 0;
+    root.lower = 0; root.lower_rev = 0; root.size = n_text;  // init_interval
+    root.start = alignment_start; root.len = 0; root.gap_f = GAP_CLOSED; root.gap_b = GAP_CLOSED; root.ngaps = 0;
     tree_insert(A.nodes, st, pack_node(pack_op(OP_MATCH, 0, 0), 0, root));
     A.heap[0] = HeapEntry{0.0f, 0u};
     st.heap_len = 1;
@@ -329,6 +352,7 @@ MAPAD_HD void search_init(const DevIndex& ix, const DevParams& P, const ReadIn& 
 }
 
 // One iteration of the `while let Some(stack_frame) = stack.pop_max()` loop.  Returns false when the search is over.
+template <int LPR, bool CONT>
 MAPAD_HD bool search_step(const DevIndex& ix, const DevParams& P, const ReadIn& rd, const Arena& A, SearchState& st, int w) {
     if (st.heap_len == 0 || st.status != ST_OK) return false;
     const int L = rd.L;
@@ -355,8 +379,8 @@ MAPAD_HD bool search_step(const DevIndex& ix, const DevParams& P, const ReadIn& 
 
     // Extension (:1245); forward extension works on the swapped interval
     Ext4 e;
-    if (forward) ext4_any(ix, f.lower_rev, f.lower, f.size, w, e);
-    else ext4_any(ix, f.lower, f.lower_rev, f.size, w, e);
+    if (forward) ext4_any<LPR>(ix, f.lower_rev, f.lower, f.size, w, e);
+    else ext4_any<LPR>(ix, f.lower, f.lower_rev, f.size, w, e);
     st.ctr.e_search += 1;
 
     // Static gates of the <= 9 children in commit order: Ins; then for k = T,G,C,A: Del(k), Match/Mismatch(k).
@@ -364,8 +388,8 @@ MAPAD_HD bool search_step(const DevIndex& ix, const DevParams& P, const ReadIn& 
     const int ins_dist = j < (L - j - 1) ? j : (L - j - 1);
     const int dist5 = forward ? j : j + 1, dist3 = L - dist5;
     const int del_dist = dist5 < dist3 ? dist5 : dist3;
-    const bool ins_ok = !mb_reject(P, insertion_score + lower_bound, L) && ins_dist >= P.gap_dist_ends;          // :1214-1216
-    const bool del_ok = !mb_reject(P, deletion_score + lower_bound, L) && del_dist >= P.gap_dist_ends;          // :1279-1281
+    const bool ins_ok = !mb_reject<CONT>(rd.thr, P.cutoff, insertion_score + lower_bound) && ins_dist >= P.gap_dist_ends;  // :1214-1216
+    const bool del_ok = !mb_reject<CONT>(rd.thr, P.cutoff, deletion_score + lower_bound) && del_dist >= P.gap_dist_ends;   // :1279-1281
     uint32_t cand = ins_ok ? 1u : 0u;
     float mm[4];
 #pragma unroll
@@ -375,7 +399,7 @@ MAPAD_HD bool search_step(const DevIndex& ix, const DevParams& P, const ReadIn& 
         mm[i] = pj.delta[cb] + f_score;      // (get - optimal) + score (:1138-1145)
         if (e.size[k] >= 1) {
             if (del_ok) cand |= 2u << (2 * i);
-            if (!mb_reject(P, mm[i] + lower_bound, L)) cand |= 4u << (2 * i);  // :1308
+            if (!mb_reject<CONT>(rd.thr, P.cutoff, mm[i] + lower_bound)) cand |= 4u << (2 * i);  // :1308
         }
     }
     const int child_start = forward ? f.start : f.start - 1;
@@ -428,19 +452,17 @@ MAPAD_HD bool search_step(const DevIndex& ix, const DevParams& P, const ReadIn& 
         if (P.stack_limit_abort) { st.status = ST_LIMIT_ABORT; return false; }
         const int64_t a = (int64_t)st.heap_len - (int64_t)P.stack_limit;
         const int64_t b = (int64_t)st.tree_len - (int64_t)P.edit_tree_limit;
-        const int64_t cnt = a > b ? a : b;
-        for (int64_t i = 0; i < cnt; ++i) {
-            if (st.heap_len == 0) break;
-            const HeapEntry m = mm_pop_min(A.heap, st.heap_len);
-            tree_remove(A.nodes, st, m.node);
-        }
+        SearchState tmp = st;
+        evict_worst(A, tmp, a > b ? a : b);
+        st = tmp;
     }
     return st.heap_len > 0;
 }
 
 MAPAD_HD void search_read(const DevIndex& ix, const DevParams& P, const ReadIn& rd, const Arena& A, SearchState& st, int w) {
-    search_init(ix, P, rd, A, st);
-    while (search_step(ix, P, rd, A, st, w)) {}
+    search_init(ix.n, alignment_start_of(P, rd.L), A, st);
+    if (P.bound_kind == BOUND_CONTINUOUS) { while (search_step<1, true>(ix, P, rd, A, st, w)) {} }
+    else { while (search_step<1, false>(ix, P, rd, A, st, w)) {} }
 }
 
 }  // namespace mapad

@@ -73,7 +73,7 @@ mapad_batch_result_t* emu_map_batch(const uint64_t* blocks, uint64_t n_blocks, u
             nodes.assign(std::min<uint32_t>(nc, 1u << 22), Node{});
             A.heap = heap.data(); A.nodes = nodes.data(); A.hits = hits.data(); A.hit_ops = hit_ops.data(); A.scratch = scratch.data();
             A.heap_cap = (uint32_t)heap.size(); A.node_cap = (uint32_t)nodes.size(); A.hit_ops_cap = (uint32_t)hit_ops.size();
-            ReadIn rd{pos.data(), L};
+            ReadIn rd{pos.data(), L, P.reject_thr[L]};
             search_read(ix, P, rd, A, st, 0);
             if (st.status != ST_ARENA_OVERFLOW) break;
             if (pass == 0) second += 1;

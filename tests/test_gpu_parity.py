@@ -46,7 +46,9 @@ def test_search_kat_on_gpu(case):
     ("damage_q20_40", DAMAGE, dict(qual_range=(20, 40), damage=dict(f=0.5, t=0.5, d=0.02, s=1.0))),
     ("mixed_len_indels", DAMAGE, dict(qual_range=(20, 40), len_range=(35, 100), indel_frac=0.05)),
 ])
-def test_synthetic_batch_matches_oracle(name, prm, kw):
+@pytest.mark.parametrize("lanes_per_read", ["4", "1"])
+def test_synthetic_batch_matches_oracle(name, prm, kw, lanes_per_read, monkeypatch):
+    monkeypatch.setenv("MAPAD_LANES_PER_READ", lanes_per_read)
     g = synth.genome(300_000, seed=99)
     n = 3000 if "len_range" not in kw else 600
     seqs, quals, offsets = synth.reads(g, n, 50, seed=7 + len(name), **kw)
