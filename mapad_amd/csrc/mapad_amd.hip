@@ -37,7 +37,8 @@ namespace {
 enum : uint32_t { ST_POOL_OVERFLOW = 4, ST_NO_TABLE = 8 };
 constexpr int kTiers = 3;  // arena tiers: small / medium / the reference's full limits
 // cursors: global bump allocators and work counters; per tier t: CUR_WORK + 2t = next work item, CUR_OVF + 2t = reads tier t handed on
-enum { CUR_HITS = 0, CUR_OPS = 1, CUR_POOL_OVF = 2, CUR_ERR = 3, CUR_WORK = 4, CUR_OVF = 5, CUR_COUNT = 4 + 2 * kTiers + 2 };
+enum { CUR_HITS = 0, CUR_OPS = 1, CUR_POOL_OVF = 2, CUR_ERR = 3, CUR_WORK = 4, CUR_OVF = 5, CUR_DONE = 4 + 2 * kTiers, CUR_COUNT = 4 + 2 * kTiers + 4 };
+enum : uint32_t { ST_SPIN_TIMEOUT = 16 };
 
 struct BatchDev {
     const uint8_t* seqs;
@@ -132,9 +133,9 @@ __device__ __attribute__((noinline)) void finalize_read(const BatchDev B, const 
     if (st.status == ST_ARENA_OVERFLOW && tier + 1 < kTiers) {  // hand the read to the next (larger) arena tier
         if (w == 0) {
             const uint32_t k = atomicAdd(&B.cursors[CUR_OVF + 2 * tier], 1u);
-            B.overflow_list[(size_t)tier * B.n_reads + k] = read;
-            B.status[read] = ST_ARENA_OVERFLOW;
-            B.hit_count[read] = 0; B.hit_first[read] = 0;
+            // nothing else is written for this read here: its result words belong to whichever tier finishes it (a consumer on
+            // another XCD may already be writing them)
+            __hip_atomic_store(B.overflow_list + (size_t)tier * B.n_reads + k, read + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         return;
     }
@@ -161,26 +162,68 @@ __device__ __attribute__((noinline)) void finalize_read(const BatchDev B, const 
     }
 }
 
+// One launch serves up to two arena tiers:
+//   blocks [0, blocks_a)      role A: tier `tier_a` workers on pool APa.  Work items are all reads (tier 0) or the overflow list
+//                                     the previous tier left behind.
+//   blocks [blocks_a, grid)   role B: tier `tier_a + 1` workers on pool APb that consume, while role A is still running, the
+//                                     reads role A hands on (those that outgrow the small arenas are the long-running tail of
+//                                     the batch, so they start early instead of after the whole first pass).
+// Hand-off: a producer publishes `read + 1` with one agent-scope store into overflow_list[tier_a][k] (k from an atomic
+// counter; the list is zeroed before the launch); a consumer claims k with an atomic and polls that single word.  The data
+// word is its own flag, so no fence is needed.  Consumers leave when every role-A wavefront has exited and their claimed
+// slot is beyond the final count.
 template <int LPR, bool CONT>
-__global__ void __launch_bounds__(64, 4) search_kernel(DevIndex ix, DevParams P, BatchDev B, ArenaPool AP, int tier) {
+__global__ void __launch_bounds__(64, 4) search_kernel(DevIndex ix, DevParams P, BatchDev B, ArenaPool APa, ArenaPool APb, int tier_a, uint32_t blocks_a) {
     const int lane = threadIdx.x & 63, w = lane & (LPR - 1);
-    const uint32_t slot = blockIdx.x * (64 / LPR) + (lane / LPR);
-    const Arena A = carve(AP, slot);
-    const uint32_t n_items = tier == 0 ? B.n_reads : B.cursors[CUR_OVF + 2 * (tier - 1)];
+    const bool role_b = blockIdx.x >= blocks_a;
+    const int tier = role_b ? tier_a + 1 : tier_a;
+    const uint32_t slot = (role_b ? blockIdx.x - blocks_a : blockIdx.x) * (64 / LPR) + (lane / LPR);
+    const Arena A = carve(role_b ? APb : APa, slot);
+    const uint32_t n_items = tier == 0 ? B.n_reads : B.cursors[CUR_OVF + 2 * (tier - 1)];  // role B re-reads the live counter below
     uint32_t* work = &B.cursors[CUR_WORK + 2 * tier];
-    const uint32_t* items = B.overflow_list + (size_t)(tier > 0 ? tier - 1 : 0) * B.n_reads;
+    uint32_t* items = B.overflow_list + (size_t)(tier > 0 ? tier - 1 : 0) * B.n_reads;
+    if (role_b) __builtin_amdgcn_s_setprio(3);  // the hand-me-down reads are the long tail of the batch: let them issue first
     bool have = false, done = false;
+    bool claimed = false;
+    uint32_t claim = 0, idle = 0;
     ReadIn rd{nullptr, 0, 0.0f};
     SearchState st;
     uint32_t read = 0;
     for (;;) {
         if (!have && !done) {
-            uint32_t item = 0;
-            if (w == 0) item = atomicAdd(work, 1u);
-            item = group_bcast<LPR>(item);
-            if (item >= n_items) done = true;
-            else {
-                read = tier == 0 ? item : items[item];
+            bool got = false;
+            if (!role_b) {
+                uint32_t item = 0;
+                if (w == 0) item = atomicAdd(work, 1u);
+                item = group_bcast<LPR>(item);
+                if (item >= n_items) done = true;
+                else { read = tier == 0 ? item : __hip_atomic_load(items + item, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - 1u; got = true; }
+            } else {
+                if (!claimed) {
+                    if (w == 0) claim = atomicAdd(work, 1u);
+                    claim = group_bcast<LPR>(claim);
+                    claimed = true;
+                    idle = 0;
+                }
+                // a tier hands on at most n_reads reads: a claim beyond that can never be served (and must not index the list)
+                const bool poll_now = claim < B.n_reads && (!__any(have) || (idle & 15u) == 0);  // working neighbours: poll 1 in 16 iterations
+                const uint32_t v = poll_now ? __hip_atomic_load(items + claim, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+                if (claim >= B.n_reads) done = true;
+                else if (v != 0) { read = v - 1u; got = true; claimed = false; }
+                else if (!poll_now) ++idle;
+                else {
+                    const uint32_t finished = __hip_atomic_load(&B.cursors[CUR_DONE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (finished >= blocks_a) {  // no more producers: the count is final
+                        const uint32_t total = __hip_atomic_load(&B.cursors[CUR_OVF + 2 * tier_a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (claim >= total) done = true;
+                    }
+                    if (!done && ++idle > (1u << 22)) {  // bounded spin: never hang the GPU
+                        if (w == 0) atomicOr(&B.cursors[CUR_ERR], ST_SPIN_TIMEOUT);
+                        done = true;
+                    }
+                }
+            }
+            if (got) {
                 const uint64_t off = B.offsets[read];
                 rd.L = (int)(B.offsets[read + 1] - off);
                 rd.pos = B.posinfo + off;
@@ -196,6 +239,7 @@ __global__ void __launch_bounds__(64, 4) search_kernel(DevIndex ix, DevParams P,
             }
         }
         if (__all(done)) break;
+        if (!__any(have)) __builtin_amdgcn_s_sleep(32);  // a whole wavefront of idle consumers: back off
         if (have) {
             if (!search_step<LPR, CONT>(ix, P, rd, A, st, w)) {
                 finalize_read<LPR>(B, A, st, read, w, tier);
@@ -203,6 +247,7 @@ __global__ void __launch_bounds__(64, 4) search_kernel(DevIndex ix, DevParams P,
             }
         }
     }
+    if (!role_b && lane == 0) atomicAdd(&B.cursors[CUR_DONE], 1u);
 }
 
 // D values out of the PosInfo table (parity tests / debugging only)
@@ -384,6 +429,7 @@ int launch_batch(mapad_ctx* c, const uint8_t* d_seqs, const uint8_t* d_quals, co
     if ((rc = c->d_ops.ensure(ops_cap))) return rc;
     HIP_TRY(hipMemsetAsync(c->d_cursors.p, 0, CUR_COUNT * 4, c->stream));
     HIP_TRY(hipMemsetAsync(c->d_status.p, 0, nr * 4, c->stream));
+    HIP_TRY(hipMemsetAsync(c->d_overflow.p, 0, nr * kTiers * 4, c->stream));  // hand-off words: 0 = not yet published
     BatchDev B{};
     B.seqs = d_seqs; B.quals = d_quals; B.offsets = d_offsets; B.n_reads = (uint32_t)n_reads;
     B.posinfo = c->d_pos.p; B.counters = c->d_counters.p; B.status = c->d_status.p;
@@ -402,22 +448,32 @@ int launch_batch(mapad_ctx* c, const uint8_t* d_seqs, const uint8_t* d_quals, co
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(c->ev[1], c->stream));
     const uint32_t rpw = 64 / c->lpr;  // reads per wavefront
-    auto launch_search = [&](uint32_t grid, const ArenaPool& ap, int tier) {
+    auto launch_search = [&](uint32_t blocks_a, uint32_t blocks_b, const ArenaPool& apa, const ArenaPool& apb, int tier_a) {
         const bool cont = c->dprm.bound_kind == BOUND_CONTINUOUS;
-        if (c->lpr == 4 && !cont) hipLaunchKernelGGL((search_kernel<4, false>), dim3(grid), dim3(64), 0, c->stream, c->dix, c->dprm, B, ap, tier);
-        else if (c->lpr == 4) hipLaunchKernelGGL((search_kernel<4, true>), dim3(grid), dim3(64), 0, c->stream, c->dix, c->dprm, B, ap, tier);
-        else if (!cont) hipLaunchKernelGGL((search_kernel<1, false>), dim3(grid), dim3(64), 0, c->stream, c->dix, c->dprm, B, ap, tier);
-        else hipLaunchKernelGGL((search_kernel<1, true>), dim3(grid), dim3(64), 0, c->stream, c->dix, c->dprm, B, ap, tier);
+        const dim3 grid(blocks_a + blocks_b), block(64);
+        if (c->lpr == 4 && !cont) hipLaunchKernelGGL((search_kernel<4, false>), grid, block, 0, c->stream, c->dix, c->dprm, B, apa, apb, tier_a, blocks_a);
+        else if (c->lpr == 4) hipLaunchKernelGGL((search_kernel<4, true>), grid, block, 0, c->stream, c->dix, c->dprm, B, apa, apb, tier_a, blocks_a);
+        else if (!cont) hipLaunchKernelGGL((search_kernel<1, false>), grid, block, 0, c->stream, c->dix, c->dprm, B, apa, apb, tier_a, blocks_a);
+        else hipLaunchKernelGGL((search_kernel<1, true>), grid, block, 0, c->stream, c->dix, c->dprm, B, apa, apb, tier_a, blocks_a);
     };
+    // launch 1: tier 0 over all reads.  MAPAD_FUSE_TIERS=1 lets tier-1 consumers ride along (role B).  Measured on MI355X
+    // (C2, 1 M reads): the fused launch takes 621 ms vs 281 + 189 ms for two launches — the hand-me-down reads are
+    // latency-bound and run ~3x slower per pop next to a chip full of tier-0 wavefronts — so two launches are the default.
     const uint32_t grid_s = (uint32_t)std::min<uint64_t>((n_reads + rpw - 1) / rpw, c->slots[0] / rpw);
-    launch_search(grid_s, c->pool[0], 0);
+    const uint32_t grid_1 = (uint32_t)std::min<uint64_t>((n_reads + rpw - 1) / rpw, c->slots[1] / rpw);
+    const bool fuse = env_u32("MAPAD_FUSE_TIERS", 0) != 0;
+    launch_search(grid_s, fuse ? grid_1 : 0, c->pool[0], c->pool[1], 0);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(c->ev[2], c->stream));
-    for (int t = 1; t < kTiers; ++t) {
-        const uint32_t grid_t = (uint32_t)std::min<uint64_t>((n_reads + rpw - 1) / rpw, c->slots[t] / rpw);
-        launch_search(grid_t, c->pool[t], t);
+    if (!fuse) {
+        HIP_TRY(hipMemsetAsync(c->d_cursors.p + CUR_DONE, 0, 4, c->stream));
+        launch_search(grid_1, 0, c->pool[1], c->pool[1], 1);
         HIP_TRY(hipGetLastError());
     }
+    // launch 2: the tier that holds the reference's full limits, for whatever is left
+    HIP_TRY(hipMemsetAsync(c->d_cursors.p + CUR_DONE, 0, 4, c->stream));
+    launch_search((uint32_t)std::min<uint64_t>((n_reads + rpw - 1) / rpw, c->slots[2] / rpw), 0, c->pool[2], c->pool[2], 2);
+    HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(c->ev[3], c->stream));
     c->ev_valid = true;
     c->launch_info[0] = grid_d; c->launch_info[1] = 64; c->launch_info[2] = (uint32_t)lds_bytes;
@@ -606,6 +662,7 @@ int mapad_fetch_result(mapad_ctx_t* ctx, mapad_batch_result_t** out) {
     uint32_t cur[CUR_COUNT] = {0};
     if (n) HIP_TRY(hipMemcpy(cur, B.cursors, sizeof cur, hipMemcpyDeviceToHost));
     if (cur[CUR_ERR] & ST_NO_TABLE) { std::fprintf(stderr, "mapad_amd: a read length had no score table (call mapad_ctx_prepare_lengths)\n"); return MAPAD_ERR_INVALID; }
+    if (cur[CUR_ERR] & ST_SPIN_TIMEOUT) { std::fprintf(stderr, "mapad_amd: tier hand-off timed out\n"); return MAPAD_ERR_DEVICE; }
     if (cur[CUR_ERR] & ST_ARENA_OVERFLOW) { std::fprintf(stderr, "mapad_amd: arena overflow in the large-arena pass\n"); return MAPAD_ERR_NOMEM; }
     if (cur[CUR_POOL_OVF]) return MAPAD_ERR_NOMEM;  // mapad_map_batch retries with larger pools
     std::vector<uint32_t> cnt(n), first(n);

@@ -61,7 +61,8 @@ def test_synthetic_batch_matches_oracle(name, prm, kw, lanes_per_read, monkeypat
     assert_same_as_oracle(ores, res, offsets)
 
 
-def test_small_arena_second_pass_and_limits(monkeypatch):
+@pytest.mark.parametrize("fuse", ["0", "1"])
+def test_small_arena_second_pass_and_limits(monkeypatch, fuse):
     """Reads that outgrow the first-pass arena are re-run from the large-arena pool; tiny STACK/EDIT_TREE limits
     exercise the overflow recovery of mapping.rs:1358-1380 on the device."""
     g = synth.genome(100_000, seed=5)
@@ -69,6 +70,7 @@ def test_small_arena_second_pass_and_limits(monkeypatch):
     reads, qs = split_reads(seqs, quals, offsets)
     pidx = mapad_amd.Index.build([("chr1", g)])
     oidx = ob.OracleIndex.from_bwt(pidx.bwt(), "$ACGTX", 128)
+    monkeypatch.setenv("MAPAD_FUSE_TIERS", fuse)  # 1: tier-1 consumers run inside the tier-0 launch (in-kernel hand-off)
     monkeypatch.setenv("MAPAD_TIER0_NODES", "64")
     monkeypatch.setenv("MAPAD_TIER1_NODES", "512")
     rp = resolve_params(NO_DAMAGE)
