@@ -101,35 +101,19 @@ def main():
     torch.cuda.synchronize(dev)
 
     def gather_hits():
-        """Final gather of the hit records on rank 0 (the only exchange of the path): hit counts per read, hit pool, op pool."""
+        """Final gather of the hit records on rank 0 (the only exchange of the path): per-read hit count + first-hit index,
+        hit pool (10 x u32 per hit) and edit-operation pool, straight out of the library's HBM buffers."""
         if world == 1:
             return None
+        from mapad_amd.distributed import gather_hit_records
         p_cnt, p_first, p_hits, p_ops, p_cur = ctx.device_result_ptrs()
-        cur = torch.as_tensor(DevArray(p_cur, (8,), "<u4"), device=dev).view(torch.int32)
-        sizes = cur[:2].to(torch.int64).clone()
-        all_sizes = [torch.zeros(2, dtype=torch.int64, device=dev) for _ in range(world)]
-        dist.all_gather(all_sizes, sizes)
-        all_sizes = torch.stack(all_sizes).cpu().numpy()
-        n_hits, n_ops = int(sizes[0]), int(sizes[1])
-        cnt = torch.as_tensor(DevArray(p_cnt, (n_reads,), "<u4"), device=dev).view(torch.int32)
+        cur = torch.as_tensor(DevArray(p_cur, (2,), "<u4"), device=dev).view(torch.int32).cpu()
+        n_hits, n_ops = int(cur[0]), int(cur[1])
+        cnt_first = torch.as_tensor(DevArray(p_cnt, (n_reads,), "<u4"), device=dev).view(torch.int32)
         first = torch.as_tensor(DevArray(p_first, (n_reads,), "<u4"), device=dev).view(torch.int32)
         hits = torch.as_tensor(DevArray(p_hits, (max(n_hits, 1) * 10,), "<u4"), device=dev).view(torch.int32)[:n_hits * 10]
         ops = torch.as_tensor(DevArray(p_ops, (max(n_ops, 1),), "<u4"), device=dev).view(torch.int32)[:n_ops]
-        if rank == 0:
-            out, reqs = [], []
-            for r in range(1, world):
-                bufs = [torch.empty(n_reads, dtype=torch.int32, device=dev), torch.empty(n_reads, dtype=torch.int32, device=dev),
-                        torch.empty(int(all_sizes[r][0]) * 10, dtype=torch.int32, device=dev), torch.empty(int(all_sizes[r][1]), dtype=torch.int32, device=dev)]
-                out.append(bufs)
-                reqs += [dist.P2POp(dist.irecv, b, r) for b in bufs if b.numel()]
-            if reqs:
-                for w in dist.batch_isend_irecv(reqs):
-                    w.wait()
-            return [(cnt, first, hits, ops)] + [tuple(b) for b in out]
-        reqs = [dist.P2POp(dist.isend, b, 0) for b in (cnt, first, hits, ops) if b.numel()]
-        for w in dist.batch_isend_irecv(reqs):
-            w.wait()
-        return None
+        return gather_hit_records(torch.cat([cnt_first, first]), hits, ops, rank, world, device=dev)
 
     def step():
         ctx.map_batch_device(d_seqs.data_ptr(), d_quals.data_ptr(), d_offsets.data_ptr(), n_reads, 50)
@@ -238,7 +222,7 @@ def main():
             "roofline": roofline, "cpu_baseline": cpu, "parity": parity,
         }
         if gathered is not None:
-            line["config"]["gathered_hit_records"] = int(sum(int(g[2].numel()) // 10 for g in gathered))
+            line["config"]["gathered_hit_records"] = int(sum(int(g[1].numel()) // 10 for g in gathered))
         print(json.dumps(line), flush=True)
     ctx.close()
     if world > 1:

@@ -14,8 +14,24 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp
          "-Wall", "-Wno-unused-function", "-Wno-unknown-pragmas"]
 
 
+CLI = os.path.join(HERE, "mapad-amd")
+CLI_SRC = os.path.join(CSRC, "cli", "main.cpp")
+
+
+def build_cli(force=False, verbose=False):
+    """`mapad-amd` command line (index / map) on top of the C ABI; plain host C++ linked against the library."""
+    deps = [CLI_SRC, os.path.join(CSRC, "cli", "bam_io.hpp"), os.path.join(os.path.dirname(HERE), "include", "mapad_amd.h"), LIB]
+    if not force and os.path.exists(CLI) and all(os.path.getmtime(d) <= os.path.getmtime(CLI) for d in deps):
+        return CLI
+    cmd = [HIPCC, "-O2", "-std=c++17", "-x", "c++", CLI_SRC, "-o", CLI, "-L" + HERE, "-lmapad_amd", "-lz", "-Wl,-rpath,$ORIGIN"]
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    subprocess.check_call(cmd)
+    return CLI
+
+
 def _deps():
-    out = [os.path.join(CSRC, f) for f in os.listdir(CSRC)]
+    out = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if os.path.isfile(os.path.join(CSRC, f))]
     out.append(os.path.join(os.path.dirname(HERE), "include", "mapad_amd.h"))
     return out
 
@@ -39,4 +55,5 @@ def build(force=False, verbose=False):
 
 if __name__ == "__main__":
     build(force="--force" in sys.argv, verbose=True)
+    build_cli(force="--force" in sys.argv, verbose=True)
     print(LIB)

@@ -1,0 +1,305 @@
+// bam_io.hpp — minimal BGZF / BAM / FASTQ plumbing for the `mapad-amd` command line (host I/O, not on the accelerated path).
+//
+// Stands in for the parts of noodles that `mapad map` uses (src/map/input_chunk_reader.rs:42-172, src/map/record.rs:138-215,
+// src/map/mapping.rs:92-110,292): BAM/FASTQ(.gz) records in, BAM records out.  CRAM input is not supported.
+#pragma once
+#include <zlib.h>
+
+#include <algorithm>
+#include <cctype>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+namespace mapad {
+namespace cli {
+
+// ---- BGZF -------------------------------------------------------------------------------------------------------------
+class BgzfWriter {
+public:
+    explicit BgzfWriter(const std::string& path, bool force) {
+        f_ = std::fopen(path.c_str(), force ? "wb" : "wbx");  // create_new(!force_overwrite) (mapping.rs:93-100)
+        if (!f_) throw std::runtime_error("cannot create output file " + path + (force ? "" : " (exists? use --force_overwrite)"));
+    }
+    ~BgzfWriter() { try { close(); } catch (...) {} }
+    void write(const void* p, size_t n) {
+        const uint8_t* b = (const uint8_t*)p;
+        while (n) {
+            const size_t k = std::min(n, kBlock - buf_.size());
+            buf_.insert(buf_.end(), b, b + k);
+            b += k; n -= k;
+            if (buf_.size() == kBlock) flush_block();
+        }
+    }
+    void close() {
+        if (!f_) return;
+        if (!buf_.empty()) flush_block();
+        static const uint8_t eof[28] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0, 0x1b, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        std::fwrite(eof, 1, 28, f_);
+        std::fclose(f_);
+        f_ = nullptr;
+    }
+
+private:
+    static constexpr size_t kBlock = 0xff00;
+    FILE* f_ = nullptr;
+    std::vector<uint8_t> buf_;
+    void flush_block() {
+        std::vector<uint8_t> out(kBlock + 1024);
+        z_stream zs{};
+        if (deflateInit2(&zs, 6, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) throw std::runtime_error("deflateInit2");
+        zs.next_in = buf_.data(); zs.avail_in = (uInt)buf_.size();
+        zs.next_out = out.data() + 18; zs.avail_out = (uInt)(out.size() - 18 - 8);
+        if (deflate(&zs, Z_FINISH) != Z_STREAM_END) throw std::runtime_error("deflate");
+        const size_t clen = zs.total_out;
+        deflateEnd(&zs);
+        const size_t bsize = clen + 18 + 8;
+        const uint8_t hdr[18] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0, (uint8_t)((bsize - 1) & 0xff), (uint8_t)((bsize - 1) >> 8)};
+        std::memcpy(out.data(), hdr, 18);
+        const uint32_t crc = (uint32_t)crc32(crc32(0, nullptr, 0), buf_.data(), (uInt)buf_.size()), isize = (uint32_t)buf_.size();
+        std::memcpy(out.data() + 18 + clen, &crc, 4);
+        std::memcpy(out.data() + 18 + clen + 4, &isize, 4);
+        if (std::fwrite(out.data(), 1, bsize, f_) != bsize) throw std::runtime_error("write failed");
+        buf_.clear();
+    }
+};
+
+// gz / BGZF / plain reader through zlib's gz layer (BGZF is a valid multi-member gzip stream)
+class GzReader {
+public:
+    explicit GzReader(const std::string& path) {
+        g_ = path == "-" ? gzdopen(0, "rb") : gzopen(path.c_str(), "rb");
+        if (!g_) throw std::runtime_error("The given input file could not be found: " + path);
+        gzbuffer(g_, 1 << 20);
+    }
+    ~GzReader() { if (g_) gzclose(g_); }
+    bool read_exact(void* p, size_t n) {
+        uint8_t* b = (uint8_t*)p;
+        while (n) {
+            const int k = gzread(g_, b, (unsigned)std::min<size_t>(n, 1u << 30));
+            if (k <= 0) return false;
+            b += k; n -= (size_t)k;
+        }
+        return true;
+    }
+    bool getline(std::string& s) {
+        s.clear();
+        char buf[4096];
+        for (;;) {
+            if (!gzgets(g_, buf, sizeof buf)) return !s.empty();
+            s += buf;
+            if (!s.empty() && s.back() == '\n') { s.pop_back(); if (!s.empty() && s.back() == '\r') s.pop_back(); return true; }
+        }
+    }
+    int peek() { const int c = gzgetc(g_); if (c >= 0) gzungetc(c, g_); return c; }
+
+private:
+    gzFile g_ = nullptr;
+};
+
+// ---- records ------------------------------------------------------------------------------------------------------------
+struct InRecord {  // Record (src/map/record.rs:129-136)
+    std::string name;
+    bool has_name = false;
+    uint16_t flags = 0;
+    std::string seq;            // mapping orientation (un-reversed if the input had 0x10, record.rs:157-160)
+    std::vector<uint8_t> qual;  // raw Phred
+    std::vector<uint8_t> aux;   // raw BAM aux bytes of the input record
+};
+
+inline char comp(char c) {
+    switch (c) {
+        case 'A': return 'T'; case 'T': return 'A'; case 'C': return 'G'; case 'G': return 'C';
+        case 'R': return 'Y'; case 'Y': return 'R'; case 'K': return 'M'; case 'M': return 'K';
+        case 'B': return 'V'; case 'V': return 'B'; case 'D': return 'H'; case 'H': return 'D';
+        default: return c;
+    }
+}
+inline std::string revcomp(const std::string& s) { std::string r(s.rbegin(), s.rend()); for (auto& c : r) c = comp(c); return r; }
+
+class ReadSource {
+public:
+    explicit ReadSource(const std::string& path) : in_(path) {
+        // format sniffing (input_chunk_reader.rs:42-135): BAM magic after gunzip, else FASTQ
+        const int c = in_.peek();
+        if (c == 'B') {
+            char magic[4];
+            if (!in_.read_exact(magic, 4) || std::memcmp(magic, "BAM\1", 4) != 0) throw std::runtime_error("unrecognised input format");
+            is_bam_ = true;
+            uint32_t l_text;
+            if (!in_.read_exact(&l_text, 4)) throw std::runtime_error("truncated BAM header");
+            header_text_.resize(l_text);
+            if (l_text && !in_.read_exact(&header_text_[0], l_text)) throw std::runtime_error("truncated BAM header");
+            while (!header_text_.empty() && header_text_.back() == '\0') header_text_.pop_back();
+            uint32_t n_ref;
+            if (!in_.read_exact(&n_ref, 4)) throw std::runtime_error("truncated BAM header");
+            for (uint32_t i = 0; i < n_ref; ++i) {
+                uint32_t l_name, l_ref;
+                if (!in_.read_exact(&l_name, 4)) throw std::runtime_error("truncated BAM header");
+                std::string nm(l_name, '\0');
+                if (!in_.read_exact(&nm[0], l_name) || !in_.read_exact(&l_ref, 4)) throw std::runtime_error("truncated BAM header");
+            }
+        } else if (c == '@' || c < 0) {
+            is_bam_ = false;
+        } else throw std::runtime_error("unrecognised input format (expected BAM or FASTQ, optionally gzip-compressed)");
+    }
+    bool is_bam() const { return is_bam_; }
+    const std::string& header_text() const { return header_text_; }
+
+    // next record; false at end of input.  Malformed records are reported and skipped (input_chunk_reader.rs:200-214).
+    bool next(InRecord& r) {
+        return is_bam_ ? next_bam(r) : next_fastq(r);
+    }
+
+private:
+    GzReader in_;
+    bool is_bam_ = false;
+    std::string header_text_;
+
+    bool next_fastq(InRecord& r) {  // TryFrom<fastq::Record> (record.rs:185-215)
+        std::string l1, l2, l3, l4;
+        for (;;) {
+            if (!in_.getline(l1)) return false;
+            if (l1.empty()) continue;
+            if (!in_.getline(l2) || !in_.getline(l3) || !in_.getline(l4)) return false;
+            if (l1[0] != '@' || l3.empty() || l3[0] != '+' || l2.size() != l4.size()) { std::fprintf(stderr, "Skip record due to an error: malformed FASTQ record\n"); continue; }
+            r = InRecord();
+            const size_t sp = l1.find_first_of(" \t");
+            r.name = l1.substr(1, sp == std::string::npos ? std::string::npos : sp - 1);
+            r.has_name = true; r.flags = 0;
+            r.seq = l2;
+            for (auto& ch : r.seq) ch = (char)std::toupper((unsigned char)ch);
+            r.qual.resize(l4.size());
+            for (size_t i = 0; i < l4.size(); ++i) r.qual[i] = (uint8_t)(l4[i] - 33);
+            return true;
+        }
+    }
+    bool next_bam(InRecord& r) {  // TryFrom<&dyn sam::alignment::Record> (record.rs:138-183)
+        uint32_t block_size;
+        if (!in_.read_exact(&block_size, 4)) return false;
+        std::vector<uint8_t> b(block_size);
+        if (!in_.read_exact(b.data(), block_size) || block_size < 32) throw std::runtime_error("truncated BAM record");
+        const uint8_t l_read_name = b[8];
+        uint16_t n_cigar, flag;
+        uint32_t l_seq;
+        std::memcpy(&n_cigar, &b[12], 2); std::memcpy(&flag, &b[14], 2); std::memcpy(&l_seq, &b[16], 4);
+        size_t o = 32;
+        r = InRecord();
+        r.name.assign((const char*)&b[o], l_read_name ? l_read_name - 1 : 0);
+        r.has_name = !(r.name.empty() || r.name == "*");
+        o += l_read_name + 4ull * n_cigar;
+        static const char code[] = "=ACMGRSVTWYHKDBN";
+        r.seq.resize(l_seq);
+        for (uint32_t i = 0; i < l_seq; ++i) r.seq[i] = code[(b[o + i / 2] >> (i % 2 ? 0 : 4)) & 0xF];
+        o += (l_seq + 1) / 2;
+        r.qual.assign(b.begin() + o, b.begin() + o + l_seq);
+        o += l_seq;
+        r.aux.assign(b.begin() + o, b.end());
+        r.flags = flag;
+        if (flag & 0x10) { r.seq = revcomp(r.seq); std::reverse(r.qual.begin(), r.qual.end()); }
+        return true;
+    }
+};
+
+// size in bytes of one BAM aux field starting at p (tag[2] type value...), 0 if malformed
+inline size_t aux_field_size(const uint8_t* p, size_t left) {
+    if (left < 3) return 0;
+    auto fixed = [](char t) -> size_t { switch (t) { case 'A': case 'c': case 'C': return 1; case 's': case 'S': return 2; case 'i': case 'I': case 'f': return 4; default: return 0; } };
+    const char t = (char)p[2];
+    if (size_t f = fixed(t)) return 3 + f <= left ? 3 + f : 0;
+    if (t == 'Z' || t == 'H') { for (size_t i = 3; i < left; ++i) if (p[i] == 0) return i + 1; return 0; }
+    if (t == 'B') {
+        if (left < 8) return 0;
+        const size_t f = fixed((char)p[3]);
+        uint32_t n; std::memcpy(&n, p + 4, 4);
+        return f && 8 + f * n <= left ? 8 + f * n : 0;
+    }
+    return 0;
+}
+
+inline uint16_t reg2bin(int64_t beg, int64_t end) {  // SAM spec 5.3
+    --end;
+    if (beg >> 14 == end >> 14) return (uint16_t)(((1 << 15) - 1) / 7 + (beg >> 14));
+    if (beg >> 17 == end >> 17) return (uint16_t)(((1 << 12) - 1) / 7 + (beg >> 17));
+    if (beg >> 20 == end >> 20) return (uint16_t)(((1 << 9) - 1) / 7 + (beg >> 20));
+    if (beg >> 23 == end >> 23) return (uint16_t)(((1 << 6) - 1) / 7 + (beg >> 23));
+    if (beg >> 26 == end >> 26) return (uint16_t)(((1 << 3) - 1) / 7 + (beg >> 26));
+    return 0;
+}
+
+struct OutFields {  // what create_bam_record (mapping.rs:722-927) puts into one record
+    bool mapped = false, reverse = false;
+    uint16_t flags = 0;
+    int32_t tid = -1;
+    int64_t pos = -1;
+    uint8_t mapq = 0;
+    std::string cigar, md, xa;
+    float as = 0, xs = 0, xd = 0;
+    int32_t nm = 0, x0 = 0, x1 = 0;
+    bool has_xs = false, has_alt = false;
+    char xt = 'N';
+};
+
+inline void encode_bam_record(const InRecord& in, const OutFields& f, const std::string& read_group, std::vector<uint8_t>& out) {
+    std::vector<uint8_t> rec(32, 0);
+    const std::string name = in.has_name ? in.name : "*";
+    // CIGAR string -> ops
+    std::vector<uint32_t> ops;
+    int64_t ref_len = 0;
+    for (size_t i = 0; i < f.cigar.size();) {
+        uint32_t n = 0;
+        while (i < f.cigar.size() && std::isdigit((unsigned char)f.cigar[i])) n = n * 10 + (uint32_t)(f.cigar[i++] - '0');
+        const char k = f.cigar[i++];
+        const uint32_t code = k == 'M' ? 0 : k == 'I' ? 1 : 2;
+        ops.push_back(n << 4 | code);
+        if (k != 'I') ref_len += n;
+    }
+    const std::string seq = f.reverse ? revcomp(in.seq) : in.seq;  // mapping.rs:795-819
+    std::vector<uint8_t> qual = in.qual;
+    if (f.reverse) std::reverse(qual.begin(), qual.end());
+    const int32_t pos32 = (int32_t)f.pos, tid = f.tid, next = -1, tlen = 0;
+    const uint32_t l_seq = (uint32_t)seq.size();
+    const uint16_t bin = reg2bin(f.pos < 0 ? -1 : f.pos, f.pos < 0 ? 0 : f.pos + (ref_len ? ref_len : 1)), n_cig = (uint16_t)ops.size();
+    std::memcpy(&rec[0], &tid, 4); std::memcpy(&rec[4], &pos32, 4);
+    rec[8] = (uint8_t)(name.size() + 1); rec[9] = f.mapq;
+    std::memcpy(&rec[10], &bin, 2); std::memcpy(&rec[12], &n_cig, 2); std::memcpy(&rec[14], &f.flags, 2); std::memcpy(&rec[16], &l_seq, 4);
+    std::memcpy(&rec[20], &next, 4); std::memcpy(&rec[24], &next, 4); std::memcpy(&rec[28], &tlen, 4);
+    rec.insert(rec.end(), name.begin(), name.end()); rec.push_back(0);
+    for (uint32_t op : ops) { const uint8_t* p = (const uint8_t*)&op; rec.insert(rec.end(), p, p + 4); }
+    static const auto nib = [](char c) -> uint8_t { const char* t = "=ACMGRSVTWYHKDBN"; const char* q = std::strchr(t, c); return q ? (uint8_t)(q - t) : 15; };
+    for (uint32_t i = 0; i < l_seq; i += 2) rec.push_back((uint8_t)(nib(seq[i]) << 4 | (i + 1 < l_seq ? nib(seq[i + 1]) : 0)));
+    rec.insert(rec.end(), qual.begin(), qual.end());
+    // aux: input tags minus the BWA/mapAD specific ones (mapping.rs:834-848), then the new ones in the reference's order (:850-918)
+    static const char* drop[] = {"AS", "MD", "NM", "X0", "X1", "XA", "XD", "XE", "XF", "XG", "XM", "XN", "XO", "XS", "XT"};
+    for (size_t o = 0; o < in.aux.size();) {
+        const size_t n = aux_field_size(in.aux.data() + o, in.aux.size() - o);
+        if (!n) break;
+        bool skip = !read_group.empty() && in.aux[o] == 'R' && in.aux[o + 1] == 'G';
+        for (const char* d : drop) skip |= in.aux[o] == (uint8_t)d[0] && in.aux[o + 1] == (uint8_t)d[1];
+        if (!skip) rec.insert(rec.end(), in.aux.begin() + o, in.aux.begin() + o + n);
+        o += n;
+    }
+    auto tag_z = [&](const char* t, const std::string& v) { rec.push_back(t[0]); rec.push_back(t[1]); rec.push_back('Z'); rec.insert(rec.end(), v.begin(), v.end()); rec.push_back(0); };
+    auto tag_f = [&](const char* t, float v) { rec.push_back(t[0]); rec.push_back(t[1]); rec.push_back('f'); const uint8_t* p = (const uint8_t*)&v; rec.insert(rec.end(), p, p + 4); };
+    auto tag_i = [&](const char* t, int32_t v) { rec.push_back(t[0]); rec.push_back(t[1]); rec.push_back('i'); const uint8_t* p = (const uint8_t*)&v; rec.insert(rec.end(), p, p + 4); };
+    if (!read_group.empty()) tag_z("RG", read_group);
+    if (f.mapped) { tag_f("AS", f.as); tag_i("NM", f.nm); tag_z("MD", f.md); }
+    if (f.has_alt) {
+        if (!f.xa.empty()) tag_z("XA", f.xa);
+        tag_i("X0", f.x0); tag_i("X1", f.x1);
+        if (f.x1 > 0) tag_f("XS", f.xs);
+        rec.push_back('X'); rec.push_back('T'); rec.push_back('A'); rec.push_back((uint8_t)f.xt);
+    }
+    tag_f("XD", f.xd);
+    const uint32_t bs = (uint32_t)rec.size();
+    const uint8_t* p = (const uint8_t*)&bs;
+    out.insert(out.end(), p, p + 4);
+    out.insert(out.end(), rec.begin(), rec.end());
+}
+
+}  // namespace cli
+}  // namespace mapad

@@ -17,7 +17,7 @@ _lib = None
 def lib():
     global _lib
     if _lib is None:
-        deps = [_SRC] + [os.path.join(_HERE, "..", "mapad_amd", "csrc", f) for f in os.listdir(os.path.join(_HERE, "..", "mapad_amd", "csrc"))]
+        deps = [_SRC] + [os.path.join(_HERE, "..", "mapad_amd", "csrc", f) for f in os.listdir(os.path.join(_HERE, "..", "mapad_amd", "csrc")) if f.endswith((".hpp", ".hip"))]
         if not os.path.exists(_OUT) or any(os.path.getmtime(d) > os.path.getmtime(_OUT) for d in deps):
             os.makedirs(os.path.dirname(_OUT), exist_ok=True)
             subprocess.check_call(["g++", "-O2", "-g", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math", "-fno-builtin-log2f", "-fno-builtin-powf",

@@ -1,0 +1,73 @@
+"""The N > 1 path on CPU: 2 processes over gloo shard a chunk, map their slices (with the host build of the kernels' logic
+standing in for the GPU) and gather the hit records on rank 0; the merged result must equal the single-process result."""
+import os
+import socket
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _map_slice(lo, hi):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import emu_util
+    import mapad_amd
+    from mapad_amd import presets, synth
+    g = synth.genome(60_000, seed=31)
+    idx = mapad_amd.Index.build([("chr1", g)])
+    seqs, quals, offsets = synth.reads(g, 101, 50, seed=32, len_range=(35, 70))
+    sub_off = offsets[lo:hi + 1] - offsets[lo]
+    s, e = int(offsets[lo]), int(offsets[hi])
+    res = emu_util.map_batch(idx, mapad_amd.make_params(presets.resolve(presets.DAMAGE)), seqs[s:e], quals[s:e], sub_off)
+    counts = np.diff(res.hit_begin.astype(np.int64)).astype(np.int32)
+    hits = res.hits_arr.view(np.int32).reshape(-1, 10).copy() if res.n_hits else np.zeros((0, 10), np.int32)
+    return counts, hits, res.ops.view(np.int32).copy()
+
+
+def _worker(rank, world, port, out_path):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sys.path.insert(0, ROOT)
+    from mapad_amd.distributed import gather_hit_records, merge_gathered, shard_bounds
+    lo, hi = shard_bounds(101, world, rank)
+    counts, hits, ops = _map_slice(lo, hi)
+    parts = gather_hit_records(torch.from_numpy(counts), torch.from_numpy(hits.reshape(-1)), torch.from_numpy(ops), rank, world)
+    if rank == 0:
+        hb, h, o = merge_gathered(parts)
+        np.savez(out_path, hit_begin=hb, hits=h, ops=o)
+    else:
+        assert parts is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_sharding_and_gather_matches_single_process(tmp_path):
+    sys.path.insert(0, ROOT)
+    from mapad_amd.distributed import shard_bounds
+    # slices tile the chunk in rank order, also for ragged splits
+    for n, w in [(101, 2), (7, 8), (0, 4), (250000, 8)]:
+        b = [shard_bounds(n, w, r) for r in range(w)]
+        assert b[0][0] == 0 and b[-1][1] == n and all(b[i][1] == b[i + 1][0] for i in range(w - 1))
+        assert max(hi - lo for lo, hi in b) - min(hi - lo for lo, hi in b) <= 1
+    out = str(tmp_path / "merged.npz")
+    mp.spawn(_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    got = np.load(out)
+    counts, hits, ops = _map_slice(0, 101)
+    hb = np.zeros(102, dtype=np.uint64)
+    hb[1:] = np.cumsum(counts)
+    assert np.array_equal(got["hit_begin"], hb)
+    assert np.array_equal(got["hits"], hits) and np.array_equal(got["ops"], ops)  # incl. rebased ops offsets
+    assert hb[-1] > 50
