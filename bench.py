@@ -141,9 +141,14 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # torch <-> library interop used by the multi-GPU gather: wrap the library's cursor words without a copy and cross-check them
+    p_cur = ctx.device_result_ptrs()[4]
+    cur_view = torch.as_tensor(DevArray(p_cur, (2,), "<u4"), device=dev).view(torch.int32).cpu().numpy()
+
     # ---- roofline of the dominant kernel (rank 0) -------------------------------------------------------------------------
     res = ctx.fetch()
     counters = ctx.last_counters()
+    assert int(cur_view[0]) == res.n_hits and int(cur_view[1]) == res.n_ops, "device-pointer interop check failed"
     e_search, e_darray, n_push, n_pop, n_node, n_hit_events = [int(x) for x in counters]
     total_bases = int(offsets[-1])
     bytes_darray = 256 * e_darray + 6 * total_bases                      # 2 x 128-B index blocks per extension + read/qual in, D out
