@@ -125,11 +125,17 @@ __global__ void __launch_bounds__(64) darray_kernel(DevIndex ix, DevParams P, Ba
 }
 
 // ---- search: persistent quads -----------------------------------------------------------------------------------------
+#if defined(MAPAD_OUTLINE_RARE)
+#define MAPAD_FINALIZE_ATTR __attribute__((noinline))
+#else
+#define MAPAD_FINALIZE_ATTR __forceinline__
+#endif
+
 template <int LPR>
 __device__ __forceinline__ uint32_t group_bcast(uint32_t v) { return LPR == 4 ? dpp_quad<0>(v) : v; }
 
 template <int LPR>
-__device__ __attribute__((noinline)) void finalize_read(const BatchDev B, const Arena A, const SearchState st, uint32_t read, int w, int tier) {
+__device__ MAPAD_FINALIZE_ATTR void finalize_read(const BatchDev B, const Arena A, const SearchState st, uint32_t read, int w, int tier) {
     if (st.status == ST_ARENA_OVERFLOW && tier + 1 < kTiers) {  // hand the read to the next (larger) arena tier
         if (w == 0) {
             const uint32_t k = atomicAdd(&B.cursors[CUR_OVF + 2 * tier], 1u);
