@@ -178,7 +178,8 @@ __device__ MAPAD_FINALIZE_ATTR void finalize_read(const BatchDev B, const Arena 
 // counter; the list is zeroed before the launch); a consumer claims k with an atomic and polls that single word.  The data
 // word is its own flag, so no fence is needed.  Consumers leave when every role-A wavefront has exited and their claimed
 // slot is beyond the final count.
-template <int LPR, bool CONT>
+// PASS only names the symbol (0 = the launch that sees every read, 1 = later arena tiers) so that profiles list them separately.
+template <int LPR, bool CONT, int PASS>
 __global__ void __launch_bounds__(64, 4) search_kernel(DevIndex ix, DevParams P, BatchDev B, ArenaPool APa, ArenaPool APb, int tier_a, uint32_t blocks_a) {
     const int lane = threadIdx.x & 63, w = lane & (LPR - 1);
     const bool role_b = blockIdx.x >= blocks_a;
@@ -457,10 +458,15 @@ int launch_batch(mapad_ctx* c, const uint8_t* d_seqs, const uint8_t* d_quals, co
     auto launch_search = [&](uint32_t blocks_a, uint32_t blocks_b, const ArenaPool& apa, const ArenaPool& apb, int tier_a) {
         const bool cont = c->dprm.bound_kind == BOUND_CONTINUOUS;
         const dim3 grid(blocks_a + blocks_b), block(64);
-        if (c->lpr == 4 && !cont) hipLaunchKernelGGL((search_kernel<4, false>), grid, block, 0, c->stream, c->dix, c->dprm, B, apa, apb, tier_a, blocks_a);
-        else if (c->lpr == 4) hipLaunchKernelGGL((search_kernel<4, true>), grid, block, 0, c->stream, c->dix, c->dprm, B, apa, apb, tier_a, blocks_a);
-        else if (!cont) hipLaunchKernelGGL((search_kernel<1, false>), grid, block, 0, c->stream, c->dix, c->dprm, B, apa, apb, tier_a, blocks_a);
-        else hipLaunchKernelGGL((search_kernel<1, true>), grid, block, 0, c->stream, c->dix, c->dprm, B, apa, apb, tier_a, blocks_a);
+#define MAPAD_LAUNCH(L, C, P) hipLaunchKernelGGL((search_kernel<L, C, P>), grid, block, 0, c->stream, c->dix, c->dprm, B, apa, apb, tier_a, blocks_a)
+        if (tier_a == 0) {
+            if (c->lpr == 4 && !cont) MAPAD_LAUNCH(4, false, 0); else if (c->lpr == 4) MAPAD_LAUNCH(4, true, 0);
+            else if (!cont) MAPAD_LAUNCH(1, false, 0); else MAPAD_LAUNCH(1, true, 0);
+        } else {
+            if (c->lpr == 4 && !cont) MAPAD_LAUNCH(4, false, 1); else if (c->lpr == 4) MAPAD_LAUNCH(4, true, 1);
+            else if (!cont) MAPAD_LAUNCH(1, false, 1); else MAPAD_LAUNCH(1, true, 1);
+        }
+#undef MAPAD_LAUNCH
     };
     // launch 1: tier 0 over all reads.  MAPAD_FUSE_TIERS=1 lets tier-1 consumers ride along (role B).  Measured on MI355X
     // (C2, 1 M reads): the fused launch takes 621 ms vs 281 + 189 ms for two launches — the hand-me-down reads are
