@@ -13,16 +13,11 @@ namespace mapad {
 
 constexpr int kMaxOffset = 15;  // bi_d_array.rs:37
 
-// Per-position work shared by both kernels, done once per read position r:
-//   * the PosInfo entry the search kernel reads per pop (delta = get - optimal, read-base class), and
-//   * the penalty a D-array chain adds when it hits a mismatch (bi_d_array.rs:152-189).
-MAPAD_HD float position_setup(const DevParams& P, const uint8_t* seq, const uint8_t* qual, int L, int r, PosInfo& out) {
+// penalty a D-array chain adds when it hits a mismatch at read position r (bi_d_array.rs:152-189)
+MAPAD_HD float d_penalty(const DevParams& P, const uint8_t* seq, const uint8_t* qual, int L, int r) {
     const int to_class = base_index(seq[r]);
     const Float4 row = sdm_row(P, L, r, qual[r], to_class);
-    const float optimal = sdm_optimal(row, to_class);
-    out.delta[0] = row.a - optimal; out.delta[1] = row.c - optimal; out.delta[2] = row.g - optimal; out.delta[3] = row.t - optimal;
-    out.d = 0.0f; out.to_class = (uint32_t)to_class; out.pad[0] = 0; out.pad[1] = 0;
-    float v = sdm_best_mismatch(row, to_class) - optimal;
+    float v = sdm_best_mismatch(row, to_class) - sdm_optimal(row, to_class);
     const int dist = r < (L - r - 1) ? r : (L - r - 1);
     if (dist >= P.gap_dist_ends) v = f32_max(v, P.gap_extend);
     return v;
@@ -67,12 +62,11 @@ MAPAD_HD uint32_t d_chain(const DevIndex& ix, const uint8_t* seq, int L, int spl
     return n_ext;
 }
 
-// Host-side composition (tests/emu): PosInfo table incl. the D array of a read, 15 chains per part, min-reduced
-// (bi_d_array.rs:40-98).
+// Host-side composition (tests/emu): the whole D array of a read, 15 chains per part, min-reduced (bi_d_array.rs:40-98).
 MAPAD_HD uint32_t d_array_scalar(const DevIndex& ix, const DevParams& P, const uint8_t* seq, const uint8_t* qual, int L, float* pen_buf,
-                                 float* chain_buf, PosInfo* pos_out) {
+                                 float* chain_buf, float* d_out) {
     const int split = P.start_at_end ? L : L / 2;
-    for (int r = 0; r < L; ++r) pen_buf[r] = position_setup(P, seq, qual, L, r, pos_out[r]);
+    for (int r = 0; r < L; ++r) { pen_buf[r] = d_penalty(P, seq, qual, L, r); d_out[r] = 0.0f; }
     uint32_t n_ext = 0;
     for (int part = 0; part < 2; ++part) {
         const bool left = part == 0;
@@ -80,7 +74,7 @@ MAPAD_HD uint32_t d_array_scalar(const DevIndex& ix, const DevParams& P, const u
         for (int o = 0; o < kMaxOffset; ++o) {
             n_ext += d_chain(ix, seq, L, split, left, o, pen_buf, chain_buf, 0);
             for (int p = 0; p < part_len; ++p) {
-                float& d = pos_out[(left ? 0 : split) + p].d;
+                float& d = d_out[(left ? 0 : split) + p];
                 d = f32_min(d, chain_buf[p]);
             }
         }

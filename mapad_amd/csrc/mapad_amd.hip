@@ -45,7 +45,7 @@ struct BatchDev {
     const uint8_t* quals;
     const uint64_t* offsets;
     uint32_t n_reads;
-    PosInfo* posinfo;  // per base: scores, read-base class and D value (written by darray_kernel, read by search_kernel)
+    float* d_arrays;   // BiDArray::d_composite of every read, same offsets as the reads (written by darray_kernel)
     ReadCounters* counters;
     uint32_t* status;
     uint32_t* hit_count;
@@ -60,18 +60,20 @@ struct BatchDev {
 struct ArenaPool {
     uint8_t* base;
     uint64_t stride;
-    uint64_t off_nodes, off_hits, off_hit_ops, off_scratch;
+    uint64_t off_nodes, off_hits, off_hit_ops, off_scratch, off_near;  // off_near: HBM stand-in for the LDS-resident data (long reads)
     uint32_t heap_cap, node_cap, hit_ops_cap;
 };
 
-__device__ __forceinline__ Arena carve(const ArenaPool& ap, uint32_t slot) {
+template <bool NL>
+__device__ __forceinline__ ArenaT<NL> carve(const ArenaPool& ap, uint32_t slot) {
     uint8_t* b = ap.base + (uint64_t)slot * ap.stride;
-    Arena a;
-    a.heap = reinterpret_cast<HeapEntry*>(b);
+    ArenaT<NL> a;
+    a.heap = reinterpret_cast<HeapEntry*>(b) + 1;  // logical slot 0 = physical slot 1 (aligned child pairs, search_core.hpp)
     a.nodes = reinterpret_cast<Node*>(b + ap.off_nodes);
     a.hits = reinterpret_cast<HitRec*>(b + ap.off_hits);
     a.hit_ops = reinterpret_cast<uint32_t*>(b + ap.off_hit_ops);
     a.scratch = reinterpret_cast<uint16_t*>(b + ap.off_scratch);
+    a.top = nullptr;  // set by the kernel (LDS or the arena's `near` area)
     a.heap_cap = ap.heap_cap; a.node_cap = ap.node_cap; a.hit_ops_cap = ap.hit_ops_cap;
     return a;
 }
@@ -88,19 +90,14 @@ __global__ void __launch_bounds__(64) darray_kernel(DevIndex ix, DevParams P, Ba
         const int L = (int)(B.offsets[read + 1] - off);
         const uint8_t* seq = B.seqs + off;
         const uint8_t* qual = B.quals + off;
-        PosInfo* pout = B.posinfo + off;
+        float* dout = B.d_arrays + off;
         if (L > lmax || P.table_base[L] < 0) {  // fail loudly: the host did not prepare this read length
             if (lane == 0) { B.status[read] = ST_NO_TABLE; atomicOr(&B.cursors[CUR_ERR], ST_NO_TABLE); B.counters[read].e_darray = 0; }
             continue;
         }
         const int split = P.start_at_end ? L : L / 2;
         if (lane == 0) n_ext_total = 0;
-        for (int r = lane; r < L; r += 64) {
-            PosInfo pi;
-            pen[r] = position_setup(P, seq, qual, L, r, pi);
-            reinterpret_cast<float4*>(pout + r)[0] = make_float4(pi.delta[0], pi.delta[1], pi.delta[2], pi.delta[3]);
-            pout[r].to_class = pi.to_class;
-        }
+        for (int r = lane; r < L; r += 64) pen[r] = d_penalty(P, seq, qual, L, r);
         __syncthreads();
         for (int part = 0; part < 2; ++part) {
             const bool left = part == 0;
@@ -115,7 +112,7 @@ __global__ void __launch_bounds__(64) darray_kernel(DevIndex ix, DevParams P, Ba
                 float acc = 0.0f;
 #pragma unroll
                 for (int o = 0; o < kMaxOffset; ++o) acc = f32_min(acc, chains[o * lmax + p]);
-                pout[(left ? 0 : split) + p].d = acc;
+                dout[(left ? 0 : split) + p] = acc;
             }
             __syncthreads();
         }
@@ -134,8 +131,8 @@ __global__ void __launch_bounds__(64) darray_kernel(DevIndex ix, DevParams P, Ba
 template <int LPR>
 __device__ __forceinline__ uint32_t group_bcast(uint32_t v) { return LPR == 4 ? dpp_quad<0>(v) : v; }
 
-template <int LPR>
-__device__ MAPAD_FINALIZE_ATTR void finalize_read(const BatchDev B, const Arena A, const SearchState st, uint32_t read, int w, int tier) {
+template <int LPR, bool NL>
+__device__ MAPAD_FINALIZE_ATTR void finalize_read(const BatchDev B, const ArenaT<NL> A, const SearchState st, uint32_t read, int w, int tier) {
     if (st.status == ST_ARENA_OVERFLOW && tier + 1 < kTiers) {  // hand the read to the next (larger) arena tier
         if (w == 0) {
             const uint32_t k = atomicAdd(&B.cursors[CUR_OVF + 2 * tier], 1u);
@@ -179,13 +176,25 @@ __device__ MAPAD_FINALIZE_ATTR void finalize_read(const BatchDev B, const Arena 
 // word is its own flag, so no fence is needed.  Consumers leave when every role-A wavefront has exited and their claimed
 // slot is beyond the final count.
 // PASS only names the symbol (0 = the launch that sees every read, 1 = later arena tiers) so that profiles list them separately.
-template <int LPR, bool CONT, int PASS>
-__global__ void __launch_bounds__(64, 4) search_kernel(DevIndex ix, DevParams P, BatchDev B, ArenaPool APa, ArenaPool APb, int tier_a, uint32_t blocks_a) {
+// NL: the near data (heap top, position data) of every read slot is in LDS and addressed with ds_* instructions; otherwise it
+// lives in the slot's HBM arena (reads longer than kMaxLdsReadLen, lanes-per-read 1).
+template <int LPR, bool CONT, int PASS, bool NL>
+__global__ void __launch_bounds__(64, 4) search_kernel(DevIndex ix, DevParams P, BatchDev B, ArenaPool APa, ArenaPool APb, int tier_a, uint32_t blocks_a,
+                                                        uint32_t near_stride, uint32_t near_lmax) {
     const int lane = threadIdx.x & 63, w = lane & (LPR - 1);
     const bool role_b = blockIdx.x >= blocks_a;
     const int tier = role_b ? tier_a + 1 : tier_a;
     const uint32_t slot = (role_b ? blockIdx.x - blocks_a : blockIdx.x) * (64 / LPR) + (lane / LPR);
-    const Arena A = carve(role_b ? APb : APa, slot);
+    ArenaT<NL> A = carve<NL>(role_b ? APb : APa, slot);
+    // near data of this read slot: [32 heap slots][2*lmax bytes class/quality][lmax floats D]
+    extern __shared__ __attribute__((aligned(16))) uint8_t near_lds[];
+    using NearBytes = typename near_ptr<uint8_t, NL>::type;
+    NearBytes near;
+    if constexpr (NL) near = (NearBytes)near_lds + (size_t)(lane / LPR) * near_stride;
+    else near = (role_b ? APb : APa).base + (uint64_t)slot * (role_b ? APb : APa).stride + (role_b ? APb : APa).off_near;
+    A.top = (typename near_ptr<HeapEntry, NL>::type)near + 1;
+    const NearBytes near_qc = near + 32 * sizeof(HeapEntry);
+    const typename near_ptr<float, NL>::type near_d = (typename near_ptr<float, NL>::type)(near_qc + ((2 * near_lmax + 15) & ~15u));
     const uint32_t n_items = tier == 0 ? B.n_reads : B.cursors[CUR_OVF + 2 * (tier - 1)];  // role B re-reads the live counter below
     uint32_t* work = &B.cursors[CUR_WORK + 2 * tier];
     uint32_t* items = B.overflow_list + (size_t)(tier > 0 ? tier - 1 : 0) * B.n_reads;
@@ -193,7 +202,7 @@ __global__ void __launch_bounds__(64, 4) search_kernel(DevIndex ix, DevParams P,
     bool have = false, done = false;
     bool claimed = false;
     uint32_t claim = 0, idle = 0;
-    ReadIn rd{nullptr, 0, 0.0f};
+    ReadInT<NL> rd{near_qc, near_d, 0, 0.0f};
     SearchState st;
     uint32_t read = 0;
     for (;;) {
@@ -233,11 +242,11 @@ __global__ void __launch_bounds__(64, 4) search_kernel(DevIndex ix, DevParams P,
             if (got) {
                 const uint64_t off = B.offsets[read];
                 rd.L = (int)(B.offsets[read + 1] - off);
-                rd.pos = B.posinfo + off;
                 rd.thr = P.reject_thr[rd.L];
                 if (tier == 0 && B.status[read] == ST_NO_TABLE) {  // the D kernel already flagged it
                     if (w == 0) { B.hit_count[read] = 0; B.hit_first[read] = 0; }
                 } else {
+                    read_setup(B.seqs + off, B.quals + off, B.d_arrays + off, rd.L, near_qc, near_d, w, LPR);
                     SearchState tmp;
                     search_init(ix.n, alignment_start_of(P, rd.L), A, tmp);
                     st = tmp;
@@ -248,18 +257,13 @@ __global__ void __launch_bounds__(64, 4) search_kernel(DevIndex ix, DevParams P,
         if (__all(done)) break;
         if (!__any(have)) __builtin_amdgcn_s_sleep(32);  // a whole wavefront of idle consumers: back off
         if (have) {
-            if (!search_step<LPR, CONT>(ix, P, rd, A, st, w)) {
-                finalize_read<LPR>(B, A, st, read, w, tier);
+            if (!search_step<LPR, CONT, NL>(ix, P, rd, A, st, w)) {
+                finalize_read<LPR, NL>(B, A, st, read, w, tier);
                 have = false;
             }
         }
     }
     if (!role_b && lane == 0) atomicAdd(&B.cursors[CUR_DONE], 1u);
-}
-
-// D values out of the PosInfo table (parity tests / debugging only)
-__global__ void extract_d_kernel(const PosInfo* pos, float* out, uint64_t n) {
-    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) out[i] = pos[i].d;
 }
 
 }  // namespace
@@ -298,15 +302,20 @@ struct DevBuf {
     void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
 };
 
+// bytes of "near" data per read slot: heap top (32 physical slots), 2 bytes + 4 bytes per read position
+uint32_t near_bytes(uint32_t lmax) { return 32 * 8 + ((2 * lmax + 15) & ~15u) + ((4 * lmax + 15) & ~15u); }
+constexpr uint32_t kMaxLdsReadLen = 256;  // longer reads keep their near data in the HBM arena instead of LDS
+
 ArenaPool make_pool_layout(uint32_t heap_cap, uint32_t node_cap, uint32_t hit_ops_cap, uint32_t lmax) {
     ArenaPool ap{};
     auto align = [](uint64_t x) { return (x + 127) & ~127ull; };
     ap.heap_cap = heap_cap; ap.node_cap = node_cap; ap.hit_ops_cap = hit_ops_cap;
-    uint64_t o = align((uint64_t)heap_cap * sizeof(HeapEntry));
+    uint64_t o = align(((uint64_t)heap_cap + 16) * sizeof(HeapEntry));  // +1 shift, + slack for the vector loads past the end
     ap.off_nodes = o; o = align(o + (uint64_t)node_cap * sizeof(Node));
     ap.off_hits = o; o = align(o + (uint64_t)kMaxHits * sizeof(HitRec));
     ap.off_hit_ops = o; o = align(o + (uint64_t)hit_ops_cap * 4);
     ap.off_scratch = o; o = align(o + 2ull * (lmax + 1) * 2);
+    ap.off_near = o; o = align(o + near_bytes(lmax));
     ap.stride = o;
     return ap;
 }
@@ -329,8 +338,7 @@ struct mapad_ctx {
     // batch buffers
     DevBuf<uint8_t> d_seqs, d_quals;
     DevBuf<uint64_t> d_offsets;
-    DevBuf<PosInfo> d_pos;
-    DevBuf<float> d_darr;  // only filled on fetch when fetch_d is set
+    DevBuf<float> d_darr;
     bool fetch_d = true;
     DevBuf<ReadCounters> d_counters;
     DevBuf<uint32_t> d_status, d_hit_count, d_hit_first, d_ops, d_cursors, d_overflow;
@@ -354,7 +362,7 @@ struct mapad_ctx {
         (void)hipSetDevice(device);
         d_blocks.release(); d_sdm.release(); d_thr.release(); d_base.release(); d_seqs.release(); d_quals.release(); d_offsets.release();
         d_darr.release(); d_counters.release(); d_status.release(); d_hit_count.release(); d_hit_first.release(); d_ops.release();
-        d_cursors.release(); d_overflow.release(); d_hits.release(); d_pos.release();
+        d_cursors.release(); d_overflow.release(); d_hits.release();
         for (auto& a : d_arena) a.release();
         for (auto& e : ev) if (e) (void)hipEventDestroy(e);
     }
@@ -423,7 +431,7 @@ int launch_batch(mapad_ctx* c, const uint8_t* d_seqs, const uint8_t* d_quals, co
     if ((rc = upload_tables(c))) return rc;
     if ((rc = ensure_arenas(c, lmax))) return rc;
     const size_t nr = std::max<uint64_t>(n_reads, 1);
-    if ((rc = c->d_pos.ensure(std::max<uint64_t>(total_bases, 1)))) return rc;
+    if ((rc = c->d_darr.ensure(std::max<uint64_t>(total_bases, 1)))) return rc;
     if ((rc = c->d_counters.ensure(nr))) return rc;
     if ((rc = c->d_status.ensure(nr))) return rc;
     if ((rc = c->d_hit_count.ensure(nr))) return rc;
@@ -439,7 +447,7 @@ int launch_batch(mapad_ctx* c, const uint8_t* d_seqs, const uint8_t* d_quals, co
     HIP_TRY(hipMemsetAsync(c->d_overflow.p, 0, nr * kTiers * 4, c->stream));  // hand-off words: 0 = not yet published
     BatchDev B{};
     B.seqs = d_seqs; B.quals = d_quals; B.offsets = d_offsets; B.n_reads = (uint32_t)n_reads;
-    B.posinfo = c->d_pos.p; B.counters = c->d_counters.p; B.status = c->d_status.p;
+    B.d_arrays = c->d_darr.p; B.counters = c->d_counters.p; B.status = c->d_status.p;
     B.hit_count = c->d_hit_count.p; B.hit_first = c->d_hit_first.p;
     B.hits_pool = c->d_hits.p; B.ops_pool = c->d_ops.p;
     B.hits_cap = (uint32_t)std::min<size_t>(c->d_hits.cap, 0xFFFFFFFFu); B.ops_cap = (uint32_t)std::min<size_t>(c->d_ops.cap, 0xFFFFFFFFu);
@@ -458,14 +466,17 @@ int launch_batch(mapad_ctx* c, const uint8_t* d_seqs, const uint8_t* d_quals, co
     auto launch_search = [&](uint32_t blocks_a, uint32_t blocks_b, const ArenaPool& apa, const ArenaPool& apb, int tier_a) {
         const bool cont = c->dprm.bound_kind == BOUND_CONTINUOUS;
         const dim3 grid(blocks_a + blocks_b), block(64);
-#define MAPAD_LAUNCH(L, C, P) hipLaunchKernelGGL((search_kernel<L, C, P>), grid, block, 0, c->stream, c->dix, c->dprm, B, apa, apb, tier_a, blocks_a)
-        if (tier_a == 0) {
-            if (c->lpr == 4 && !cont) MAPAD_LAUNCH(4, false, 0); else if (c->lpr == 4) MAPAD_LAUNCH(4, true, 0);
-            else if (!cont) MAPAD_LAUNCH(1, false, 0); else MAPAD_LAUNCH(1, true, 0);
-        } else {
-            if (c->lpr == 4 && !cont) MAPAD_LAUNCH(4, false, 1); else if (c->lpr == 4) MAPAD_LAUNCH(4, true, 1);
-            else if (!cont) MAPAD_LAUNCH(1, false, 1); else MAPAD_LAUNCH(1, true, 1);
-        }
+        // near data in LDS (16 or 64 read slots per wavefront) unless the batch has very long reads
+        const uint32_t near_lmax = std::max<uint32_t>(lmax, 1);
+        const uint32_t near_stride = (c->lpr == 4 && near_lmax <= kMaxLdsReadLen && env_u32("MAPAD_NEAR_LDS", 1)) ? near_bytes(near_lmax) : 0;
+        const size_t lds = (size_t)near_stride * rpw;
+#define MAPAD_LAUNCH(L, C, P, N) hipLaunchKernelGGL((search_kernel<L, C, P, N>), grid, block, lds, c->stream, c->dix, c->dprm, B, apa, apb, tier_a, blocks_a, near_stride, near_lmax)
+#define MAPAD_LAUNCH_PASS(P)                                                                                      \
+        if (c->lpr == 4 && near_stride) { if (!cont) MAPAD_LAUNCH(4, false, P, true); else MAPAD_LAUNCH(4, true, P, true); }   \
+        else if (c->lpr == 4) { if (!cont) MAPAD_LAUNCH(4, false, P, false); else MAPAD_LAUNCH(4, true, P, false); }          \
+        else { if (!cont) MAPAD_LAUNCH(1, false, P, false); else MAPAD_LAUNCH(1, true, P, false); }
+        if (tier_a == 0) { MAPAD_LAUNCH_PASS(0) } else { MAPAD_LAUNCH_PASS(1) }
+#undef MAPAD_LAUNCH_PASS
 #undef MAPAD_LAUNCH
     };
     // launch 1: tier 0 over all reads.  MAPAD_FUSE_TIERS=1 lets tier-1 consumers ride along (role B).  Measured on MI355X
@@ -689,14 +700,7 @@ int mapad_fetch_result(mapad_ctx_t* ctx, mapad_batch_result_t** out) {
         HIP_TRY(hipMemcpy(r->counters.data(), B.counters, n * sizeof(ReadCounters), hipMemcpyDeviceToHost));
         if (!pool.empty()) HIP_TRY(hipMemcpy(pool.data(), B.hits_pool, pool.size() * sizeof(HitRec), hipMemcpyDeviceToHost));
         if (!ops_pool.empty()) HIP_TRY(hipMemcpy(ops_pool.data(), B.ops_pool, ops_pool.size() * 4, hipMemcpyDeviceToHost));
-        if (ctx->fetch_d && ctx->last_total_bases) {
-            int rc2;
-            if ((rc2 = ctx->d_darr.ensure(ctx->last_total_bases))) return rc2;
-            hipLaunchKernelGGL(extract_d_kernel, dim3(1024), dim3(256), 0, ctx->stream, B.posinfo, ctx->d_darr.p, ctx->last_total_bases);
-            HIP_TRY(hipGetLastError());
-            HIP_TRY(hipStreamSynchronize(ctx->stream));
-            HIP_TRY(hipMemcpy(r->d_arrays.data(), ctx->d_darr.p, ctx->last_total_bases * 4, hipMemcpyDeviceToHost));
-        }
+        if (ctx->fetch_d && ctx->last_total_bases) HIP_TRY(hipMemcpy(r->d_arrays.data(), B.d_arrays, ctx->last_total_bases * 4, hipMemcpyDeviceToHost));
     }
     // order-preserving collect (mapping.rs:288): hits in read order, BinaryHeap array order inside a read
     r->hit_begin.assign(n + 1, 0);

@@ -77,24 +77,31 @@ struct HitRec {  // 40 bytes; the public hit record (include/mapad_amd.h: mapad_
 };
 static_assert(sizeof(HitRec) == 40, "hit record is 40 bytes");
 
-// What the D-array kernel leaves per read position j (32 bytes):
-//   delta[b] = sdm.get(j, L, from = b, to = read[j], q[j]) - optimal_penalties[j]   (mapping.rs:1138-1145, first operation)
-//   d        = BiDArray::d_composite[j]
-//   to_class = 0..3 read base is ACGT, 4 otherwise
-struct alignas(16) PosInfo {
-    float delta[4];
-    float d;
-    uint32_t to_class;
-    uint32_t pad[2];
-};
-static_assert(sizeof(PosInfo) == 32, "PosInfo is 32 bytes");
+// Per-read position data kept next to the quad (LDS on the device; MAPAD_MAX_LDS_READ_LEN and shorter reads):
+//   qc[2j] = read-base class (0..3 = ACGT, 4 otherwise), qc[2j+1] = Phred quality  -> one shared score-table row per pop
+//   d[j]   = BiDArray::d_composite[j] (written by darray_kernel)
+constexpr int kTop = 31;  // logical heap slots 0..30 (levels 0-4) live in the `top` array (LDS on the device)
 
 constexpr int kMaxHits = 20;  // a pop adds <= 9 hits and the search returns once more than 9 exist (mapping.rs:1348)
 
 enum : uint32_t { ST_OK = 0, ST_ARENA_OVERFLOW = 1, ST_LIMIT_ABORT = 2 };
 
-struct Arena {
-    HeapEntry* heap;
+// "Near" data of a read slot (heap top, position data) is addressed through LDS-typed pointers on the device when NL is set, so the
+// compiler emits ds_* instructions for it and global_* for the arena (a pointer that may be either would force flat_* accesses,
+// which occupy the texture addresser and make every wait a full vmcnt(0)+lgkmcnt(0) wait).  NL = false: plain pointers (host build,
+// very long reads whose near data stays in the HBM arena).
+#if defined(__HIP_DEVICE_COMPILE__)
+#define MAPAD_LDS __attribute__((address_space(3)))
+#else
+#define MAPAD_LDS
+#endif
+template <class T, bool NL> struct near_ptr { using type = T*; };
+template <class T> struct near_ptr<T, true> { using type = MAPAD_LDS T*; };
+
+template <bool NL>
+struct ArenaT {
+    typename near_ptr<HeapEntry, NL>::type top;  // logical heap slots [0, kTop), shifted by one entry like `heap`
+    HeapEntry* heap;    // logical heap slots [kTop, ..) are used from here
     Node* nodes;
     HitRec* hits;       // kMaxHits
     uint32_t* hit_ops;  // staging for the hits' edit tracks
@@ -102,11 +109,43 @@ struct Arena {
     uint32_t heap_cap, node_cap, hit_ops_cap;
 };
 
-struct ReadIn {
-    const PosInfo* pos;  // per-position table of this read (darray_core.hpp)
+using Arena = ArenaT<false>;
+
+template <bool NL>
+struct ReadInT {
+    typename near_ptr<const uint8_t, NL>::type qc;  // 2 bytes per position: base class, quality
+    typename near_ptr<const float, NL>::type d;     // D array
     int L;
-    float thr;           // DevParams::reject_thr[L]
+    float thr;          // DevParams::reject_thr[L]
 };
+using ReadIn = ReadInT<false>;
+
+struct alignas(16) HeapPair { HeapEntry a, b; };
+MAPAD_HD HeapPair load_pair(const HeapEntry* p) {  // p is 16-byte aligned
+#if defined(__HIP_DEVICE_COMPILE__)
+    const uint4 q = *reinterpret_cast<const uint4*>(p);
+    HeapPair r;
+    r.a.score = __uint_as_float(q.x); r.a.node = q.y; r.b.score = __uint_as_float(q.z); r.b.node = q.w;
+    return r;
+#else
+    HeapPair r;
+    std::memcpy(&r, p, sizeof r);
+    return r;
+#endif
+}
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ HeapPair load_pair(const MAPAD_LDS HeapEntry* p) {
+    const uint4 q = *(const MAPAD_LDS uint4*)p;
+    HeapPair r;
+    r.a.score = __uint_as_float(q.x); r.a.node = q.y; r.b.score = __uint_as_float(q.z); r.b.node = q.w;
+    return r;
+}
+#endif
+
+// heap slot i of this read: the top levels sit in the near array (LDS), the rest in the HBM arena
+template <bool NL> MAPAD_HD HeapEntry hp_get(const ArenaT<NL>& A, uint32_t i) { if (i < (uint32_t)kTop) return A.top[i]; return A.heap[i]; }
+template <bool NL> MAPAD_HD void hp_set(const ArenaT<NL>& A, uint32_t i, const HeapEntry e) { if (i < (uint32_t)kTop) A.top[i] = e; else A.heap[i] = e; }
+template <bool NL> MAPAD_HD HeapPair hp_pair(const ArenaT<NL>& A, uint32_t i) { if (i < (uint32_t)kTop) return load_pair(A.top + i); return load_pair(A.heap + i); }
 
 struct SearchState {
     uint32_t heap_len;
@@ -140,76 +179,79 @@ MAPAD_HD bool mm_is_min_level(uint32_t pos) {
 #endif
 }
 
-MAPAD_HD void mm_bubble_up(HeapEntry* v, uint32_t pos, const HeapEntry elt) {  // elt is the new element, destined for slot pos
+template <bool NL>
+MAPAD_HD void mm_bubble_up(const ArenaT<NL>& A, uint32_t pos, const HeapEntry elt) {  // elt is the new element, destined for slot pos
     bool greater = false;  // which grandparent chain to follow
     if (pos > 0) {
         const uint32_t parent = (pos - 1) >> 1;
-        const HeapEntry pe = v[parent];
+        const HeapEntry pe = hp_get(A, parent);
         if (mm_is_min_level(pos)) {
-            if (elt.score > pe.score) { v[pos] = pe; pos = parent; greater = true; } else greater = false;
+            if (elt.score > pe.score) { hp_set(A, pos, pe); pos = parent; greater = true; } else greater = false;
         } else {
-            if (elt.score < pe.score) { v[pos] = pe; pos = parent; greater = false; } else greater = true;
+            if (elt.score < pe.score) { hp_set(A, pos, pe); pos = parent; greater = false; } else greater = true;
         }
         while (pos > 2) {
             const uint32_t gp = (pos - 3) >> 2;
-            const HeapEntry ge = v[gp];
+            const HeapEntry ge = hp_get(A, gp);
             const bool go = greater ? (elt.score > ge.score) : (elt.score < ge.score);
             if (!go) break;
-            v[pos] = ge;
+            hp_set(A, pos, ge);
             pos = gp;
         }
     }
-    v[pos] = elt;
+    hp_set(A, pos, elt);
 }
 
+// The heap array is stored shifted by one entry (logical index i lives in physical slot i + 1; `v` points at logical 0), so the
+// two children of a node (logical 2p+1, 2p+2) form one 16-byte aligned pair and its four grandchildren (4p+3 .. 4p+6) one
+// 32-byte aligned group: a trickle-down level is three 16-byte loads instead of six 8-byte ones and touches at most 2 lines.
 // candidates scanned in ascending index order (child1, child2, grandchildren); a later one wins only if strictly better.
-// `elt` is the element being placed, starting at the hole `pos`.
-template <bool MAX>
-MAPAD_HD void mm_trickle_down(HeapEntry* v, uint32_t n, uint32_t pos, HeapEntry elt) {
+// `elt` is the element being placed, starting at the hole `pos`.  Entries at or beyond n are stale memory: they are loaded
+// (the arena has slack) but neutralised by an index test.
+template <bool MAX, bool NL>
+MAPAD_HD void mm_trickle_down(const ArenaT<NL>& A, uint32_t n, uint32_t pos, HeapEntry elt) {
     while (2 * pos + 1 < n) {
         const uint32_t c1 = 2 * pos + 1, g1 = 2 * c1 + 1;
-        // six independent loads (clamped in-bounds); out-of-range candidates are neutralised below
-        const HeapEntry e0 = v[c1];
-        const HeapEntry e1 = v[c1 + 1 < n ? c1 + 1 : c1];
-        const HeapEntry e2 = v[g1 < n ? g1 : c1];
-        const HeapEntry e3 = v[g1 + 1 < n ? g1 + 1 : c1];
-        const HeapEntry e4 = v[g1 + 2 < n ? g1 + 2 : c1];
-        const HeapEntry e5 = v[g1 + 3 < n ? g1 + 3 : c1];
+        const HeapPair c = hp_pair(A, c1), ga = hp_pair(A, g1), gb = hp_pair(A, g1 + 2);  // groups never straddle kTop
         uint32_t best = c1;
-        HeapEntry be = e0;
-        // a clamped duplicate of e0 never wins (strict comparison), so no explicit range test is needed
-        if (MAX ? (e1.score > be.score) : (e1.score < be.score)) { best = c1 + 1; be = e1; }
-        if (MAX ? (e2.score > be.score) : (e2.score < be.score)) { best = g1; be = e2; }
-        if (MAX ? (e3.score > be.score) : (e3.score < be.score)) { best = g1 + 1; be = e3; }
-        if (MAX ? (e4.score > be.score) : (e4.score < be.score)) { best = g1 + 2; be = e4; }
-        if (MAX ? (e5.score > be.score) : (e5.score < be.score)) { best = g1 + 3; be = e5; }
+        HeapEntry be = c.a;
+        if (c1 + 1 < n && (MAX ? (c.b.score > be.score) : (c.b.score < be.score))) { best = c1 + 1; be = c.b; }
+        if (g1 < n && (MAX ? (ga.a.score > be.score) : (ga.a.score < be.score))) { best = g1; be = ga.a; }
+        if (g1 + 1 < n && (MAX ? (ga.b.score > be.score) : (ga.b.score < be.score))) { best = g1 + 1; be = ga.b; }
+        if (g1 + 2 < n && (MAX ? (gb.a.score > be.score) : (gb.a.score < be.score))) { best = g1 + 2; be = gb.a; }
+        if (g1 + 3 < n && (MAX ? (gb.b.score > be.score) : (gb.b.score < be.score))) { best = g1 + 3; be = gb.b; }
         if (!(MAX ? (be.score > elt.score) : (be.score < elt.score))) break;
-        v[pos] = be;
+        hp_set(A, pos, be);
         pos = best;
         if (best < g1) break;  // moved to a child: done
         const uint32_t parent = (pos - 1) >> 1;
-        const HeapEntry pe = parent == c1 ? e0 : e1;  // the parent of a grandchild is one of the two children just loaded
-        if (MAX ? (pe.score > elt.score) : (pe.score < elt.score)) { v[parent] = elt; elt = pe; }
+        const HeapEntry pe = parent == c1 ? c.a : c.b;  // the parent of a grandchild is one of the two children just loaded
+        if (MAX ? (pe.score > elt.score) : (pe.score < elt.score)) { hp_set(A, parent, elt); elt = pe; }
     }
-    v[pos] = elt;
+    hp_set(A, pos, elt);
 }
 
-// Removes and returns the maximum.  (pop_max of the crate: slot 2 wins a tie between slots 1 and 2.)
-MAPAD_HD HeapEntry mm_pop_max(HeapEntry* v, uint32_t& n) {
-    const uint32_t last_i = n - 1;
-    const HeapEntry last = v[last_i];
-    const HeapEntry a = v[last_i < 1 ? last_i : 1], b = v[last_i < 2 ? last_i : 2];  // n == 1: both v[0]; n == 2: both v[1]
-    const uint32_t idx = n >= 3 ? (a.score > b.score ? 1u : 2u) : last_i;
-    const HeapEntry item = idx == 2 ? b : a;
-    n = last_i;
-    if (idx < n) mm_trickle_down<true>(v, n, idx, last);
-    return item;
+// pop_max of the crate in two steps so that the caller can start loading the popped frame's node before the sift's stores:
+// mm_find_max() says which slot holds the maximum (slot 2 wins a tie between slots 1 and 2), mm_remove_at() removes it.
+template <bool NL>
+MAPAD_HD HeapEntry mm_find_max(const ArenaT<NL>& A, uint32_t n, uint32_t& idx) {
+    const HeapPair p = load_pair(A.top + 1);  // logical slots 1 and 2 (stale if n < 3, handled below)
+    const HeapEntry first = A.top[0];
+    if (n >= 3) { if (p.a.score > p.b.score) { idx = 1; return p.a; } idx = 2; return p.b; }
+    if (n == 2) { idx = 1; return p.a; }
+    idx = 0;
+    return first;
 }
-MAPAD_HD HeapEntry mm_pop_min(HeapEntry* v, uint32_t& n) {
-    const HeapEntry last = v[n - 1];
-    const HeapEntry item = v[0];
+template <bool MAX, bool NL>
+MAPAD_HD void mm_remove_at(const ArenaT<NL>& A, uint32_t& n, uint32_t idx) {
+    const HeapEntry last = hp_get(A, n - 1);
     n -= 1;
-    if (n > 0) mm_trickle_down<false>(v, n, 0, last);
+    if (idx < n) mm_trickle_down<MAX>(A, n, idx, last);
+}
+template <bool NL>
+MAPAD_HD HeapEntry mm_pop_min(const ArenaT<NL>& A, uint32_t& n) {
+    const HeapEntry item = A.top[0];
+    mm_remove_at<false>(A, n, 0);
     return item;
 }
 
@@ -279,21 +321,33 @@ MAPAD_HD void hits_push(HitRec* hits, uint32_t& n, const HitRec& h) {
 }
 
 // ---- D array access (src/map/bi_d_array.rs:200-224) ------------------------------------------------------------------------
-MAPAD_HD float d_get(const PosInfo* pos, int L, int split, int backward_index, int forward_index) {
+template <class DPtr>
+MAPAD_HD float d_get(DPtr d, int L, int split, int backward_index, int forward_index) {
     float d_rev = 0.0f, d_fwd = 0.0f;
-    if (backward_index >= 0 && backward_index < L) d_rev = pos[backward_index].d;
+    if (backward_index >= 0 && backward_index < L) d_rev = d[backward_index];
     const int sub = 1 + forward_index;
     if (L >= sub) {
         const int idx = (L - sub) + split;
-        if (idx < L) d_fwd = pos[idx].d;
+        if (idx < L) d_fwd = d[idx];
     }
     return d_rev + d_fwd;
+}
+
+// Fills the quad's per-read position data; lane w of LPR lanes handles positions w, w + LPR, ...
+template <class QcPtr, class DPtr>
+MAPAD_HD void read_setup(const uint8_t* seq, const uint8_t* qual, const float* d_in, int L, QcPtr qc, DPtr d, int w, int lpr) {
+    for (int j = w; j < L; j += lpr) {
+        qc[2 * j] = (uint8_t)base_index(seq[j]);
+        qc[2 * j + 1] = qual[j];
+        d[j] = d_in[j];
+    }
 }
 
 MAPAD_HD int alignment_start_of(const DevParams& P, int L) { return P.start_at_end ? L : (L / 2); }  // find_alignment_start
 
 // The `len == pattern.len()` branch of check_and_push_stack_frame (mapping.rs:973-984): a finished alignment becomes a hit.
-MAPAD_RARE void record_hit(const ReadIn rd, const Arena A, SearchState& st, int alignment_start, uint64_t lower, uint64_t lower_rev, uint64_t size,
+template <bool NL>
+MAPAD_RARE void record_hit(const ReadInT<NL> rd, const ArenaT<NL> A, SearchState& st, int alignment_start, uint64_t lower, uint64_t lower_rev, uint64_t size,
                            float score, uint32_t id) {
     if (st.n_hits >= (uint32_t)kMaxHits) { st.status = ST_ARENA_OVERFLOW; return; }
     HitRec h;
@@ -309,7 +363,8 @@ MAPAD_RARE void record_hit(const ReadIn rd, const Arena A, SearchState& st, int 
 }
 
 // check_and_push_stack_frame (mapping.rs:932-987)
-MAPAD_HD void check_and_push(const DevParams& P, const ReadIn& rd, const Arena& A, SearchState& st, int alignment_start, const Frame& c, float score,
+template <bool NL>
+MAPAD_HD void check_and_push(const DevParams& P, const ReadInT<NL>& rd, const ArenaT<NL>& A, SearchState& st, int alignment_start, const Frame& c, float score,
                              uint32_t parent_node, uint32_t op) {
     if (st.n_hits > 0 && mb_reject_iterative(P, score, st.best_score)) return;
     if ((int)c.ngaps > P.max_num_gaps_open) return;
@@ -324,22 +379,24 @@ MAPAD_HD void check_and_push(const DevParams& P, const ReadIn& rd, const Arena& 
     }
     if (st.heap_len >= A.heap_cap) { st.status = ST_ARENA_OVERFLOW; return; }
     st.heap_len += 1;
-    mm_bubble_up(A.heap, st.heap_len - 1, HeapEntry{score, id});
+    mm_bubble_up(A, st.heap_len - 1, HeapEntry{score, id});
     st.ctr.n_push += 1;
 }
 
 // Overflow recovery (mapping.rs:1371-1379): evict the worst frames and free their tree nodes.
-MAPAD_RARE void evict_worst(const Arena A, SearchState& st, int64_t cnt) {
+template <bool NL>
+MAPAD_RARE void evict_worst(const ArenaT<NL> A, SearchState& st, int64_t cnt) {
     for (int64_t i = 0; i < cnt; ++i) {
         if (st.heap_len == 0) break;
-        const HeapEntry m = mm_pop_min(A.heap, st.heap_len);
+        const HeapEntry m = mm_pop_min(A, st.heap_len);
         tree_remove(A.nodes, st, m.node);
     }
 }
 
 // k_mismatch_search (mapping.rs:1012-1383) after the D array has been computed, split into init / step so that a
 // persistent quad can fetch its next read as soon as the current one finishes.  `w` = lane index inside the quad.
-MAPAD_RARE void search_init(uint64_t n_text, int alignment_start, const Arena A, SearchState& st) {
+template <bool NL>
+MAPAD_RARE void search_init(uint64_t n_text, int alignment_start, const ArenaT<NL> A, SearchState& st) {
     st.heap_len = 0; st.tree_entries = 0; st.tree_next = 0; st.tree_len = 0; st.n_hits = 0; st.hit_ops_used = 0; st.status = ST_OK;
     st.best_score = 0.0f; st.best_size = 0;
     st.ctr.e_search = 0; st.ctr.n_push = 0; st.ctr.n_pop = 0; st.ctr.n_node = 0; st.ctr.n_hits = 0;
@@ -347,21 +404,24 @@ MAPAD_RARE void search_init(uint64_t n_text, int alignment_start, const Arena A,
     root.lower = 0; root.lower_rev = 0; root.size = n_text;  // init_interval
     root.start = alignment_start; root.len = 0; root.gap_f = GAP_CLOSED; root.gap_b = GAP_CLOSED; root.ngaps = 0;
     tree_insert(A.nodes, st, pack_node(pack_op(OP_MATCH, 0, 0), 0, root));
-    A.heap[0] = HeapEntry{0.0f, 0u};
+    A.top[0] = HeapEntry{0.0f, 0u};
     st.heap_len = 1;
     st.ctr.n_push += 1;
 }
 
 // One iteration of the `while let Some(stack_frame) = stack.pop_max()` loop.  Returns false when the search is over.
-template <int LPR, bool CONT>
-MAPAD_HD bool search_step(const DevIndex& ix, const DevParams& P, const ReadIn& rd, const Arena& A, SearchState& st, int w) {
+template <int LPR, bool CONT, bool NL>
+MAPAD_HD bool search_step(const DevIndex& ix, const DevParams& P, const ReadInT<NL>& rd, const ArenaT<NL>& A, SearchState& st, int w) {
     if (st.heap_len == 0 || st.status != ST_OK) return false;
     const int L = rd.L;
     const int alignment_start = alignment_start_of(P, L);
     const float open_ext = P.gap_open + P.gap_extend;
-    const HeapEntry top = mm_pop_max(A.heap, st.heap_len);
+    uint32_t top_idx;
+    const HeapEntry top = mm_find_max(A, st.heap_len, top_idx);
+    const Node top_node = A.nodes[top.node];  // in flight while the heap is repaired
+    mm_remove_at<true>(A, st.heap_len, top_idx);
     st.ctr.n_pop += 1;
-    const Frame f = unpack_frame(A.nodes[top.node]);
+    const Frame f = unpack_frame(top_node);
     const float f_score = top.score;
     int j, d_k, d_l;
     bool forward;
@@ -370,12 +430,14 @@ MAPAD_HD bool search_step(const DevIndex& ix, const DevParams& P, const ReadIn& 
     } else {
         j = f.start - 1; forward = false; d_k = f.start - 1; d_l = f.start + f.len - 1;
     }
-    const PosInfo pj = rd.pos[j];
+    const int to_class = rd.qc[2 * j];
+    const Float4 row = sdm_row(P, L, j, rd.qc[2 * j + 1], to_class);  // shared score table: hot in L1/L2
+    const float optimal = sdm_optimal(row, to_class);
     const uint32_t gap_side = forward ? f.gap_f : f.gap_b;
     const float insertion_score = (gap_side == GAP_INS ? P.gap_extend : open_ext) + f_score;  // :1127-1136,1165-1174
     const float deletion_score = (gap_side == GAP_DEL ? P.gap_extend : open_ext) + f_score;
     const uint32_t num_gaps_open = gap_side == GAP_CLOSED ? f.ngaps + 1 : f.ngaps;             // :1148-1152
-    const float lower_bound = d_get(rd.pos, L, alignment_start, d_k, d_l);                       // :1195
+    const float lower_bound = d_get(rd.d, L, alignment_start, d_k, d_l);                       // :1195
     if (st.n_hits > 0 && mb_reject_iterative(P, f_score + lower_bound, st.best_score)) return false;  // :1201-1208
 
     // Extension (:1245); forward extension works on the swapped interval
@@ -397,7 +459,7 @@ MAPAD_HD bool search_step(const DevIndex& ix, const DevParams& P, const ReadIn& 
     for (int i = 0; i < 4; ++i) {
         const int k = 3 - i;
         const int cb = forward ? 3 - k : k;  // symbol in read orientation: backward = base k, forward = its complement
-        mm[i] = pj.delta[cb] + f_score;      // (get - optimal) + score (:1138-1145)
+        mm[i] = f4_get(row, cb) - optimal + f_score;  // get - optimal + score, left to right (:1138-1145)
         if (e.size[k] >= 1) {
             if (del_ok) cand |= 2u << (2 * i);
             if (!mb_reject<CONT>(rd.thr, P.cutoff, mm[i] + lower_bound)) cand |= 4u << (2 * i);  // :1308
@@ -440,7 +502,7 @@ MAPAD_HD bool search_step(const DevIndex& ix, const DevParams& P, const ReadIn& 
                 c.gap_f = forward ? (uint32_t)GAP_CLOSED : f.gap_f; c.gap_b = forward ? f.gap_b : (uint32_t)GAP_CLOSED;
                 c.ngaps = f.ngaps;
                 score = i == 0 ? mm[0] : i == 1 ? mm[1] : i == 2 ? mm[2] : mm[3];
-                op = ((uint32_t)cb == pj.to_class) ? pack_op(OP_MATCH, (uint32_t)j, 0) : pack_op(OP_MISMATCH, (uint32_t)j, c_ascii);
+                op = (cb == to_class) ? pack_op(OP_MATCH, (uint32_t)j, 0) : pack_op(OP_MISMATCH, (uint32_t)j, c_ascii);
             }
         }
         check_and_push(P, rd, A, st, alignment_start, c, score, top.node, op);
@@ -462,8 +524,8 @@ MAPAD_HD bool search_step(const DevIndex& ix, const DevParams& P, const ReadIn& 
 
 MAPAD_HD void search_read(const DevIndex& ix, const DevParams& P, const ReadIn& rd, const Arena& A, SearchState& st, int w) {
     search_init(ix.n, alignment_start_of(P, rd.L), A, st);
-    if (P.bound_kind == BOUND_CONTINUOUS) { while (search_step<1, true>(ix, P, rd, A, st, w)) {} }
-    else { while (search_step<1, false>(ix, P, rd, A, st, w)) {} }
+    if (P.bound_kind == BOUND_CONTINUOUS) { while (search_step<1, true, false>(ix, P, rd, A, st, w)) {} }
+    else { while (search_step<1, false, false>(ix, P, rd, A, st, w)) {} }
 }
 
 }  // namespace mapad

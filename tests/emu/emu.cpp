@@ -49,7 +49,9 @@ mapad_batch_result_t* emu_map_batch(const uint64_t* blocks, uint64_t n_blocks, u
     auto* r = new EmuResult();
     r->hit_begin.assign(n_reads + 1, 0); r->status.resize(n_reads); r->counters.resize(n_reads);
     r->d_arrays.resize(n_reads ? offsets[n_reads] : 0);
-    std::vector<PosInfo> pos(lmax + 1);
+    std::vector<HeapEntry> top(32);
+    std::vector<uint8_t> qc(2 * (lmax + 1));
+    std::vector<float> dnear(lmax + 1);
     std::vector<float> pen(lmax + 1), chain(lmax + 1);
     std::vector<HeapEntry> heap;
     std::vector<Node> nodes;
@@ -62,18 +64,18 @@ mapad_batch_result_t* emu_map_batch(const uint64_t* blocks, uint64_t n_blocks, u
         const int L = (int)(offsets[i + 1] - off);
         float* d = r->d_arrays.data() + off;
         ReadCounters ctr{};
-        ctr.e_darray = d_array_scalar(ix, P, seqs + off, quals + off, L, pen.data(), chain.data(), pos.data());
-        for (int k = 0; k < L; ++k) d[k] = pos[k].d;
+        ctr.e_darray = d_array_scalar(ix, P, seqs + off, quals + off, L, pen.data(), chain.data(), d);
+        read_setup(seqs + off, quals + off, d, L, qc.data(), dnear.data(), 0, 1);
         SearchState st;
         for (int pass = 0; pass < 2; ++pass) {
             const uint32_t hc = pass == 0 ? heap_cap : P.stack_limit + 10, nc = pass == 0 ? node_cap : P.edit_tree_limit + 10;
             // lazily grown backing stores keep the host emulation cheap even with the reference's 2M / 10M limits
             Arena A;
-            heap.assign(std::min<uint32_t>(hc, 1u << 22), HeapEntry{});
+            heap.assign(std::min<uint32_t>(hc, 1u << 22) + 16, HeapEntry{});
             nodes.assign(std::min<uint32_t>(nc, 1u << 22), Node{});
-            A.heap = heap.data(); A.nodes = nodes.data(); A.hits = hits.data(); A.hit_ops = hit_ops.data(); A.scratch = scratch.data();
-            A.heap_cap = (uint32_t)heap.size(); A.node_cap = (uint32_t)nodes.size(); A.hit_ops_cap = (uint32_t)hit_ops.size();
-            ReadIn rd{pos.data(), L, P.reject_thr[L]};
+            A.top = top.data() + 1; A.heap = heap.data() + 1; A.nodes = nodes.data(); A.hits = hits.data(); A.hit_ops = hit_ops.data(); A.scratch = scratch.data();
+            A.heap_cap = (uint32_t)heap.size() - 16; A.node_cap = (uint32_t)nodes.size(); A.hit_ops_cap = (uint32_t)hit_ops.size();
+            ReadIn rd{qc.data(), dnear.data(), L, P.reject_thr[L]};
             search_read(ix, P, rd, A, st, 0);
             if (st.status != ST_ARENA_OVERFLOW) break;
             if (pass == 0) second += 1;

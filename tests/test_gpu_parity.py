@@ -114,7 +114,10 @@ def test_empty_and_edge_batches():
     r = ctx.map_batch(np.zeros(0, np.uint8), np.zeros(0, np.uint8), np.zeros(1, np.uint64))
     assert r.n_reads == 0 and r.n_hits == 0
     # ragged: a 1-base read, a read of N's, a read shorter than the 17 bp minimum of the Discrete bound
-    reads = [b"A", b"NNNNNNNNNNNNNNNNNNNNNNNNN", g[1000:1016].tobytes(), g[2000:2050].tobytes()]
+    long_read = g[5000:5300].copy()
+    long_read[[10, 150, 290]] = ord("A")
+    reads = [b"A", b"NNNNNNNNNNNNNNNNNNNNNNNNN", g[1000:1016].tobytes(), g[2000:2050].tobytes(), long_read.tobytes(), g[7000:8000].tobytes(),
+             synth.revcomp(g[9000:9130]).tobytes()]
     offsets = np.zeros(len(reads) + 1, dtype=np.uint64)
     offsets[1:] = np.cumsum([len(r) for r in reads])
     seqs = np.frombuffer(b"".join(reads), dtype=np.uint8)

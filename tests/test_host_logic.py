@@ -242,6 +242,25 @@ def test_kernel_logic_second_pass_and_limit_recovery():
             assert (res.status == 2).any()
 
 
+def test_kernel_logic_long_and_degenerate_reads():
+    g = synth.genome(50_000, seed=3)
+    long_read = g[5000:5300].copy()
+    long_read[[10, 150, 290]] = ord("A")
+    reads = [b"A", b"NNNNNNNNNNNNNNNNNNNNNNNNN", g[1000:1016].tobytes(), g[2000:2050].tobytes(), long_read.tobytes(), g[7000:8000].tobytes(),
+             synth.revcomp(g[9000:9130]).tobytes()]
+    offsets = np.zeros(len(reads) + 1, dtype=np.uint64)
+    offsets[1:] = np.cumsum([len(r) for r in reads])
+    seqs = np.frombuffer(b"".join(reads), dtype=np.uint8)
+    quals = np.full(len(seqs), 40, np.uint8)
+    pidx = mapad_amd.Index.build([("chr1", g)])
+    rp = resolve_params(NO_DAMAGE)
+    res = emu_util.map_batch(pidx, mapad_amd.make_params(rp), seqs, quals, offsets)
+    oidx = ob.OracleIndex.from_bwt(pidx.bwt(), "$ACGTX", 128)
+    ores = oidx.map_batch(ob.make_params(rp), reads, [quals[int(offsets[i]):int(offsets[i + 1])] for i in range(len(reads))], keep_d=True)
+    assert_same_as_oracle(ores, res, offsets)
+    assert [len(res.hits(i)) for i in range(len(reads))][3:] == [1, 1, 1, 1]
+
+
 # ---- post-search ----------------------------------------------------------------------------------------------------------
 def check_integration_records(k, recs):
     """shared_expectation of tests/integration_tests.rs:464-868 on decoded record fields."""
