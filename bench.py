@@ -172,7 +172,7 @@ def main():
                 "algorithmic_bytes_per_launch": dom_bytes, "kernel_ms": round(float(dom_ms), 4),
                 "all_kernels": {"darray_kernel": {"ms": round(float(ms_darray), 4), "bytes": bytes_darray, "GB/s": round(bytes_darray / (ms_darray * 1e-3) / 1e9, 2)},
                                 "search_kernel": {"ms": round(float(ms_search), 4), "bytes": bytes_search, "GB/s": round(bytes_search / (ms_search * 1e-3) / 1e9, 2)},
-                                "search_kernel_tiers_1_2": {"ms": round(float(ms_pass2), 4), "reads_tier1": res.n_second_pass, "reads_tier2": res.n_third_pass}},
+                                "search_kernel_last_pass": {"ms": round(float(ms_pass2), 4), "arena_migrations": res.n_second_pass, "reads": res.n_third_pass}},
                 "whole_step_GB/s": round((bytes_darray + bytes_search) / ((ms_darray + ms_search + ms_pass2) * 1e-3) / 1e9, 2),
                 "events": {"E_search": e_search, "E_darray": e_darray, "N_push": n_push, "N_pop": n_pop, "N_node": n_node}}
 

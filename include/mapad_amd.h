@@ -145,8 +145,8 @@ typedef struct mapad_batch_result {
     const uint32_t* status;                /* per read: 0 ok, 2 stopped by --no_search_limit_recovery */
     const mapad_read_counters_t* counters; /* per read */
     const float* d_arrays;                 /* concatenated BiDArray::d_composite, same offsets as the reads (debug/parity) */
-    uint64_t n_second_pass;                /* reads that outgrew the small per-quad arena and were re-run in the medium tier */
-    uint64_t n_third_pass;                 /* ... and in the tier that holds the reference's full STACK_LIMIT / EDIT_TREE_LIMIT */
+    uint64_t n_second_pass;                /* arena migrations: times a read slot outgrew its arena and moved into a larger size class */
+    uint64_t n_third_pass;                 /* reads re-run by the pass that holds the reference's full STACK_LIMIT / EDIT_TREE_LIMIT */
 } mapad_batch_result_t;
 
 /* k_mismatch_search over a chunk of reads (host buffers): seqs/quals concatenated, read i = [offsets[i], offsets[i+1]).

@@ -35,10 +35,13 @@ using namespace mapad;
 namespace {
 
 enum : uint32_t { ST_POOL_OVERFLOW = 4, ST_NO_TABLE = 8 };
-constexpr int kTiers = 3;  // arena tiers: small / medium / the reference's full limits
-// cursors: global bump allocators and work counters; per tier t: CUR_WORK + 2t = next work item, CUR_OVF + 2t = reads tier t handed on
-enum { CUR_HITS = 0, CUR_OPS = 1, CUR_POOL_OVF = 2, CUR_ERR = 3, CUR_WORK = 4, CUR_OVF = 5, CUR_DONE = 4 + 2 * kTiers, CUR_COUNT = 4 + 2 * kTiers + 4 };
-enum : uint32_t { ST_SPIN_TIMEOUT = 16 };
+// Two passes over a batch: pass 0 maps every read from a small per-slot arena that GROWS on demand (size classes below, the grown
+// arena stays with the slot); pass 1 re-runs, with the reference's full limits, the few reads pass 0 could not finish because a
+// size-class pool ran dry.
+constexpr int kTiers = 2;
+constexpr int kClasses = 5;  // grown arenas: 4x steps above the base arena
+// cursors: global bump allocators and work counters; per pass t: CUR_WORK + 2t = next work item, CUR_OVF + 2t = reads pass t handed on
+enum { CUR_HITS = 0, CUR_OPS = 1, CUR_POOL_OVF = 2, CUR_ERR = 3, CUR_WORK = 4, CUR_OVF = 5, CUR_GROWN = 4 + 2 * kTiers, CUR_COUNT = 4 + 2 * kTiers + 4 };
 
 struct BatchDev {
     const uint8_t* seqs;
@@ -54,7 +57,7 @@ struct BatchDev {
     uint32_t* ops_pool;
     uint32_t hits_cap, ops_cap;
     uint32_t* cursors;
-    uint32_t* overflow_list;  // [kTiers][n_reads]: read ids tier t could not finish in its arena
+    uint32_t* overflow_list;  // [kTiers][n_reads]: read ids (+1) pass t could not finish
 };
 
 struct ArenaPool {
@@ -63,6 +66,17 @@ struct ArenaPool {
     uint64_t off_nodes, off_hits, off_hit_ops, off_scratch, off_near;  // off_near: HBM stand-in for the LDS-resident data (long reads)
     uint32_t heap_cap, node_cap, hit_ops_cap;
 };
+
+// Size-class pools of grown arenas (heap + nodes only; hit staging stays in the slot's base arena).  A read that outgrows its
+// arena acquires a free arena of the next class (CAS on its owner word), migrates its heap and nodes, and gives the arena back when
+// the read is finished.  The descriptor lives in HBM (only the rare grow path reads it).
+struct GrowPools {
+    uint8_t* base[kClasses];
+    uint32_t* owner[kClasses];  // [count] 0 = free
+    uint64_t stride[kClasses], off_nodes[kClasses];
+    uint32_t heap_cap[kClasses], node_cap[kClasses], count[kClasses];
+};
+constexpr uint32_t kGrownShift = 27;
 
 template <bool NL>
 __device__ __forceinline__ ArenaT<NL> carve(const ArenaPool& ap, uint32_t slot) {
@@ -133,12 +147,10 @@ __device__ __forceinline__ uint32_t group_bcast(uint32_t v) { return LPR == 4 ? 
 
 template <int LPR, bool NL>
 __device__ MAPAD_FINALIZE_ATTR void finalize_read(const BatchDev B, const ArenaT<NL> A, const SearchState st, uint32_t read, int w, int tier) {
-    if (st.status == ST_ARENA_OVERFLOW && tier + 1 < kTiers) {  // hand the read to the next (larger) arena tier
+    if (st.status == ST_ARENA_OVERFLOW && tier + 1 < kTiers) {  // hand the read to the full-limit pass
         if (w == 0) {
             const uint32_t k = atomicAdd(&B.cursors[CUR_OVF + 2 * tier], 1u);
-            // nothing else is written for this read here: its result words belong to whichever tier finishes it (a consumer on
-            // another XCD may already be writing them)
-            __hip_atomic_store(B.overflow_list + (size_t)tier * B.n_reads + k, read + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            B.overflow_list[(size_t)tier * B.n_reads + k] = read + 1u;  // consumed by the next launch
         }
         return;
     }
@@ -165,81 +177,90 @@ __device__ MAPAD_FINALIZE_ATTR void finalize_read(const BatchDev B, const ArenaT
     }
 }
 
-// One launch serves up to two arena tiers:
-//   blocks [0, blocks_a)      role A: tier `tier_a` workers on pool APa.  Work items are all reads (tier 0) or the overflow list
-//                                     the previous tier left behind.
-//   blocks [blocks_a, grid)   role B: tier `tier_a + 1` workers on pool APb that consume, while role A is still running, the
-//                                     reads role A hands on (those that outgrow the small arenas are the long-running tail of
-//                                     the batch, so they start early instead of after the whole first pass).
-// Hand-off: a producer publishes `read + 1` with one agent-scope store into overflow_list[tier_a][k] (k from an atomic
-// counter; the list is zeroed before the launch); a consumer claims k with an atomic and polls that single word.  The data
-// word is its own flag, so no fence is needed.  Consumers leave when every role-A wavefront has exited and their claimed
-// slot is beyond the final count.
-// PASS only names the symbol (0 = the launch that sees every read, 1 = later arena tiers) so that profiles list them separately.
+// grow(A, st): called by check_and_push when the heap or the node slab is full (search_core.hpp).  All lanes of the read's lane
+// group call it together with identical arguments.  Arenas change owners inside a launch and the L2s of the eight XCDs are not
+// coherent with each other for ordinary stores, hence the agent-scope fences around acquire and release.
+template <int LPR>
+__device__ __forceinline__ void release_grown(const GrowPools* gp, uint32_t grown, int w) {
+    __threadfence();  // every access to the arena has completed and is written back before another slot may take it
+    if (w == 0) atomicExch(&gp->owner[(grown >> kGrownShift) - 1][grown & ((1u << kGrownShift) - 1)], 0u);
+}
+
+template <int LPR, bool NL>
+struct DeviceGrow {
+    const GrowPools* gp;
+    uint32_t* grown_counter;
+    uint32_t slot;
+    int w;
+    __device__ __forceinline__ bool operator()(ArenaT<NL>& A, const SearchState& st) const {
+        const uint32_t cls = A.grown >> kGrownShift;  // class to move into (0 = from the base arena)
+        if (cls >= (uint32_t)kClasses) return false;
+        uint32_t idx = ~0u;
+        if (w == 0) {
+            const uint32_t n = gp->count[cls];
+            if (n) {
+                uint32_t i = (uint32_t)(((uint64_t)slot * 2654435761u) % n);
+                const uint32_t tries = n < 256u ? n : 256u;
+                uint32_t* own = gp->owner[cls];
+                for (uint32_t t = 0; t < tries; ++t) {
+                    if (atomicCAS(&own[i], 0u, 1u) == 0u) { idx = i; break; }
+                    if (++i == n) i = 0;
+                }
+            }
+        }
+        idx = group_bcast<LPR>(idx);
+        if (idx == ~0u) return false;  // pool dry: the read goes to the full-limit pass
+        __threadfence();
+        uint8_t* b = gp->base[cls] + (uint64_t)idx * gp->stride[cls];
+        HeapEntry* nheap = reinterpret_cast<HeapEntry*>(b) + 1;
+        Node* nnodes = reinterpret_cast<Node*>(b + gp->off_nodes[cls]);
+        // migrate heap slots [kTop, heap_len) (the top of the heap lives in the near array) and nodes [0, tree_entries)
+        for (uint32_t i = kTop + w; i < st.heap_len; i += LPR) nheap[i] = A.heap[i];
+        const uint4* ns = reinterpret_cast<const uint4*>(A.nodes);
+        uint4* nd = reinterpret_cast<uint4*>(nnodes);
+        for (uint32_t i = w; i < 2 * st.tree_entries; i += LPR) nd[i] = ns[i];
+        if (A.grown) release_grown<LPR>(gp, A.grown, w);
+        A.heap = nheap; A.nodes = nnodes; A.heap_cap = gp->heap_cap[cls]; A.node_cap = gp->node_cap[cls];
+        A.grown = ((cls + 1) << kGrownShift) | idx;
+        if (w == 0) atomicAdd(grown_counter, 1u);
+        return true;
+    }
+};
+
+// PASS 0: every read, growable arenas.  PASS 1: the reads pass 0 handed on, arenas with the reference's full limits.
 // NL: the near data (heap top, position data) of every read slot is in LDS and addressed with ds_* instructions; otherwise it
 // lives in the slot's HBM arena (reads longer than kMaxLdsReadLen, lanes-per-read 1).
 template <int LPR, bool CONT, int PASS, bool NL>
-__global__ void __launch_bounds__(64, 4) search_kernel(DevIndex ix, DevParams P, BatchDev B, ArenaPool APa, ArenaPool APb, int tier_a, uint32_t blocks_a,
-                                                        uint32_t near_stride, uint32_t near_lmax) {
+__global__ void __launch_bounds__(64, 4) search_kernel(DevIndex ix, DevParams P, BatchDev B, ArenaPool AP, const GrowPools* GP, uint32_t near_stride, uint32_t near_lmax) {
     const int lane = threadIdx.x & 63, w = lane & (LPR - 1);
-    const bool role_b = blockIdx.x >= blocks_a;
-    const int tier = role_b ? tier_a + 1 : tier_a;
-    const uint32_t slot = (role_b ? blockIdx.x - blocks_a : blockIdx.x) * (64 / LPR) + (lane / LPR);
-    ArenaT<NL> A = carve<NL>(role_b ? APb : APa, slot);
+    constexpr int tier = PASS;
+    const uint32_t slot = blockIdx.x * (64 / LPR) + (lane / LPR);
+    ArenaT<NL> A = carve<NL>(AP, slot);
     // near data of this read slot: [32 heap slots][2*lmax bytes class/quality][lmax floats D]
     extern __shared__ __attribute__((aligned(16))) uint8_t near_lds[];
     using NearBytes = typename near_ptr<uint8_t, NL>::type;
     NearBytes near;
     if constexpr (NL) near = (NearBytes)near_lds + (size_t)(lane / LPR) * near_stride;
-    else near = (role_b ? APb : APa).base + (uint64_t)slot * (role_b ? APb : APa).stride + (role_b ? APb : APa).off_near;
+    else near = AP.base + (uint64_t)slot * AP.stride + AP.off_near;
     A.top = (typename near_ptr<HeapEntry, NL>::type)near + 1;
     const NearBytes near_qc = near + 32 * sizeof(HeapEntry);
     const typename near_ptr<float, NL>::type near_d = (typename near_ptr<float, NL>::type)(near_qc + ((2 * near_lmax + 15) & ~15u));
-    const uint32_t n_items = tier == 0 ? B.n_reads : B.cursors[CUR_OVF + 2 * (tier - 1)];  // role B re-reads the live counter below
+    const uint32_t n_items = tier == 0 ? B.n_reads : B.cursors[CUR_OVF + 2 * (tier - 1)];
     uint32_t* work = &B.cursors[CUR_WORK + 2 * tier];
-    uint32_t* items = B.overflow_list + (size_t)(tier > 0 ? tier - 1 : 0) * B.n_reads;
-    if (role_b) __builtin_amdgcn_s_setprio(3);  // the hand-me-down reads are the long tail of the batch: let them issue first
+    const uint32_t* items = B.overflow_list + (size_t)(tier > 0 ? tier - 1 : 0) * B.n_reads;
+    const DeviceGrow<LPR, NL> grow{GP, &B.cursors[CUR_GROWN], slot, w};
     bool have = false, done = false;
-    bool claimed = false;
-    uint32_t claim = 0, idle = 0;
     ReadInT<NL> rd{near_qc, near_d, 0, 0.0f};
     SearchState st;
     uint32_t read = 0;
     for (;;) {
         if (!have && !done) {
-            bool got = false;
-            if (!role_b) {
-                uint32_t item = 0;
-                if (w == 0) item = atomicAdd(work, 1u);
-                item = group_bcast<LPR>(item);
-                if (item >= n_items) done = true;
-                else { read = tier == 0 ? item : __hip_atomic_load(items + item, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - 1u; got = true; }
-            } else {
-                if (!claimed) {
-                    if (w == 0) claim = atomicAdd(work, 1u);
-                    claim = group_bcast<LPR>(claim);
-                    claimed = true;
-                    idle = 0;
-                }
-                // a tier hands on at most n_reads reads: a claim beyond that can never be served (and must not index the list)
-                const bool poll_now = claim < B.n_reads && (!__any(have) || (idle & 15u) == 0);  // working neighbours: poll 1 in 16 iterations
-                const uint32_t v = poll_now ? __hip_atomic_load(items + claim, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
-                if (claim >= B.n_reads) done = true;
-                else if (v != 0) { read = v - 1u; got = true; claimed = false; }
-                else if (!poll_now) ++idle;
-                else {
-                    const uint32_t finished = __hip_atomic_load(&B.cursors[CUR_DONE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (finished >= blocks_a) {  // no more producers: the count is final
-                        const uint32_t total = __hip_atomic_load(&B.cursors[CUR_OVF + 2 * tier_a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        if (claim >= total) done = true;
-                    }
-                    if (!done && ++idle > (1u << 22)) {  // bounded spin: never hang the GPU
-                        if (w == 0) atomicOr(&B.cursors[CUR_ERR], ST_SPIN_TIMEOUT);
-                        done = true;
-                    }
-                }
-            }
-            if (got) {
+            uint32_t item = 0;
+            if (w == 0) item = atomicAdd(work, 1u);
+            item = group_bcast<LPR>(item);
+            if (item >= n_items) done = true;
+            else {
+                read = tier == 0 ? item : items[item] - 1u;
                 const uint64_t off = B.offsets[read];
                 rd.L = (int)(B.offsets[read + 1] - off);
                 rd.thr = P.reject_thr[rd.L];
@@ -255,15 +276,21 @@ __global__ void __launch_bounds__(64, 4) search_kernel(DevIndex ix, DevParams P,
             }
         }
         if (__all(done)) break;
-        if (!__any(have)) __builtin_amdgcn_s_sleep(32);  // a whole wavefront of idle consumers: back off
         if (have) {
-            if (!search_step<LPR, CONT, NL>(ix, P, rd, A, st, w)) {
+            bool cont;
+            if constexpr (PASS == 0) cont = search_step<LPR, CONT, NL>(ix, P, rd, A, st, w, grow);
+            else cont = search_step<LPR, CONT, NL>(ix, P, rd, A, st, w, NoGrow());
+            if (!cont) {
                 finalize_read<LPR, NL>(B, A, st, read, w, tier);
+                if (PASS == 0 && A.grown) {  // give the grown arena back; the next read starts in the base arena again
+                    release_grown<LPR>(GP, A.grown, w);
+                    const ArenaT<NL> base = carve<NL>(AP, slot);
+                    A.heap = base.heap; A.nodes = base.nodes; A.heap_cap = base.heap_cap; A.node_cap = base.node_cap; A.grown = 0;
+                }
                 have = false;
             }
         }
     }
-    if (!role_b && lane == 0) atomicAdd(&B.cursors[CUR_DONE], 1u);
 }
 
 }  // namespace
@@ -345,7 +372,11 @@ struct mapad_ctx {
     DevBuf<HitRec> d_hits;
     DevBuf<uint8_t> d_arena[kTiers];
     ArenaPool pool[kTiers] = {};
-    uint32_t slots[kTiers] = {0, 0, 0}, arena_lmax = 0;
+    uint32_t slots[kTiers] = {0, 0}, arena_lmax = 0;
+    DevBuf<uint8_t> d_class[kClasses];
+    DevBuf<uint32_t> d_owner[kClasses];
+    DevBuf<GrowPools> d_grow;
+    GrowPools grow{};
     int lpr = 4;  // lanes per read in the search kernel (MAPAD_LANES_PER_READ = 4 | 1)
     int n_cu = 256;
     // last batch
@@ -364,6 +395,9 @@ struct mapad_ctx {
         d_darr.release(); d_counters.release(); d_status.release(); d_hit_count.release(); d_hit_first.release(); d_ops.release();
         d_cursors.release(); d_overflow.release(); d_hits.release();
         for (auto& a : d_arena) a.release();
+        for (auto& a : d_class) a.release();
+        for (auto& a : d_owner) a.release();
+        d_grow.release();
         for (auto& e : ev) if (e) (void)hipEventDestroy(e);
     }
 };
@@ -399,28 +433,54 @@ uint32_t env_u32(const char* name, uint32_t dflt) {
     return e && e[0] ? (uint32_t)std::strtoul(e, nullptr, 10) : dflt;
 }
 
-// Three arena tiers (per quad): tier 0 small and plentiful, tier 1 medium, tier 2 = the reference's full limits
-// (STACK_LIMIT + 9 frames, EDIT_TREE_LIMIT + 9 nodes: mapping.rs:52-54,147-148).  A read that outgrows its tier's arena is
-// re-run from scratch by the next tier; semantic limits (stack_limit / edit_tree_limit) are the same in every tier.
+// Pass 0: one base arena per read slot (MAPAD_TIER0_NODES nodes) plus size-class pools the slots grow into (x4 per class).
+// Pass 1: arenas with the reference's full limits (STACK_LIMIT + 9 frames, EDIT_TREE_LIMIT + 9 nodes: mapping.rs:52-54,147-148) for
+// the reads pass 0 could not finish (a size-class pool ran dry).  Semantic limits are the same everywhere.
 int ensure_arenas(mapad_ctx* c, uint32_t lmax) {
     if (c->d_arena[0].p && lmax <= c->arena_lmax) return MAPAD_OK;
     c->lpr = env_u32("MAPAD_LANES_PER_READ", 4) == 1 ? 1 : 4;
     const uint32_t lm = std::max<uint32_t>(lmax, 128);
-    const uint32_t stack_limit = c->dprm.stack_limit, tree_limit = c->dprm.edit_tree_limit;
+    const uint64_t stack_cap = (uint64_t)c->dprm.stack_limit + 10, tree_cap = (uint64_t)c->dprm.edit_tree_limit + 10;
     const uint32_t hit_ops_cap = kMaxHits * (lm + 32);
-    const uint32_t nodes[kTiers] = {env_u32("MAPAD_TIER0_NODES", 4096), env_u32("MAPAD_TIER1_NODES", 65536), 0xFFFFFFFFu};
-    // wavefronts per tier: tier 0 fills the chip; tiers 1 and 2 keep the same number of read slots for either lanes-per-read setting
-    const uint32_t waves[kTiers] = {env_u32("MAPAD_TIER0_WAVES_PER_CU", c->lpr == 4 ? 16 : 8) * (uint32_t)c->n_cu,
-                                    env_u32("MAPAD_TIER1_WAVES", (uint32_t)c->n_cu * 4 * c->lpr / 4), env_u32("MAPAD_TIER2_WAVES", c->lpr == 4 ? 4 : 1)};
-    for (int t = 0; t < kTiers; ++t) {
-        const uint32_t node_cap = std::min<uint64_t>(nodes[t], (uint64_t)tree_limit + 10);
-        const uint32_t heap_cap = std::min<uint64_t>(nodes[t], (uint64_t)stack_limit + 10);
-        c->pool[t] = make_pool_layout(heap_cap, node_cap, hit_ops_cap, lm);
-        c->slots[t] = std::max<uint32_t>(waves[t], 1) * (64 / c->lpr);
-        int rc;
-        if ((rc = c->d_arena[t].ensure((size_t)c->slots[t] * c->pool[t].stride))) return rc;
-        c->pool[t].base = c->d_arena[t].p;
+    const uint32_t rpw = 64 / c->lpr;
+    int rc;
+    {   // pass 0 base arenas
+        const uint32_t nodes = env_u32("MAPAD_TIER0_NODES", 4096);
+        c->pool[0] = make_pool_layout((uint32_t)std::min<uint64_t>(nodes, stack_cap), (uint32_t)std::min<uint64_t>(nodes, tree_cap), hit_ops_cap, lm);
+        c->slots[0] = env_u32("MAPAD_TIER0_WAVES_PER_CU", c->lpr == 4 ? 16 : 8) * (uint32_t)c->n_cu * rpw;
+        if ((rc = c->d_arena[0].ensure((size_t)c->slots[0] * c->pool[0].stride))) return rc;
+        c->pool[0].base = c->d_arena[0].p;
     }
+    {   // pass 1: full limits
+        c->pool[1] = make_pool_layout((uint32_t)stack_cap, (uint32_t)tree_cap, hit_ops_cap, lm);
+        c->slots[1] = std::max<uint32_t>(env_u32("MAPAD_LAST_PASS_WAVES", c->lpr == 4 ? 2 : 1), 1) * rpw;
+        if ((rc = c->d_arena[1].ensure((size_t)c->slots[1] * c->pool[1].stride))) return rc;
+        c->pool[1].base = c->d_arena[1].p;
+    }
+    // size classes
+    static const char* kCountEnv[kClasses] = {"MAPAD_CLASS0_COUNT", "MAPAD_CLASS1_COUNT", "MAPAD_CLASS2_COUNT", "MAPAD_CLASS3_COUNT", "MAPAD_CLASS4_COUNT"};
+    const uint32_t dflt_count[kClasses] = {32768, 8192, 1024, 128, 32};
+    uint64_t nodes = (uint64_t)c->pool[0].node_cap;
+    GrowPools& g = c->grow;
+    for (int k = 0; k < kClasses; ++k) {
+        nodes = nodes * 4;
+        g.heap_cap[k] = (uint32_t)std::min<uint64_t>(nodes, stack_cap);
+        g.node_cap[k] = (uint32_t)std::min<uint64_t>(nodes, tree_cap);
+        auto align = [](uint64_t x) { return (x + 127) & ~127ull; };
+        g.off_nodes[k] = align(((uint64_t)g.heap_cap[k] + 16) * sizeof(HeapEntry));
+        g.stride[k] = align(g.off_nodes[k] + (uint64_t)g.node_cap[k] * sizeof(Node));
+        // a class that is no bigger than the previous one (tiny semantic limits) is pointless: give it no arenas
+        const bool useful = g.node_cap[k] > (k ? g.node_cap[k - 1] : c->pool[0].node_cap) || g.heap_cap[k] > (k ? g.heap_cap[k - 1] : c->pool[0].heap_cap);
+        g.count[k] = useful ? std::min<uint32_t>(env_u32(kCountEnv[k], dflt_count[k]), (1u << kGrownShift) - 1) : 0;
+        if ((rc = c->d_class[k].ensure(std::max<size_t>((size_t)g.count[k] * g.stride[k], 128)))) return rc;
+        if ((rc = c->d_owner[k].ensure(std::max<size_t>(g.count[k], 1)))) return rc;
+        HIP_TRY(hipMemsetAsync(c->d_owner[k].p, 0, std::max<size_t>(g.count[k], 1) * 4, c->stream));
+        g.base[k] = c->d_class[k].p;
+        g.owner[k] = c->d_owner[k].p;
+    }
+    if ((rc = c->d_grow.ensure(1))) return rc;
+    HIP_TRY(hipMemcpyAsync(c->d_grow.p, &c->grow, sizeof(GrowPools), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
     c->arena_lmax = lm;
     return MAPAD_OK;
 }
@@ -444,7 +504,6 @@ int launch_batch(mapad_ctx* c, const uint8_t* d_seqs, const uint8_t* d_quals, co
     if ((rc = c->d_ops.ensure(ops_cap))) return rc;
     HIP_TRY(hipMemsetAsync(c->d_cursors.p, 0, CUR_COUNT * 4, c->stream));
     HIP_TRY(hipMemsetAsync(c->d_status.p, 0, nr * 4, c->stream));
-    HIP_TRY(hipMemsetAsync(c->d_overflow.p, 0, nr * kTiers * 4, c->stream));  // hand-off words: 0 = not yet published
     BatchDev B{};
     B.seqs = d_seqs; B.quals = d_quals; B.offsets = d_offsets; B.n_reads = (uint32_t)n_reads;
     B.d_arrays = c->d_darr.p; B.counters = c->d_counters.p; B.status = c->d_status.p;
@@ -463,40 +522,32 @@ int launch_batch(mapad_ctx* c, const uint8_t* d_seqs, const uint8_t* d_quals, co
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(c->ev[1], c->stream));
     const uint32_t rpw = 64 / c->lpr;  // reads per wavefront
-    auto launch_search = [&](uint32_t blocks_a, uint32_t blocks_b, const ArenaPool& apa, const ArenaPool& apb, int tier_a) {
-        const bool cont = c->dprm.bound_kind == BOUND_CONTINUOUS;
-        const dim3 grid(blocks_a + blocks_b), block(64);
-        // near data in LDS (16 or 64 read slots per wavefront) unless the batch has very long reads
-        const uint32_t near_lmax = std::max<uint32_t>(lmax, 1);
-        const uint32_t near_stride = (c->lpr == 4 && near_lmax <= kMaxLdsReadLen && env_u32("MAPAD_NEAR_LDS", 1)) ? near_bytes(near_lmax) : 0;
-        const size_t lds = (size_t)near_stride * rpw;
-#define MAPAD_LAUNCH(L, C, P, N) hipLaunchKernelGGL((search_kernel<L, C, P, N>), grid, block, lds, c->stream, c->dix, c->dprm, B, apa, apb, tier_a, blocks_a, near_stride, near_lmax)
+    // near data in LDS (16 read slots per wavefront) unless the batch has very long reads or every lane owns a read
+    const uint32_t near_lmax = std::max<uint32_t>(lmax, 1);
+    const uint32_t near_stride = (c->lpr == 4 && near_lmax <= kMaxLdsReadLen && env_u32("MAPAD_NEAR_LDS", 1)) ? near_bytes(near_lmax) : 0;
+    const size_t lds = (size_t)near_stride * rpw;
+    const bool cont = c->dprm.bound_kind == BOUND_CONTINUOUS;
+#define MAPAD_LAUNCH(L, C, P, N) hipLaunchKernelGGL((search_kernel<L, C, P, N>), dim3(grid), dim3(64), lds, c->stream, c->dix, c->dprm, B, ap, c->d_grow.p, near_stride, near_lmax)
 #define MAPAD_LAUNCH_PASS(P)                                                                                      \
-        if (c->lpr == 4 && near_stride) { if (!cont) MAPAD_LAUNCH(4, false, P, true); else MAPAD_LAUNCH(4, true, P, true); }   \
-        else if (c->lpr == 4) { if (!cont) MAPAD_LAUNCH(4, false, P, false); else MAPAD_LAUNCH(4, true, P, false); }          \
-        else { if (!cont) MAPAD_LAUNCH(1, false, P, false); else MAPAD_LAUNCH(1, true, P, false); }
-        if (tier_a == 0) { MAPAD_LAUNCH_PASS(0) } else { MAPAD_LAUNCH_PASS(1) }
-#undef MAPAD_LAUNCH_PASS
-#undef MAPAD_LAUNCH
-    };
-    // launch 1: tier 0 over all reads.  MAPAD_FUSE_TIERS=1 lets tier-1 consumers ride along (role B).  Measured on MI355X
-    // (C2, 1 M reads): the fused launch takes 621 ms vs 281 + 189 ms for two launches — the hand-me-down reads are
-    // latency-bound and run ~3x slower per pop next to a chip full of tier-0 wavefronts — so two launches are the default.
+    if (c->lpr == 4 && near_stride) { if (!cont) MAPAD_LAUNCH(4, false, P, true); else MAPAD_LAUNCH(4, true, P, true); }   \
+    else if (c->lpr == 4) { if (!cont) MAPAD_LAUNCH(4, false, P, false); else MAPAD_LAUNCH(4, true, P, false); }          \
+    else { if (!cont) MAPAD_LAUNCH(1, false, P, false); else MAPAD_LAUNCH(1, true, P, false); }
     const uint32_t grid_s = (uint32_t)std::min<uint64_t>((n_reads + rpw - 1) / rpw, c->slots[0] / rpw);
-    const uint32_t grid_1 = (uint32_t)std::min<uint64_t>((n_reads + rpw - 1) / rpw, c->slots[1] / rpw);
-    const bool fuse = env_u32("MAPAD_FUSE_TIERS", 0) != 0;
-    launch_search(grid_s, fuse ? grid_1 : 0, c->pool[0], c->pool[1], 0);
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipEventRecord(c->ev[2], c->stream));
-    if (!fuse) {
-        HIP_TRY(hipMemsetAsync(c->d_cursors.p + CUR_DONE, 0, 4, c->stream));
-        launch_search(grid_1, 0, c->pool[1], c->pool[1], 1);
+    {   // pass 0: every read, growable arenas
+        const uint32_t grid = grid_s;
+        const ArenaPool& ap = c->pool[0];
+        MAPAD_LAUNCH_PASS(0)
         HIP_TRY(hipGetLastError());
     }
-    // launch 2: the tier that holds the reference's full limits, for whatever is left
-    HIP_TRY(hipMemsetAsync(c->d_cursors.p + CUR_DONE, 0, 4, c->stream));
-    launch_search((uint32_t)std::min<uint64_t>((n_reads + rpw - 1) / rpw, c->slots[2] / rpw), 0, c->pool[2], c->pool[2], 2);
-    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(c->ev[2], c->stream));
+    {   // pass 1: leftovers with the reference's full limits
+        const uint32_t grid = (uint32_t)std::min<uint64_t>((n_reads + rpw - 1) / rpw, c->slots[1] / rpw);
+        const ArenaPool& ap = c->pool[1];
+        MAPAD_LAUNCH_PASS(1)
+        HIP_TRY(hipGetLastError());
+    }
+#undef MAPAD_LAUNCH_PASS
+#undef MAPAD_LAUNCH
     HIP_TRY(hipEventRecord(c->ev[3], c->stream));
     c->ev_valid = true;
     c->launch_info[0] = grid_d; c->launch_info[1] = 64; c->launch_info[2] = (uint32_t)lds_bytes;
@@ -685,7 +736,6 @@ int mapad_fetch_result(mapad_ctx_t* ctx, mapad_batch_result_t** out) {
     uint32_t cur[CUR_COUNT] = {0};
     if (n) HIP_TRY(hipMemcpy(cur, B.cursors, sizeof cur, hipMemcpyDeviceToHost));
     if (cur[CUR_ERR] & ST_NO_TABLE) { std::fprintf(stderr, "mapad_amd: a read length had no score table (call mapad_ctx_prepare_lengths)\n"); return MAPAD_ERR_INVALID; }
-    if (cur[CUR_ERR] & ST_SPIN_TIMEOUT) { std::fprintf(stderr, "mapad_amd: tier hand-off timed out\n"); return MAPAD_ERR_DEVICE; }
     if (cur[CUR_ERR] & ST_ARENA_OVERFLOW) { std::fprintf(stderr, "mapad_amd: arena overflow in the large-arena pass\n"); return MAPAD_ERR_NOMEM; }
     if (cur[CUR_POOL_OVF]) return MAPAD_ERR_NOMEM;  // mapad_map_batch retries with larger pools
     std::vector<uint32_t> cnt(n), first(n);
@@ -722,8 +772,8 @@ int mapad_fetch_result(mapad_ctx_t* ctx, mapad_batch_result_t** out) {
     r->pub.n_reads = n; r->pub.n_hits = r->hits.size(); r->pub.n_ops = r->ops.size();
     r->pub.hit_begin = r->hit_begin.data(); r->pub.hits = r->hits.data(); r->pub.ops = r->ops.data();
     r->pub.status = r->status.data(); r->pub.counters = r->counters.data(); r->pub.d_arrays = ctx->fetch_d ? r->d_arrays.data() : nullptr;
-    r->pub.n_second_pass = cur[CUR_OVF];
-    r->pub.n_third_pass = cur[CUR_OVF + 2];
+    r->pub.n_second_pass = cur[CUR_GROWN];  // arena migrations in pass 0
+    r->pub.n_third_pass = cur[CUR_OVF];    // reads re-run by the full-limit pass
     *out = &r.release()->pub;
     return MAPAD_OK;
 }

@@ -107,6 +107,7 @@ struct ArenaT {
     uint32_t* hit_ops;  // staging for the hits' edit tracks
     uint16_t* scratch;  // 2 * (Lmax + 1) u16 for the bucket sort of extract_edit_operations
     uint32_t heap_cap, node_cap, hit_ops_cap;
+    uint32_t grown = 0;  // 0: heap/nodes are the slot's base arena; else (class + 1) << 27 | arena index (mapad_amd.hip: DeviceGrow)
 };
 
 using Arena = ArenaT<false>;
@@ -362,13 +363,19 @@ MAPAD_RARE void record_hit(const ReadInT<NL> rd, const ArenaT<NL> A, SearchState
     st.ctr.n_hits += 1;
 }
 
+// A full arena asks `grow` for a bigger one before giving up: grow(A, st) migrates heap and nodes into a larger arena and updates
+// A (device: slot-owned arenas from size-class pools, mapad_amd.hip; host emulation: NoGrow).
+struct NoGrow {
+    template <class AR> MAPAD_HD bool operator()(AR&, const SearchState&) const { return false; }
+};
+
 // check_and_push_stack_frame (mapping.rs:932-987)
-template <bool NL>
-MAPAD_HD void check_and_push(const DevParams& P, const ReadInT<NL>& rd, const ArenaT<NL>& A, SearchState& st, int alignment_start, const Frame& c, float score,
-                             uint32_t parent_node, uint32_t op) {
+template <bool NL, class Grow>
+MAPAD_HD void check_and_push(const DevParams& P, const ReadInT<NL>& rd, ArenaT<NL>& A, SearchState& st, int alignment_start, const Frame& c, float score,
+                             uint32_t parent_node, uint32_t op, const Grow& grow) {
     if (st.n_hits > 0 && mb_reject_iterative(P, score, st.best_score)) return;
     if ((int)c.ngaps > P.max_num_gaps_open) return;
-    if (st.tree_next == st.tree_entries && st.tree_entries >= A.node_cap) { st.status = ST_ARENA_OVERFLOW; return; }
+    if (st.tree_next == st.tree_entries && st.tree_entries >= A.node_cap && !(grow(A, st) && st.tree_entries < A.node_cap)) { st.status = ST_ARENA_OVERFLOW; return; }
     const uint32_t id = tree_insert(A.nodes, st, pack_node(op, parent_node, c));
     st.ctr.n_node += 1;
     if (c.len == rd.L) {  // rare: the state takes a round trip through memory only here, so it can live in registers otherwise
@@ -377,7 +384,7 @@ MAPAD_HD void check_and_push(const DevParams& P, const ReadInT<NL>& rd, const Ar
         st = tmp;
         return;
     }
-    if (st.heap_len >= A.heap_cap) { st.status = ST_ARENA_OVERFLOW; return; }
+    if (st.heap_len >= A.heap_cap && !(grow(A, st) && st.heap_len < A.heap_cap)) { st.status = ST_ARENA_OVERFLOW; return; }
     st.heap_len += 1;
     mm_bubble_up(A, st.heap_len - 1, HeapEntry{score, id});
     st.ctr.n_push += 1;
@@ -410,8 +417,8 @@ MAPAD_RARE void search_init(uint64_t n_text, int alignment_start, const ArenaT<N
 }
 
 // One iteration of the `while let Some(stack_frame) = stack.pop_max()` loop.  Returns false when the search is over.
-template <int LPR, bool CONT, bool NL>
-MAPAD_HD bool search_step(const DevIndex& ix, const DevParams& P, const ReadInT<NL>& rd, const ArenaT<NL>& A, SearchState& st, int w) {
+template <int LPR, bool CONT, bool NL, class Grow>
+MAPAD_HD bool search_step(const DevIndex& ix, const DevParams& P, const ReadInT<NL>& rd, ArenaT<NL>& A, SearchState& st, int w, const Grow& grow) {
     if (st.heap_len == 0 || st.status != ST_OK) return false;
     const int L = rd.L;
     const int alignment_start = alignment_start_of(P, L);
@@ -505,7 +512,7 @@ MAPAD_HD bool search_step(const DevIndex& ix, const DevParams& P, const ReadInT<
                 op = (cb == to_class) ? pack_op(OP_MATCH, (uint32_t)j, 0) : pack_op(OP_MISMATCH, (uint32_t)j, c_ascii);
             }
         }
-        check_and_push(P, rd, A, st, alignment_start, c, score, top.node, op);
+        check_and_push(P, rd, A, st, alignment_start, c, score, top.node, op, grow);
     }
     if (st.status != ST_OK) return false;
     // :1348-1355
@@ -522,10 +529,11 @@ MAPAD_HD bool search_step(const DevIndex& ix, const DevParams& P, const ReadInT<
     return st.heap_len > 0;
 }
 
-MAPAD_HD void search_read(const DevIndex& ix, const DevParams& P, const ReadIn& rd, const Arena& A, SearchState& st, int w) {
+template <class Grow = NoGrow>
+MAPAD_HD void search_read(const DevIndex& ix, const DevParams& P, const ReadIn& rd, Arena& A, SearchState& st, int w, const Grow& grow = Grow()) {
     search_init(ix.n, alignment_start_of(P, rd.L), A, st);
-    if (P.bound_kind == BOUND_CONTINUOUS) { while (search_step<1, true, false>(ix, P, rd, A, st, w)) {} }
-    else { while (search_step<1, false, false>(ix, P, rd, A, st, w)) {} }
+    if (P.bound_kind == BOUND_CONTINUOUS) { while (search_step<1, true, false>(ix, P, rd, A, st, w, grow)) {} }
+    else { while (search_step<1, false, false>(ix, P, rd, A, st, w, grow)) {} }
 }
 
 }  // namespace mapad

@@ -58,7 +58,27 @@ mapad_batch_result_t* emu_map_batch(const uint64_t* blocks, uint64_t n_blocks, u
     std::vector<HitRec> hits(kMaxHits);
     std::vector<uint32_t> hit_ops(kMaxHits * (lmax + 32));
     std::vector<uint16_t> scratch(2 * (lmax + 2));
-    uint64_t second = 0;
+    uint64_t second = 0, migrations = 0;
+    // host stand-in for DeviceGrow (mapad_amd.hip): up to two x4 migrations of heap slots [kTop, heap_len) and nodes [0, tree_entries)
+    std::vector<HeapEntry> gheap[2];
+    std::vector<Node> gnodes[2];
+    struct HostGrow {
+        std::vector<HeapEntry>* gheap; std::vector<Node>* gnodes; uint64_t* migrations; uint32_t stack_cap, tree_cap;
+        bool operator()(Arena& A, const SearchState& st) const {
+            const uint32_t cls = A.grown >> 27;
+            if (cls >= 2) return false;
+            const uint32_t hc = std::min<uint64_t>((uint64_t)A.heap_cap * 4, stack_cap), nc = std::min<uint64_t>((uint64_t)A.node_cap * 4, tree_cap);
+            gheap[cls].assign(hc + 16, HeapEntry{});
+            gnodes[cls].assign(nc, Node{});
+            HeapEntry* nheap = gheap[cls].data() + 1;
+            for (uint32_t i = kTop; i < st.heap_len; ++i) nheap[i] = A.heap[i];
+            for (uint32_t i = 0; i < st.tree_entries; ++i) gnodes[cls][i] = A.nodes[i];
+            A.heap = nheap; A.nodes = gnodes[cls].data(); A.heap_cap = hc; A.node_cap = nc; A.grown = ((cls + 1) << 27) | 1u;
+            ++*migrations;
+            return true;
+        }
+    };
+    const HostGrow grow{gheap, gnodes, &migrations, P.stack_limit + 10, P.edit_tree_limit + 10};
     for (uint64_t i = 0; i < n_reads; ++i) {
         const uint64_t off = offsets[i];
         const int L = (int)(offsets[i + 1] - off);
@@ -76,7 +96,8 @@ mapad_batch_result_t* emu_map_batch(const uint64_t* blocks, uint64_t n_blocks, u
             A.top = top.data() + 1; A.heap = heap.data() + 1; A.nodes = nodes.data(); A.hits = hits.data(); A.hit_ops = hit_ops.data(); A.scratch = scratch.data();
             A.heap_cap = (uint32_t)heap.size() - 16; A.node_cap = (uint32_t)nodes.size(); A.hit_ops_cap = (uint32_t)hit_ops.size();
             ReadIn rd{qc.data(), dnear.data(), L, P.reject_thr[L]};
-            search_read(ix, P, rd, A, st, 0);
+            if (pass == 0) search_read(ix, P, rd, A, st, 0, grow);
+            else search_read(ix, P, rd, A, st, 0);
             if (st.status != ST_ARENA_OVERFLOW) break;
             if (pass == 0) second += 1;
         }
@@ -93,7 +114,7 @@ mapad_batch_result_t* emu_map_batch(const uint64_t* blocks, uint64_t n_blocks, u
     }
     r->pub.n_reads = n_reads; r->pub.n_hits = r->hits.size(); r->pub.n_ops = r->ops.size();
     r->pub.hit_begin = r->hit_begin.data(); r->pub.hits = r->hits.data(); r->pub.ops = r->ops.data(); r->pub.status = r->status.data();
-    r->pub.counters = r->counters.data(); r->pub.d_arrays = r->d_arrays.data(); r->pub.n_second_pass = second; r->pub.n_third_pass = 0;
+    r->pub.counters = r->counters.data(); r->pub.d_arrays = r->d_arrays.data(); r->pub.n_second_pass = migrations; r->pub.n_third_pass = second;
     return &r->pub;
 }
 void emu_result_free(mapad_batch_result_t* r) { if (r) delete reinterpret_cast<EmuResult*>(r); }

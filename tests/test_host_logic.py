@@ -228,8 +228,8 @@ def test_kernel_logic_second_pass_and_limit_recovery():
     pidx = mapad_amd.Index.build([("chr1", g)])
     oidx = ob.OracleIndex.from_bwt(pidx.bwt(), "$ACGTX", 128)
     rp = resolve_params(NO_DAMAGE)
-    res = emu_util.map_batch(pidx, mapad_amd.make_params(rp), seqs, quals, offsets, node_cap=64, heap_cap=64)
-    assert res.n_second_pass > 0
+    res = emu_util.map_batch(pidx, mapad_amd.make_params(rp), seqs, quals, offsets, node_cap=16, heap_cap=16)
+    assert res.n_second_pass > 0 and res.n_third_pass > 0  # arena migrations (x4, twice) and full-limit re-runs
     assert_same_as_oracle(oidx.map_batch(ob.make_params(rp), reads, qs, n_threads=8, keep_d=True), res, offsets)
     for limits in ({"stack_limit": 40, "edit_tree_limit": 100000}, {"stack_limit": 100000, "edit_tree_limit": 120},
                    {"stack_limit": 40, "edit_tree_limit": 100000, "stack_limit_abort": 1}):
