@@ -143,6 +143,32 @@ __device__ __forceinline__ void ext4_quad(const DevIndex& ix, uint64_t lower, ui
     finish_ext4(ix, lower, lower_rev, size, lo, hi, out);
 }
 
+// Lane w of the quad returns the extension by base w only (plus the quad-uniform mask of non-empty extensions): the search builds
+// the children of a frame lane-parallel, so nobody needs all twelve values (search_core.hpp: search_step).
+struct ExtLane {
+    uint64_t lower, lower_rev, size;
+    uint32_t nonempty;  // bit k: extension by base k has size >= 1
+};
+__device__ __forceinline__ uint64_t quad_pick64(uint64_t v, int k) {  // value of lane k (k quad-uniform, dynamic)
+    const uint64_t a = quad_bcast64<0>(v), b = quad_bcast64<1>(v), c = quad_bcast64<2>(v), d = quad_bcast64<3>(v);
+    return k == 0 ? a : k == 1 ? b : k == 2 ? c : d;
+}
+__device__ __forceinline__ void ext4_quad_lane(const DevIndex& ix, uint64_t lower, uint64_t lower_rev, uint64_t size, int w, ExtLane& out) {
+    const uint64_t my_lo = lower == 0 ? 0 : quad_occ(ix, lower - 1, w);
+    const uint64_t my_hi = quad_occ(ix, lower + size - 1, w);
+    const uint64_t my_size = my_hi - my_lo;
+    const uint64_t s0 = quad_bcast64<0>(my_size), s1 = quad_bcast64<1>(my_size), s2 = quad_bcast64<2>(my_size), s3 = quad_bcast64<3>(my_size);
+    const uint64_t o_s = lower == 0 ? 0 : sentinel_le(ix, lower - 1);
+    const uint64_t sent = sentinel_le(ix, lower + size - 1) - o_s;  // '$' rows inside the interval
+    // fmd_index.rs:137-181 iterates T, G, C, A: lower_rev of base k = lower_rev + '$' rows + sizes of the bases above k
+    const uint64_t above = w == 3 ? 0 : w == 2 ? s3 : w == 1 ? s3 + s2 : s3 + s2 + s1;
+    const uint64_t less = w == 0 ? ix.less[1] : w == 1 ? ix.less[2] : w == 2 ? ix.less[3] : ix.less[4];
+    out.lower = less + my_lo;
+    out.lower_rev = lower_rev + sent + above;
+    out.size = my_size;
+    out.nonempty = (s0 >= 1 ? 1u : 0u) | (s1 >= 1 ? 2u : 0u) | (s2 >= 1 ? 4u : 0u) | (s3 >= 1 ? 8u : 0u);
+}
+
 // Single-base step for the D-array chains: new (lower, size) of the quad-uniform interval extended by base k (0..3).
 __device__ __forceinline__ void ext1_quad(const DevIndex& ix, uint64_t lower, uint64_t size, int k, int w, uint64_t& new_lower, uint64_t& new_size) {
     const uint64_t my_lo = lower == 0 ? 0 : quad_occ(ix, lower - 1, w);

@@ -39,7 +39,8 @@ enum : uint32_t { ST_POOL_OVERFLOW = 4, ST_NO_TABLE = 8 };
 // arena stays with the slot); pass 1 re-runs, with the reference's full limits, the few reads pass 0 could not finish because a
 // size-class pool ran dry.
 constexpr int kTiers = 2;
-constexpr int kClasses = 5;  // grown arenas: 4x steps above the base arena
+constexpr int kClasses = 5;
+constexpr int kKeyBins = kMaxReadLen + 2;  // grown arenas: 4x steps above the base arena
 // cursors: global bump allocators and work counters; per pass t: CUR_WORK + 2t = next work item, CUR_OVF + 2t = reads pass t handed on
 enum { CUR_HITS = 0, CUR_OPS = 1, CUR_POOL_OVF = 2, CUR_ERR = 3, CUR_WORK = 4, CUR_OVF = 5, CUR_GROWN = 4 + 2 * kTiers, CUR_COUNT = 4 + 2 * kTiers + 4 };
 
@@ -58,6 +59,9 @@ struct BatchDev {
     uint32_t hits_cap, ops_cap;
     uint32_t* cursors;
     uint32_t* overflow_list;  // [kTiers][n_reads]: read ids (+1) pass t could not finish
+    uint32_t* sort_key;       // [n_reads] cost class of a read (zero positions of its D array), written by darray_kernel
+    uint32_t* key_hist;       // [kKeyBins] reads per cost class, then the running scatter cursors
+    uint32_t* order;          // [n_reads] read ids, most expensive class first (nullptr: in input order)
 };
 
 struct ArenaPool {
@@ -106,10 +110,14 @@ __global__ void __launch_bounds__(64) darray_kernel(DevIndex ix, DevParams P, Ba
         const uint8_t* qual = B.quals + off;
         float* dout = B.d_arrays + off;
         if (L > lmax || P.table_base[L] < 0) {  // fail loudly: the host did not prepare this read length
-            if (lane == 0) { B.status[read] = ST_NO_TABLE; atomicOr(&B.cursors[CUR_ERR], ST_NO_TABLE); B.counters[read].e_darray = 0; }
+            if (lane == 0) {
+                B.status[read] = ST_NO_TABLE; atomicOr(&B.cursors[CUR_ERR], ST_NO_TABLE); B.counters[read].e_darray = 0;
+                if (B.order) { B.sort_key[read] = 0; atomicAdd(&B.key_hist[0], 1u); }
+            }
             continue;
         }
         const int split = P.start_at_end ? L : L / 2;
+        uint32_t zeros = 0;  // positions where the D array proves nothing: the search runs unpruned there
         if (lane == 0) n_ext_total = 0;
         for (int r = lane; r < L; r += 64) pen[r] = d_penalty(P, seq, qual, L, r);
         __syncthreads();
@@ -127,12 +135,49 @@ __global__ void __launch_bounds__(64) darray_kernel(DevIndex ix, DevParams P, Ba
 #pragma unroll
                 for (int o = 0; o < kMaxOffset; ++o) acc = f32_min(acc, chains[o * lmax + p]);
                 dout[(left ? 0 : split) + p] = acc;
+                zeros += (uint32_t)__popcll(__ballot(acc == 0.0f));
             }
             __syncthreads();
         }
-        if (lane == 0) B.counters[read].e_darray = n_ext_total;
+        if (lane == 0) {
+            B.counters[read].e_darray = n_ext_total;
+            if (B.order) { B.sort_key[read] = zeros; atomicAdd(&B.key_hist[zeros], 1u); }
+        }
         __syncthreads();
     }
+}
+
+// ---- schedule: most expensive cost class first ----------------------------------------------------------------------------
+// A read's search cost is heavy-tailed (C2: mean 860 pops, maximum > 30000) and one read is a serial chain of dependent memory
+// accesses, so a heavy read that starts late sets the finish time of the whole batch.  The reads whose D array leaves the search
+// unpruned the longest (many zero positions) hold all of the heavy ones; starting those first overlaps their tail with the bulk.
+// The order only changes when a read is processed, never its result.
+__global__ void order_scan_kernel(uint32_t* hist) {  // hist[k] -> first position of class k when classes are laid out descending
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    uint32_t acc = 0;
+    for (int k = kKeyBins - 1; k >= 0; --k) { const uint32_t c = hist[k]; hist[k] = acc; acc += c; }
+}
+__global__ void __launch_bounds__(256) order_scatter_kernel(BatchDev B) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= B.n_reads) return;
+    const uint32_t key = B.sort_key[i];
+    // one atomic per distinct key of the wavefront
+    uint64_t todo = __ballot(1);
+    uint32_t pos = 0;
+    const int lane = threadIdx.x & 63;
+    while (todo) {
+        const int leader = __ffsll((long long)todo) - 1;
+        const uint32_t k = (uint32_t)__shfl((int)key, leader);
+        const uint64_t same = __ballot(key == k);
+        if (key == k) {
+            uint32_t base = 0;
+            if (lane == leader) base = atomicAdd(&B.key_hist[k], (uint32_t)__popcll(same));
+            base = (uint32_t)__shfl((int)base, leader);
+            pos = base + (uint32_t)__popcll(same & ((1ull << lane) - 1ull));
+        }
+        todo &= ~same;
+    }
+    B.order[pos] = i;
 }
 
 // ---- search: persistent quads -----------------------------------------------------------------------------------------
@@ -193,23 +238,26 @@ struct DeviceGrow {
     uint32_t slot;
     int w;
     __device__ __forceinline__ bool operator()(ArenaT<NL>& A, const SearchState& st) const {
-        const uint32_t cls = A.grown >> kGrownShift;  // class to move into (0 = from the base arena)
-        if (cls >= (uint32_t)kClasses) return false;
+        uint32_t cls = A.grown >> kGrownShift;  // class to move into (0 = from the base arena); a dry class falls through to the next
         uint32_t idx = ~0u;
-        if (w == 0) {
-            const uint32_t n = gp->count[cls];
-            if (n) {
-                uint32_t i = (uint32_t)(((uint64_t)slot * 2654435761u) % n);
-                const uint32_t tries = n < 256u ? n : 256u;
-                uint32_t* own = gp->owner[cls];
-                for (uint32_t t = 0; t < tries; ++t) {
-                    if (atomicCAS(&own[i], 0u, 1u) == 0u) { idx = i; break; }
-                    if (++i == n) i = 0;
+        for (; cls < (uint32_t)kClasses; ++cls) {
+            if (w == 0) {
+                const uint32_t n = gp->count[cls];
+                if (n) {
+                    uint32_t i = (uint32_t)(((uint64_t)slot * 2654435761u) % n);
+                    const uint32_t tries = n < 256u ? n : 256u;
+                    uint32_t* own = gp->owner[cls];
+                    for (uint32_t t = 0; t < tries; ++t) {
+                        if (atomicCAS(&own[i], 0u, 1u) == 0u) { idx = i; break; }
+                        if (++i == n) i = 0;
+                    }
                 }
+                if (idx == ~0u) atomicOr(grown_counter + 1, 1u << cls);  // debugging aid: classes that ran dry
             }
+            idx = group_bcast<LPR>(idx);
+            if (idx != ~0u) break;
         }
-        idx = group_bcast<LPR>(idx);
-        if (idx == ~0u) return false;  // pool dry: the read goes to the full-limit pass
+        if (idx == ~0u) return false;  // every pool is dry: the read goes to the full-limit pass
         __threadfence();
         uint8_t* b = gp->base[cls] + (uint64_t)idx * gp->stride[cls];
         HeapEntry* nheap = reinterpret_cast<HeapEntry*>(b) + 1;
@@ -260,7 +308,7 @@ __global__ void __launch_bounds__(64, 4) search_kernel(DevIndex ix, DevParams P,
             item = group_bcast<LPR>(item);
             if (item >= n_items) done = true;
             else {
-                read = tier == 0 ? item : items[item] - 1u;
+                read = tier == 0 ? (B.order ? B.order[item] : item) : items[item] - 1u;
                 const uint64_t off = B.offsets[read];
                 rd.L = (int)(B.offsets[read + 1] - off);
                 rd.thr = P.reject_thr[rd.L];
@@ -276,6 +324,12 @@ __global__ void __launch_bounds__(64, 4) search_kernel(DevIndex ix, DevParams P,
             }
         }
         if (__all(done)) break;
+#if !defined(MAPAD_NO_PRIO)
+        // wavefronts that carry a long-running read get issue priority: their serial chain bounds the batch
+        if (__any(have && st.ctr.n_pop > 12288u)) __builtin_amdgcn_s_setprio(3);
+        else if (__any(have && st.ctr.n_pop > 3072u)) __builtin_amdgcn_s_setprio(1);
+        else __builtin_amdgcn_s_setprio(0);
+#endif
         if (have) {
             bool cont;
             if constexpr (PASS == 0) cont = search_step<LPR, CONT, NL>(ix, P, rd, A, st, w, grow);
@@ -368,7 +422,7 @@ struct mapad_ctx {
     DevBuf<float> d_darr;
     bool fetch_d = true;
     DevBuf<ReadCounters> d_counters;
-    DevBuf<uint32_t> d_status, d_hit_count, d_hit_first, d_ops, d_cursors, d_overflow;
+    DevBuf<uint32_t> d_status, d_hit_count, d_hit_first, d_ops, d_cursors, d_overflow, d_sort_key, d_key_hist, d_order;
     DevBuf<HitRec> d_hits;
     DevBuf<uint8_t> d_arena[kTiers];
     ArenaPool pool[kTiers] = {};
@@ -393,7 +447,7 @@ struct mapad_ctx {
         (void)hipSetDevice(device);
         d_blocks.release(); d_sdm.release(); d_thr.release(); d_base.release(); d_seqs.release(); d_quals.release(); d_offsets.release();
         d_darr.release(); d_counters.release(); d_status.release(); d_hit_count.release(); d_hit_first.release(); d_ops.release();
-        d_cursors.release(); d_overflow.release(); d_hits.release();
+        d_cursors.release(); d_overflow.release(); d_hits.release(); d_sort_key.release(); d_key_hist.release(); d_order.release();
         for (auto& a : d_arena) a.release();
         for (auto& a : d_class) a.release();
         for (auto& a : d_owner) a.release();
@@ -459,7 +513,7 @@ int ensure_arenas(mapad_ctx* c, uint32_t lmax) {
     }
     // size classes
     static const char* kCountEnv[kClasses] = {"MAPAD_CLASS0_COUNT", "MAPAD_CLASS1_COUNT", "MAPAD_CLASS2_COUNT", "MAPAD_CLASS3_COUNT", "MAPAD_CLASS4_COUNT"};
-    const uint32_t dflt_count[kClasses] = {32768, 8192, 1024, 128, 32};
+    const uint32_t dflt_count[kClasses] = {c->slots[0], c->slots[0] / 4, 2048, 128, 32};
     uint64_t nodes = (uint64_t)c->pool[0].node_cap;
     GrowPools& g = c->grow;
     for (int k = 0; k < kClasses; ++k) {
@@ -497,6 +551,13 @@ int launch_batch(mapad_ctx* c, const uint8_t* d_seqs, const uint8_t* d_quals, co
     if ((rc = c->d_hit_count.ensure(nr))) return rc;
     if ((rc = c->d_hit_first.ensure(nr))) return rc;
     if ((rc = c->d_overflow.ensure(nr * kTiers))) return rc;
+    const bool ordered = env_u32("MAPAD_ORDER", 1) != 0;
+    if (ordered) {
+        if ((rc = c->d_sort_key.ensure(nr))) return rc;
+        if ((rc = c->d_order.ensure(nr))) return rc;
+        if ((rc = c->d_key_hist.ensure(kKeyBins))) return rc;
+        HIP_TRY(hipMemsetAsync(c->d_key_hist.p, 0, kKeyBins * 4, c->stream));
+    }
     if ((rc = c->d_cursors.ensure(CUR_COUNT))) return rc;
     const size_t hits_cap = std::max(c->d_hits.cap, (size_t)(2 * nr + 1024));
     const size_t ops_cap = std::max(c->d_ops.cap, hits_cap * (size_t)(std::min<uint32_t>(lmax, 256) + 8));
@@ -511,6 +572,7 @@ int launch_batch(mapad_ctx* c, const uint8_t* d_seqs, const uint8_t* d_quals, co
     B.hits_pool = c->d_hits.p; B.ops_pool = c->d_ops.p;
     B.hits_cap = (uint32_t)std::min<size_t>(c->d_hits.cap, 0xFFFFFFFFu); B.ops_cap = (uint32_t)std::min<size_t>(c->d_ops.cap, 0xFFFFFFFFu);
     B.cursors = c->d_cursors.p; B.overflow_list = c->d_overflow.p;
+    B.sort_key = ordered ? c->d_sort_key.p : nullptr; B.key_hist = ordered ? c->d_key_hist.p : nullptr; B.order = ordered ? c->d_order.p : nullptr;
     c->last = B; c->last_total_bases = total_bases; c->last_lmax = lmax;
     if (n_reads == 0) return MAPAD_OK;
     const uint32_t lds_lmax = std::max<uint32_t>(lmax, 1);
@@ -520,6 +582,11 @@ int launch_batch(mapad_ctx* c, const uint8_t* d_seqs, const uint8_t* d_quals, co
     HIP_TRY(hipEventRecord(c->ev[0], c->stream));
     hipLaunchKernelGGL(darray_kernel, dim3(grid_d), dim3(64), lds_bytes, c->stream, c->dix, c->dprm, B, (int)lds_lmax);
     HIP_TRY(hipGetLastError());
+    if (ordered) {
+        hipLaunchKernelGGL(order_scan_kernel, dim3(1), dim3(64), 0, c->stream, c->d_key_hist.p);
+        hipLaunchKernelGGL(order_scatter_kernel, dim3((uint32_t)((n_reads + 255) / 256)), dim3(256), 0, c->stream, B);
+        HIP_TRY(hipGetLastError());
+    }
     HIP_TRY(hipEventRecord(c->ev[1], c->stream));
     const uint32_t rpw = 64 / c->lpr;  // reads per wavefront
     // near data in LDS (16 read slots per wavefront) unless the batch has very long reads or every lane owns a read
@@ -773,6 +840,7 @@ int mapad_fetch_result(mapad_ctx_t* ctx, mapad_batch_result_t** out) {
     r->pub.hit_begin = r->hit_begin.data(); r->pub.hits = r->hits.data(); r->pub.ops = r->ops.data();
     r->pub.status = r->status.data(); r->pub.counters = r->counters.data(); r->pub.d_arrays = ctx->fetch_d ? r->d_arrays.data() : nullptr;
     r->pub.n_second_pass = cur[CUR_GROWN];  // arena migrations in pass 0
+    if (cur[CUR_GROWN + 1] && std::getenv("MAPAD_DEBUG")) std::fprintf(stderr, "mapad_amd: size-class pools that ran dry (bit per class): 0x%x, reads re-run: %u\n", cur[CUR_GROWN + 1], cur[CUR_OVF]);
     r->pub.n_third_pass = cur[CUR_OVF];    // reads re-run by the full-limit pass
     *out = &r.release()->pub;
     return MAPAD_OK;

@@ -265,6 +265,14 @@ MAPAD_HD uint32_t tree_insert(Node* nodes, SearchState& st, const Node& nd) {
     st.tree_len += 1;
     return key;
 }
+// tree_insert without the store: the caller writes the node (one lane of the quad owns it, search_step)
+MAPAD_HD uint32_t tree_alloc(const Node* nodes, SearchState& st) {
+    const uint32_t key = st.tree_next;
+    if (key == st.tree_entries) { st.tree_entries += 1; st.tree_next = key + 1; }
+    else st.tree_next = node_parent(nodes[key]);
+    st.tree_len += 1;
+    return key;
+}
 MAPAD_HD void tree_remove(Node* nodes, SearchState& st, uint32_t key) {  // backtrack_tree.rs:50-54
     if (key == 0) return;
     Node nd = nodes[key];
@@ -369,16 +377,25 @@ struct NoGrow {
     template <class AR> MAPAD_HD bool operator()(AR&, const SearchState&) const { return false; }
 };
 
-// check_and_push_stack_frame (mapping.rs:932-987)
-template <bool NL, class Grow>
-MAPAD_HD void check_and_push(const DevParams& P, const ReadInT<NL>& rd, ArenaT<NL>& A, SearchState& st, int alignment_start, const Frame& c, float score,
-                             uint32_t parent_node, uint32_t op, const Grow& grow) {
+// check_and_push_stack_frame (mapping.rs:932-987) for a child whose tree node `nd` is already packed.  On the device the quad
+// builds the <= 9 children of a frame lane-parallel (search_step); `store` says whether this lane owns the child and writes its node,
+// `owner` is the owning lane (the frame of a finished alignment is fetched from it).  Everything else is quad-uniform.
+template <int LPR, bool NL, class Grow>
+MAPAD_HD void commit_child(const DevParams& P, const ReadInT<NL>& rd, ArenaT<NL>& A, SearchState& st, int alignment_start, float score, uint32_t ngaps, int len,
+                           const Node& nd, bool store, int owner, const Grow& grow) {
     if (st.n_hits > 0 && mb_reject_iterative(P, score, st.best_score)) return;
-    if ((int)c.ngaps > P.max_num_gaps_open) return;
+    if ((int)ngaps > P.max_num_gaps_open) return;
     if (st.tree_next == st.tree_entries && st.tree_entries >= A.node_cap && !(grow(A, st) && st.tree_entries < A.node_cap)) { st.status = ST_ARENA_OVERFLOW; return; }
-    const uint32_t id = tree_insert(A.nodes, st, pack_node(op, parent_node, c));
+    const uint32_t id = tree_alloc(A.nodes, st);
+    if (store) A.nodes[id] = nd;
     st.ctr.n_node += 1;
-    if (c.len == rd.L) {  // rare: the state takes a round trip through memory only here, so it can live in registers otherwise
+    if (len == rd.L) {  // rare: the state takes a round trip through memory only here, so it can live in registers otherwise
+        Node u = nd;
+#if defined(__HIP_DEVICE_COMPILE__)
+        if (LPR == 4) { u.w1 = quad_pick64(nd.w1, owner); u.w2 = quad_pick64(nd.w2, owner); u.w3 = quad_pick64(nd.w3, owner); }
+#endif
+        (void)owner;
+        const Frame c = unpack_frame(u);
         SearchState tmp = st;
         record_hit(rd, A, tmp, alignment_start, c.lower, c.lower_rev, c.size, score, id);
         st = tmp;
@@ -447,10 +464,27 @@ MAPAD_HD bool search_step(const DevIndex& ix, const DevParams& P, const ReadInT<
     const float lower_bound = d_get(rd.d, L, alignment_start, d_k, d_l);                       // :1195
     if (st.n_hits > 0 && mb_reject_iterative(P, f_score + lower_bound, st.best_score)) return false;  // :1201-1208
 
-    // Extension (:1245); forward extension works on the swapped interval
+    // Extension (:1245); forward extension works on the swapped interval.  Device quads: lane w keeps the extension by base w only.
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr bool kLaneKids = LPR == 4;
+#else
+    constexpr bool kLaneKids = false;
+#endif
     Ext4 e;
-    if (forward) ext4_any<LPR>(ix, f.lower_rev, f.lower, f.size, w, e);
-    else ext4_any<LPR>(ix, f.lower, f.lower_rev, f.size, w, e);
+    uint64_t my_lower = 0, my_lower_rev = 0, my_size = 0;  // kLaneKids: extension by base w
+    uint32_t nonempty;
+    if constexpr (kLaneKids) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        ExtLane x;
+        if (forward) ext4_quad_lane(ix, f.lower_rev, f.lower, f.size, w, x);
+        else ext4_quad_lane(ix, f.lower, f.lower_rev, f.size, w, x);
+        my_lower = x.lower; my_lower_rev = x.lower_rev; my_size = x.size; nonempty = x.nonempty;
+#endif
+    } else {
+        if (forward) ext4_any<LPR>(ix, f.lower_rev, f.lower, f.size, w, e);
+        else ext4_any<LPR>(ix, f.lower, f.lower_rev, f.size, w, e);
+        nonempty = (e.size[0] >= 1 ? 1u : 0u) | (e.size[1] >= 1 ? 2u : 0u) | (e.size[2] >= 1 ? 4u : 0u) | (e.size[3] >= 1 ? 8u : 0u);
+    }
     st.ctr.e_search += 1;
 
     // Static gates of the <= 9 children in commit order: Ins; then for k = T,G,C,A: Del(k), Match/Mismatch(k).
@@ -467,12 +501,48 @@ MAPAD_HD bool search_step(const DevIndex& ix, const DevParams& P, const ReadInT<
         const int k = 3 - i;
         const int cb = forward ? 3 - k : k;  // symbol in read orientation: backward = base k, forward = its complement
         mm[i] = f4_get(row, cb) - optimal + f_score;  // get - optimal + score, left to right (:1138-1145)
-        if (e.size[k] >= 1) {
+        if ((nonempty >> k) & 1u) {
             if (del_ok) cand |= 2u << (2 * i);
             if (!mb_reject<CONT>(rd.thr, P.cutoff, mm[i] + lower_bound)) cand |= 4u << (2 * i);  // :1308
         }
     }
     const int child_start = forward ? f.start : f.start - 1;
+    // tree node (= frame payload) of child t; (xl, xr, xs) = extension of the frame's interval by base k (unused for t = 0)
+    auto make_child = [&](int t, int k, uint64_t xl, uint64_t xr, uint64_t xs) -> Node {
+        Frame c;
+        uint32_t op;
+        if (t == 0) {  // Insertion in read (:1213-1242)
+            c.lower = f.lower; c.lower_rev = f.lower_rev; c.size = f.size;
+            c.start = child_start; c.len = f.len + 1;
+            c.gap_f = forward ? (uint32_t)GAP_INS : f.gap_f; c.gap_b = forward ? f.gap_b : (uint32_t)GAP_INS;
+            c.ngaps = num_gaps_open;
+            op = pack_op(OP_INS, (uint32_t)j, 0);
+        } else {
+            const int cb = forward ? 3 - k : k;
+            const uint32_t c_ascii = cb == 0 ? 'A' : cb == 1 ? 'C' : cb == 2 ? 'G' : 'T';
+            c.size = xs;
+            c.lower = forward ? xr : xl;  // swapped back for forward extension (:1256)
+            c.lower_rev = forward ? xl : xr;
+            if (t & 1) {  // Deletion in read (:1265-1302)
+                c.start = f.start; c.len = f.len;
+                c.gap_f = forward ? (uint32_t)GAP_DEL : f.gap_f; c.gap_b = forward ? f.gap_b : (uint32_t)GAP_DEL;
+                c.ngaps = num_gaps_open;
+                op = pack_op(OP_DEL, (uint32_t)j, c_ascii);
+            } else {  // Match / mismatch (:1307-1338)
+                c.start = child_start; c.len = f.len + 1;
+                c.gap_f = forward ? (uint32_t)GAP_CLOSED : f.gap_f; c.gap_b = forward ? f.gap_b : (uint32_t)GAP_CLOSED;
+                c.ngaps = f.ngaps;
+                op = (cb == to_class) ? pack_op(OP_MATCH, (uint32_t)j, 0) : pack_op(OP_MISMATCH, (uint32_t)j, c_ascii);
+            }
+        }
+        return pack_node(op, top.node, c);
+    };
+    Node nd_ins{}, nd_del{}, nd_mm{};
+    if constexpr (kLaneKids) {  // lane w packs the two children of base w once; the commit loop below only selects and stores
+        nd_ins = make_child(0, 0, 0, 0, 0);
+        nd_del = make_child(1 + 2 * (3 - w), w, my_lower, my_lower_rev, my_size);
+        nd_mm = make_child(2 + 2 * (3 - w), w, my_lower, my_lower_rev, my_size);
+    }
     while (cand != 0 && st.status == ST_OK) {
 #if defined(__HIP_DEVICE_COMPILE__)
         const int t = __ffs((int)cand) - 1;
@@ -480,39 +550,21 @@ MAPAD_HD bool search_step(const DevIndex& ix, const DevParams& P, const ReadInT<
         const int t = __builtin_ctz(cand);
 #endif
         cand &= cand - 1;
-        Frame c;
-        float score;
-        uint32_t op;
-        if (t == 0) {  // Insertion in read (:1213-1242)
-            c.lower = f.lower; c.lower_rev = f.lower_rev; c.size = f.size;
-            c.start = child_start; c.len = f.len + 1;
-            c.gap_f = forward ? (uint32_t)GAP_INS : f.gap_f; c.gap_b = forward ? f.gap_b : (uint32_t)GAP_INS;
-            c.ngaps = num_gaps_open; score = insertion_score;
-            op = pack_op(OP_INS, (uint32_t)j, 0);
+        const bool is_ins = t == 0, is_del = (t & 1) != 0;
+        const int i = is_ins ? 0 : (t - 1) >> 1, k = 3 - i;
+        const float score = is_ins ? insertion_score : is_del ? deletion_score : (i == 0 ? mm[0] : i == 1 ? mm[1] : i == 2 ? mm[2] : mm[3]);
+        const uint32_t ngaps = (is_ins || is_del) ? num_gaps_open : f.ngaps;
+        const int len = is_del ? f.len : f.len + 1;
+        if constexpr (kLaneKids) {
+            const Node nd = is_ins ? nd_ins : is_del ? nd_del : nd_mm;
+            const int owner = is_ins ? 0 : k;
+            commit_child<LPR>(P, rd, A, st, alignment_start, score, ngaps, len, nd, w == owner, owner, grow);
         } else {
-            const int i = (t - 1) >> 1, k = 3 - i;
-            const bool is_del = (t & 1) != 0;
-            const int cb = forward ? 3 - k : k;
-            const uint32_t c_ascii = cb == 0 ? 'A' : cb == 1 ? 'C' : cb == 2 ? 'G' : 'T';
-            const uint64_t el = k == 0 ? e.lower[0] : k == 1 ? e.lower[1] : k == 2 ? e.lower[2] : e.lower[3];
-            const uint64_t er = k == 0 ? e.lower_rev[0] : k == 1 ? e.lower_rev[1] : k == 2 ? e.lower_rev[2] : e.lower_rev[3];
-            c.size = k == 0 ? e.size[0] : k == 1 ? e.size[1] : k == 2 ? e.size[2] : e.size[3];
-            c.lower = forward ? er : el;  // swapped back for forward extension (:1256)
-            c.lower_rev = forward ? el : er;
-            if (is_del) {  // Deletion in read (:1265-1302)
-                c.start = f.start; c.len = f.len;
-                c.gap_f = forward ? (uint32_t)GAP_DEL : f.gap_f; c.gap_b = forward ? f.gap_b : (uint32_t)GAP_DEL;
-                c.ngaps = num_gaps_open; score = deletion_score;
-                op = pack_op(OP_DEL, (uint32_t)j, c_ascii);
-            } else {  // Match / mismatch (:1307-1338)
-                c.start = child_start; c.len = f.len + 1;
-                c.gap_f = forward ? (uint32_t)GAP_CLOSED : f.gap_f; c.gap_b = forward ? f.gap_b : (uint32_t)GAP_CLOSED;
-                c.ngaps = f.ngaps;
-                score = i == 0 ? mm[0] : i == 1 ? mm[1] : i == 2 ? mm[2] : mm[3];
-                op = (cb == to_class) ? pack_op(OP_MATCH, (uint32_t)j, 0) : pack_op(OP_MISMATCH, (uint32_t)j, c_ascii);
-            }
+            const uint64_t xl = k == 0 ? e.lower[0] : k == 1 ? e.lower[1] : k == 2 ? e.lower[2] : e.lower[3];
+            const uint64_t xr = k == 0 ? e.lower_rev[0] : k == 1 ? e.lower_rev[1] : k == 2 ? e.lower_rev[2] : e.lower_rev[3];
+            const uint64_t xs = k == 0 ? e.size[0] : k == 1 ? e.size[1] : k == 2 ? e.size[2] : e.size[3];
+            commit_child<LPR>(P, rd, A, st, alignment_start, score, ngaps, len, make_child(t, k, xl, xr, xs), true, 0, grow);
         }
-        check_and_push(P, rd, A, st, alignment_start, c, score, top.node, op, grow);
     }
     if (st.status != ST_OK) return false;
     // :1348-1355
