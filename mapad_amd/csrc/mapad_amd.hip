@@ -39,8 +39,8 @@ enum : uint32_t { ST_POOL_OVERFLOW = 4, ST_NO_TABLE = 8 };
 // arena stays with the slot); pass 1 re-runs, with the reference's full limits, the few reads pass 0 could not finish because a
 // size-class pool ran dry.
 constexpr int kTiers = 2;
-constexpr int kClasses = 5;
-constexpr int kKeyBins = kMaxReadLen + 2;  // grown arenas: 4x steps above the base arena
+constexpr int kClasses = 11;  // grown arenas: 2x steps above the base arena (4096 nodes -> 8 Ki ... 4 Mi), the last one with the full limits
+constexpr int kKeyBins = kMaxReadLen + 2;
 // cursors: global bump allocators and work counters; per pass t: CUR_WORK + 2t = next work item, CUR_OVF + 2t = reads pass t handed on
 enum { CUR_HITS = 0, CUR_OPS = 1, CUR_POOL_OVF = 2, CUR_ERR = 3, CUR_WORK = 4, CUR_OVF = 5, CUR_GROWN = 4 + 2 * kTiers, CUR_COUNT = 4 + 2 * kTiers + 4 };
 
@@ -237,27 +237,35 @@ struct DeviceGrow {
     uint32_t* grown_counter;
     uint32_t slot;
     int w;
-    __device__ __forceinline__ bool operator()(ArenaT<NL>& A, const SearchState& st) const {
-        uint32_t cls = A.grown >> kGrownShift;  // class to move into (0 = from the base arena); a dry class falls through to the next
+    __device__ __forceinline__ int operator()(ArenaT<NL>& A, const SearchState& st) const {
+        if (A.wait) { A.wait -= 1; return GROW_WAIT; }
+        const uint32_t first = A.grown >> kGrownShift;  // first class to try (0 = from the base arena); a dry class falls through to the next
+        uint32_t cls = first;
         uint32_t idx = ~0u;
+        bool exists = false;
         for (; cls < (uint32_t)kClasses; ++cls) {
+            const uint32_t n = gp->count[cls];
+            if (n == 0 || gp->node_cap[cls] < st.tree_len + kStepNodes || gp->heap_cap[cls] < st.heap_len + kStepNodes) continue;
+            exists = true;
             if (w == 0) {
-                const uint32_t n = gp->count[cls];
-                if (n) {
-                    uint32_t i = (uint32_t)(((uint64_t)slot * 2654435761u) % n);
-                    const uint32_t tries = n < 256u ? n : 256u;
-                    uint32_t* own = gp->owner[cls];
-                    for (uint32_t t = 0; t < tries; ++t) {
-                        if (atomicCAS(&own[i], 0u, 1u) == 0u) { idx = i; break; }
-                        if (++i == n) i = 0;
-                    }
+                uint32_t i = (uint32_t)(((uint64_t)(slot + st.ctr.n_pop) * 2654435761u) % n);
+                const uint32_t tries = n < 64u ? n : 64u;
+                uint32_t* own = gp->owner[cls];
+                for (uint32_t t = 0; t < tries; ++t) {
+                    if (atomicCAS(&own[i], 0u, 1u) == 0u) { idx = i; break; }
+                    if (++i == n) i = 0;
                 }
                 if (idx == ~0u) atomicOr(grown_counter + 1, 1u << cls);  // debugging aid: classes that ran dry
             }
             idx = group_bcast<LPR>(idx);
             if (idx != ~0u) break;
         }
-        if (idx == ~0u) return false;  // every pool is dry: the read goes to the full-limit pass
+        if (idx == ~0u) {
+            if (!exists) return GROW_NEVER;  // no class can hold this read: it goes to the full-limit pass
+            A.wait = 64;                     // every suitable arena is taken: its owners finish and give it back
+            if (w == 0) atomicAdd(grown_counter + 2, 1u);
+            return GROW_WAIT;
+        }
         __threadfence();
         uint8_t* b = gp->base[cls] + (uint64_t)idx * gp->stride[cls];
         HeapEntry* nheap = reinterpret_cast<HeapEntry*>(b) + 1;
@@ -271,7 +279,7 @@ struct DeviceGrow {
         A.heap = nheap; A.nodes = nnodes; A.heap_cap = gp->heap_cap[cls]; A.node_cap = gp->node_cap[cls];
         A.grown = ((cls + 1) << kGrownShift) | idx;
         if (w == 0) atomicAdd(grown_counter, 1u);
-        return true;
+        return GROW_OK;
     }
 };
 
@@ -298,6 +306,9 @@ __global__ void __launch_bounds__(64, 4) search_kernel(DevIndex ix, DevParams P,
     const uint32_t* items = B.overflow_list + (size_t)(tier > 0 ? tier - 1 : 0) * B.n_reads;
     const DeviceGrow<LPR, NL> grow{GP, &B.cursors[CUR_GROWN], slot, w};
     bool have = false, done = false;
+#if defined(MAPAD_ACTIVE_QUADS)
+    if ((lane / LPR) >= MAPAD_ACTIVE_QUADS) done = true;  // experiment: fewer reads per wavefront
+#endif
     ReadInT<NL> rd{near_qc, near_d, 0, 0.0f};
     SearchState st;
     uint32_t read = 0;
@@ -511,13 +522,17 @@ int ensure_arenas(mapad_ctx* c, uint32_t lmax) {
         if ((rc = c->d_arena[1].ensure((size_t)c->slots[1] * c->pool[1].stride))) return rc;
         c->pool[1].base = c->d_arena[1].p;
     }
-    // size classes
-    static const char* kCountEnv[kClasses] = {"MAPAD_CLASS0_COUNT", "MAPAD_CLASS1_COUNT", "MAPAD_CLASS2_COUNT", "MAPAD_CLASS3_COUNT", "MAPAD_CLASS4_COUNT"};
-    const uint32_t dflt_count[kClasses] = {c->slots[0], c->slots[0] / 4, 2048, 128, 32};
+    // size classes: 2x steps; the last one holds the reference's full limits so that its owners never have to grow (no wait cycles)
+    uint32_t counts[kClasses] = {c->slots[0], c->slots[0] / 2, c->slots[0] / 4, c->slots[0] / 8, 2048, 512, 128, 64, 32, 16, 16};
+    if (const char* e = std::getenv("MAPAD_CLASS_COUNTS")) {  // comma list, missing entries = 0
+        for (int k = 0; k < kClasses; ++k) counts[k] = 0;
+        int k = 0;
+        for (const char* q = e; *q && k < kClasses; ++k) { counts[k] = (uint32_t)std::strtoul(q, const_cast<char**>(&q), 10); if (*q == ',') ++q; }
+    }
     uint64_t nodes = (uint64_t)c->pool[0].node_cap;
     GrowPools& g = c->grow;
     for (int k = 0; k < kClasses; ++k) {
-        nodes = nodes * 4;
+        nodes = k + 1 == kClasses ? tree_cap : nodes * 2;
         g.heap_cap[k] = (uint32_t)std::min<uint64_t>(nodes, stack_cap);
         g.node_cap[k] = (uint32_t)std::min<uint64_t>(nodes, tree_cap);
         auto align = [](uint64_t x) { return (x + 127) & ~127ull; };
@@ -525,7 +540,7 @@ int ensure_arenas(mapad_ctx* c, uint32_t lmax) {
         g.stride[k] = align(g.off_nodes[k] + (uint64_t)g.node_cap[k] * sizeof(Node));
         // a class that is no bigger than the previous one (tiny semantic limits) is pointless: give it no arenas
         const bool useful = g.node_cap[k] > (k ? g.node_cap[k - 1] : c->pool[0].node_cap) || g.heap_cap[k] > (k ? g.heap_cap[k - 1] : c->pool[0].heap_cap);
-        g.count[k] = useful ? std::min<uint32_t>(env_u32(kCountEnv[k], dflt_count[k]), (1u << kGrownShift) - 1) : 0;
+        g.count[k] = useful ? std::min<uint32_t>(counts[k], (1u << kGrownShift) - 1) : 0;
         if ((rc = c->d_class[k].ensure(std::max<size_t>((size_t)g.count[k] * g.stride[k], 128)))) return rc;
         if ((rc = c->d_owner[k].ensure(std::max<size_t>(g.count[k], 1)))) return rc;
         HIP_TRY(hipMemsetAsync(c->d_owner[k].p, 0, std::max<size_t>(g.count[k], 1) * 4, c->stream));
@@ -840,7 +855,7 @@ int mapad_fetch_result(mapad_ctx_t* ctx, mapad_batch_result_t** out) {
     r->pub.hit_begin = r->hit_begin.data(); r->pub.hits = r->hits.data(); r->pub.ops = r->ops.data();
     r->pub.status = r->status.data(); r->pub.counters = r->counters.data(); r->pub.d_arrays = ctx->fetch_d ? r->d_arrays.data() : nullptr;
     r->pub.n_second_pass = cur[CUR_GROWN];  // arena migrations in pass 0
-    if (cur[CUR_GROWN + 1] && std::getenv("MAPAD_DEBUG")) std::fprintf(stderr, "mapad_amd: size-class pools that ran dry (bit per class): 0x%x, reads re-run: %u\n", cur[CUR_GROWN + 1], cur[CUR_OVF]);
+    if (cur[CUR_GROWN + 1] && std::getenv("MAPAD_DEBUG")) std::fprintf(stderr, "mapad_amd: size-class pools that ran dry (bit per class): 0x%x, waits: %u, reads re-run: %u\n", cur[CUR_GROWN + 1], cur[CUR_GROWN + 2], cur[CUR_OVF]);
     r->pub.n_third_pass = cur[CUR_OVF];    // reads re-run by the full-limit pass
     *out = &r.release()->pub;
     return MAPAD_OK;

@@ -108,6 +108,7 @@ struct ArenaT {
     uint16_t* scratch;  // 2 * (Lmax + 1) u16 for the bucket sort of extract_edit_operations
     uint32_t heap_cap, node_cap, hit_ops_cap;
     uint32_t grown = 0;  // 0: heap/nodes are the slot's base arena; else (class + 1) << 27 | arena index (mapad_amd.hip: DeviceGrow)
+    uint32_t wait = 0;   // steps to sit out before asking the pools again
 };
 
 using Arena = ArenaT<false>;
@@ -180,24 +181,35 @@ MAPAD_HD bool mm_is_min_level(uint32_t pos) {
 #endif
 }
 
+// The first two compares of a bubble-up (parent, then the grandparent of wherever the element sits after the first compare) decide
+// 98 % of all pushes (measured, C2/C3); their three possible slots are known from `pos` alone, so they are loaded together and the
+// dependent chain of a push is one memory round trip instead of two.
 template <bool NL>
 MAPAD_HD void mm_bubble_up(const ArenaT<NL>& A, uint32_t pos, const HeapEntry elt) {  // elt is the new element, destined for slot pos
-    bool greater = false;  // which grandparent chain to follow
     if (pos > 0) {
-        const uint32_t parent = (pos - 1) >> 1;
-        const HeapEntry pe = hp_get(A, parent);
-        if (mm_is_min_level(pos)) {
-            if (elt.score > pe.score) { hp_set(A, pos, pe); pos = parent; greater = true; } else greater = false;
-        } else {
-            if (elt.score < pe.score) { hp_set(A, pos, pe); pos = parent; greater = false; } else greater = true;
-        }
-        while (pos > 2) {
-            const uint32_t gp = (pos - 3) >> 2;
-            const HeapEntry ge = hp_get(A, gp);
-            const bool go = greater ? (elt.score > ge.score) : (elt.score < ge.score);
-            if (!go) break;
-            hp_set(A, pos, ge);
-            pos = gp;
+        const uint32_t i1 = (pos - 1) >> 1;                 // parent
+        const uint32_t i2 = pos > 2 ? (pos - 3) >> 2 : 0;   // grandparent of pos
+        const uint32_t i3 = i1 > 2 ? (i1 - 3) >> 2 : 0;     // grandparent of the parent
+        const HeapEntry e1 = hp_get(A, i1), e2 = hp_get(A, i2), e3 = hp_get(A, i3);
+        bool greater;  // which grandparent chain to follow
+        bool moved;
+        if (mm_is_min_level(pos)) { moved = elt.score > e1.score; greater = moved; }
+        else { moved = elt.score < e1.score; greater = !moved; }
+        if (moved) { hp_set(A, pos, e1); pos = i1; }
+        if (pos > 2) {
+            const HeapEntry ge = moved ? e3 : e2;
+            const uint32_t gp = moved ? i3 : i2;
+            if (greater ? (elt.score > ge.score) : (elt.score < ge.score)) {
+                hp_set(A, pos, ge);
+                pos = gp;
+                while (pos > 2) {
+                    const uint32_t g2 = (pos - 3) >> 2;
+                    const HeapEntry g = hp_get(A, g2);
+                    if (!(greater ? (elt.score > g.score) : (elt.score < g.score))) break;
+                    hp_set(A, pos, g);
+                    pos = g2;
+                }
+            }
         }
     }
     hp_set(A, pos, elt);
@@ -371,21 +383,25 @@ MAPAD_RARE void record_hit(const ReadInT<NL> rd, const ArenaT<NL> A, SearchState
     st.ctr.n_hits += 1;
 }
 
-// A full arena asks `grow` for a bigger one before giving up: grow(A, st) migrates heap and nodes into a larger arena and updates
-// A (device: slot-owned arenas from size-class pools, mapad_amd.hip; host emulation: NoGrow).
+// Before a step starts, an arena that cannot take the step's worst case (9 new nodes, 8 more frames) asks `grow` for a bigger one:
+// grow(A, st) migrates heap and nodes into a larger arena and updates A (device: arenas from size-class pools, mapad_amd.hip).
+// It returns GROW_OK, GROW_WAIT (a suitable arena exists but none is free right now: the step is retried later, nothing has been
+// touched) or GROW_NEVER (the read goes to the full-limit pass).
+enum : int { GROW_OK = 1, GROW_WAIT = 0, GROW_NEVER = -1 };
+constexpr uint32_t kStepNodes = 9;
 struct NoGrow {
-    template <class AR> MAPAD_HD bool operator()(AR&, const SearchState&) const { return false; }
+    template <class AR> MAPAD_HD int operator()(AR&, const SearchState&) const { return GROW_NEVER; }
 };
 
 // check_and_push_stack_frame (mapping.rs:932-987) for a child whose tree node `nd` is already packed.  On the device the quad
 // builds the <= 9 children of a frame lane-parallel (search_step); `store` says whether this lane owns the child and writes its node,
 // `owner` is the owning lane (the frame of a finished alignment is fetched from it).  Everything else is quad-uniform.
-template <int LPR, bool NL, class Grow>
+template <int LPR, bool NL>
 MAPAD_HD void commit_child(const DevParams& P, const ReadInT<NL>& rd, ArenaT<NL>& A, SearchState& st, int alignment_start, float score, uint32_t ngaps, int len,
-                           const Node& nd, bool store, int owner, const Grow& grow) {
+                           const Node& nd, bool store, int owner) {
     if (st.n_hits > 0 && mb_reject_iterative(P, score, st.best_score)) return;
     if ((int)ngaps > P.max_num_gaps_open) return;
-    if (st.tree_next == st.tree_entries && st.tree_entries >= A.node_cap && !(grow(A, st) && st.tree_entries < A.node_cap)) { st.status = ST_ARENA_OVERFLOW; return; }
+    if (st.tree_next == st.tree_entries && st.tree_entries >= A.node_cap) { st.status = ST_ARENA_OVERFLOW; return; }  // cannot happen (search_step)
     const uint32_t id = tree_alloc(A.nodes, st);
     if (store) A.nodes[id] = nd;
     st.ctr.n_node += 1;
@@ -401,7 +417,7 @@ MAPAD_HD void commit_child(const DevParams& P, const ReadInT<NL>& rd, ArenaT<NL>
         st = tmp;
         return;
     }
-    if (st.heap_len >= A.heap_cap && !(grow(A, st) && st.heap_len < A.heap_cap)) { st.status = ST_ARENA_OVERFLOW; return; }
+    if (st.heap_len >= A.heap_cap) { st.status = ST_ARENA_OVERFLOW; return; }  // cannot happen (search_step)
     st.heap_len += 1;
     mm_bubble_up(A, st.heap_len - 1, HeapEntry{score, id});
     st.ctr.n_push += 1;
@@ -437,6 +453,11 @@ MAPAD_RARE void search_init(uint64_t n_text, int alignment_start, const ArenaT<N
 template <int LPR, bool CONT, bool NL, class Grow>
 MAPAD_HD bool search_step(const DevIndex& ix, const DevParams& P, const ReadInT<NL>& rd, ArenaT<NL>& A, SearchState& st, int w, const Grow& grow) {
     if (st.heap_len == 0 || st.status != ST_OK) return false;
+    if (st.tree_len + kStepNodes > A.node_cap || st.heap_len + kStepNodes > A.heap_cap) {
+        const int g = grow(A, st);
+        if (g == GROW_WAIT) return true;
+        if (g == GROW_NEVER || st.tree_len + kStepNodes > A.node_cap || st.heap_len + kStepNodes > A.heap_cap) { st.status = ST_ARENA_OVERFLOW; return false; }
+    }
     const int L = rd.L;
     const int alignment_start = alignment_start_of(P, L);
     const float open_ext = P.gap_open + P.gap_extend;
@@ -558,12 +579,12 @@ MAPAD_HD bool search_step(const DevIndex& ix, const DevParams& P, const ReadInT<
         if constexpr (kLaneKids) {
             const Node nd = is_ins ? nd_ins : is_del ? nd_del : nd_mm;
             const int owner = is_ins ? 0 : k;
-            commit_child<LPR>(P, rd, A, st, alignment_start, score, ngaps, len, nd, w == owner, owner, grow);
+            commit_child<LPR>(P, rd, A, st, alignment_start, score, ngaps, len, nd, w == owner, owner);
         } else {
             const uint64_t xl = k == 0 ? e.lower[0] : k == 1 ? e.lower[1] : k == 2 ? e.lower[2] : e.lower[3];
             const uint64_t xr = k == 0 ? e.lower_rev[0] : k == 1 ? e.lower_rev[1] : k == 2 ? e.lower_rev[2] : e.lower_rev[3];
             const uint64_t xs = k == 0 ? e.size[0] : k == 1 ? e.size[1] : k == 2 ? e.size[2] : e.size[3];
-            commit_child<LPR>(P, rd, A, st, alignment_start, score, ngaps, len, make_child(t, k, xl, xr, xs), true, 0, grow);
+            commit_child<LPR>(P, rd, A, st, alignment_start, score, ngaps, len, make_child(t, k, xl, xr, xs), true, 0);
         }
     }
     if (st.status != ST_OK) return false;

@@ -64,9 +64,9 @@ mapad_batch_result_t* emu_map_batch(const uint64_t* blocks, uint64_t n_blocks, u
     std::vector<Node> gnodes[2];
     struct HostGrow {
         std::vector<HeapEntry>* gheap; std::vector<Node>* gnodes; uint64_t* migrations; uint32_t stack_cap, tree_cap;
-        bool operator()(Arena& A, const SearchState& st) const {
+        int operator()(Arena& A, const SearchState& st) const {
             const uint32_t cls = A.grown >> 27;
-            if (cls >= 2) return false;
+            if (cls >= 2) return GROW_NEVER;
             const uint32_t hc = std::min<uint64_t>((uint64_t)A.heap_cap * 4, stack_cap), nc = std::min<uint64_t>((uint64_t)A.node_cap * 4, tree_cap);
             gheap[cls].assign(hc + 16, HeapEntry{});
             gnodes[cls].assign(nc, Node{});
@@ -75,7 +75,7 @@ mapad_batch_result_t* emu_map_batch(const uint64_t* blocks, uint64_t n_blocks, u
             for (uint32_t i = 0; i < st.tree_entries; ++i) gnodes[cls][i] = A.nodes[i];
             A.heap = nheap; A.nodes = gnodes[cls].data(); A.heap_cap = hc; A.node_cap = nc; A.grown = ((cls + 1) << 27) | 1u;
             ++*migrations;
-            return true;
+            return GROW_OK;
         }
     };
     const HostGrow grow{gheap, gnodes, &migrations, P.stack_limit + 10, P.edit_tree_limit + 10};

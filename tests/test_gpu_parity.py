@@ -61,7 +61,7 @@ def test_synthetic_batch_matches_oracle(name, prm, kw, lanes_per_read, monkeypat
     assert_same_as_oracle(ores, res, offsets)
 
 
-@pytest.mark.parametrize("class_counts", [("512", "512", "512", "512", "512"), ("8", "2", "0", "0", "0")])
+@pytest.mark.parametrize("class_counts", ["512,512,512,512,512,512,512,512,512", "8,2"])
 def test_small_arena_growth_last_pass_and_limits(monkeypatch, class_counts):
     """Reads that outgrow their arena migrate into the size-class pools (owner-word acquire / release); when a pool is dry the
     read is re-run by the full-limit pass.  Tiny STACK/EDIT_TREE limits exercise the overflow recovery of mapping.rs:1358-1380."""
@@ -70,13 +70,12 @@ def test_small_arena_growth_last_pass_and_limits(monkeypatch, class_counts):
     reads, qs = split_reads(seqs, quals, offsets)
     pidx = mapad_amd.Index.build([("chr1", g)])
     oidx = ob.OracleIndex.from_bwt(pidx.bwt(), "$ACGTX", 128)
-    monkeypatch.setenv("MAPAD_TIER0_NODES", "16")  # classes: 64, 256, 1024, 4096, 16384 nodes
-    for k, v in enumerate(class_counts):
-        monkeypatch.setenv(f"MAPAD_CLASS{k}_COUNT", v)
+    monkeypatch.setenv("MAPAD_TIER0_NODES", "32")  # classes: 64, 128, 256, ... nodes
+    monkeypatch.setenv("MAPAD_CLASS_COUNTS", class_counts)  # "8,2": reads wait for the few arenas; those that need > 128 nodes are re-run
     rp = resolve_params(NO_DAMAGE)
     res = _gpu_map(pidx, mapad_amd.make_params(rp), seqs, quals, offsets)
     assert res.n_second_pass > 0  # migrations
-    assert (res.n_third_pass > 0) == (class_counts[0] == "8")  # reads handed to the full-limit pass only when the pools are small
+    assert (res.n_third_pass > 0) == (class_counts == "8,2")  # reads handed to the full-limit pass only when no class can hold them
     ores = oidx.map_batch(ob.make_params(rp), reads, qs, n_threads=8, keep_d=True)
     assert_same_as_oracle(ores, res, offsets)
     for limits in ({"stack_limit": 40, "edit_tree_limit": 100000}, {"stack_limit": 100000, "edit_tree_limit": 120},
