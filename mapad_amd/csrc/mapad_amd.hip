@@ -39,7 +39,7 @@ enum : uint32_t { ST_POOL_OVERFLOW = 4, ST_NO_TABLE = 8 };
 // arena stays with the slot); pass 1 re-runs, with the reference's full limits, the few reads pass 0 could not finish because a
 // size-class pool ran dry.
 constexpr int kTiers = 2;
-constexpr int kClasses = 11;  // grown arenas: 2x steps above the base arena (4096 nodes -> 8 Ki ... 4 Mi), the last one with the full limits
+constexpr int kClasses = 10;  // grown arenas: 2x steps above the base arena (8 Ki nodes -> 16 Ki ... 4 Mi), the last one with the full limits
 constexpr int kKeyBins = kMaxReadLen + 2;
 // cursors: global bump allocators and work counters; per pass t: CUR_WORK + 2t = next work item, CUR_OVF + 2t = reads pass t handed on
 enum { CUR_HITS = 0, CUR_OPS = 1, CUR_POOL_OVF = 2, CUR_ERR = 3, CUR_WORK = 4, CUR_OVF = 5, CUR_GROWN = 4 + 2 * kTiers, CUR_COUNT = 4 + 2 * kTiers + 4 };
@@ -231,6 +231,16 @@ __device__ __forceinline__ void release_grown(const GrowPools* gp, uint32_t grow
     if (w == 0) atomicExch(&gp->owner[(grown >> kGrownShift) - 1][grown & ((1u << kGrownShift) - 1)], 0u);
 }
 
+template <int LPR>
+__device__ __forceinline__ void copy_units(uint4* dst, const uint4* src, uint32_t begin, uint32_t end, int w) {
+    uint32_t i = begin + w;
+    for (; i + 3 * LPR < end; i += 4 * LPR) {
+        const uint4 a = src[i], b = src[i + LPR], c = src[i + 2 * LPR], d = src[i + 3 * LPR];
+        dst[i] = a; dst[i + LPR] = b; dst[i + 2 * LPR] = c; dst[i + 3 * LPR] = d;
+    }
+    for (; i < end; i += LPR) dst[i] = src[i];
+}
+
 template <int LPR, bool NL>
 struct DeviceGrow {
     const GrowPools* gp;
@@ -271,10 +281,14 @@ struct DeviceGrow {
         HeapEntry* nheap = reinterpret_cast<HeapEntry*>(b) + 1;
         Node* nnodes = reinterpret_cast<Node*>(b + gp->off_nodes[cls]);
         // migrate heap slots [kTop, heap_len) (the top of the heap lives in the near array) and nodes [0, tree_entries)
-        for (uint32_t i = kTop + w; i < st.heap_len; i += LPR) nheap[i] = A.heap[i];
-        const uint4* ns = reinterpret_cast<const uint4*>(A.nodes);
-        uint4* nd = reinterpret_cast<uint4*>(nnodes);
-        for (uint32_t i = w; i < 2 * st.tree_entries; i += LPR) nd[i] = ns[i];
+        // (16-byte units, four loads in flight per lane: the other reads of the wavefront wait for this copy)
+        {
+            const uint4* hs = reinterpret_cast<const uint4*>(A.heap - 1);  // physical slot 0 is 16-byte aligned
+            uint4* hd = reinterpret_cast<uint4*>(nheap - 1);
+            const uint32_t h_end = (st.heap_len + 2) >> 1;  // pairs covering physical slots [kTop + 1, heap_len + 1)
+            copy_units<LPR>(hd, hs, (kTop + 1) >> 1, h_end, w);
+            copy_units<LPR>(reinterpret_cast<uint4*>(nnodes), reinterpret_cast<const uint4*>(A.nodes), 0, 2 * st.tree_entries, w);
+        }
         if (A.grown) release_grown<LPR>(gp, A.grown, w);
         A.heap = nheap; A.nodes = nnodes; A.heap_cap = gp->heap_cap[cls]; A.node_cap = gp->node_cap[cls];
         A.grown = ((cls + 1) << kGrownShift) | idx;
@@ -438,6 +452,7 @@ struct mapad_ctx {
     DevBuf<uint8_t> d_arena[kTiers];
     ArenaPool pool[kTiers] = {};
     uint32_t slots[kTiers] = {0, 0}, arena_lmax = 0;
+    uint64_t arena_reads = 0;
     DevBuf<uint8_t> d_class[kClasses];
     DevBuf<uint32_t> d_owner[kClasses];
     DevBuf<GrowPools> d_grow;
@@ -501,8 +516,9 @@ uint32_t env_u32(const char* name, uint32_t dflt) {
 // Pass 0: one base arena per read slot (MAPAD_TIER0_NODES nodes) plus size-class pools the slots grow into (x4 per class).
 // Pass 1: arenas with the reference's full limits (STACK_LIMIT + 9 frames, EDIT_TREE_LIMIT + 9 nodes: mapping.rs:52-54,147-148) for
 // the reads pass 0 could not finish (a size-class pool ran dry).  Semantic limits are the same everywhere.
-int ensure_arenas(mapad_ctx* c, uint32_t lmax) {
-    if (c->d_arena[0].p && lmax <= c->arena_lmax) return MAPAD_OK;
+int ensure_arenas(mapad_ctx* c, uint32_t lmax, uint64_t n_reads) {
+    if (c->d_arena[0].p && lmax <= c->arena_lmax && n_reads <= c->arena_reads) return MAPAD_OK;
+    n_reads = std::max<uint64_t>(n_reads, c->arena_reads);  // pools never shrink; a batch cannot use more arenas than it has reads
     c->lpr = env_u32("MAPAD_LANES_PER_READ", 4) == 1 ? 1 : 4;
     const uint32_t lm = std::max<uint32_t>(lmax, 128);
     const uint64_t stack_cap = (uint64_t)c->dprm.stack_limit + 10, tree_cap = (uint64_t)c->dprm.edit_tree_limit + 10;
@@ -510,20 +526,22 @@ int ensure_arenas(mapad_ctx* c, uint32_t lmax) {
     const uint32_t rpw = 64 / c->lpr;
     int rc;
     {   // pass 0 base arenas
-        const uint32_t nodes = env_u32("MAPAD_TIER0_NODES", 4096);
+        const uint32_t nodes = env_u32("MAPAD_TIER0_NODES", 8192);
         c->pool[0] = make_pool_layout((uint32_t)std::min<uint64_t>(nodes, stack_cap), (uint32_t)std::min<uint64_t>(nodes, tree_cap), hit_ops_cap, lm);
         c->slots[0] = env_u32("MAPAD_TIER0_WAVES_PER_CU", c->lpr == 4 ? 16 : 8) * (uint32_t)c->n_cu * rpw;
+        c->slots[0] = (uint32_t)std::min<uint64_t>(c->slots[0], (std::max<uint64_t>(n_reads, 1) + rpw - 1) / rpw * rpw);
         if ((rc = c->d_arena[0].ensure((size_t)c->slots[0] * c->pool[0].stride))) return rc;
         c->pool[0].base = c->d_arena[0].p;
     }
     {   // pass 1: full limits
         c->pool[1] = make_pool_layout((uint32_t)stack_cap, (uint32_t)tree_cap, hit_ops_cap, lm);
-        c->slots[1] = std::max<uint32_t>(env_u32("MAPAD_LAST_PASS_WAVES", c->lpr == 4 ? 2 : 1), 1) * rpw;
+        c->slots[1] = std::max<uint32_t>(env_u32("MAPAD_LAST_PASS_WAVES", 1), 1) * rpw;
         if ((rc = c->d_arena[1].ensure((size_t)c->slots[1] * c->pool[1].stride))) return rc;
         c->pool[1].base = c->d_arena[1].p;
     }
     // size classes: 2x steps; the last one holds the reference's full limits so that its owners never have to grow (no wait cycles)
-    uint32_t counts[kClasses] = {c->slots[0], c->slots[0] / 2, c->slots[0] / 4, c->slots[0] / 8, 2048, 512, 128, 64, 32, 16, 16};
+    uint32_t counts[kClasses] = {c->slots[0] / 2, c->slots[0] / 4, c->slots[0] / 8, c->slots[0] / 16, 1024, 256, 64, 32, 16, 16};
+    for (int k = 0; k < kClasses; ++k) counts[k] = std::max<uint32_t>(counts[k], 16);
     if (const char* e = std::getenv("MAPAD_CLASS_COUNTS")) {  // comma list, missing entries = 0
         for (int k = 0; k < kClasses; ++k) counts[k] = 0;
         int k = 0;
@@ -551,6 +569,7 @@ int ensure_arenas(mapad_ctx* c, uint32_t lmax) {
     HIP_TRY(hipMemcpyAsync(c->d_grow.p, &c->grow, sizeof(GrowPools), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->arena_lmax = lm;
+    c->arena_reads = n_reads;
     return MAPAD_OK;
 }
 
@@ -558,7 +577,7 @@ int launch_batch(mapad_ctx* c, const uint8_t* d_seqs, const uint8_t* d_quals, co
                  uint32_t lmax) {
     int rc;
     if ((rc = upload_tables(c))) return rc;
-    if ((rc = ensure_arenas(c, lmax))) return rc;
+    if ((rc = ensure_arenas(c, lmax, n_reads))) return rc;
     const size_t nr = std::max<uint64_t>(n_reads, 1);
     if ((rc = c->d_darr.ensure(std::max<uint64_t>(total_bases, 1)))) return rc;
     if ((rc = c->d_counters.ensure(nr))) return rc;

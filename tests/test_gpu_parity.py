@@ -70,7 +70,7 @@ def test_small_arena_growth_last_pass_and_limits(monkeypatch, class_counts):
     reads, qs = split_reads(seqs, quals, offsets)
     pidx = mapad_amd.Index.build([("chr1", g)])
     oidx = ob.OracleIndex.from_bwt(pidx.bwt(), "$ACGTX", 128)
-    monkeypatch.setenv("MAPAD_TIER0_NODES", "32")  # classes: 64, 128, 256, ... nodes
+    monkeypatch.setenv("MAPAD_TIER0_NODES", "32")  # classes: 64, 128, 256, ..., 16384 nodes, full limits
     monkeypatch.setenv("MAPAD_CLASS_COUNTS", class_counts)  # "8,2": reads wait for the few arenas; those that need > 128 nodes are re-run
     rp = resolve_params(NO_DAMAGE)
     res = _gpu_map(pidx, mapad_amd.make_params(rp), seqs, quals, offsets)
