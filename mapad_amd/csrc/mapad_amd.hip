@@ -225,10 +225,19 @@ __device__ MAPAD_FINALIZE_ATTR void finalize_read(const BatchDev B, const ArenaT
 // grow(A, st): called by check_and_push when the heap or the node slab is full (search_core.hpp).  All lanes of the read's lane
 // group call it together with identical arguments.  Arenas change owners inside a launch and the L2s of the eight XCDs are not
 // coherent with each other for ordinary stores, hence the agent-scope fences around acquire and release.
+// Pools with at least kPartitionMin arenas are split into eight parts, one per XCD (HW_REG_XCC_ID): an arena of such a pool is only
+// ever touched through one L2, so handing it to another read needs no L2 write-back (`buffer_wbl2` flushes every dirty line of the
+// XCD, measured 4 % of C3's run time), only the completion of the old owner's stores and an L1 invalidate on the new owner's CU.
+// Smaller pools (the big, rare classes) are shared by all XCDs and use full agent-scope fences.
+constexpr uint32_t kPartitionMin = 64;
+__device__ __forceinline__ uint32_t xcc_id() { return (uint32_t)__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u; }  // HW_REG_XCC_ID[3:0]
+
 template <int LPR>
 __device__ __forceinline__ void release_grown(const GrowPools* gp, uint32_t grown, int w) {
-    __threadfence();  // every access to the arena has completed and is written back before another slot may take it
-    if (w == 0) atomicExch(&gp->owner[(grown >> kGrownShift) - 1][grown & ((1u << kGrownShift) - 1)], 0u);
+    const uint32_t cls = (grown >> kGrownShift) - 1;
+    if (gp->count[cls] >= kPartitionMin) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // stores have reached the (shared) L2
+    else __threadfence();  // every access to the arena has completed and is written back before another XCD may take it
+    if (w == 0) atomicExch(&gp->owner[cls][grown & ((1u << kGrownShift) - 1)], 0u);
 }
 
 template <int LPR>
@@ -258,12 +267,14 @@ struct DeviceGrow {
             if (n == 0 || gp->node_cap[cls] < st.tree_len + kStepNodes || gp->heap_cap[cls] < st.heap_len + kStepNodes) continue;
             exists = true;
             if (w == 0) {
-                uint32_t i = (uint32_t)(((uint64_t)(slot + st.ctr.n_pop) * 2654435761u) % n);
-                const uint32_t tries = n < 64u ? n : 64u;
-                uint32_t* own = gp->owner[cls];
+                const bool part = n >= kPartitionMin;
+                const uint32_t m = part ? n / 8 : n, lo = part ? xcc_id() * m : 0;  // this XCD's part of the pool
+                uint32_t i = (uint32_t)(((uint64_t)(slot + st.ctr.n_pop) * 2654435761u) % m);
+                const uint32_t tries = m < 64u ? m : 64u;
+                uint32_t* own = gp->owner[cls] + lo;
                 for (uint32_t t = 0; t < tries; ++t) {
-                    if (atomicCAS(&own[i], 0u, 1u) == 0u) { idx = i; break; }
-                    if (++i == n) i = 0;
+                    if (atomicCAS(&own[i], 0u, 1u) == 0u) { idx = lo + i; break; }
+                    if (++i == m) i = 0;
                 }
                 if (idx == ~0u) atomicOr(grown_counter + 1, 1u << cls);  // debugging aid: classes that ran dry
             }
@@ -276,7 +287,8 @@ struct DeviceGrow {
             if (w == 0) atomicAdd(grown_counter + 2, 1u);
             return GROW_WAIT;
         }
-        __threadfence();
+        if (gp->count[cls] >= kPartitionMin) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // drop stale lines of this CU's L1
+        else __threadfence();
         uint8_t* b = gp->base[cls] + (uint64_t)idx * gp->stride[cls];
         HeapEntry* nheap = reinterpret_cast<HeapEntry*>(b) + 1;
         Node* nnodes = reinterpret_cast<Node*>(b + gp->off_nodes[cls]);
@@ -349,12 +361,6 @@ __global__ void __launch_bounds__(64, 4) search_kernel(DevIndex ix, DevParams P,
             }
         }
         if (__all(done)) break;
-#if !defined(MAPAD_NO_PRIO)
-        // wavefronts that carry a long-running read get issue priority: their serial chain bounds the batch
-        if (__any(have && st.ctr.n_pop > 12288u)) __builtin_amdgcn_s_setprio(3);
-        else if (__any(have && st.ctr.n_pop > 3072u)) __builtin_amdgcn_s_setprio(1);
-        else __builtin_amdgcn_s_setprio(0);
-#endif
         if (have) {
             bool cont;
             if constexpr (PASS == 0) cont = search_step<LPR, CONT, NL>(ix, P, rd, A, st, w, grow);
