@@ -88,11 +88,13 @@ constexpr float kF32Min = -3.402823466e+38f;  // Rust f32::MIN
 struct Float4 { float a, c, g, t; };
 MAPAD_HD float f4_get(const Float4& f, int i) { return i == 0 ? f.a : i == 1 ? f.c : i == 2 ? f.g : f.t; }
 
-MAPAD_HD Float4 sdm_row(const DevParams& p, int L, int i, int q, int to_class) {
+// `base` = DevParams::table_base[L] of the read (looked up once per read: it is a dependent load otherwise)
+MAPAD_HD Float4 sdm_row_at(const DevParams& p, int32_t base, int i, int q, int to_class) {
     const int qi = p.nq == 1 ? 0 : q;
-    const float* e = p.sdm_table + 4 * ((size_t)p.table_base[L] + ((size_t)i * p.nq + qi) * 5 + to_class);
+    const float* e = p.sdm_table + 4 * ((size_t)base + ((size_t)i * p.nq + qi) * 5 + to_class);
     return Float4{e[0], e[1], e[2], e[3]};
 }
+MAPAD_HD Float4 sdm_row(const DevParams& p, int L, int i, int q, int to_class) { return sdm_row_at(p, p.table_base[L], i, q, to_class); }
 // get_min_penalty(.., only_mismatches=false)  (sequence_difference_models.rs:34-57)
 MAPAD_HD float sdm_optimal(const Float4& r, int to_class) {
     if (to_class > 3) return 0.0f;

@@ -117,26 +117,38 @@ __device__ __forceinline__ uint32_t quad_sum32(uint32_t v) {
     return v;
 }
 
-// lane w (= threadIdx & 3) returns occ(r, base w) for the quad-uniform row r.
-__device__ __forceinline__ uint64_t quad_occ(const DevIndex& ix, uint64_t r, int w) {
+// lane w (= threadIdx & 3) returns occ(r, base w) for the quad-uniform row r.  Split into the loads and the arithmetic so that a
+// caller with two queries has all four loads in flight before the first popcount (the DPP moves are scheduling barriers for the
+// compiler, it does not hoist the second query's loads over them by itself).
+struct OccLoads { ulonglong2 v0, v1; };
+__device__ __forceinline__ OccLoads quad_occ_issue(const DevIndex& ix, uint64_t r, int w) {
     const uint64_t* sb = ix.blocks + (r >> 8) * 16 + 4 * w;
-    const ulonglong2 v0 = *reinterpret_cast<const ulonglong2*>(sb);      // count_w, plane0
-    const ulonglong2 v1 = *reinterpret_cast<const ulonglong2*>(sb + 2);  // plane1, plane2
+    OccLoads l;
+    l.v0 = *reinterpret_cast<const ulonglong2*>(sb);      // count_w, plane0
+    l.v1 = *reinterpret_cast<const ulonglong2*>(sb + 2);  // plane1, plane2
+    return l;
+}
+__device__ __forceinline__ uint64_t quad_occ_finish(const OccLoads& l, uint64_t r, int w) {
     const uint64_t m = row_mask(w, (int)(r & 255));
-    const uint64_t p0 = v0.y, p1 = v1.x, p2 = v1.y & m;
+    const uint64_t p0 = l.v0.y, p1 = l.v1.x, p2 = l.v1.y & m;
     const uint64_t hi1 = p2 & p1, lo1 = p2 & ~p1;  // {G,T} / {A,C}
     uint32_t ac = (uint32_t)popc64(lo1 & ~p0) | ((uint32_t)popc64(lo1 & p0) << 16);
     uint32_t gt = (uint32_t)popc64(hi1 & ~p0) | ((uint32_t)popc64(hi1 & p0) << 16);
     ac = quad_sum32(ac);
     gt = quad_sum32(gt);
     const uint32_t pair = (w & 2) ? gt : ac;
-    return v0.x + ((w & 1) ? (pair >> 16) : (pair & 0xFFFFu));
+    return l.v0.x + ((w & 1) ? (pair >> 16) : (pair & 0xFFFFu));
 }
+__device__ __forceinline__ uint64_t quad_occ(const DevIndex& ix, uint64_t r, int w) { return quad_occ_finish(quad_occ_issue(ix, r, w), r, w); }
 
 // All four lanes of the quad return the complete Ext4 of the (quad-uniform) input interval.
 __device__ __forceinline__ void ext4_quad(const DevIndex& ix, uint64_t lower, uint64_t lower_rev, uint64_t size, int w, Ext4& out) {
-    const uint64_t my_lo = lower == 0 ? 0 : quad_occ(ix, lower - 1, w);
-    const uint64_t my_hi = quad_occ(ix, lower + size - 1, w);
+    // both rank queries unconditionally, so that their four loads are in flight together (lower == 0: the result is discarded)
+    const uint64_t r_lo = lower == 0 ? 0 : lower - 1, r_hi = lower + size - 1;
+    const OccLoads l_lo = quad_occ_issue(ix, r_lo, w), l_hi = quad_occ_issue(ix, r_hi, w);
+    const uint64_t occ_lo = quad_occ_finish(l_lo, r_lo, w);
+    const uint64_t my_hi = quad_occ_finish(l_hi, r_hi, w);
+    const uint64_t my_lo = lower == 0 ? 0 : occ_lo;
     uint64_t lo[4], hi[4];
     lo[0] = quad_bcast64<0>(my_lo); lo[1] = quad_bcast64<1>(my_lo); lo[2] = quad_bcast64<2>(my_lo); lo[3] = quad_bcast64<3>(my_lo);
     hi[0] = quad_bcast64<0>(my_hi); hi[1] = quad_bcast64<1>(my_hi); hi[2] = quad_bcast64<2>(my_hi); hi[3] = quad_bcast64<3>(my_hi);
@@ -154,8 +166,12 @@ __device__ __forceinline__ uint64_t quad_pick64(uint64_t v, int k) {  // value o
     return k == 0 ? a : k == 1 ? b : k == 2 ? c : d;
 }
 __device__ __forceinline__ void ext4_quad_lane(const DevIndex& ix, uint64_t lower, uint64_t lower_rev, uint64_t size, int w, ExtLane& out) {
-    const uint64_t my_lo = lower == 0 ? 0 : quad_occ(ix, lower - 1, w);
-    const uint64_t my_hi = quad_occ(ix, lower + size - 1, w);
+    // both rank queries unconditionally, so that their four loads are in flight together (lower == 0: the result is discarded)
+    const uint64_t r_lo = lower == 0 ? 0 : lower - 1, r_hi = lower + size - 1;
+    const OccLoads l_lo = quad_occ_issue(ix, r_lo, w), l_hi = quad_occ_issue(ix, r_hi, w);
+    const uint64_t occ_lo = quad_occ_finish(l_lo, r_lo, w);
+    const uint64_t my_hi = quad_occ_finish(l_hi, r_hi, w);
+    const uint64_t my_lo = lower == 0 ? 0 : occ_lo;
     const uint64_t my_size = my_hi - my_lo;
     const uint64_t s0 = quad_bcast64<0>(my_size), s1 = quad_bcast64<1>(my_size), s2 = quad_bcast64<2>(my_size), s3 = quad_bcast64<3>(my_size);
     const uint64_t o_s = lower == 0 ? 0 : sentinel_le(ix, lower - 1);
@@ -171,8 +187,12 @@ __device__ __forceinline__ void ext4_quad_lane(const DevIndex& ix, uint64_t lowe
 
 // Single-base step for the D-array chains: new (lower, size) of the quad-uniform interval extended by base k (0..3).
 __device__ __forceinline__ void ext1_quad(const DevIndex& ix, uint64_t lower, uint64_t size, int k, int w, uint64_t& new_lower, uint64_t& new_size) {
-    const uint64_t my_lo = lower == 0 ? 0 : quad_occ(ix, lower - 1, w);
-    const uint64_t my_hi = quad_occ(ix, lower + size - 1, w);
+    // both rank queries unconditionally, so that their four loads are in flight together (lower == 0: the result is discarded)
+    const uint64_t r_lo = lower == 0 ? 0 : lower - 1, r_hi = lower + size - 1;
+    const OccLoads l_lo = quad_occ_issue(ix, r_lo, w), l_hi = quad_occ_issue(ix, r_hi, w);
+    const uint64_t occ_lo = quad_occ_finish(l_lo, r_lo, w);
+    const uint64_t my_hi = quad_occ_finish(l_hi, r_hi, w);
+    const uint64_t my_lo = lower == 0 ? 0 : occ_lo;
     // pick lane k's values (k is quad-uniform but dynamic): 4 broadcasts + selects
     const uint64_t l0 = quad_bcast64<0>(my_lo), l1 = quad_bcast64<1>(my_lo), l2 = quad_bcast64<2>(my_lo), l3 = quad_bcast64<3>(my_lo);
     const uint64_t h0 = quad_bcast64<0>(my_hi), h1 = quad_bcast64<1>(my_hi), h2 = quad_bcast64<2>(my_hi), h3 = quad_bcast64<3>(my_hi);

@@ -86,11 +86,11 @@ template <bool NL>
 __device__ __forceinline__ ArenaT<NL> carve(const ArenaPool& ap, uint32_t slot) {
     uint8_t* b = ap.base + (uint64_t)slot * ap.stride;
     ArenaT<NL> a;
-    a.heap = reinterpret_cast<HeapEntry*>(b) + 1;  // logical slot 0 = physical slot 1 (aligned child pairs, search_core.hpp)
-    a.nodes = reinterpret_cast<Node*>(b + ap.off_nodes);
-    a.hits = reinterpret_cast<HitRec*>(b + ap.off_hits);
-    a.hit_ops = reinterpret_cast<uint32_t*>(b + ap.off_hit_ops);
-    a.scratch = reinterpret_cast<uint16_t*>(b + ap.off_scratch);
+    a.heap = (MAPAD_GLOBAL HeapEntry*)(b) + 1;  // logical slot 0 = physical slot 1 (aligned child pairs, search_core.hpp)
+    a.nodes = (MAPAD_GLOBAL Node*)(b + ap.off_nodes);
+    a.hits = (MAPAD_GLOBAL HitRec*)(b + ap.off_hits);
+    a.hit_ops = (MAPAD_GLOBAL uint32_t*)(b + ap.off_hit_ops);
+    a.scratch = (MAPAD_GLOBAL uint16_t*)(b + ap.off_scratch);
     a.top = nullptr;  // set by the kernel (LDS or the arena's `near` area)
     a.heap_cap = ap.heap_cap; a.node_cap = ap.node_cap; a.hit_ops_cap = ap.hit_ops_cap;
     return a;
@@ -241,7 +241,7 @@ __device__ __forceinline__ void release_grown(const GrowPools* gp, uint32_t grow
 }
 
 template <int LPR>
-__device__ __forceinline__ void copy_units(uint4* dst, const uint4* src, uint32_t begin, uint32_t end, int w) {
+__device__ __forceinline__ void copy_units(MAPAD_GLOBAL uint4* dst, const MAPAD_GLOBAL uint4* src, uint32_t begin, uint32_t end, int w) {
     uint32_t i = begin + w;
     for (; i + 3 * LPR < end; i += 4 * LPR) {
         const uint4 a = src[i], b = src[i + LPR], c = src[i + 2 * LPR], d = src[i + 3 * LPR];
@@ -290,16 +290,16 @@ struct DeviceGrow {
         if (gp->count[cls] >= kPartitionMin) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // drop stale lines of this CU's L1
         else __threadfence();
         uint8_t* b = gp->base[cls] + (uint64_t)idx * gp->stride[cls];
-        HeapEntry* nheap = reinterpret_cast<HeapEntry*>(b) + 1;
-        Node* nnodes = reinterpret_cast<Node*>(b + gp->off_nodes[cls]);
+        MAPAD_GLOBAL HeapEntry* nheap = (MAPAD_GLOBAL HeapEntry*)(b) + 1;
+        MAPAD_GLOBAL Node* nnodes = (MAPAD_GLOBAL Node*)(b + gp->off_nodes[cls]);
         // migrate heap slots [kTop, heap_len) (the top of the heap lives in the near array) and nodes [0, tree_entries)
         // (16-byte units, four loads in flight per lane: the other reads of the wavefront wait for this copy)
         {
-            const uint4* hs = reinterpret_cast<const uint4*>(A.heap - 1);  // physical slot 0 is 16-byte aligned
-            uint4* hd = reinterpret_cast<uint4*>(nheap - 1);
+            const MAPAD_GLOBAL uint4* hs = (const MAPAD_GLOBAL uint4*)(A.heap - 1);  // physical slot 0 is 16-byte aligned
+            MAPAD_GLOBAL uint4* hd = (MAPAD_GLOBAL uint4*)(nheap - 1);
             const uint32_t h_end = (st.heap_len + 2) >> 1;  // pairs covering physical slots [kTop + 1, heap_len + 1)
             copy_units<LPR>(hd, hs, (kTop + 1) >> 1, h_end, w);
-            copy_units<LPR>(reinterpret_cast<uint4*>(nnodes), reinterpret_cast<const uint4*>(A.nodes), 0, 2 * st.tree_entries, w);
+            copy_units<LPR>((MAPAD_GLOBAL uint4*)nnodes, (const MAPAD_GLOBAL uint4*)A.nodes, 0, 2 * st.tree_entries, w);
         }
         if (A.grown) release_grown<LPR>(gp, A.grown, w);
         A.heap = nheap; A.nodes = nnodes; A.heap_cap = gp->heap_cap[cls]; A.node_cap = gp->node_cap[cls];
@@ -335,7 +335,7 @@ __global__ void __launch_bounds__(64, 4) search_kernel(DevIndex ix, DevParams P,
 #if defined(MAPAD_ACTIVE_QUADS)
     if ((lane / LPR) >= MAPAD_ACTIVE_QUADS) done = true;  // experiment: fewer reads per wavefront
 #endif
-    ReadInT<NL> rd{near_qc, near_d, 0, 0.0f};
+    ReadInT<NL> rd{near_qc, near_d, 0, 0.0f, 0};
     SearchState st;
     uint32_t read = 0;
     for (;;) {
@@ -349,6 +349,7 @@ __global__ void __launch_bounds__(64, 4) search_kernel(DevIndex ix, DevParams P,
                 const uint64_t off = B.offsets[read];
                 rd.L = (int)(B.offsets[read + 1] - off);
                 rd.thr = P.reject_thr[rd.L];
+                rd.table = P.table_base[rd.L];
                 if (tier == 0 && B.status[read] == ST_NO_TABLE) {  // the D kernel already flagged it
                     if (w == 0) { B.hit_count[read] = 0; B.hit_first[read] = 0; }
                 } else {

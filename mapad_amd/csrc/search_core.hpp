@@ -90,10 +90,15 @@ enum : uint32_t { ST_OK = 0, ST_ARENA_OVERFLOW = 1, ST_LIMIT_ABORT = 2 };
 // compiler emits ds_* instructions for it and global_* for the arena (a pointer that may be either would force flat_* accesses,
 // which occupy the texture addresser and make every wait a full vmcnt(0)+lgkmcnt(0) wait).  NL = false: plain pointers (host build,
 // very long reads whose near data stays in the HBM arena).
+// The arena pointers of a grown read come out of a descriptor in memory, so their address space must be spelled out as well: left
+// generic they turn every heap and node access into a flat_* instruction, which counts against both vmcnt and lgkmcnt and so
+// serialises the LDS and the HBM halves of every sift.
 #if defined(__HIP_DEVICE_COMPILE__)
 #define MAPAD_LDS __attribute__((address_space(3)))
+#define MAPAD_GLOBAL __attribute__((address_space(1)))
 #else
 #define MAPAD_LDS
+#define MAPAD_GLOBAL
 #endif
 template <class T, bool NL> struct near_ptr { using type = T*; };
 template <class T> struct near_ptr<T, true> { using type = MAPAD_LDS T*; };
@@ -101,11 +106,11 @@ template <class T> struct near_ptr<T, true> { using type = MAPAD_LDS T*; };
 template <bool NL>
 struct ArenaT {
     typename near_ptr<HeapEntry, NL>::type top;  // logical heap slots [0, kTop), shifted by one entry like `heap`
-    HeapEntry* heap;    // logical heap slots [kTop, ..) are used from here
-    Node* nodes;
-    HitRec* hits;       // kMaxHits
-    uint32_t* hit_ops;  // staging for the hits' edit tracks
-    uint16_t* scratch;  // 2 * (Lmax + 1) u16 for the bucket sort of extract_edit_operations
+    MAPAD_GLOBAL HeapEntry* heap;    // logical heap slots [kTop, ..) are used from here
+    MAPAD_GLOBAL Node* nodes;
+    MAPAD_GLOBAL HitRec* hits;       // kMaxHits
+    MAPAD_GLOBAL uint32_t* hit_ops;  // staging for the hits' edit tracks
+    MAPAD_GLOBAL uint16_t* scratch;  // 2 * (Lmax + 1) u16 for the bucket sort of extract_edit_operations
     uint32_t heap_cap, node_cap, hit_ops_cap;
     uint32_t grown = 0;  // 0: heap/nodes are the slot's base arena; else (class + 1) << 27 | arena index (mapad_amd.hip: DeviceGrow)
     uint32_t wait = 0;   // steps to sit out before asking the pools again
@@ -119,6 +124,7 @@ struct ReadInT {
     typename near_ptr<const float, NL>::type d;     // D array
     int L;
     float thr;          // DevParams::reject_thr[L]
+    int32_t table;      // DevParams::table_base[L]
 };
 using ReadIn = ReadInT<false>;
 
@@ -136,6 +142,12 @@ MAPAD_HD HeapPair load_pair(const HeapEntry* p) {  // p is 16-byte aligned
 #endif
 }
 #if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ HeapPair load_pair(const MAPAD_GLOBAL HeapEntry* p) {
+    const uint4 q = *(const MAPAD_GLOBAL uint4*)p;
+    HeapPair r;
+    r.a.score = __uint_as_float(q.x); r.a.node = q.y; r.b.score = __uint_as_float(q.z); r.b.node = q.w;
+    return r;
+}
 __device__ __forceinline__ HeapPair load_pair(const MAPAD_LDS HeapEntry* p) {
     const uint4 q = *(const MAPAD_LDS uint4*)p;
     HeapPair r;
@@ -145,8 +157,18 @@ __device__ __forceinline__ HeapPair load_pair(const MAPAD_LDS HeapEntry* p) {
 #endif
 
 // heap slot i of this read: the top levels sit in the near array (LDS), the rest in the HBM arena
-template <bool NL> MAPAD_HD HeapEntry hp_get(const ArenaT<NL>& A, uint32_t i) { if (i < (uint32_t)kTop) return A.top[i]; return A.heap[i]; }
-template <bool NL> MAPAD_HD void hp_set(const ArenaT<NL>& A, uint32_t i, const HeapEntry e) { if (i < (uint32_t)kTop) A.top[i] = e; else A.heap[i] = e; }
+// Entries are moved field by field: copying the struct would bind the source to a reference in the generic address space, and after
+// the near/arena branches are merged the access would stay a flat_* instruction (vmcnt and lgkmcnt, no overlap with anything).
+template <class P> MAPAD_HD HeapEntry load_entry(P p) { HeapEntry e; e.score = p->score; e.node = p->node; return e; }
+template <class P> MAPAD_HD void store_entry(P p, const HeapEntry e) { p->score = e.score; p->node = e.node; }
+template <bool NL> MAPAD_HD HeapEntry hp_get(const ArenaT<NL>& A, uint32_t i) {
+    if (i < (uint32_t)kTop) return load_entry(A.top + i);
+    return load_entry(A.heap + i);
+}
+template <bool NL> MAPAD_HD void hp_set(const ArenaT<NL>& A, uint32_t i, const HeapEntry e) {
+    if (i < (uint32_t)kTop) store_entry(A.top + i, e);
+    else store_entry(A.heap + i, e);
+}
 template <bool NL> MAPAD_HD HeapPair hp_pair(const ArenaT<NL>& A, uint32_t i) { if (i < (uint32_t)kTop) return load_pair(A.top + i); return load_pair(A.heap + i); }
 
 struct SearchState {
@@ -269,7 +291,8 @@ MAPAD_HD HeapEntry mm_pop_min(const ArenaT<NL>& A, uint32_t& n) {
 }
 
 // ---- slab tree ----------------------------------------------------------------------------------------------------
-MAPAD_HD uint32_t tree_insert(Node* nodes, SearchState& st, const Node& nd) {
+template <class NP>
+MAPAD_HD uint32_t tree_insert(NP nodes, SearchState& st, const Node& nd) {
     const uint32_t key = st.tree_next;
     if (key == st.tree_entries) { st.tree_entries += 1; st.tree_next = key + 1; }
     else st.tree_next = node_parent(nodes[key]);  // vacant slot stores the next free key
@@ -278,14 +301,16 @@ MAPAD_HD uint32_t tree_insert(Node* nodes, SearchState& st, const Node& nd) {
     return key;
 }
 // tree_insert without the store: the caller writes the node (one lane of the quad owns it, search_step)
-MAPAD_HD uint32_t tree_alloc(const Node* nodes, SearchState& st) {
+template <class NP>
+MAPAD_HD uint32_t tree_alloc(NP nodes, SearchState& st) {
     const uint32_t key = st.tree_next;
     if (key == st.tree_entries) { st.tree_entries += 1; st.tree_next = key + 1; }
     else st.tree_next = node_parent(nodes[key]);
     st.tree_len += 1;
     return key;
 }
-MAPAD_HD void tree_remove(Node* nodes, SearchState& st, uint32_t key) {  // backtrack_tree.rs:50-54
+template <class NP>
+MAPAD_HD void tree_remove(NP nodes, SearchState& st, uint32_t key) {  // backtrack_tree.rs:50-54
     if (key == 0) return;
     Node nd = nodes[key];
     nd.w2 &= ~(1ull << 52);
@@ -298,10 +323,11 @@ MAPAD_HD void tree_remove(Node* nodes, SearchState& st, uint32_t key) {  // back
 // ---- extract_edit_operations (src/map/record.rs:465-500) -------------------------------------------------------------
 // Walk leaf -> root (root excluded, stop at a vacant slot), bucket by read position ascending; a bucket keeps walk order
 // if its position is left of the alignment start, else it is reversed.  Counting sort over positions 0..L.
-MAPAD_RARE uint32_t extract_ops(const Node* nodes, uint32_t end_node, int alignment_start, int L, uint16_t* scratch, uint32_t* out,
+template <class NP, class SP, class OP>
+MAPAD_RARE uint32_t extract_ops(NP nodes, uint32_t end_node, int alignment_start, int L, SP scratch, OP out,
                               uint32_t out_cap) {
-    uint16_t* cnt = scratch;           // [L + 1]
-    uint16_t* fill = scratch + L + 1;  // [L + 1]
+    SP cnt = scratch;           // [L + 1]
+    SP fill = scratch + L + 1;  // [L + 1]
     for (int i = 0; i <= L; ++i) { cnt[i] = 0; fill[i] = 0; }
     uint32_t m = 0;
     for (uint32_t s = end_node; s != 0;) {
@@ -328,7 +354,8 @@ MAPAD_RARE uint32_t extract_ops(const Node* nodes, uint32_t end_node, int alignm
 }
 
 // ---- hit list: Rust BinaryHeap::push (sift_up moves while strictly greater than the parent) -----------------------------------
-MAPAD_HD void hits_push(HitRec* hits, uint32_t& n, const HitRec& h) {
+template <class HP>
+MAPAD_HD void hits_push(HP hits, uint32_t& n, const HitRec& h) {
     uint32_t pos = n;
     n += 1;
     while (pos > 0) {
@@ -476,8 +503,7 @@ MAPAD_HD bool search_step(const DevIndex& ix, const DevParams& P, const ReadInT<
         j = f.start - 1; forward = false; d_k = f.start - 1; d_l = f.start + f.len - 1;
     }
     const int to_class = rd.qc[2 * j];
-    const Float4 row = sdm_row(P, L, j, rd.qc[2 * j + 1], to_class);  // shared score table: hot in L1/L2
-    const float optimal = sdm_optimal(row, to_class);
+    const Float4 row = sdm_row_at(P, rd.table, j, rd.qc[2 * j + 1], to_class);  // shared score table: hot in L1/L2; consumed after the rank queries
     const uint32_t gap_side = forward ? f.gap_f : f.gap_b;
     const float insertion_score = (gap_side == GAP_INS ? P.gap_extend : open_ext) + f_score;  // :1127-1136,1165-1174
     const float deletion_score = (gap_side == GAP_DEL ? P.gap_extend : open_ext) + f_score;
@@ -496,14 +522,12 @@ MAPAD_HD bool search_step(const DevIndex& ix, const DevParams& P, const ReadInT<
     uint32_t nonempty;
     if constexpr (kLaneKids) {
 #if defined(__HIP_DEVICE_COMPILE__)
-        ExtLane x;
-        if (forward) ext4_quad_lane(ix, f.lower_rev, f.lower, f.size, w, x);
-        else ext4_quad_lane(ix, f.lower, f.lower_rev, f.size, w, x);
+        ExtLane x;  // one call site: the rank queries of forward and backward quads of a wavefront share their memory round trip
+        ext4_quad_lane(ix, forward ? f.lower_rev : f.lower, forward ? f.lower : f.lower_rev, f.size, w, x);
         my_lower = x.lower; my_lower_rev = x.lower_rev; my_size = x.size; nonempty = x.nonempty;
 #endif
     } else {
-        if (forward) ext4_any<LPR>(ix, f.lower_rev, f.lower, f.size, w, e);
-        else ext4_any<LPR>(ix, f.lower, f.lower_rev, f.size, w, e);
+        ext4_any<LPR>(ix, forward ? f.lower_rev : f.lower, forward ? f.lower : f.lower_rev, f.size, w, e);
         nonempty = (e.size[0] >= 1 ? 1u : 0u) | (e.size[1] >= 1 ? 2u : 0u) | (e.size[2] >= 1 ? 4u : 0u) | (e.size[3] >= 1 ? 8u : 0u);
     }
     st.ctr.e_search += 1;
@@ -516,6 +540,7 @@ MAPAD_HD bool search_step(const DevIndex& ix, const DevParams& P, const ReadInT<
     const bool ins_ok = !mb_reject<CONT>(rd.thr, P.cutoff, insertion_score + lower_bound) && ins_dist >= P.gap_dist_ends;  // :1214-1216
     const bool del_ok = !mb_reject<CONT>(rd.thr, P.cutoff, deletion_score + lower_bound) && del_dist >= P.gap_dist_ends;   // :1279-1281
     uint32_t cand = ins_ok ? 1u : 0u;
+    const float optimal = sdm_optimal(row, to_class);
     float mm[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {

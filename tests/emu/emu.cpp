@@ -95,7 +95,7 @@ mapad_batch_result_t* emu_map_batch(const uint64_t* blocks, uint64_t n_blocks, u
             nodes.assign(std::min<uint32_t>(nc, 1u << 22), Node{});
             A.top = top.data() + 1; A.heap = heap.data() + 1; A.nodes = nodes.data(); A.hits = hits.data(); A.hit_ops = hit_ops.data(); A.scratch = scratch.data();
             A.heap_cap = (uint32_t)heap.size() - 16; A.node_cap = (uint32_t)nodes.size(); A.hit_ops_cap = (uint32_t)hit_ops.size();
-            ReadIn rd{qc.data(), dnear.data(), L, P.reject_thr[L]};
+            ReadIn rd{qc.data(), dnear.data(), L, P.reject_thr[L], P.table_base[L]};
             if (pass == 0) search_read(ix, P, rd, A, st, 0, grow);
             else search_read(ix, P, rd, A, st, 0);
             if (st.status != ST_ARENA_OVERFLOW) break;
