@@ -212,7 +212,11 @@ MAPAD_HD void mm_bubble_up(const ArenaT<NL>& A, uint32_t pos, const HeapEntry el
         const uint32_t i1 = (pos - 1) >> 1;                 // parent
         const uint32_t i2 = pos > 2 ? (pos - 3) >> 2 : 0;   // grandparent of pos
         const uint32_t i3 = i1 > 2 ? (i1 - 3) >> 2 : 0;     // grandparent of the parent
-        const HeapEntry e1 = hp_get(A, i1), e2 = hp_get(A, i2), e3 = hp_get(A, i3);
+        HeapEntry e1, e2, e3;  // i3 <= i2 <= i1: one branch per near/arena split, so that the arena loads of a case are in flight together
+        if (i1 < (uint32_t)kTop) { e1 = load_entry(A.top + i1); e2 = load_entry(A.top + i2); e3 = load_entry(A.top + i3); }
+        else if (i2 < (uint32_t)kTop) { e1 = load_entry(A.heap + i1); e2 = load_entry(A.top + i2); e3 = load_entry(A.top + i3); }
+        else if (i3 < (uint32_t)kTop) { e1 = load_entry(A.heap + i1); e2 = load_entry(A.heap + i2); e3 = load_entry(A.top + i3); }
+        else { e1 = load_entry(A.heap + i1); e2 = load_entry(A.heap + i2); e3 = load_entry(A.heap + i3); }
         bool greater;  // which grandparent chain to follow
         bool moved;
         if (mm_is_min_level(pos)) { moved = elt.score > e1.score; greater = moved; }
@@ -247,7 +251,10 @@ template <bool MAX, bool NL>
 MAPAD_HD void mm_trickle_down(const ArenaT<NL>& A, uint32_t n, uint32_t pos, HeapEntry elt) {
     while (2 * pos + 1 < n) {
         const uint32_t c1 = 2 * pos + 1, g1 = 2 * c1 + 1;
-        const HeapPair c = hp_pair(A, c1), ga = hp_pair(A, g1), gb = hp_pair(A, g1 + 2);  // groups never straddle kTop
+        HeapPair c, ga, gb;  // a level is entirely near or entirely in the arena; one branch per split keeps a case's loads in flight together
+        if (g1 + 3 < (uint32_t)kTop) { c = load_pair(A.top + c1); ga = load_pair(A.top + g1); gb = load_pair(A.top + g1 + 2); }
+        else if (c1 < (uint32_t)kTop) { c = load_pair(A.top + c1); ga = load_pair(A.heap + g1); gb = load_pair(A.heap + g1 + 2); }
+        else { c = load_pair(A.heap + c1); ga = load_pair(A.heap + g1); gb = load_pair(A.heap + g1 + 2); }
         uint32_t best = c1;
         HeapEntry be = c.a;
         if (c1 + 1 < n && (MAX ? (c.b.score > be.score) : (c.b.score < be.score))) { best = c1 + 1; be = c.b; }
