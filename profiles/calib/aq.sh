@@ -1,4 +1,4 @@
-for q in 16 8 4 2 1; do
+for q in ${AQ_LIST:-16 8 4 2 1}; do
   MAPAD_EXTRA_FLAGS="-DMAPAD_ACTIVE_QUADS=$q" python -m mapad_amd.build --force >/dev/null 2>&1
   n=$((q*125000))
   timeout 300 python bench.py --reads $n --steps 2 --warmup 1 --no-cpu-baseline 2>&1 | tail -1 > gpurun_out/aq.json
