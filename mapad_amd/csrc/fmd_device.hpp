@@ -26,10 +26,10 @@ MAPAD_HD int popc64(uint64_t x) {
 
 // rows of sub-block w that are <= r_in (r_in = row index inside the block, 0..255), as a bit mask
 MAPAD_HD uint64_t row_mask(int w, int r_in) {
-    const int wq = r_in >> 6, bit = r_in & 63;
-    if (w < wq) return ~0ull;
-    if (w > wq) return 0ull;
-    return bit == 63 ? ~0ull : ((2ull << bit) - 1ull);
+    const int t = r_in + 1 - 64 * w;  // rows of this sub-block that count: <= 0 none, >= 64 all
+    const int lo = t < 0 ? 0 : (t > 32 ? 32 : t), hi = t - 32 < 0 ? 0 : (t - 32 > 32 ? 32 : t - 32);  // bits set in each half
+    const uint32_t mlo = lo == 0 ? 0u : (0xFFFFFFFFu >> (32 - lo)), mhi = hi == 0 ? 0u : (0xFFFFFFFFu >> (32 - hi));
+    return ((uint64_t)mhi << 32) | mlo;
 }
 
 // ---- scalar reference of the same layout (host emulation + device single-lane paths such as SA walks) -------------
@@ -185,20 +185,22 @@ __device__ __forceinline__ void ext4_quad_lane(const DevIndex& ix, uint64_t lowe
     out.nonempty = (s0 >= 1 ? 1u : 0u) | (s1 >= 1 ? 2u : 0u) | (s2 >= 1 ? 4u : 0u) | (s3 >= 1 ? 8u : 0u);
 }
 
-// Single-base step for the D-array chains: new (lower, size) of the quad-uniform interval extended by base k (0..3).
+// Single-base step for the D-array chains: new (lower, size) of the quad-uniform interval extended by base k (0..3, quad-uniform).
+// Lane w counts base k in its own sub-block only (one popcount instead of four) and every lane reads the block's count word of base k.
 __device__ __forceinline__ void ext1_quad(const DevIndex& ix, uint64_t lower, uint64_t size, int k, int w, uint64_t& new_lower, uint64_t& new_size) {
-    // both rank queries unconditionally, so that their four loads are in flight together (lower == 0: the result is discarded)
     const uint64_t r_lo = lower == 0 ? 0 : lower - 1, r_hi = lower + size - 1;
-    const OccLoads l_lo = quad_occ_issue(ix, r_lo, w), l_hi = quad_occ_issue(ix, r_hi, w);
-    const uint64_t occ_lo = quad_occ_finish(l_lo, r_lo, w);
-    const uint64_t my_hi = quad_occ_finish(l_hi, r_hi, w);
-    const uint64_t my_lo = lower == 0 ? 0 : occ_lo;
-    // pick lane k's values (k is quad-uniform but dynamic): 4 broadcasts + selects
-    const uint64_t l0 = quad_bcast64<0>(my_lo), l1 = quad_bcast64<1>(my_lo), l2 = quad_bcast64<2>(my_lo), l3 = quad_bcast64<3>(my_lo);
-    const uint64_t h0 = quad_bcast64<0>(my_hi), h1 = quad_bcast64<1>(my_hi), h2 = quad_bcast64<2>(my_hi), h3 = quad_bcast64<3>(my_hi);
-    const uint64_t lo = k == 0 ? l0 : k == 1 ? l1 : k == 2 ? l2 : l3;
-    const uint64_t hi = k == 0 ? h0 : k == 1 ? h1 : k == 2 ? h2 : h3;
-    new_lower = ix.less[k + 1] + lo;
+    const uint64_t* b_lo = ix.blocks + (r_lo >> 8) * 16;
+    const uint64_t* b_hi = ix.blocks + (r_hi >> 8) * 16;
+    const ulonglong2 a0 = *reinterpret_cast<const ulonglong2*>(b_lo + 4 * w), a1 = *reinterpret_cast<const ulonglong2*>(b_lo + 4 * w + 2);
+    const ulonglong2 h0 = *reinterpret_cast<const ulonglong2*>(b_hi + 4 * w), h1 = *reinterpret_cast<const ulonglong2*>(b_hi + 4 * w + 2);
+    const uint64_t c_lo = b_lo[4 * k], c_hi = b_hi[4 * k];
+    const uint64_t inv1 = (k & 2) ? 0ull : ~0ull, inv0 = (k & 1) ? 0ull : ~0ull;
+    uint32_t n_lo = (uint32_t)popc64(a1.y & (a1.x ^ inv1) & (a0.y ^ inv0) & row_mask(w, (int)(r_lo & 255)));
+    uint32_t n_hi = (uint32_t)popc64(h1.y & (h1.x ^ inv1) & (h0.y ^ inv0) & row_mask(w, (int)(r_hi & 255)));
+    const uint32_t both = quad_sum32(n_lo | (n_hi << 16));  // each count <= 256
+    const uint64_t lo = lower == 0 ? 0 : c_lo + (both & 0xFFFFu);
+    const uint64_t hi = c_hi + (both >> 16);
+    new_lower = (k == 0 ? ix.less[1] : k == 1 ? ix.less[2] : k == 2 ? ix.less[3] : ix.less[4]) + lo;
     new_size = hi - lo;
 }
 #endif

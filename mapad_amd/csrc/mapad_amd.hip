@@ -157,27 +157,18 @@ __global__ void order_scan_kernel(uint32_t* hist) {  // hist[k] -> first positio
     uint32_t acc = 0;
     for (int k = kKeyBins - 1; k >= 0; --k) { const uint32_t c = hist[k]; hist[k] = acc; acc += c; }
 }
-__global__ void __launch_bounds__(256) order_scatter_kernel(BatchDev B) {
-    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    if (i >= B.n_reads) return;
-    const uint32_t key = B.sort_key[i];
-    // one atomic per distinct key of the wavefront
-    uint64_t todo = __ballot(1);
-    uint32_t pos = 0;
-    const int lane = threadIdx.x & 63;
-    while (todo) {
-        const int leader = __ffsll((long long)todo) - 1;
-        const uint32_t k = (uint32_t)__shfl((int)key, leader);
-        const uint64_t same = __ballot(key == k);
-        if (key == k) {
-            uint32_t base = 0;
-            if (lane == leader) base = atomicAdd(&B.key_hist[k], (uint32_t)__popcll(same));
-            base = (uint32_t)__shfl((int)base, leader);
-            pos = base + (uint32_t)__popcll(same & ((1ull << lane) - 1ull));
-        }
-        todo &= ~same;
-    }
-    B.order[pos] = i;
+__global__ void __launch_bounds__(1024) order_scatter_kernel(BatchDev B) {
+    // ranks inside the block through LDS atomics, one global atomic per (block, class that occurs in it)
+    __shared__ uint32_t cnt[kKeyBins], base[kKeyBins];
+    for (int k = threadIdx.x; k < kKeyBins; k += 1024) cnt[k] = 0;
+    __syncthreads();
+    const uint32_t i = blockIdx.x * 1024u + threadIdx.x;
+    uint32_t key = 0, r = 0;
+    if (i < B.n_reads) { key = B.sort_key[i]; r = atomicAdd(&cnt[key], 1u); }
+    __syncthreads();
+    for (int k = threadIdx.x; k < kKeyBins; k += 1024) { const uint32_t c = cnt[k]; if (c) base[k] = atomicAdd(&B.key_hist[k], c); }
+    __syncthreads();
+    if (i < B.n_reads) B.order[base[key] + r] = i;
 }
 
 // ---- search: persistent quads -----------------------------------------------------------------------------------------
@@ -625,7 +616,7 @@ int launch_batch(mapad_ctx* c, const uint8_t* d_seqs, const uint8_t* d_quals, co
     HIP_TRY(hipGetLastError());
     if (ordered) {
         hipLaunchKernelGGL(order_scan_kernel, dim3(1), dim3(64), 0, c->stream, c->d_key_hist.p);
-        hipLaunchKernelGGL(order_scatter_kernel, dim3((uint32_t)((n_reads + 255) / 256)), dim3(256), 0, c->stream, B);
+        hipLaunchKernelGGL(order_scatter_kernel, dim3((uint32_t)((n_reads + 1023) / 1024)), dim3(1024), 0, c->stream, B);
         HIP_TRY(hipGetLastError());
     }
     HIP_TRY(hipEventRecord(c->ev[1], c->stream));
