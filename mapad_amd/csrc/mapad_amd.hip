@@ -394,11 +394,11 @@ template <class T>
 struct DevBuf {
     T* p = nullptr;
     size_t cap = 0;
-    int ensure(size_t n) {
+    int ensure(size_t n, bool exact = false) {
         if (n <= cap) return MAPAD_OK;
         if (p) (void)hipFree(p);
         p = nullptr; cap = 0;
-        const size_t want = n + n / 8 + 64;
+        const size_t want = exact ? n : n + n / 8 + 64;
         if (hipMalloc((void**)&p, want * sizeof(T)) != hipSuccess) { p = nullptr; return MAPAD_ERR_NOMEM; }
         cap = want;
         return MAPAD_OK;
@@ -528,13 +528,13 @@ int ensure_arenas(mapad_ctx* c, uint32_t lmax, uint64_t n_reads) {
         c->pool[0] = make_pool_layout((uint32_t)std::min<uint64_t>(nodes, stack_cap), (uint32_t)std::min<uint64_t>(nodes, tree_cap), hit_ops_cap, lm);
         c->slots[0] = env_u32("MAPAD_TIER0_WAVES_PER_CU", c->lpr == 4 ? 16 : 8) * (uint32_t)c->n_cu * rpw;
         c->slots[0] = (uint32_t)std::min<uint64_t>(c->slots[0], (std::max<uint64_t>(n_reads, 1) + rpw - 1) / rpw * rpw);
-        if ((rc = c->d_arena[0].ensure((size_t)c->slots[0] * c->pool[0].stride))) return rc;
+        if ((rc = c->d_arena[0].ensure((size_t)c->slots[0] * c->pool[0].stride, true))) return rc;
         c->pool[0].base = c->d_arena[0].p;
     }
     {   // pass 1: full limits
         c->pool[1] = make_pool_layout((uint32_t)stack_cap, (uint32_t)tree_cap, hit_ops_cap, lm);
         c->slots[1] = std::max<uint32_t>(env_u32("MAPAD_LAST_PASS_WAVES", 1), 1) * rpw;
-        if ((rc = c->d_arena[1].ensure((size_t)c->slots[1] * c->pool[1].stride))) return rc;
+        if ((rc = c->d_arena[1].ensure((size_t)c->slots[1] * c->pool[1].stride, true))) return rc;
         c->pool[1].base = c->d_arena[1].p;
     }
     // size classes: 2x steps; the last one holds the reference's full limits so that its owners never have to grow (no wait cycles)
@@ -557,7 +557,25 @@ int ensure_arenas(mapad_ctx* c, uint32_t lmax, uint64_t n_reads) {
         // a class that is no bigger than the previous one (tiny semantic limits) is pointless: give it no arenas
         const bool useful = g.node_cap[k] > (k ? g.node_cap[k - 1] : c->pool[0].node_cap) || g.heap_cap[k] > (k ? g.heap_cap[k - 1] : c->pool[0].heap_cap);
         g.count[k] = useful ? std::min<uint32_t>(counts[k], (1u << kGrownShift) - 1) : 0;
-        if ((rc = c->d_class[k].ensure(std::max<size_t>((size_t)g.count[k] * g.stride[k], 128)))) return rc;
+    }
+    {   // fit the pools into the HBM that is free (index, tables and base arenas are already there; keep room for the batch buffers)
+        for (auto& a : c->d_class) a.release();
+        size_t free_b = 0, total_b = 0;
+        HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+        const uint64_t reserve = std::min<uint64_t>(16ull << 30, free_b / 4);
+        uint64_t budget = free_b > reserve ? free_b - reserve : 0;
+        if (const uint32_t gb = env_u32("MAPAD_POOL_BUDGET_GB", 0)) budget = std::min<uint64_t>(budget, (uint64_t)gb << 30);
+        for (;;) {
+            uint64_t need = 0;
+            for (int k = 0; k < kClasses; ++k) need += (uint64_t)g.count[k] * g.stride[k];
+            if (need <= budget) break;
+            bool shrunk = false;
+            for (int k = 0; k < kClasses; ++k) if (g.count[k] > 4) { g.count[k] /= 2; shrunk = true; }
+            if (!shrunk) break;  // back-pressure copes with small pools; the allocation below reports a real shortage
+        }
+    }
+    for (int k = 0; k < kClasses; ++k) {
+        if ((rc = c->d_class[k].ensure(std::max<size_t>((size_t)g.count[k] * g.stride[k], 128), true))) return rc;
         if ((rc = c->d_owner[k].ensure(std::max<size_t>(g.count[k], 1)))) return rc;
         HIP_TRY(hipMemsetAsync(c->d_owner[k].p, 0, std::max<size_t>(g.count[k], 1) * 4, c->stream));
         g.base[k] = c->d_class[k].p;

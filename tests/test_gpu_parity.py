@@ -61,6 +61,24 @@ def test_synthetic_batch_matches_oracle(name, prm, kw, lanes_per_read, monkeypat
     assert_same_as_oracle(ores, res, offsets)
 
 
+@pytest.mark.parametrize("env", [{"MAPAD_ORDER": "0"}, {"MAPAD_POOL_BUDGET_GB": "1", "MAPAD_TIER0_NODES": "256"}, {"MAPAD_NEAR_LDS": "0"}],
+                         ids=["input_order", "tiny_pool_budget", "near_data_in_hbm"])
+def test_scheduling_and_memory_variants_do_not_change_results(env, monkeypatch):
+    """The cost-class order, the size of the arena pools and where the near data lives only change when and where a read is
+    processed, never its result."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    g = synth.genome(300_000, seed=21)
+    seqs, quals, offsets = synth.reads(g, 2500, 50, seed=5, qual_range=(20, 40), damage=dict(f=0.5, t=0.5, d=0.02, s=1.0))
+    rp = resolve_params(DAMAGE)
+    pidx = mapad_amd.Index.build([("chr1", g)])
+    oidx = ob.OracleIndex.from_bwt(pidx.bwt(), "$ACGTX", 128)
+    res = _gpu_map(pidx, mapad_amd.make_params(rp), seqs, quals, offsets)
+    reads, qs = split_reads(seqs, quals, offsets)
+    ores = oidx.map_batch(ob.make_params(rp), reads, qs, n_threads=8, keep_d=True)
+    assert_same_as_oracle(ores, res, offsets)
+
+
 @pytest.mark.parametrize("class_counts", ["512,512,512,512,512,512,512,512,512", "8,2"])
 def test_small_arena_growth_last_pass_and_limits(monkeypatch, class_counts):
     """Reads that outgrow their arena migrate into the size-class pools (owner-word acquire / release); when a pool is dry the
