@@ -212,6 +212,27 @@ def main():
         if not ok:
             log("PARITY FAILURE: GPU hits differ from the oracle on the sample")
 
+    # ---- the next row of the path, outside the timed region: SA locate of the hits' rows on the device -------------
+    locate = None
+    if rank == 0:
+        small = res.hits_arr["size"] <= 8
+        lo, sz = res.hits_arr["lower"][small].astype(np.uint64), res.hits_arr["size"][small].astype(np.uint64)
+        rows = np.unique(np.concatenate([(lo + np.uint64(k))[sz > k] for k in range(8)]))
+        pos = ctx.sa_locate(rows)
+        pos = ctx.sa_locate(rows)  # second call: SA samples already resident
+        l_ms, l_rows, l_steps = ctx.locate_info()
+        l_bytes = 128 * l_steps + 16 * l_rows  # one index block per LF step, row in, sample + position out
+        locate = {"rows": int(l_rows), "lf_steps": int(l_steps), "kernel_ms": round(l_ms, 4), "rows_per_s": round(l_rows / (l_ms * 1e-3), 1) if l_ms else None,
+                  "algorithmic_GB/s": round(l_bytes / (l_ms * 1e-3) / 1e9, 2) if l_ms else None}
+        if not args.no_cpu_baseline:
+            n_s = int(min(rows.size, 300000))
+            t = time.perf_counter()
+            want = index.sa_get_batch(rows[:n_s])
+            dt = time.perf_counter() - t
+            locate["cpu_baseline"] = {"value": round(n_s / dt, 1), "unit": "rows/s", "cores": 1, "kind": "port",
+                                      "sample": f"first {n_s} rows, host restatement of SampledSuffixArray::get on one thread"}
+            locate["identical_positions"] = bool(np.array_equal(want, pos[:n_s]))
+
     if rank == 0:
         total_reads = n_reads * n_gpus * args.steps
         line = {
@@ -224,7 +245,7 @@ def main():
                        "parallelism": f"reads sharded over {n_gpus} GPU(s), index replicated, hit records gathered on rank 0" if n_gpus > 1 else "1 GPU",
                        "mapped_fraction": round(float((np.diff(res.hit_begin.astype(np.int64)) > 0).mean()), 4),
                        "index_build_s": round(t_index, 1)},
-            "roofline": roofline, "cpu_baseline": cpu, "parity": parity,
+            "roofline": roofline, "cpu_baseline": cpu, "parity": parity, "sa_locate": locate,
         }
         if gathered is not None:
             line["config"]["gathered_hit_records"] = int(sum(int(g[1].numel()) // 10 for g in gathered))

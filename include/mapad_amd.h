@@ -104,6 +104,8 @@ int mapad_index_copy_sa(const mapad_index_t* idx, uint64_t* sample, uint64_t* ex
 int mapad_index_device_view(const mapad_index_t* idx, const uint64_t** blocks, uint64_t* n_blocks, uint64_t less[8], uint64_t sentinel[2]);
 /* SampledSuffixArray::get (src/index/mod.rs:160-187) */
 int mapad_index_sa_get(const mapad_index_t* idx, uint64_t row, uint64_t* out);
+/* the same for n rows on one host thread (UINT64_MAX for rows past the text): the CPU side of mapad_sa_locate() */
+int mapad_index_sa_get_batch(const mapad_index_t* idx, const uint64_t* rows, uint64_t n, uint64_t* out);
 
 /* ---- mapping context: one GPU, index resident in HBM ---------------------------------------------------------------- */
 typedef struct mapad_ctx mapad_ctx_t;
@@ -197,6 +199,19 @@ typedef struct mapad_records {
 int mapad_hits_to_records(const mapad_index_t* idx, const mapad_params_t* params, const mapad_batch_result_t* res, const uint8_t* seqs,
                           const uint8_t* quals, const uint64_t* offsets, const uint16_t* in_flags, uint64_t seed, mapad_records_t** out);
 void mapad_records_free(mapad_records_t* r);
+
+/* ---- SA locate on the device ---------------------------------------------------------------------------
+ * SampledSuffixArray::get (src/index/mod.rs:160-187) for a batch of BWT rows: LF walk to the next sampled row (or '$' row) in a
+ * kernel, one quad per row, against the index blocks already resident in HBM.  rows / out are host arrays; out[i] = suffix-array
+ * value, UINT64_MAX for a row >= text length.  Results are identical to mapad_index_sa_get(). */
+int mapad_sa_locate(mapad_ctx_t* ctx, const uint64_t* rows, uint64_t n, uint64_t* out);
+/* kernel time (HIP events on the context's stream), rows and LF steps of the last locate call */
+int mapad_last_locate_info(mapad_ctx_t* ctx, float* kernel_ms, uint64_t* rows, uint64_t* lf_steps);
+/* mapad_hits_to_records() with the suffix-array lookups of all hit intervals of <= 8 rows done by mapad_sa_locate's kernel first
+ * (interval2coordinate, mapping.rs:590-649, is the second random-access loop of the reference); same records, uses the context's
+ * index and parameters. */
+int mapad_hits_to_records_gpu(mapad_ctx_t* ctx, const mapad_batch_result_t* res, const uint8_t* seqs, const uint8_t* quals, const uint64_t* offsets,
+                              const uint16_t* in_flags, uint64_t seed, mapad_records_t** out);
 
 const char* mapad_version(void);
 

@@ -100,6 +100,7 @@ SYMBOLS = {
     "mapad_index_copy_sa": (_i32, [_vp, _vp, _vp, _vp]),
     "mapad_index_device_view": (_i32, [_vp, C.POINTER(_vp), C.POINTER(_u64), _vp, _vp]),
     "mapad_index_sa_get": (_i32, [_vp, _u64, C.POINTER(_u64)]),
+    "mapad_index_sa_get_batch": (_i32, [_vp, _vp, _u64, _vp]),
     "mapad_ctx_create": (_i32, [_vp, _PP, _i32, C.POINTER(_vp)]),
     "mapad_ctx_destroy": (None, [_vp]),
     "mapad_ctx_set_stream": (_i32, [_vp, _vp]),
@@ -115,6 +116,9 @@ SYMBOLS = {
     "mapad_last_launch_info": (_i32, [_vp, _vp]),
     "mapad_hits_to_records": (_i32, [_vp, _PP, C.POINTER(BatchResultC), _vp, _vp, _vp, _vp, _u64, C.POINTER(C.POINTER(RecordsC))]),
     "mapad_records_free": (None, [C.POINTER(RecordsC)]),
+    "mapad_sa_locate": (_i32, [_vp, _vp, _u64, _vp]),
+    "mapad_last_locate_info": (_i32, [_vp, C.POINTER(C.c_float), C.POINTER(_u64), C.POINTER(_u64)]),
+    "mapad_hits_to_records_gpu": (_i32, [_vp, C.POINTER(BatchResultC), _vp, _vp, _vp, _vp, _u64, C.POINTER(C.POINTER(RecordsC))]),
 }
 
 _lib = None
@@ -277,6 +281,12 @@ class Index:
         _check(lib().mapad_index_sa_get(self.h, row, C.byref(out)), "mapad_index_sa_get")
         return out.value
 
+    def sa_get_batch(self, rows):
+        rows = np.ascontiguousarray(rows, dtype=np.uint64)
+        out = np.zeros(rows.size, np.uint64)
+        _check(lib().mapad_index_sa_get_batch(self.h, _ptr(rows) if rows.size else None, rows.size, _ptr(out) if rows.size else None), "mapad_index_sa_get_batch")
+        return out
+
     def device_view(self):
         blocks, nb = C.c_void_p(), C.c_uint64()
         less, sent = np.zeros(8, np.uint64), np.zeros(2, np.uint64)
@@ -351,6 +361,29 @@ class Context:
         _check(lib().mapad_last_launch_info(self.h, _ptr(out)), "mapad_last_launch_info")
         return out
 
+    def sa_locate(self, rows):
+        """Suffix-array values of BWT rows, located by the device kernel (UINT64_MAX for rows past the text)."""
+        rows = np.ascontiguousarray(rows, dtype=np.uint64)
+        out = np.zeros(rows.size, np.uint64)
+        _check(lib().mapad_sa_locate(self.h, _ptr(rows) if rows.size else None, rows.size, _ptr(out) if rows.size else None), "mapad_sa_locate")
+        return out
+
+    def locate_info(self):
+        ms, rows, steps = C.c_float(), C.c_uint64(), C.c_uint64()
+        _check(lib().mapad_last_locate_info(self.h, C.byref(ms), C.byref(rows), C.byref(steps)), "mapad_last_locate_info")
+        return float(ms.value), int(rows.value), int(steps.value)
+
+    def hits_to_records(self, result_cptr_owner, seqs, quals, offsets, in_flags=None, seed=0):
+        """mapad_hits_to_records_gpu -> list of dicts, same as hits_to_records() with the SA lookups done on the device."""
+        seqs = np.ascontiguousarray(seqs, dtype=np.uint8)
+        quals = np.ascontiguousarray(quals, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        fl = None if in_flags is None else np.ascontiguousarray(in_flags, dtype=np.uint16)
+        out = C.POINTER(RecordsC)()
+        _check(lib().mapad_hits_to_records_gpu(self.h, result_cptr_owner._cptr, _ptr(seqs), _ptr(quals), _ptr(offsets),
+                                               _ptr(fl) if fl is not None else None, seed, C.byref(out)), "mapad_hits_to_records_gpu")
+        return _decode_records(out)
+
 
 def hits_to_records(index, params, result_cptr_owner, seqs, quals, offsets, in_flags=None, seed=0):
     """mapad_hits_to_records -> list of dicts (decoded record fields)."""
@@ -361,6 +394,10 @@ def hits_to_records(index, params, result_cptr_owner, seqs, quals, offsets, in_f
     out = C.POINTER(RecordsC)()
     _check(lib().mapad_hits_to_records(index.h, C.byref(params), result_cptr_owner._cptr, _ptr(seqs), _ptr(quals), _ptr(offsets),
                                        _ptr(fl) if fl is not None else None, seed, C.byref(out)), "mapad_hits_to_records")
+    return _decode_records(out)
+
+
+def _decode_records(out):
     r = out.contents
     text = C.string_at(r.text, r.text_len)
     recs = []

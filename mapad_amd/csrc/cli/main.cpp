@@ -1,6 +1,6 @@
 // mapad-amd — command line with the `mapad index` / `mapad map` flag surface (src/main.rs:57-302) on top of the C ABI
 // (include/mapad_amd.h).  Everything a Rust `mapad` would do around the hot path is done here through the same extern "C"
-// calls a Rust caller would bind: index open/build, parameters, mapad_map_batch (GPU), mapad_hits_to_records, BAM output.
+// calls a Rust caller would bind: index open/build, parameters, mapad_map_batch (GPU), mapad_hits_to_records_gpu (SA locate on the GPU), BAM output.
 //
 //   mapad-amd [--seed N] [--device K] index -g ref.fa
 //   mapad-amd [--seed N] [--device K] map -r reads.{bam,fastq,fastq.gz} -g ref.fa -o out.bam -l single_stranded|double_stranded
@@ -160,7 +160,7 @@ int cmd_map(const Args& a, uint64_t seed, int device, const std::string& cmdline
         check(mapad_map_batch(ctx, seqs.data(), quals.data(), offsets.data(), chunk.size(), &res), "mapad_map_batch");
         const float per_read_s = std::chrono::duration<float>(std::chrono::steady_clock::now() - t0).count() / (float)chunk.size();
         mapad_records_t* recs = nullptr;
-        check(mapad_hits_to_records(idx, &prm, res, seqs.data(), quals.data(), offsets.data(), flags.data(), seed + chunk_no, &recs), "mapad_hits_to_records");
+        check(mapad_hits_to_records_gpu(ctx, res, seqs.data(), quals.data(), offsets.data(), flags.data(), seed + chunk_no, &recs), "mapad_hits_to_records_gpu");
         enc.clear();
         for (size_t i = 0; i < chunk.size(); ++i) {
             const mapad_record_t& c = recs->recs[i];

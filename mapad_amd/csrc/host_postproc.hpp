@@ -6,6 +6,7 @@
 // (src/map/prrange.rs) and EditOperationsTrack::{to_bam_fields, effective_len, read_len} (src/map/record.rs:269-449).
 // BAM byte encoding is done by the caller (bam_writer.hpp).
 #pragma once
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -176,14 +177,27 @@ inline std::vector<uint32_t> sorted_ascending(const mapad_hit_t* hits, uint32_t 
 struct Coord { uint32_t tid; uint64_t rel, abs; bool backward; uint64_t num_skipped; };
 
 // interval2coordinate (:590-649), eager; `seed` stands in for rng.next_u32()
-inline bool interval2coordinate(const Index& ix, const mapad_hit_t& h, const Track& t, uint32_t seed, std::vector<Coord>& out, size_t max_items) {
+// Pre-computed suffix-array values (row -> position), e.g. from the device's locate kernel; rows that are absent fall back to
+// Index::sa_get().  Sorted by row.
+struct SaCache {
+    std::vector<std::pair<uint64_t, uint64_t>> v;
+    bool get(uint64_t row, uint64_t& out) const {
+        auto it = std::lower_bound(v.begin(), v.end(), std::make_pair(row, (uint64_t)0));
+        if (it == v.end() || it->first != row) return false;
+        out = it->second;
+        return true;
+    }
+};
+
+inline bool interval2coordinate(const Index& ix, const mapad_hit_t& h, const Track& t, uint32_t seed, std::vector<Coord>& out, size_t max_items,
+                                const SaCache* cache = nullptr) {
     const uint64_t strand_len = ix.n / 2, eff = t.effective_len();
     PrRange pr;
     if (!PrRange::make(h.lower, h.lower + h.size, seed, pr)) return false;
     uint64_t row, i = 0;
     while (out.size() < max_items && pr.next(row)) {
         uint64_t p;
-        if (ix.sa_get(row, p)) {
+        if ((cache && cache->get(row, p)) || ix.sa_get(row, p)) {
             bool backward = false;
             if (p >= strand_len) { p = ix.n - p - eff - 1; backward = true; }
             uint32_t tid; uint64_t rel;
@@ -237,7 +251,7 @@ struct RecordsOwner {
 };
 
 inline mapad_records_t* hits_to_records(const Index& ix, const mapad_params_t& prm, const mapad_batch_result_t& res, const uint8_t* seqs, const uint8_t* quals,
-                                        const uint64_t* offsets, const uint16_t* in_flags, uint64_t seed) {
+                                        const uint64_t* offsets, const uint16_t* in_flags, uint64_t seed, const SaCache* cache = nullptr) {
     (void)seqs; (void)quals; (void)offsets;
     auto* own = new RecordsOwner();
     own->recs.resize(res.n_reads);
@@ -257,7 +271,7 @@ inline mapad_records_t* hits_to_records(const Index& ix, const mapad_params_t& p
             const mapad_hit_t& best = hits[bi];
             const Track bt{res.ops + best.ops_offset, best.n_ops};
             std::vector<Coord> bc;
-            if (!interval2coordinate(ix, best, bt, seed_for(seed, r, call++), bc, 3)) throw std::runtime_error("Could not enumerate possible reference positions");
+            if (!interval2coordinate(ix, best, bt, seed_for(seed, r, call++), bc, 3, cache)) throw std::runtime_error("Could not enumerate possible reference positions");
             if (bc.empty()) continue;  // :541-543
             const Coord first = bc.front();
             const uint64_t upd = best.size - first.num_skipped;  // :430-431
@@ -279,7 +293,7 @@ inline mapad_records_t* hits_to_records(const Index& ix, const mapad_params_t& p
                 if (cross_check(best, sub)) continue;
                 std::vector<Coord> sc;
                 const Track st{res.ops + sub.ops_offset, sub.n_ops};
-                if (!interval2coordinate(ix, sub, st, seed_for(seed, r, call++), sc, (size_t)(2 - n_xa))) continue;
+                if (!interval2coordinate(ix, sub, st, seed_for(seed, r, call++), sc, (size_t)(2 - n_xa), cache)) continue;
                 for (auto& c : sc) { if (n_xa >= 2) break; emit(c, sub); }
             }
             uint64_t x1 = 0;

@@ -171,6 +171,67 @@ __global__ void __launch_bounds__(1024) order_scatter_kernel(BatchDev B) {
     if (i < B.n_reads) B.order[base[key] + r] = i;
 }
 
+// ---- SA locate: SampledSuffixArray::get (src/index/mod.rs:160-187) on the device, one quad per row ------------------------
+// Walk LF steps (pos = less[c] + occ(pos - 1, c), c = bwt[pos]) until a sampled row (pos % 32 == 0) or a '$' row (extra_rows).
+// Every step reads the 128-byte block of `pos`: lane w of the quad holds sub-block w, the lane that owns the row extracts the
+// symbol, all four count it up to row pos - 1.  <= 31 dependent steps per row: latency-bound, hidden by 16 rows per wavefront.
+struct LocateDev {
+    const uint64_t* rows;
+    uint64_t* out;
+    uint64_t n_rows;
+    const uint64_t* sa_sample;
+    const uint64_t* x_counts;  // per block: 'X' symbols before it; nullptr if the text has none
+    uint64_t extra_row[2], extra_val[2];  // the two '$' rows of the BWT and their suffix-array values
+    uint32_t sa_shift;         // log2(sampling rate)
+    unsigned long long* steps; // LF steps taken (event counter for the roofline)
+};
+__device__ __forceinline__ uint32_t quad_or32(uint32_t v) { v |= dpp_quad<0xB1>(v); v |= dpp_quad<0x4E>(v); return v; }
+
+__global__ void __launch_bounds__(64) locate_kernel(DevIndex ix, LocateDev Q) {
+    const int lane = threadIdx.x & 63, w = lane & 3;
+    const uint64_t q = (uint64_t)blockIdx.x * 16 + (lane >> 2);
+    const bool active = q < Q.n_rows;
+    uint64_t pos = active ? Q.rows[q] : 0, offset = 0, result = ~0ull;
+    bool done = !active || pos >= ix.n;
+    uint32_t n_steps = 0;
+    const uint64_t rate_mask = (1ull << Q.sa_shift) - 1;
+    while (!__all(done)) {
+        if (!done) {
+            if ((pos & rate_mask) == 0) { result = Q.sa_sample[pos >> Q.sa_shift] + offset; done = true; }
+            else {
+                const uint64_t blk = pos >> 8;
+                const uint64_t* sb = ix.blocks + blk * 16 + 4 * w;
+                const ulonglong2 v0 = *reinterpret_cast<const ulonglong2*>(sb), v1 = *reinterpret_cast<const ulonglong2*>(sb + 2);
+                const int sub = (int)((pos >> 6) & 3), bit = (int)(pos & 63);
+                uint32_t code = (uint32_t)((v0.y >> bit) & 1) | ((uint32_t)((v1.x >> bit) & 1) << 1) | ((uint32_t)((v1.y >> bit) & 1) << 2);
+                code = quad_or32(w == sub ? code : 0u);  // bwt[pos]: 0 '$', 1 'X', 4..7 ACGT
+                if (code == 0) { result = (pos == Q.extra_row[0] ? Q.extra_val[0] : Q.extra_val[1]) + offset; done = true; }
+                else {
+                    // occ(pos - 1, c): pos is not a multiple of 32 here, so pos - 1 lies in the same block
+                    const int r_in = (int)((pos - 1) & 255);
+                    const uint64_t m = row_mask(w, r_in);
+                    uint64_t sel, base_count, less;
+                    if (code >= 4) {
+                        const int k = (int)code - 4;
+                        const uint64_t inv1 = (k & 2) ? 0ull : ~0ull, inv0 = (k & 1) ? 0ull : ~0ull;
+                        sel = v1.y & (v1.x ^ inv1) & (v0.y ^ inv0) & m;
+                        base_count = ix.blocks[blk * 16 + 4 * k];
+                        less = k == 0 ? ix.less[1] : k == 1 ? ix.less[2] : k == 2 ? ix.less[3] : ix.less[4];
+                    } else {  // 'X' (rank 5): plane0 only
+                        sel = v0.y & ~v1.x & ~v1.y & m;
+                        base_count = Q.x_counts ? Q.x_counts[blk] : 0;
+                        less = ix.less[5];
+                    }
+                    pos = less + base_count + quad_sum32((uint32_t)popc64(sel));
+                    offset += 1;
+                    n_steps += 1;
+                }
+            }
+        }
+    }
+    if (active && w == 0) { Q.out[q] = result; if (Q.steps) atomicAdd(Q.steps, (unsigned long long)n_steps); }
+}
+
 // ---- search: persistent quads -----------------------------------------------------------------------------------------
 #if defined(MAPAD_OUTLINE_RARE)
 #define MAPAD_FINALIZE_ATTR __attribute__((noinline))
@@ -303,8 +364,11 @@ struct DeviceGrow {
 // PASS 0: every read, growable arenas.  PASS 1: the reads pass 0 handed on, arenas with the reference's full limits.
 // NL: the near data (heap top, position data) of every read slot is in LDS and addressed with ds_* instructions; otherwise it
 // lives in the slot's HBM arena (reads longer than kMaxLdsReadLen, lanes-per-read 1).
+#if !defined(MAPAD_MIN_WAVES)
+#define MAPAD_MIN_WAVES 4
+#endif
 template <int LPR, bool CONT, int PASS, bool NL>
-__global__ void __launch_bounds__(64, 4) search_kernel(DevIndex ix, DevParams P, BatchDev B, ArenaPool AP, const GrowPools* GP, uint32_t near_stride, uint32_t near_lmax) {
+__global__ void __launch_bounds__(64, MAPAD_MIN_WAVES) search_kernel(DevIndex ix, DevParams P, BatchDev B, ArenaPool AP, const GrowPools* GP, uint32_t near_stride, uint32_t near_lmax) {
     const int lane = threadIdx.x & 63, w = lane & (LPR - 1);
     constexpr int tier = PASS;
     const uint32_t slot = blockIdx.x * (64 / LPR) + (lane / LPR);
@@ -316,7 +380,7 @@ __global__ void __launch_bounds__(64, 4) search_kernel(DevIndex ix, DevParams P,
     if constexpr (NL) near = (NearBytes)near_lds + (size_t)(lane / LPR) * near_stride;
     else near = AP.base + (uint64_t)slot * AP.stride + AP.off_near;
     A.top = (typename near_ptr<HeapEntry, NL>::type)near + 1;
-    const NearBytes near_qc = near + 32 * sizeof(HeapEntry);
+    const NearBytes near_qc = near + (kTop + 1) * sizeof(HeapEntry);
     const typename near_ptr<float, NL>::type near_d = (typename near_ptr<float, NL>::type)(near_qc + ((2 * near_lmax + 15) & ~15u));
     const uint32_t n_items = tier == 0 ? B.n_reads : B.cursors[CUR_OVF + 2 * (tier - 1)];
     uint32_t* work = &B.cursors[CUR_WORK + 2 * tier];
@@ -407,7 +471,7 @@ struct DevBuf {
 };
 
 // bytes of "near" data per read slot: heap top (32 physical slots), 2 bytes + 4 bytes per read position
-uint32_t near_bytes(uint32_t lmax) { return 32 * 8 + ((2 * lmax + 15) & ~15u) + ((4 * lmax + 15) & ~15u); }
+uint32_t near_bytes(uint32_t lmax) { return (kTop + 1) * 8 + ((2 * lmax + 15) & ~15u) + ((4 * lmax + 15) & ~15u); }
 constexpr uint32_t kMaxLdsReadLen = 256;  // longer reads keep their near data in the HBM arena instead of LDS
 
 ArenaPool make_pool_layout(uint32_t heap_cap, uint32_t node_cap, uint32_t hit_ops_cap, uint32_t lmax) {
@@ -455,6 +519,13 @@ struct mapad_ctx {
     DevBuf<uint32_t> d_owner[kClasses];
     DevBuf<GrowPools> d_grow;
     GrowPools grow{};
+    // SA locate
+    DevBuf<uint64_t> d_sa, d_xc, d_rows, d_pos;
+    DevBuf<unsigned long long> d_steps;
+    bool sa_uploaded = false;
+    hipEvent_t lev[2] = {nullptr, nullptr};
+    unsigned long long last_locate_steps = 0;
+    uint64_t last_locate_rows = 0;
     int lpr = 4;  // lanes per read in the search kernel (MAPAD_LANES_PER_READ = 4 | 1)
     int n_cu = 256;
     // last batch
@@ -476,6 +547,8 @@ struct mapad_ctx {
         for (auto& a : d_class) a.release();
         for (auto& a : d_owner) a.release();
         d_grow.release();
+        d_sa.release(); d_xc.release(); d_rows.release(); d_pos.release(); d_steps.release();
+        for (auto& e : lev) if (e) (void)hipEventDestroy(e);
         for (auto& e : ev) if (e) (void)hipEventDestroy(e);
     }
 };
@@ -784,6 +857,13 @@ int mapad_index_device_view(const mapad_index_t* idx, const uint64_t** blocks, u
     if (sentinel) { sentinel[0] = idx->ix.sentinel[0]; sentinel[1] = idx->ix.sentinel[1]; }
     return MAPAD_OK;
 }
+int mapad_index_sa_get_batch(const mapad_index_t* idx, const uint64_t* rows, uint64_t n, uint64_t* out) {
+    if (!idx || (n && (!rows || !out))) return MAPAD_ERR_INVALID;
+    try {
+        for (uint64_t i = 0; i < n; ++i) if (!idx->ix.sa_get(rows[i], out[i])) out[i] = ~0ull;
+        return MAPAD_OK;
+    } catch (const std::exception&) { return MAPAD_ERR_PARSE; }
+}
 int mapad_index_sa_get(const mapad_index_t* idx, uint64_t row, uint64_t* out) {
     if (!idx || !out) return MAPAD_ERR_INVALID;
     try { return idx->ix.sa_get(row, *out) ? MAPAD_OK : MAPAD_ERR_INVALID; } catch (const std::exception&) { return MAPAD_ERR_PARSE; }
@@ -971,6 +1051,89 @@ int mapad_last_launch_info(mapad_ctx_t* ctx, uint32_t out[8]) {
     return MAPAD_OK;
 }
 
+}  // extern "C"
+
+// ---- SA locate on the device ---------------------------------------------------------------------------------------------
+namespace {
+int locate_rows(mapad_ctx* c, const uint64_t* rows, uint64_t n, uint64_t* out) {
+    if (hipSetDevice(c->device) != hipSuccess) return MAPAD_ERR_NO_DEVICE;
+    const host::Index& ix = c->index->ix;
+    uint32_t shift = 0;
+    while ((1ull << shift) < ix.sa_rate) ++shift;
+    if ((1ull << shift) != ix.sa_rate || shift < 1 || shift > 8 || ix.extra_rows.size() > 2) return MAPAD_ERR_INVALID;  // the kernel's assumptions
+    int rc;
+    if (!c->sa_uploaded) {
+        if ((rc = c->d_sa.ensure(std::max<size_t>(ix.sa_sample.size(), 1), true))) return rc;
+        HIP_TRY(hipMemcpyAsync(c->d_sa.p, ix.sa_sample.data(), ix.sa_sample.size() * 8, hipMemcpyHostToDevice, c->stream));
+        if (!ix.x_counts.empty()) {
+            if ((rc = c->d_xc.ensure(ix.x_counts.size(), true))) return rc;
+            HIP_TRY(hipMemcpyAsync(c->d_xc.p, ix.x_counts.data(), ix.x_counts.size() * 8, hipMemcpyHostToDevice, c->stream));
+        }
+        if ((rc = c->d_steps.ensure(1))) return rc;
+        for (auto& e : c->lev) if (!e) HIP_TRY(hipEventCreate(&e));
+        c->sa_uploaded = true;
+    }
+    c->last_locate_rows = n; c->last_locate_steps = 0;
+    if (n == 0) return MAPAD_OK;
+    if ((rc = c->d_rows.ensure(n))) return rc;
+    if ((rc = c->d_pos.ensure(n))) return rc;
+    HIP_TRY(hipMemcpyAsync(c->d_rows.p, rows, n * 8, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemsetAsync(c->d_steps.p, 0, sizeof(unsigned long long), c->stream));
+    LocateDev q{};
+    q.rows = c->d_rows.p; q.out = c->d_pos.p; q.n_rows = n; q.sa_sample = c->d_sa.p; q.x_counts = ix.x_counts.empty() ? nullptr : c->d_xc.p;
+    q.sa_shift = shift; q.steps = c->d_steps.p;
+    int k = 0;
+    for (const auto& kv : ix.extra_rows) { q.extra_row[k] = kv.first; q.extra_val[k] = kv.second; ++k; }
+    for (; k < 2; ++k) { q.extra_row[k] = ~0ull; q.extra_val[k] = 0; }
+    HIP_TRY(hipEventRecord(c->lev[0], c->stream));
+    hipLaunchKernelGGL(locate_kernel, dim3((uint32_t)((n + 15) / 16)), dim3(64), 0, c->stream, c->dix, q);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(c->lev[1], c->stream));
+    HIP_TRY(hipMemcpyAsync(out, c->d_pos.p, n * 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(&c->last_locate_steps, c->d_steps.p, sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return MAPAD_OK;
+}
+}  // namespace
+
+extern "C" {
+int mapad_sa_locate(mapad_ctx_t* ctx, const uint64_t* rows, uint64_t n, uint64_t* out) {
+    if (!ctx || (n && (!rows || !out))) return MAPAD_ERR_INVALID;
+    return locate_rows(ctx, rows, n, out);
+}
+int mapad_last_locate_info(mapad_ctx_t* ctx, float* kernel_ms, uint64_t* rows, uint64_t* lf_steps) {
+    if (!ctx || !kernel_ms || !rows || !lf_steps) return MAPAD_ERR_INVALID;
+    *rows = ctx->last_locate_rows; *lf_steps = ctx->last_locate_steps; *kernel_ms = 0.0f;
+    if (ctx->last_locate_rows && ctx->lev[0]) HIP_TRY(hipEventElapsedTime(kernel_ms, ctx->lev[0], ctx->lev[1]));
+    return MAPAD_OK;
+}
+int mapad_hits_to_records_gpu(mapad_ctx_t* ctx, const mapad_batch_result_t* res, const uint8_t* seqs, const uint8_t* quals, const uint64_t* offsets,
+                              const uint16_t* in_flags, uint64_t seed, mapad_records_t** out) {
+    if (!ctx || !res || !out || (res->n_reads && (!seqs || !quals || !offsets))) return MAPAD_ERR_INVALID;
+    try {
+        // rows of every small hit interval are located on the device; the (rare) larger intervals are walked on the host on demand
+        constexpr uint64_t kMaxRows = 8;
+        std::vector<uint64_t> rows;
+        for (uint64_t i = 0; i < res->n_hits; ++i)
+            if (res->hits[i].size <= kMaxRows) for (uint64_t r = 0; r < res->hits[i].size; ++r) rows.push_back(res->hits[i].lower + r);
+        std::sort(rows.begin(), rows.end());
+        rows.erase(std::unique(rows.begin(), rows.end()), rows.end());
+        std::vector<uint64_t> pos(rows.size());
+        const int rc = locate_rows(ctx, rows.data(), rows.size(), pos.data());
+        if (rc) return rc;
+        host::SaCache cache;
+        cache.v.reserve(rows.size());
+        for (size_t i = 0; i < rows.size(); ++i) if (pos[i] != ~0ull) cache.v.emplace_back(rows[i], pos[i]);
+        *out = host::hits_to_records(ctx->index->ix, ctx->params, *res, seqs, quals, offsets, in_flags, seed, &cache);
+        return MAPAD_OK;
+    } catch (const std::bad_alloc&) { return MAPAD_ERR_NOMEM; } catch (const std::exception& e) {
+        std::fprintf(stderr, "mapad_hits_to_records_gpu: %s\n", e.what());
+        return MAPAD_ERR_INVALID;
+    }
+}
+}  // extern "C"
+
+extern "C" {
 // ---- post-search ----------------------------------------------------------------------------------------------------------
 int mapad_hits_to_records(const mapad_index_t* idx, const mapad_params_t* params, const mapad_batch_result_t* res, const uint8_t* seqs, const uint8_t* quals,
                           const uint64_t* offsets, const uint16_t* in_flags, uint64_t seed, mapad_records_t** out) {

@@ -80,7 +80,10 @@ static_assert(sizeof(HitRec) == 40, "hit record is 40 bytes");
 // Per-read position data kept next to the quad (LDS on the device; MAPAD_MAX_LDS_READ_LEN and shorter reads):
 //   qc[2j] = read-base class (0..3 = ACGT, 4 otherwise), qc[2j+1] = Phred quality  -> one shared score-table row per pop
 //   d[j]   = BiDArray::d_composite[j] (written by darray_kernel)
-constexpr int kTop = 31;  // logical heap slots 0..30 (levels 0-4) live in the `top` array (LDS on the device)
+#if !defined(MAPAD_KTOP)
+#define MAPAD_KTOP 31
+#endif
+constexpr int kTop = MAPAD_KTOP;  // logical heap slots 0..kTop-1 (31: levels 0-4) live in the `top` array (LDS on the device)
 
 constexpr int kMaxHits = 20;  // a pop adds <= 9 hits and the search returns once more than 9 exist (mapping.rs:1348)
 

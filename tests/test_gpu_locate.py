@@ -1,0 +1,83 @@
+"""GPU tests of the on-device SA locate: the kernel's LF walk vs the host's SampledSuffixArray::get restatement,
+and the record fields built from device-located positions vs the host path."""
+import numpy as np
+import pytest
+
+import mapad_amd
+from mapad_amd import synth
+
+from kat_util import load, resolve_params
+from parity_util import DAMAGE, NO_DAMAGE
+from test_oracle_kats import integration_reads
+
+pytestmark = pytest.mark.gpu
+
+
+def _genome_with_x_runs(n, seed):
+    g = np.array(synth.genome(n, seed=seed), dtype=np.uint8).copy()
+    g[1000:1040] = ord("N")     # a run of >= 20 ambiguous bases stays 'X' in the index (indexing.rs:98-107)
+    g[5000] = ord("R")          # single ambiguity codes are replaced by a random compatible base
+    g[n // 2:n // 2 + 25] = ord("N")
+    return g.tobytes()
+
+
+@pytest.mark.parametrize("with_x", [False, True], ids=["acgt", "with_X_runs"])
+def test_sa_locate_matches_host_walk(with_x):
+    g = _genome_with_x_runs(60_000, 3) if with_x else synth.genome(60_000, seed=3)
+    idx = mapad_amd.Index.build([("chr1", g), ("chr2", synth.genome(3_000, seed=4))])
+    n = len(idx)
+    ctx = mapad_amd.Context(idx, mapad_amd.make_params(resolve_params(NO_DAMAGE)), 0)
+    try:
+        rows = np.arange(n, dtype=np.uint64)
+        got = ctx.sa_locate(rows)
+        want = np.array([idx.sa_get(int(r)) for r in rows], dtype=np.uint64)
+        assert np.array_equal(got, want)
+        assert np.array_equal(np.sort(got), rows)  # the suffix array is a permutation of the text positions
+        ms, n_rows, steps = ctx.locate_info()
+        assert n_rows == n and 0 < steps <= 31 * n
+        # ragged / out-of-range / empty requests
+        odd = np.array([0, n - 1, n, n + 5, 31, 32, 33], dtype=np.uint64)
+        out = ctx.sa_locate(odd)
+        assert out[2] == np.uint64(0xFFFFFFFFFFFFFFFF) and out[3] == np.uint64(0xFFFFFFFFFFFFFFFF)
+        assert [int(x) for x in out[[0, 1, 4, 5, 6]]] == [idx.sa_get(int(r)) for r in (0, n - 1, 31, 32, 33)]
+        assert ctx.sa_locate(np.zeros(0, np.uint64)).size == 0
+    finally:
+        ctx.close()
+
+
+def test_records_from_device_located_positions_equal_host_path():
+    g = synth.genome(400_000, seed=17)
+    seqs, quals, offsets = synth.reads(g, 3000, 50, seed=9, qual_range=(20, 40), damage=dict(f=0.5, t=0.5, d=0.02, s=1.0))
+    idx = mapad_amd.Index.build([("chr1", g)])
+    params = mapad_amd.make_params(resolve_params(DAMAGE))
+    ctx = mapad_amd.Context(idx, params, 0)
+    try:
+        res = ctx.map_batch(seqs, quals, offsets)
+        host = mapad_amd.hits_to_records(idx, params, res, seqs, quals, offsets, seed=77)
+        dev = ctx.hits_to_records(res, seqs, quals, offsets, seed=77)
+        assert dev == host
+        assert sum(r["mapped"] for r in dev) > 2000
+    finally:
+        ctx.close()
+
+
+def test_integration_records_through_device_locate(monkeypatch):
+    """tests/integration_tests.rs expectation, with the suffix-array lookups done by the kernel."""
+    from test_host_logic import check_integration_records
+    k = load("integration")
+    monkeypatch.setenv("MAPAD_INDEX_FIXED_REPLACEMENT", k["n_replacement"])
+    idx = mapad_amd.Index.build([(c["name"], c["seq"].encode()) for c in k["contigs"]], seed=1234)
+    params = mapad_amd.make_params(resolve_params(k["params"]))
+    reads, quals = integration_reads(k)
+    offsets = np.zeros(len(reads) + 1, dtype=np.uint64)
+    offsets[1:] = np.cumsum([len(r) for r in reads])
+    seqs = np.frombuffer(b"".join(reads), dtype=np.uint8)
+    qs = np.concatenate(quals)
+    ctx = mapad_amd.Context(idx, params, 0)
+    try:
+        res = ctx.map_batch(seqs, qs, offsets)
+        flags = np.array([r["flags"] for r in k["reads"]], dtype=np.uint16)
+        recs = ctx.hits_to_records(res, seqs, qs, offsets, in_flags=flags)
+        check_integration_records(k, recs)
+    finally:
+        ctx.close()
