@@ -7,6 +7,7 @@
 #pragma once
 #include <algorithm>
 #include <cstdint>
+#include <cstdlib>
 #include <map>
 #include <stdexcept>
 #include <string>
@@ -295,7 +296,8 @@ inline Index build_index(const std::vector<std::string>& names, const std::vecto
             else if (ix.bwt[i] == 0) ix.extra_rows[i] = p;
         }
     };
-    if (ix.n < (1ull << 31)) { std::vector<int32_t> sa(ix.n); sais<uint8_t, int32_t>(t.data(), sa.data(), (int32_t)ix.n, 6); finish(sa.data()); }
+    const char* force64 = std::getenv("MAPAD_INDEX_FORCE_64");  // test hook: exercise the 64-bit suffix sorter (texts >= 2^31 rows) on small inputs
+    if (ix.n < (1ull << 31) && !(force64 && force64[0] == '1')) { std::vector<int32_t> sa(ix.n); sais<uint8_t, int32_t>(t.data(), sa.data(), (int32_t)ix.n, 6); finish(sa.data()); }
     else { std::vector<int64_t> sa(ix.n); sais<uint8_t, int64_t>(t.data(), sa.data(), (int64_t)ix.n, 6); finish(sa.data()); }
     build_blocks(ix);
     return ix;

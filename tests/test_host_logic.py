@@ -63,8 +63,11 @@ def _random_text(rng, n, kind):
     raise ValueError(kind)
 
 
+@pytest.mark.parametrize("wide", [False, True], ids=["sa32", "sa64"])
 @pytest.mark.parametrize("kind", ["uniform", "repeat", "poly"])
-def test_index_build_matches_naive_suffix_sort(kind):
+def test_index_build_matches_naive_suffix_sort(kind, wide, monkeypatch):
+    if wide:  # the 64-bit suffix sorter that texts of >= 2^31 rows (3 Gbp references) take
+        monkeypatch.setenv("MAPAD_INDEX_FORCE_64", "1")
     rng = np.random.default_rng(12345)
     for n in [1, 2, 3, 7, 31, 32, 33, 255, 256, 257, 1000, 5000]:
         text = _random_text(rng, n, kind)
@@ -83,6 +86,9 @@ def test_index_build_matches_naive_suffix_sort(kind):
         assert sent.tolist() == [i for i in range(len(bwt)) if bwt[i] == 0]
         for row in rng.integers(0, len(sa), 20):
             assert p.sa_get(int(row)) == int(sa[int(row)])
+        rows = rng.integers(0, len(sa) + 3, 50).astype(np.uint64)
+        want_pos = [int(sa[int(r)]) if r < len(sa) else 0xFFFFFFFFFFFFFFFF for r in rows]
+        assert [int(x) for x in p.sa_get_batch(rows)] == want_pos
 
 
 def test_index_ambiguous_bases_and_contigs(monkeypatch):
