@@ -60,7 +60,8 @@ struct BatchDev {
     uint32_t* cursors;
     uint32_t* overflow_list;  // [kTiers][n_reads]: read ids (+1) pass t could not finish
     uint32_t* sort_key;       // [n_reads] cost class of a read (zero positions of its D array), written by darray_kernel
-    uint32_t* key_hist;       // [kKeyBins] reads per cost class, then the running scatter cursors
+    uint32_t* key_hist;       // [n_chunks][kKeyBins] reads per (chunk, cost class), then the running scatter cursors
+    uint32_t order_shift;     // log2 of the chunk size: reads are ordered inside chunks of 2^order_shift consecutive reads
     uint32_t* order;          // [n_reads] read ids, most expensive class first (nullptr: in input order)
 };
 
@@ -112,7 +113,7 @@ __global__ void __launch_bounds__(64) darray_kernel(DevIndex ix, DevParams P, Ba
         if (L > lmax || P.table_base[L] < 0) {  // fail loudly: the host did not prepare this read length
             if (lane == 0) {
                 B.status[read] = ST_NO_TABLE; atomicOr(&B.cursors[CUR_ERR], ST_NO_TABLE); B.counters[read].e_darray = 0;
-                if (B.order) { B.sort_key[read] = 0; atomicAdd(&B.key_hist[0], 1u); }
+                if (B.order) { B.sort_key[read] = 0; atomicAdd(&B.key_hist[(size_t)(read >> B.order_shift) * kKeyBins], 1u); }
             }
             continue;
         }
@@ -141,7 +142,7 @@ __global__ void __launch_bounds__(64) darray_kernel(DevIndex ix, DevParams P, Ba
         }
         if (lane == 0) {
             B.counters[read].e_darray = n_ext_total;
-            if (B.order) { B.sort_key[read] = zeros; atomicAdd(&B.key_hist[zeros], 1u); }
+            if (B.order) { B.sort_key[read] = zeros; atomicAdd(&B.key_hist[(size_t)(read >> B.order_shift) * kKeyBins + zeros], 1u); }
         }
         __syncthreads();
     }
@@ -152,10 +153,16 @@ __global__ void __launch_bounds__(64) darray_kernel(DevIndex ix, DevParams P, Ba
 // accesses, so a heavy read that starts late sets the finish time of the whole batch.  The reads whose D array leaves the search
 // unpruned the longest (many zero positions) hold all of the heavy ones; starting those first overlaps their tail with the bulk.
 // The order only changes when a read is processed, never its result.
-__global__ void order_scan_kernel(uint32_t* hist) {  // hist[k] -> first position of class k when classes are laid out descending
+// hist[chunk][k] -> first position of class k of that chunk: chunks in input order, classes descending inside a chunk.  A chunk
+// (2^20 reads by default, the scale of the reference's --batch_size) bounds how many of the expensive reads start together: sorting
+// a 10 M-read batch as a whole put 150 000 arena-hungry reads in front of everything else and the size-class pools ran dry.
+__global__ void order_scan_kernel(uint32_t* hist, uint32_t n_chunks) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     uint32_t acc = 0;
-    for (int k = kKeyBins - 1; k >= 0; --k) { const uint32_t c = hist[k]; hist[k] = acc; acc += c; }
+    for (uint32_t ch = 0; ch < n_chunks; ++ch) {
+        uint32_t* h = hist + (size_t)ch * kKeyBins;
+        for (int k = kKeyBins - 1; k >= 0; --k) { const uint32_t c = h[k]; h[k] = acc; acc += c; }
+    }
 }
 __global__ void __launch_bounds__(1024) order_scatter_kernel(BatchDev B) {
     // ranks inside the block through LDS atomics, one global atomic per (block, class that occurs in it)
@@ -166,7 +173,8 @@ __global__ void __launch_bounds__(1024) order_scatter_kernel(BatchDev B) {
     uint32_t key = 0, r = 0;
     if (i < B.n_reads) { key = B.sort_key[i]; r = atomicAdd(&cnt[key], 1u); }
     __syncthreads();
-    for (int k = threadIdx.x; k < kKeyBins; k += 1024) { const uint32_t c = cnt[k]; if (c) base[k] = atomicAdd(&B.key_hist[k], c); }
+    uint32_t* hist = B.key_hist + (size_t)((blockIdx.x * 1024u) >> B.order_shift) * kKeyBins;  // a block never straddles chunks (chunk size >= 1024)
+    for (int k = threadIdx.x; k < kKeyBins; k += 1024) { const uint32_t c = cnt[k]; if (c) base[k] = atomicAdd(&hist[k], c); }
     __syncthreads();
     if (i < B.n_reads) B.order[base[key] + r] = i;
 }
@@ -675,11 +683,13 @@ int launch_batch(mapad_ctx* c, const uint8_t* d_seqs, const uint8_t* d_quals, co
     if ((rc = c->d_hit_first.ensure(nr))) return rc;
     if ((rc = c->d_overflow.ensure(nr * kTiers))) return rc;
     const bool ordered = env_u32("MAPAD_ORDER", 1) != 0;
+    const uint32_t order_shift = std::min<uint32_t>(std::max<uint32_t>(env_u32("MAPAD_ORDER_CHUNK_LOG2", 20), 10), 31);
+    const uint32_t n_chunks = (uint32_t)((nr + (1ull << order_shift) - 1) >> order_shift);
     if (ordered) {
         if ((rc = c->d_sort_key.ensure(nr))) return rc;
         if ((rc = c->d_order.ensure(nr))) return rc;
-        if ((rc = c->d_key_hist.ensure(kKeyBins))) return rc;
-        HIP_TRY(hipMemsetAsync(c->d_key_hist.p, 0, kKeyBins * 4, c->stream));
+        if ((rc = c->d_key_hist.ensure((size_t)n_chunks * kKeyBins))) return rc;
+        HIP_TRY(hipMemsetAsync(c->d_key_hist.p, 0, (size_t)n_chunks * kKeyBins * 4, c->stream));
     }
     if ((rc = c->d_cursors.ensure(CUR_COUNT))) return rc;
     const size_t hits_cap = std::max(c->d_hits.cap, (size_t)(2 * nr + 1024));
@@ -696,6 +706,7 @@ int launch_batch(mapad_ctx* c, const uint8_t* d_seqs, const uint8_t* d_quals, co
     B.hits_cap = (uint32_t)std::min<size_t>(c->d_hits.cap, 0xFFFFFFFFu); B.ops_cap = (uint32_t)std::min<size_t>(c->d_ops.cap, 0xFFFFFFFFu);
     B.cursors = c->d_cursors.p; B.overflow_list = c->d_overflow.p;
     B.sort_key = ordered ? c->d_sort_key.p : nullptr; B.key_hist = ordered ? c->d_key_hist.p : nullptr; B.order = ordered ? c->d_order.p : nullptr;
+    B.order_shift = order_shift;
     c->last = B; c->last_total_bases = total_bases; c->last_lmax = lmax;
     if (n_reads == 0) return MAPAD_OK;
     const uint32_t lds_lmax = std::max<uint32_t>(lmax, 1);
@@ -706,7 +717,7 @@ int launch_batch(mapad_ctx* c, const uint8_t* d_seqs, const uint8_t* d_quals, co
     hipLaunchKernelGGL(darray_kernel, dim3(grid_d), dim3(64), lds_bytes, c->stream, c->dix, c->dprm, B, (int)lds_lmax);
     HIP_TRY(hipGetLastError());
     if (ordered) {
-        hipLaunchKernelGGL(order_scan_kernel, dim3(1), dim3(64), 0, c->stream, c->d_key_hist.p);
+        hipLaunchKernelGGL(order_scan_kernel, dim3(1), dim3(64), 0, c->stream, c->d_key_hist.p, n_chunks);
         hipLaunchKernelGGL(order_scatter_kernel, dim3((uint32_t)((n_reads + 1023) / 1024)), dim3(1024), 0, c->stream, B);
         HIP_TRY(hipGetLastError());
     }
