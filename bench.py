@@ -174,6 +174,8 @@ def main():
                                 "search_kernel": {"ms": round(float(ms_search), 4), "bytes": bytes_search, "GB/s": round(bytes_search / (ms_search * 1e-3) / 1e9, 2)},
                                 "search_kernel_last_pass": {"ms": round(float(ms_pass2), 4), "arena_migrations": res.n_second_pass, "reads": res.n_third_pass}},
                 "whole_step_GB/s": round((bytes_darray + bytes_search) / ((ms_darray + ms_search + ms_pass2) * 1e-3) / 1e9, 2),
+                # secondary bound of SURVEY 8(d): dependent random 128-byte index lines per second (2 per extension)
+                "index_lines_per_s": {"search_kernel": round(2 * e_search / (ms_search * 1e-3), 1), "darray_kernel": round(2 * e_darray / (ms_darray * 1e-3), 1)},
                 "events": {"E_search": e_search, "E_darray": e_darray, "N_push": n_push, "N_pop": n_pop, "N_node": n_node}}
 
     # ---- CPU baseline + parity on a bounded sample (rank 0) ------------------------------------------------------------------
