@@ -38,11 +38,12 @@ enum : uint32_t { ST_POOL_OVERFLOW = 4, ST_NO_TABLE = 8 };
 // Two passes over a batch: pass 0 maps every read from a small per-slot arena that GROWS on demand (size classes below, the grown
 // arena stays with the slot); pass 1 re-runs, with the reference's full limits, the few reads pass 0 could not finish because a
 // size-class pool ran dry.
-constexpr int kTiers = 2;
+constexpr int kTiers = 2;   // arena pools: growable base arenas, full-limit arenas
+constexpr int kStages = 4;  // launches over a batch: every read; two retries of reads that gave up waiting for an arena; full limits
 constexpr int kClasses = 10;  // grown arenas: 2x steps above the base arena (8 Ki nodes -> 16 Ki ... 4 Mi), the last one with the full limits
 constexpr int kKeyBins = kMaxReadLen + 2;
 // cursors: global bump allocators and work counters; per pass t: CUR_WORK + 2t = next work item, CUR_OVF + 2t = reads pass t handed on
-enum { CUR_HITS = 0, CUR_OPS = 1, CUR_POOL_OVF = 2, CUR_ERR = 3, CUR_WORK = 4, CUR_OVF = 5, CUR_GROWN = 4 + 2 * kTiers, CUR_COUNT = 4 + 2 * kTiers + 4 };
+enum { CUR_HITS = 0, CUR_OPS = 1, CUR_POOL_OVF = 2, CUR_ERR = 3, CUR_WORK = 4, CUR_OVF = 5, CUR_GROWN = 4 + 2 * kStages, CUR_COUNT = 4 + 2 * kStages + 4 };
 
 struct BatchDev {
     const uint8_t* seqs;
@@ -58,7 +59,7 @@ struct BatchDev {
     uint32_t* ops_pool;
     uint32_t hits_cap, ops_cap;
     uint32_t* cursors;
-    uint32_t* overflow_list;  // [kTiers][n_reads]: read ids (+1) pass t could not finish
+    uint32_t* overflow_list;  // [kStages][n_reads]: read ids (+1) stage t could not finish
     uint32_t* sort_key;       // [n_reads] cost class of a read (zero positions of its D array), written by darray_kernel
     uint32_t* key_hist;       // [n_chunks][kKeyBins] reads per (chunk, cost class), then the running scatter cursors
     uint32_t order_shift;     // log2 of the chunk size: reads are ordered inside chunks of 2^order_shift consecutive reads
@@ -80,6 +81,7 @@ struct GrowPools {
     uint32_t* owner[kClasses];  // [count] 0 = free
     uint64_t stride[kClasses], off_nodes[kClasses];
     uint32_t heap_cap[kClasses], node_cap[kClasses], count[kClasses];
+    uint32_t max_waits;  // fruitless requests (x 64 steps sat out each) after which a read of the first stages gives up and is restarted later
 };
 constexpr uint32_t kGrownShift = 27;
 
@@ -252,7 +254,7 @@ __device__ __forceinline__ uint32_t group_bcast(uint32_t v) { return LPR == 4 ? 
 
 template <int LPR, bool NL>
 __device__ MAPAD_FINALIZE_ATTR void finalize_read(const BatchDev B, const ArenaT<NL> A, const SearchState st, uint32_t read, int w, int tier) {
-    if (st.status == ST_ARENA_OVERFLOW && tier + 1 < kTiers) {  // hand the read to the full-limit pass
+    if (st.status == ST_ARENA_OVERFLOW && tier + 1 < kStages) {  // hand the read to the next stage
         if (w == 0) {
             const uint32_t k = atomicAdd(&B.cursors[CUR_OVF + 2 * tier], 1u);
             B.overflow_list[(size_t)tier * B.n_reads + k] = read + 1u;  // consumed by the next launch
@@ -316,6 +318,7 @@ struct DeviceGrow {
     uint32_t* grown_counter;
     uint32_t slot;
     int w;
+    bool may_give_up;
     __device__ __forceinline__ int operator()(ArenaT<NL>& A, const SearchState& st) const {
         if (A.wait) { A.wait -= 1; return GROW_WAIT; }
         const uint32_t first = A.grown >> kGrownShift;  // first class to try (0 = from the base arena); a dry class falls through to the next
@@ -343,6 +346,7 @@ struct DeviceGrow {
         }
         if (idx == ~0u) {
             if (!exists) return GROW_NEVER;  // no class can hold this read: it goes to the full-limit pass
+            if (may_give_up && ++A.n_waits > gp->max_waits) return GROW_NEVER;
             A.wait = 64;                     // every suitable arena is taken: its owners finish and give it back
             if (w == 0) atomicAdd(grown_counter + 2, 1u);
             return GROW_WAIT;
@@ -376,9 +380,9 @@ struct DeviceGrow {
 #define MAPAD_MIN_WAVES 4
 #endif
 template <int LPR, bool CONT, int PASS, bool NL>
-__global__ void __launch_bounds__(64, MAPAD_MIN_WAVES) search_kernel(DevIndex ix, DevParams P, BatchDev B, ArenaPool AP, const GrowPools* GP, uint32_t near_stride, uint32_t near_lmax) {
+__global__ void __launch_bounds__(64, MAPAD_MIN_WAVES) search_kernel(DevIndex ix, DevParams P, BatchDev B, ArenaPool AP, const GrowPools* GP, uint32_t near_stride, uint32_t near_lmax, int stage) {
     const int lane = threadIdx.x & 63, w = lane & (LPR - 1);
-    constexpr int tier = PASS;
+    const int tier = stage;
     const uint32_t slot = blockIdx.x * (64 / LPR) + (lane / LPR);
     ArenaT<NL> A = carve<NL>(AP, slot);
     // near data of this read slot: [32 heap slots][2*lmax bytes class/quality][lmax floats D]
@@ -393,7 +397,9 @@ __global__ void __launch_bounds__(64, MAPAD_MIN_WAVES) search_kernel(DevIndex ix
     const uint32_t n_items = tier == 0 ? B.n_reads : B.cursors[CUR_OVF + 2 * (tier - 1)];
     uint32_t* work = &B.cursors[CUR_WORK + 2 * tier];
     const uint32_t* items = B.overflow_list + (size_t)(tier > 0 ? tier - 1 : 0) * B.n_reads;
-    const DeviceGrow<LPR, NL> grow{GP, &B.cursors[CUR_GROWN], slot, w};
+    // reads of the first stages give up after kMaxWaits fruitless waits for an arena and are restarted by the next stage, when the
+    // pools are quiet; the last growable stage waits as long as it takes
+    const DeviceGrow<LPR, NL> grow{GP, &B.cursors[CUR_GROWN], slot, w, stage + 2 < kStages};
     bool have = false, done = false;
 #if defined(MAPAD_ACTIVE_QUADS)
     if ((lane / LPR) >= MAPAD_ACTIVE_QUADS) done = true;  // experiment: fewer reads per wavefront
@@ -418,6 +424,7 @@ __global__ void __launch_bounds__(64, MAPAD_MIN_WAVES) search_kernel(DevIndex ix
                 } else {
                     read_setup(B.seqs + off, B.quals + off, B.d_arrays + off, rd.L, near_qc, near_d, w, LPR);
                     SearchState tmp;
+                    A.n_waits = 0;
                     search_init(ix.n, alignment_start_of(P, rd.L), A, tmp);
                     st = tmp;
                     have = true;
@@ -662,6 +669,7 @@ int ensure_arenas(mapad_ctx* c, uint32_t lmax, uint64_t n_reads) {
         g.base[k] = c->d_class[k].p;
         g.owner[k] = c->d_owner[k].p;
     }
+    g.max_waits = env_u32("MAPAD_MAX_WAITS", 64);
     if ((rc = c->d_grow.ensure(1))) return rc;
     HIP_TRY(hipMemcpyAsync(c->d_grow.p, &c->grow, sizeof(GrowPools), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -681,7 +689,7 @@ int launch_batch(mapad_ctx* c, const uint8_t* d_seqs, const uint8_t* d_quals, co
     if ((rc = c->d_status.ensure(nr))) return rc;
     if ((rc = c->d_hit_count.ensure(nr))) return rc;
     if ((rc = c->d_hit_first.ensure(nr))) return rc;
-    if ((rc = c->d_overflow.ensure(nr * kTiers))) return rc;
+    if ((rc = c->d_overflow.ensure(nr * kStages))) return rc;
     const bool ordered = env_u32("MAPAD_ORDER", 1) != 0;
     const uint32_t order_shift = std::min<uint32_t>(std::max<uint32_t>(env_u32("MAPAD_ORDER_CHUNK_LOG2", 20), 10), 31);
     const uint32_t n_chunks = (uint32_t)((nr + (1ull << order_shift) - 1) >> order_shift);
@@ -728,20 +736,21 @@ int launch_batch(mapad_ctx* c, const uint8_t* d_seqs, const uint8_t* d_quals, co
     const uint32_t near_stride = (c->lpr == 4 && near_lmax <= kMaxLdsReadLen && env_u32("MAPAD_NEAR_LDS", 1)) ? near_bytes(near_lmax) : 0;
     const size_t lds = (size_t)near_stride * rpw;
     const bool cont = c->dprm.bound_kind == BOUND_CONTINUOUS;
-#define MAPAD_LAUNCH(L, C, P, N) hipLaunchKernelGGL((search_kernel<L, C, P, N>), dim3(grid), dim3(64), lds, c->stream, c->dix, c->dprm, B, ap, c->d_grow.p, near_stride, near_lmax)
+#define MAPAD_LAUNCH(L, C, P, N) hipLaunchKernelGGL((search_kernel<L, C, P, N>), dim3(grid), dim3(64), lds, c->stream, c->dix, c->dprm, B, ap, c->d_grow.p, near_stride, near_lmax, stage)
 #define MAPAD_LAUNCH_PASS(P)                                                                                      \
     if (c->lpr == 4 && near_stride) { if (!cont) MAPAD_LAUNCH(4, false, P, true); else MAPAD_LAUNCH(4, true, P, true); }   \
     else if (c->lpr == 4) { if (!cont) MAPAD_LAUNCH(4, false, P, false); else MAPAD_LAUNCH(4, true, P, false); }          \
     else { if (!cont) MAPAD_LAUNCH(1, false, P, false); else MAPAD_LAUNCH(1, true, P, false); }
     const uint32_t grid_s = (uint32_t)std::min<uint64_t>((n_reads + rpw - 1) / rpw, c->slots[0] / rpw);
-    {   // pass 0: every read, growable arenas
+    for (int stage = 0; stage + 1 < kStages; ++stage) {  // every read, then the reads that gave up waiting (normally none: the launch exits at once)
         const uint32_t grid = grid_s;
         const ArenaPool& ap = c->pool[0];
         MAPAD_LAUNCH_PASS(0)
         HIP_TRY(hipGetLastError());
     }
     HIP_TRY(hipEventRecord(c->ev[2], c->stream));
-    {   // pass 1: leftovers with the reference's full limits
+    {   // leftovers with the reference's full limits
+        const int stage = kStages - 1;
         const uint32_t grid = (uint32_t)std::min<uint64_t>((n_reads + rpw - 1) / rpw, c->slots[1] / rpw);
         const ArenaPool& ap = c->pool[1];
         MAPAD_LAUNCH_PASS(1)
@@ -981,8 +990,8 @@ int mapad_fetch_result(mapad_ctx_t* ctx, mapad_batch_result_t** out) {
     r->pub.hit_begin = r->hit_begin.data(); r->pub.hits = r->hits.data(); r->pub.ops = r->ops.data();
     r->pub.status = r->status.data(); r->pub.counters = r->counters.data(); r->pub.d_arrays = ctx->fetch_d ? r->d_arrays.data() : nullptr;
     r->pub.n_second_pass = cur[CUR_GROWN];  // arena migrations in pass 0
-    if (cur[CUR_GROWN + 1] && std::getenv("MAPAD_DEBUG")) std::fprintf(stderr, "mapad_amd: size-class pools that ran dry (bit per class): 0x%x, waits: %u, reads re-run: %u\n", cur[CUR_GROWN + 1], cur[CUR_GROWN + 2], cur[CUR_OVF]);
-    r->pub.n_third_pass = cur[CUR_OVF];    // reads re-run by the full-limit pass
+    if (cur[CUR_GROWN + 1] && std::getenv("MAPAD_DEBUG")) std::fprintf(stderr, "mapad_amd: size-class pools that ran dry (bit per class): 0x%x, waits: %u, reads restarted: %u, re-run with full limits: %u\n", cur[CUR_GROWN + 1], cur[CUR_GROWN + 2], cur[CUR_OVF], cur[CUR_OVF + 2 * (kStages - 2)]);
+    r->pub.n_third_pass = cur[CUR_OVF + 2 * (kStages - 2)];  // reads re-run by the full-limit pass
     *out = &r.release()->pub;
     return MAPAD_OK;
 }

@@ -117,6 +117,7 @@ struct ArenaT {
     uint32_t heap_cap, node_cap, hit_ops_cap;
     uint32_t grown = 0;  // 0: heap/nodes are the slot's base arena; else (class + 1) << 27 | arena index (mapad_amd.hip: DeviceGrow)
     uint32_t wait = 0;   // steps to sit out before asking the pools again
+    uint32_t n_waits = 0;  // fruitless requests of the current read
 };
 
 using Arena = ArenaT<false>;
