@@ -49,7 +49,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--genome-bp", type=int, default=48_000_000)
     ap.add_argument("--reads", type=int, default=1_000_000, help="reads per GPU")
-    ap.add_argument("--config", default="c2", choices=["c2", "c3"])
+    ap.add_argument("--config", default="c2", choices=["c2", "c3", "c5"])
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target wall time of the CPU baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -82,8 +82,10 @@ def main():
     t_index = time.time() - t0
     if args.config == "c2":
         prm, kw, cfg_id = NO_DAMAGE, dict(qual=40), 2
-    else:
+    elif args.config == "c3":
         prm, kw, cfg_id = DAMAGE, dict(qual_range=(20, 40), damage=dict(f=0.5, t=0.5, d=0.02, s=1.0)), 3
+    else:  # the read mix of C5 (35-100 bp, 5 % of the reads with an indel, damage model) on this genome
+        prm, kw, cfg_id = DAMAGE, dict(qual_range=(20, 40), damage=dict(f=0.5, t=0.5, d=0.02, s=1.0), len_range=(35, 100), indel_frac=0.05), 5
     rp = resolve_params(prm)
     params = mapad_amd.make_params(rp)
     seqs, quals, offsets = synth.reads(genome, args.reads, 50, seed=4321 + cfg_id + 1000 * rank, **kw)
@@ -93,7 +95,8 @@ def main():
     stream = torch.cuda.current_stream(dev)
     ctx = mapad_amd.Context(index, params, local_rank)
     ctx.set_stream(ctypes.c_void_p(stream.cuda_stream))
-    ctx.prepare_lengths([50])
+    max_len = int(np.diff(offsets.astype(np.int64)).max())
+    ctx.prepare_lengths(sorted(set(np.diff(offsets.astype(np.int64)).tolist())))
     ctx.set_fetch_d_arrays(False)
     d_seqs = torch.from_numpy(seqs).to(dev)
     d_quals = torch.from_numpy(quals).to(dev)
@@ -116,7 +119,7 @@ def main():
         return gather_hit_records(torch.cat([cnt_first, first]), hits, ops, rank, world, device=dev)
 
     def step():
-        ctx.map_batch_device(d_seqs.data_ptr(), d_quals.data_ptr(), d_offsets.data_ptr(), n_reads, 50)
+        ctx.map_batch_device(d_seqs.data_ptr(), d_quals.data_ptr(), d_offsets.data_ptr(), n_reads, max_len)
         return gather_hits()
 
     kernel_ms = []
@@ -241,8 +244,9 @@ def main():
             "metric": "mapped reads/sec (50 bp, -p 0.03)", "value": round(total_reads / elapsed, 1), "unit": "reads/s",
             "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64+f32", "data": "synthetic",
-            "config": {"workload": f"{'C2' if args.config == 'c2' else 'C3'}: chr21-size synthetic genome ({args.genome_bp} bp, n = {len(index)}), "
-                                   f"{n_reads} x 50 bp reads per GPU, -p 0.03, {'no-damage' if args.config == 'c2' else 'ss 50% deamination'} model",
+            "config": {"workload": f"{args.config.upper()}: synthetic genome ({args.genome_bp} bp, n = {len(index)}), "
+                                   f"{n_reads} x {'50' if args.config != 'c5' else '35-100'} bp reads per GPU, -p 0.03, "
+                                   f"{'no-damage' if args.config == 'c2' else 'ss 50% deamination'} model{', 5 % of the reads with an indel' if args.config == 'c5' else ''}",
                        "reads_per_gpu": n_reads, "genome_bp": args.genome_bp, "index_bytes_hbm": int((len(index) + 255) // 256 * 128),
                        "parallelism": f"reads sharded over {n_gpus} GPU(s), index replicated, hit records gathered on rank 0" if n_gpus > 1 else "1 GPU",
                        "mapped_fraction": round(float((np.diff(res.hit_begin.astype(np.int64)) > 0).mean()), 4),
