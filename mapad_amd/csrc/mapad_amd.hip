@@ -346,7 +346,9 @@ struct DeviceGrow {
         }
         if (idx == ~0u) {
             if (!exists) return GROW_NEVER;  // no class can hold this read: it goes to the full-limit pass
-            if (may_give_up && ++A.n_waits > gp->max_waits) return GROW_NEVER;
+            // only reads that are still small give up (cheap to restart, and it is the many mid-size reads that clog the big pools);
+            // a read that already fills a large arena keeps waiting for the few larger ones
+            if (may_give_up && first < 4 && ++A.n_waits > gp->max_waits) return GROW_NEVER;
             A.wait = 64;                     // every suitable arena is taken: its owners finish and give it back
             if (w == 0) atomicAdd(grown_counter + 2, 1u);
             return GROW_WAIT;
