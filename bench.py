@@ -238,6 +238,32 @@ def main():
                                       "sample": f"first {n_s} rows, host restatement of SampledSuffixArray::get on one thread"}
             locate["identical_positions"] = bool(np.array_equal(want, pos[:n_s]))
 
+    # ---- hits -> record fields (intervals_to_bam minus BAM encoding; rows a14-a17 of SURVEY 8a), outside the timed region ----------
+    post = None
+    if rank == 0:
+        from mapad_amd import binding as mb
+        import ctypes as C
+
+        def records_call():
+            out = C.POINTER(mb.RecordsC)()
+            t = time.perf_counter()
+            rc = mb.lib().mapad_hits_to_records_gpu(ctx.h, res._cptr, seqs.ctypes.data_as(C.c_void_p), quals.ctypes.data_as(C.c_void_p),
+                                                    offsets.ctypes.data_as(C.c_void_p), None, 0, C.byref(out))
+            dt = time.perf_counter() - t
+            assert rc == 0
+            n_mapped = sum(1 for i in range(0, int(out.contents.n), max(1, int(out.contents.n) // 1000)) if out.contents.recs[i].mapped)
+            mb.lib().mapad_records_free(out)
+            return dt, n_mapped
+
+        dt_all, _ = records_call()
+        post = {"reads_per_s": round(n_reads / dt_all, 1), "wall_s": round(dt_all, 3), "host_threads": min(os.cpu_count() or 1, 64),
+                "what": "mapad_hits_to_records_gpu: SA locate kernel + coordinates, MAPQ, CIGAR/MD/XA strings on host threads"}
+        if not args.no_cpu_baseline:
+            os.environ["MAPAD_POSTPROC_THREADS"] = "1"
+            dt_one, _ = records_call()
+            del os.environ["MAPAD_POSTPROC_THREADS"]
+            post["one_host_thread_reads_per_s"] = round(n_reads / dt_one, 1)
+
     if rank == 0:
         total_reads = n_reads * n_gpus * args.steps
         line = {
@@ -251,7 +277,7 @@ def main():
                        "parallelism": f"reads sharded over {n_gpus} GPU(s), index replicated, hit records gathered on rank 0" if n_gpus > 1 else "1 GPU",
                        "mapped_fraction": round(float((np.diff(res.hit_begin.astype(np.int64)) > 0).mean()), 4),
                        "index_build_s": round(t_index, 1)},
-            "roofline": roofline, "cpu_baseline": cpu, "parity": parity, "sa_locate": locate,
+            "roofline": roofline, "cpu_baseline": cpu, "parity": parity, "sa_locate": locate, "post_search": post,
         }
         if gathered is not None:
             line["config"]["gathered_hit_records"] = int(sum(int(g[1].numel()) // 10 for g in gathered))

@@ -8,6 +8,11 @@
 #pragma once
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
+#include <exception>
+#include <memory>
+#include <stdexcept>
+#include <thread>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -253,10 +258,22 @@ struct RecordsOwner {
 inline mapad_records_t* hits_to_records(const Index& ix, const mapad_params_t& prm, const mapad_batch_result_t& res, const uint8_t* seqs, const uint8_t* quals,
                                         const uint64_t* offsets, const uint16_t* in_flags, uint64_t seed, const SaCache* cache = nullptr) {
     (void)seqs; (void)quals; (void)offsets;
-    auto* own = new RecordsOwner();
+    auto own = std::unique_ptr<RecordsOwner>(new RecordsOwner());
     own->recs.resize(res.n_reads);
-    auto put = [&](const std::string& s, uint32_t& off, uint32_t& len) { off = (uint32_t)own->text.size(); len = (uint32_t)s.size(); own->text += s; };
-    for (uint64_t r = 0; r < res.n_reads; ++r) {
+    // Reads are independent (the reference runs this stage in a rayon map, mapping.rs:153-271): contiguous ranges go to host threads,
+    // each with its own text blob; blobs are concatenated in read order afterwards, so the output does not depend on the thread count.
+    unsigned n_threads = 1;
+    if (const char* e = std::getenv("MAPAD_POSTPROC_THREADS")) n_threads = (unsigned)std::max(1, std::atoi(e));
+    else n_threads = std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 64u);
+    n_threads = (unsigned)std::min<uint64_t>(n_threads, std::max<uint64_t>(1, res.n_reads / 2048));
+    std::vector<std::string> texts(n_threads);
+    std::vector<std::exception_ptr> errors(n_threads);
+    auto work = [&](unsigned t) {
+      try {
+        const uint64_t r0 = res.n_reads * t / n_threads, r1 = res.n_reads * (t + 1) / n_threads;
+        std::string& text = texts[t];
+        auto put = [&](const std::string& s, uint32_t& off, uint32_t& len) { off = (uint32_t)text.size(); len = (uint32_t)s.size(); text += s; };
+        for (uint64_t r = r0; r < r1; ++r) {
         mapad_record_t rec{};
         uint16_t flags = in_flags ? in_flags[r] : 0;
         flags &= (uint16_t)~(0x8 | 0x20 | 0x2 | 0x100 | 0x800);  // :750-755
@@ -321,9 +338,30 @@ inline mapad_records_t* hits_to_records(const Index& ix, const mapad_params_t& p
         }
         rec.flags = flags;
         own->recs[r] = rec;
+        }
+      } catch (...) { errors[t] = std::current_exception(); }
+    };
+    if (n_threads == 1) work(0);
+    else {
+        std::vector<std::thread> pool;
+        for (unsigned t = 0; t < n_threads; ++t) pool.emplace_back(work, t);
+        for (auto& th : pool) th.join();
+    }
+    for (auto& e : errors) if (e) std::rethrow_exception(e);
+    uint64_t total = 0;
+    for (auto& t : texts) total += t.size();
+    if (total > 0xFFFFFFFFull) throw std::runtime_error("record text of one batch exceeds 4 GiB");
+    own->text.reserve(total);
+    for (unsigned t = 0; t < n_threads; ++t) {
+        const uint32_t base = (uint32_t)own->text.size();
+        if (base) for (uint64_t r = res.n_reads * t / n_threads; r < res.n_reads * (t + 1) / n_threads; ++r) {
+            mapad_record_t& rec = own->recs[r];
+            if (rec.mapped) { rec.cigar_off += base; rec.md_off += base; rec.xa_off += base; }
+        }
+        own->text += texts[t];
     }
     own->pub.n = res.n_reads; own->pub.recs = own->recs.data(); own->pub.text = own->text.c_str(); own->pub.text_len = own->text.size();
-    return &own->pub;
+    return &own.release()->pub;
 }
 inline void free_records(mapad_records_t* r) { if (r) delete reinterpret_cast<RecordsOwner*>(r); }
 

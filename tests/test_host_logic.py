@@ -342,3 +342,18 @@ def test_postproc_matches_oracle_on_multicontig_genome():
             assert g_["tid"] == int(o["tid"]) and g_["pos"] == int(o["pos"]) and (g_["xa"] or "*") == o["xa"], (i, o, g_)
         n_multi += int(o["x0"]) > 1
     assert n_multi > 10
+
+
+def test_postproc_thread_count_does_not_change_records(monkeypatch):
+    """hits -> records runs on host threads over contiguous read ranges; the record array and text offsets must not depend on it."""
+    g = synth.genome(200_000, seed=31)
+    g[150_000:150_300] = g[20_000:20_300]  # some multi-mapping
+    seqs, quals, offsets = synth.reads(g, 9000, 50, seed=5)
+    pidx = mapad_amd.Index.build([("c1", g[:120_000]), ("c2", g[120_000:])])
+    params = mapad_amd.make_params(resolve_params(NO_DAMAGE))
+    res = emu_util.map_batch(pidx, params, seqs, quals, offsets)
+    monkeypatch.setenv("MAPAD_POSTPROC_THREADS", "1")
+    one = mapad_amd.hits_to_records(pidx, params, res, seqs, quals, offsets, seed=3)
+    monkeypatch.setenv("MAPAD_POSTPROC_THREADS", "4")
+    four = mapad_amd.hits_to_records(pidx, params, res, seqs, quals, offsets, seed=3)
+    assert one == four and sum(r["mapped"] for r in one) > 7000
