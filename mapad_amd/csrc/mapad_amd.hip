@@ -703,7 +703,8 @@ int launch_batch(mapad_ctx* c, const uint8_t* d_seqs, const uint8_t* d_quals, co
         HIP_TRY(hipMemsetAsync(c->d_key_hist.p, 0, (size_t)n_chunks * kKeyBins * 4, c->stream));
     }
     if ((rc = c->d_cursors.ensure(CUR_COUNT))) return rc;
-    const size_t hits_cap = std::max(c->d_hits.cap, (size_t)(2 * nr + 1024));
+    // 2 hits per read on average + slack; MAPAD_HIT_POOL (test hook) starts smaller so that the retry of mapad_map_batch is exercised
+    const size_t hits_cap = std::max(c->d_hits.cap, (size_t)env_u32("MAPAD_HIT_POOL", (uint32_t)std::min<size_t>(2 * nr + 1024, 0xFFFFFFFFu)));
     const size_t ops_cap = std::max(c->d_ops.cap, hits_cap * (size_t)(std::min<uint32_t>(lmax, 256) + 8));
     if ((rc = c->d_hits.ensure(hits_cap))) return rc;
     if ((rc = c->d_ops.ensure(ops_cap))) return rc;

@@ -63,8 +63,9 @@ def test_synthetic_batch_matches_oracle(name, prm, kw, lanes_per_read, monkeypat
 
 @pytest.mark.parametrize("env", [{"MAPAD_ORDER": "0"}, {"MAPAD_POOL_BUDGET_GB": "1", "MAPAD_TIER0_NODES": "256"}, {"MAPAD_NEAR_LDS": "0"},
                                  {"MAPAD_TIER0_NODES": "32", "MAPAD_CLASS_COUNTS": "4,4,4,4,4,4,4,4,4,4", "MAPAD_MAX_WAITS": "0"},
-                                 {"MAPAD_ORDER_CHUNK_LOG2": "10"}],
-                         ids=["input_order", "tiny_pool_budget", "near_data_in_hbm", "give_up_and_restart", "order_chunks_of_1024"])
+                                 {"MAPAD_ORDER_CHUNK_LOG2": "10"}, {"MAPAD_HIT_POOL": "64"}],
+                         ids=["input_order", "tiny_pool_budget", "near_data_in_hbm", "give_up_and_restart", "order_chunks_of_1024",
+                              "hit_pool_overflow_retry"])
 def test_scheduling_and_memory_variants_do_not_change_results(env, monkeypatch):
     """The cost-class order, the size of the arena pools and where the near data lives only change when and where a read is
     processed, never its result."""
