@@ -9,6 +9,8 @@ LIB = os.path.join(HERE, "libmapad_amd.so")
 SOURCES = ["mapad_amd.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math",
+         # device code at -O2: fewer branches and scalar instructions in the search kernel than -O3 (measured 1-3 % faster on MI355X)
+         "-Xarch_device", "-O2",
          # keep libm out of the constant folder / pow->exp10 rewrites: the reference evaluates these at run time with glibc
          "-fno-builtin-log2f", "-fno-builtin-powf", "-fno-builtin-expf", "-fno-builtin-exp2f", "-fno-builtin-log10f",
          "-Wall", "-Wno-unused-function", "-Wno-unknown-pragmas"]
