@@ -210,17 +210,24 @@ MAPAD_HD bool mm_is_min_level(uint32_t pos) {
 // The first two compares of a bubble-up (parent, then the grandparent of wherever the element sits after the first compare) decide
 // 98 % of all pushes (measured, C2/C3); their three possible slots are known from `pos` alone, so they are loaded together and the
 // dependent chain of a push is one memory round trip instead of two.
+struct Ancestors { HeapEntry e1, e2, e3; };  // parent, grandparent of pos, grandparent of the parent (slot 0 where there is none)
 template <bool NL>
-MAPAD_HD void mm_bubble_up(const ArenaT<NL>& A, uint32_t pos, const HeapEntry elt) {  // elt is the new element, destined for slot pos
+MAPAD_HD Ancestors load_ancestors(const ArenaT<NL>& A, uint32_t pos) {
+    const uint32_t i1 = pos > 0 ? (pos - 1) >> 1 : 0, i2 = pos > 2 ? (pos - 3) >> 2 : 0, i3 = i1 > 2 ? (i1 - 3) >> 2 : 0;
+    Ancestors a;  // i3 <= i2 <= i1: one branch per near/arena split, so that the arena loads of a case are in flight together
+    if (i1 < (uint32_t)kTop) { a.e1 = load_entry(A.top + i1); a.e2 = load_entry(A.top + i2); a.e3 = load_entry(A.top + i3); }
+    else if (i2 < (uint32_t)kTop) { a.e1 = load_entry(A.heap + i1); a.e2 = load_entry(A.top + i2); a.e3 = load_entry(A.top + i3); }
+    else if (i3 < (uint32_t)kTop) { a.e1 = load_entry(A.heap + i1); a.e2 = load_entry(A.heap + i2); a.e3 = load_entry(A.top + i3); }
+    else { a.e1 = load_entry(A.heap + i1); a.e2 = load_entry(A.heap + i2); a.e3 = load_entry(A.heap + i3); }
+    return a;
+}
+template <bool NL>
+MAPAD_HD void mm_bubble_up(const ArenaT<NL>& A, uint32_t pos, const HeapEntry elt, const Ancestors& an) {  // elt is the new element, destined for slot pos
     if (pos > 0) {
         const uint32_t i1 = (pos - 1) >> 1;                 // parent
         const uint32_t i2 = pos > 2 ? (pos - 3) >> 2 : 0;   // grandparent of pos
         const uint32_t i3 = i1 > 2 ? (i1 - 3) >> 2 : 0;     // grandparent of the parent
-        HeapEntry e1, e2, e3;  // i3 <= i2 <= i1: one branch per near/arena split, so that the arena loads of a case are in flight together
-        if (i1 < (uint32_t)kTop) { e1 = load_entry(A.top + i1); e2 = load_entry(A.top + i2); e3 = load_entry(A.top + i3); }
-        else if (i2 < (uint32_t)kTop) { e1 = load_entry(A.heap + i1); e2 = load_entry(A.top + i2); e3 = load_entry(A.top + i3); }
-        else if (i3 < (uint32_t)kTop) { e1 = load_entry(A.heap + i1); e2 = load_entry(A.heap + i2); e3 = load_entry(A.top + i3); }
-        else { e1 = load_entry(A.heap + i1); e2 = load_entry(A.heap + i2); e3 = load_entry(A.heap + i3); }
+        const HeapEntry e1 = an.e1, e2 = an.e2, e3 = an.e3;
         bool greater;  // which grandparent chain to follow
         bool moved;
         if (mm_is_min_level(pos)) { moved = elt.score > e1.score; greater = moved; }
@@ -244,6 +251,8 @@ MAPAD_HD void mm_bubble_up(const ArenaT<NL>& A, uint32_t pos, const HeapEntry el
     }
     hp_set(A, pos, elt);
 }
+template <bool NL>
+MAPAD_HD void mm_bubble_up(const ArenaT<NL>& A, uint32_t pos, const HeapEntry elt) { mm_bubble_up(A, pos, elt, load_ancestors(A, pos)); }
 
 // The heap array is stored shifted by one entry (logical index i lives in physical slot i + 1; `v` points at logical 0), so the
 // two children of a node (logical 2p+1, 2p+2) form one 16-byte aligned pair and its four grandchildren (4p+3 .. 4p+6) one
