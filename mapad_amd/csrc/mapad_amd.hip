@@ -253,7 +253,7 @@ template <int LPR>
 __device__ __forceinline__ uint32_t group_bcast(uint32_t v) { return LPR == 4 ? dpp_quad<0>(v) : v; }
 
 template <int LPR, bool NL>
-__device__ MAPAD_FINALIZE_ATTR void finalize_read(const BatchDev B, const ArenaT<NL> A, const SearchState st, uint32_t read, int w, int tier) {
+__device__ MAPAD_FINALIZE_ATTR void finalize_read(const BatchDev B, const ReadInT<NL> rd, const ArenaT<NL> A, const SearchState st, uint32_t read, int w, int tier) {
     if (st.status == ST_ARENA_OVERFLOW && tier + 1 < kStages) {  // hand the read to the next stage
         if (w == 0) {
             const uint32_t k = atomicAdd(&B.cursors[CUR_OVF + 2 * tier], 1u);
@@ -279,7 +279,8 @@ __device__ MAPAD_FINALIZE_ATTR void finalize_read(const BatchDev B, const ArenaT
         B.hit_first[read] = hbase;
         B.status[read] = status;
         ReadCounters* c = B.counters + read;
-        c->e_search = st.ctr.e_search; c->n_push = st.ctr.n_push; c->n_pop = st.ctr.n_pop; c->n_node = st.ctr.n_node; c->n_hits = st.ctr.n_hits;
+        c->e_search = rd.ctr[CTR_E_SEARCH] / LPR; c->n_push = rd.ctr[CTR_N_PUSH] / LPR; c->n_pop = rd.ctr[CTR_N_POP] / LPR;
+        c->n_node = rd.ctr[CTR_N_NODE] / LPR; c->n_hits = rd.ctr[CTR_N_HITS] / LPR;  // every lane of the group counted
         if (status == ST_ARENA_OVERFLOW) atomicOr(&B.cursors[CUR_ERR], ST_ARENA_OVERFLOW);  // cannot happen: the last tier holds the reference's limits
     }
 }
@@ -332,7 +333,7 @@ struct DeviceGrow {
             if (w == 0) {
                 const bool part = n >= kPartitionMin;
                 const uint32_t m = part ? n / 8 : n, lo = part ? xcc_id() * m : 0;  // this XCD's part of the pool
-                uint32_t i = (uint32_t)(((uint64_t)(slot + st.ctr.n_pop) * 2654435761u) % m);
+                uint32_t i = (uint32_t)(((uint64_t)(slot + st.tree_len) * 2654435761u) % m);
                 const uint32_t tries = m < 64u ? m : 64u;
                 uint32_t* own = gp->owner[cls] + lo;
                 for (uint32_t t = 0; t < tries; ++t) {
@@ -388,7 +389,7 @@ __global__ void __launch_bounds__(64, MAPAD_MIN_WAVES) search_kernel(DevIndex ix
     const int tier = stage;
     const uint32_t slot = blockIdx.x * (64 / LPR) + (lane / LPR);
     ArenaT<NL> A = carve<NL>(AP, slot);
-    // near data of this read slot: [32 heap slots][2*lmax bytes class/quality][lmax floats D]
+    // near data of this read slot: [32 heap slots][2*lmax bytes class/quality][lmax floats D][event counters]
     extern __shared__ __attribute__((aligned(16))) uint8_t near_lds[];
     using NearBytes = typename near_ptr<uint8_t, NL>::type;
     NearBytes near;
@@ -407,7 +408,8 @@ __global__ void __launch_bounds__(64, MAPAD_MIN_WAVES) search_kernel(DevIndex ix
 #if defined(MAPAD_ACTIVE_QUADS)
     if ((lane / LPR) >= MAPAD_ACTIVE_QUADS) done = true;  // experiment: fewer reads per wavefront
 #endif
-    ReadInT<NL> rd{near_qc, near_d, 0, 0.0f, 0};
+    const typename near_ptr<uint32_t, NL>::type near_ctr = (typename near_ptr<uint32_t, NL>::type)((NearBytes)near_d + ((4 * near_lmax + 15) & ~15u));
+    ReadInT<NL> rd{near_qc, near_d, 0, 0.0f, 0, near_ctr};
     SearchState st;
     uint32_t read = 0;
     for (;;) {
@@ -428,7 +430,7 @@ __global__ void __launch_bounds__(64, MAPAD_MIN_WAVES) search_kernel(DevIndex ix
                     read_setup(B.seqs + off, B.quals + off, B.d_arrays + off, rd.L, near_qc, near_d, w, LPR);
                     SearchState tmp;
                     A.n_waits = 0;
-                    search_init(ix.n, alignment_start_of(P, rd.L), A, tmp);
+                    search_init(ix.n, alignment_start_of(P, rd.L), rd, A, tmp);
                     st = tmp;
                     have = true;
                 }
@@ -440,7 +442,7 @@ __global__ void __launch_bounds__(64, MAPAD_MIN_WAVES) search_kernel(DevIndex ix
             if constexpr (PASS != 1) cont = search_step<LPR, CONT, NL>(ix, P, rd, A, st, w, grow);
             else cont = search_step<LPR, CONT, NL>(ix, P, rd, A, st, w, NoGrow());
             if (!cont) {
-                finalize_read<LPR, NL>(B, A, st, read, w, tier);
+                finalize_read<LPR, NL>(B, rd, A, st, read, w, tier);
                 if (PASS != 1 && A.grown) {  // give the grown arena back; the next read starts in the base arena again
                     release_grown<LPR>(GP, A.grown, w);
                     const ArenaT<NL> base = carve<NL>(AP, slot);
@@ -489,7 +491,7 @@ struct DevBuf {
 };
 
 // bytes of "near" data per read slot: heap top (32 physical slots), 2 bytes + 4 bytes per read position
-uint32_t near_bytes(uint32_t lmax) { return (kTop + 1) * 8 + ((2 * lmax + 15) & ~15u) + ((4 * lmax + 15) & ~15u); }
+uint32_t near_bytes(uint32_t lmax) { return (kTop + 1) * 8 + ((2 * lmax + 15) & ~15u) + ((4 * lmax + 15) & ~15u) + CTR_COUNT * 4; }
 constexpr uint32_t kMaxLdsReadLen = 256;  // longer reads keep their near data in the HBM arena instead of LDS
 
 ArenaPool make_pool_layout(uint32_t heap_cap, uint32_t node_cap, uint32_t hit_ops_cap, uint32_t lmax) {

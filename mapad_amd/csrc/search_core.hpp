@@ -129,7 +129,18 @@ struct ReadInT {
     int L;
     float thr;          // DevParams::reject_thr[L]
     int32_t table;      // DevParams::table_base[L]
+    typename near_ptr<uint32_t, NL>::type ctr;  // event counters of the read, kCtr* below (near data: they would cost five registers)
 };
+enum : int { CTR_E_SEARCH = 0, CTR_N_PUSH = 1, CTR_N_POP = 2, CTR_N_NODE = 3, CTR_N_HITS = 4, CTR_COUNT = 8 };
+// Every lane of the read's lane group counts (LPR increments per event on the device, one atomic-add instruction without a return
+// value); the reader divides by the group size.
+template <class P> MAPAD_HD void count_event(P ctr, int k) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __hip_atomic_fetch_add(ctr + k, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+#else
+    ctr[k] += 1;
+#endif
+}
 using ReadIn = ReadInT<false>;
 
 struct alignas(16) HeapPair { HeapEntry a, b; };
@@ -182,7 +193,6 @@ struct SearchState {
     uint32_t status;
     float best_score;     // hits[0] (BinaryHeap::peek) kept in registers
     uint64_t best_size;
-    ReadCounters ctr;
 };
 
 // LPR = lanes per read: 4 = the quad splits every rank query (one coalesced 128-byte line per query);
@@ -427,7 +437,7 @@ MAPAD_RARE void record_hit(const ReadInT<NL> rd, const ArenaT<NL> A, SearchState
     st.hit_ops_used += m;
     hits_push(A.hits, st.n_hits, h);
     if (st.n_hits == 1 || score > st.best_score) { st.best_score = score; st.best_size = size; }  // new BinaryHeap root
-    st.ctr.n_hits += 1;
+    count_event(rd.ctr, CTR_N_HITS);
 }
 
 // Before a step starts, an arena that cannot take the step's worst case (9 new nodes, 8 more frames) asks `grow` for a bigger one:
@@ -451,7 +461,7 @@ MAPAD_HD void commit_child(const DevParams& P, const ReadInT<NL>& rd, ArenaT<NL>
     if (st.tree_next == st.tree_entries && st.tree_entries >= A.node_cap) { st.status = ST_ARENA_OVERFLOW; return; }  // cannot happen (search_step)
     const uint32_t id = tree_alloc(A.nodes, st);
     if (store) A.nodes[id] = nd;
-    st.ctr.n_node += 1;
+    count_event(rd.ctr, CTR_N_NODE);
     if (len == rd.L) {  // rare: the state takes a round trip through memory only here, so it can live in registers otherwise
         Node u = nd;
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -467,7 +477,7 @@ MAPAD_HD void commit_child(const DevParams& P, const ReadInT<NL>& rd, ArenaT<NL>
     if (st.heap_len >= A.heap_cap) { st.status = ST_ARENA_OVERFLOW; return; }  // cannot happen (search_step)
     st.heap_len += 1;
     mm_bubble_up(A, st.heap_len - 1, HeapEntry{score, id});
-    st.ctr.n_push += 1;
+    count_event(rd.ctr, CTR_N_PUSH);
 }
 
 // Overflow recovery (mapping.rs:1371-1379): evict the worst frames and free their tree nodes.
@@ -483,17 +493,17 @@ MAPAD_RARE void evict_worst(const ArenaT<NL> A, SearchState& st, int64_t cnt) {
 // k_mismatch_search (mapping.rs:1012-1383) after the D array has been computed, split into init / step so that a
 // persistent quad can fetch its next read as soon as the current one finishes.  `w` = lane index inside the quad.
 template <bool NL>
-MAPAD_RARE void search_init(uint64_t n_text, int alignment_start, const ArenaT<NL> A, SearchState& st) {
+MAPAD_RARE void search_init(uint64_t n_text, int alignment_start, const ReadInT<NL> rd, const ArenaT<NL> A, SearchState& st) {
+    for (int k = 0; k < CTR_COUNT; ++k) rd.ctr[k] = 0;
     st.heap_len = 0; st.tree_entries = 0; st.tree_next = 0; st.tree_len = 0; st.n_hits = 0; st.hit_ops_used = 0; st.status = ST_OK;
     st.best_score = 0.0f; st.best_size = 0;
-    st.ctr.e_search = 0; st.ctr.n_push = 0; st.ctr.n_pop = 0; st.ctr.n_node = 0; st.ctr.n_hits = 0;
     Frame root;  // Tree::clear() -> id 0; root frame (mapping.rs:1045-1054)
     root.lower = 0; root.lower_rev = 0; root.size = n_text;  // init_interval
     root.start = alignment_start; root.len = 0; root.gap_f = GAP_CLOSED; root.gap_b = GAP_CLOSED; root.ngaps = 0;
     tree_insert(A.nodes, st, pack_node(pack_op(OP_MATCH, 0, 0), 0, root));
     A.top[0] = HeapEntry{0.0f, 0u};
     st.heap_len = 1;
-    st.ctr.n_push += 1;
+    count_event(rd.ctr, CTR_N_PUSH);
 }
 
 // One iteration of the `while let Some(stack_frame) = stack.pop_max()` loop.  Returns false when the search is over.
@@ -512,7 +522,7 @@ MAPAD_HD bool search_step(const DevIndex& ix, const DevParams& P, const ReadInT<
     const HeapEntry top = mm_find_max(A, st.heap_len, top_idx);
     const Node top_node = A.nodes[top.node];  // in flight while the heap is repaired
     mm_remove_at<true>(A, st.heap_len, top_idx);
-    st.ctr.n_pop += 1;
+    count_event(rd.ctr, CTR_N_POP);
     const Frame f = unpack_frame(top_node);
     const float f_score = top.score;
     int j, d_k, d_l;
@@ -550,7 +560,7 @@ MAPAD_HD bool search_step(const DevIndex& ix, const DevParams& P, const ReadInT<
         ext4_any<LPR>(ix, forward ? f.lower_rev : f.lower, forward ? f.lower : f.lower_rev, f.size, w, e);
         nonempty = (e.size[0] >= 1 ? 1u : 0u) | (e.size[1] >= 1 ? 2u : 0u) | (e.size[2] >= 1 ? 4u : 0u) | (e.size[3] >= 1 ? 8u : 0u);
     }
-    st.ctr.e_search += 1;
+    count_event(rd.ctr, CTR_E_SEARCH);
 
     // Static gates of the <= 9 children in commit order: Ins; then for k = T,G,C,A: Del(k), Match/Mismatch(k).
     // bit 0 = Ins, bit 1+2i = Del, bit 2+2i = M/MM with i = 0..3 <-> k = 3..0.
@@ -649,7 +659,7 @@ MAPAD_HD bool search_step(const DevIndex& ix, const DevParams& P, const ReadInT<
 
 template <class Grow = NoGrow>
 MAPAD_HD void search_read(const DevIndex& ix, const DevParams& P, const ReadIn& rd, Arena& A, SearchState& st, int w, const Grow& grow = Grow()) {
-    search_init(ix.n, alignment_start_of(P, rd.L), A, st);
+    search_init(ix.n, alignment_start_of(P, rd.L), rd, A, st);
     if (P.bound_kind == BOUND_CONTINUOUS) { while (search_step<1, true, false>(ix, P, rd, A, st, w, grow)) {} }
     else { while (search_step<1, false, false>(ix, P, rd, A, st, w, grow)) {} }
 }
