@@ -168,11 +168,11 @@ int mapad_fetch_result(mapad_ctx_t* ctx, mapad_batch_result_t** out);
 int mapad_device_result_ptrs(mapad_ctx_t* ctx, void** d_hit_count, void** d_hit_first, void** d_hits, void** d_ops, void** d_cursors);
 /* sums of the per-read counters of the last batch (after a fetch or a stream sync): {e_search, e_darray, n_push, n_pop, n_node, n_hits} */
 int mapad_last_batch_counters(mapad_ctx_t* ctx, uint64_t out[6]);
-/* HIP-event durations (ms) of the last batch's launches on the context's stream: {darray_kernel, search_kernel, second-pass
- * search_kernel}.  Synchronises on the last event. */
+/* HIP-event durations (ms) of the last batch's launches on the context's stream: {darray_kernel + the two ordering kernels,
+ * search_kernel over every read + its (normally empty) retry launches, full-limit search_kernel}.  Synchronises on the last event. */
 int mapad_last_kernel_ms(mapad_ctx_t* ctx, float out[3]);
-/* launch geometry of the last batch, for bench.py's report: {darray grid, block, LDS bytes, search grid, block, second-pass grid,
- * first-pass node capacity, first-pass arena KiB per quad} */
+/* launch geometry of the last batch, for bench.py's report: {darray grid, block, LDS bytes, search grid, block, full-limit grid,
+ * base arena node capacity, base arena KiB per read slot} */
 int mapad_last_launch_info(mapad_ctx_t* ctx, uint32_t out[8]);
 
 /* ---- post-search: intervals_to_bam minus BAM byte encoding (mapping.rs:402-718, record.rs:269-449) ------------------- */

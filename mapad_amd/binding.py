@@ -351,7 +351,7 @@ class Context:
         return out
 
     def kernel_ms(self):
-        """HIP-event durations (ms) of the last batch: (darray_kernel, search_kernel, second-pass search_kernel)"""
+        """HIP-event durations (ms) of the last batch: (D arrays + ordering, search over every read + retries, full-limit search)"""
         out = np.zeros(3, np.float32)
         _check(lib().mapad_last_kernel_ms(self.h, _ptr(out)), "mapad_last_kernel_ms")
         return out

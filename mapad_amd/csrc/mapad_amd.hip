@@ -35,9 +35,9 @@ using namespace mapad;
 namespace {
 
 enum : uint32_t { ST_POOL_OVERFLOW = 4, ST_NO_TABLE = 8 };
-// Two passes over a batch: pass 0 maps every read from a small per-slot arena that GROWS on demand (size classes below, the grown
-// arena stays with the slot); pass 1 re-runs, with the reference's full limits, the few reads pass 0 could not finish because a
-// size-class pool ran dry.
+// Launches over a batch: stage 0 maps every read from a per-slot base arena that GROWS on demand (size classes below; the grown arena
+// goes back to its pool when the read ends); stages 1-2 restart the reads that gave up waiting for an arena; the last stage re-runs,
+// with the reference's full limits, reads that no size class could hold.
 constexpr int kTiers = 2;   // arena pools: growable base arenas, full-limit arenas
 constexpr int kStages = 4;  // launches over a batch: every read; two retries of reads that gave up waiting for an arena; full limits
 constexpr int kClasses = 10;  // grown arenas: 2x steps above the base arena (8 Ki nodes -> 16 Ki ... 4 Mi), the last one with the full limits
@@ -281,7 +281,7 @@ __device__ MAPAD_FINALIZE_ATTR void finalize_read(const BatchDev B, const ReadIn
         ReadCounters* c = B.counters + read;
         c->e_search = rd.ctr[CTR_E_SEARCH] / LPR; c->n_push = rd.ctr[CTR_N_PUSH] / LPR; c->n_pop = rd.ctr[CTR_N_POP] / LPR;
         c->n_node = rd.ctr[CTR_N_NODE] / LPR; c->n_hits = rd.ctr[CTR_N_HITS] / LPR;  // every lane of the group counted
-        if (status == ST_ARENA_OVERFLOW) atomicOr(&B.cursors[CUR_ERR], ST_ARENA_OVERFLOW);  // cannot happen: the last tier holds the reference's limits
+        if (status == ST_ARENA_OVERFLOW) atomicOr(&B.cursors[CUR_ERR], ST_ARENA_OVERFLOW);  // cannot happen: the last stage holds the reference's limits
     }
 }
 
@@ -555,7 +555,7 @@ struct mapad_ctx {
     bool last_owned_inputs = false;
     uint32_t launch_info[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     uint64_t counter_sums[6] = {0, 0, 0, 0, 0, 0};
-    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};  // around darray / search / second-pass launches, on `stream`
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};  // around D arrays + ordering / growable search stages / full-limit stage, on `stream`
     bool ev_valid = false;
 
     ~mapad_ctx() {
