@@ -5,10 +5,11 @@
 //   * the edit tree = slab (slab 0.4 semantics: LIFO key reuse) whose 32-byte nodes also carry the frame payload
 //     (a frame and the tree node created for it are 1:1, mapping.rs:969-971, so the node id doubles as the frame id),
 //   * the hit list = Rust std BinaryHeap array order,
-// all living in a per-quad arena in HBM.  Per-position scores and the D array come from the PosInfo table the D-array
-// kernel leaves behind (darray_core.hpp), so one pop costs: heap sift + one 32-byte node + one 32-byte PosInfo + two
-// 128-byte index blocks.  The four lanes of the quad execute this control flow redundantly on quad-uniform values; they
-// split the work only inside ext4_any() (rank queries, fmd_device.hpp).
+// living in the read slot's arena in HBM, except for the top 31 heap entries, the read's position data and its D array, which are
+// "near" data (LDS on the device).  One pop costs: heap sift + one 32-byte node + one 16-byte score-table row + two 128-byte index
+// blocks.  The four lanes of the quad execute the control flow on quad-uniform values; they split the work in the rank queries
+// (fmd_device.hpp: lane w counts sub-block w and keeps the extension by base w) and in building the children of a frame (lane w packs
+// the deletion and match/mismatch nodes of base w; search_step / commit_child).
 // The same source compiles for the host (tests/emu) so that the CPU test-suite can run it against the oracle.
 #pragma once
 #include "fmd_device.hpp"
