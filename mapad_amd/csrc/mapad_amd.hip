@@ -279,8 +279,8 @@ __device__ MAPAD_FINALIZE_ATTR void finalize_read(const BatchDev B, const ReadIn
         B.hit_first[read] = hbase;
         B.status[read] = status;
         ReadCounters* c = B.counters + read;
-        c->e_search = rd.ctr[CTR_E_SEARCH] / LPR; c->n_push = rd.ctr[CTR_N_PUSH] / LPR; c->n_pop = rd.ctr[CTR_N_POP] / LPR;
-        c->n_node = rd.ctr[CTR_N_NODE] / LPR; c->n_hits = rd.ctr[CTR_N_HITS] / LPR;  // every lane of the group counted
+        c->e_search = read_event(rd.ctr, CTR_E_SEARCH) / LPR; c->n_push = read_event(rd.ctr, CTR_N_PUSH) / LPR; c->n_pop = read_event(rd.ctr, CTR_N_POP) / LPR;
+        c->n_node = read_event(rd.ctr, CTR_N_NODE) / LPR; c->n_hits = read_event(rd.ctr, CTR_N_HITS) / LPR;  // every lane of the group counted
         if (status == ST_ARENA_OVERFLOW) atomicOr(&B.cursors[CUR_ERR], ST_ARENA_OVERFLOW);  // cannot happen: the last stage holds the reference's limits
     }
 }

@@ -17,6 +17,7 @@
 // Rare paths (a hit is found, limit recovery, read set-up).  Out-of-line variants were measured on MI355X (C2): they shrink the
 // kernel by 30 % of its instructions but cost 5-10 % run time and +25 % memory traffic (call-site spills through scratch),
 // so they are inlined by default; -DMAPAD_OUTLINE_RARE builds the out-of-line variant.
+#define MAPAD_UNLIKELY(x) __builtin_expect(!!(x), 0)
 #if defined(__HIPCC__) && defined(MAPAD_OUTLINE_RARE)
 #define MAPAD_RARE __host__ __device__ __attribute__((noinline))
 #elif defined(__HIPCC__)
@@ -135,6 +136,15 @@ struct ReadInT {
 enum : int { CTR_E_SEARCH = 0, CTR_N_PUSH = 1, CTR_N_POP = 2, CTR_N_NODE = 3, CTR_N_HITS = 4, CTR_COUNT = 8 };
 // Every lane of the read's lane group counts (LPR increments per event on the device, one atomic-add instruction without a return
 // value); the reader divides by the group size.
+// reads a counter back (device: at agent scope, so that a copy of the line in the CU's L1 cannot hide the atomic adds when the near
+// data lives in HBM)
+template <class P> MAPAD_HD uint32_t read_event(P ctr, int k) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __hip_atomic_load(ctr + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
+    return ctr[k];
+#endif
+}
 template <class P> MAPAD_HD void count_event(P ctr, int k) {
 #if defined(__HIP_DEVICE_COMPILE__)
     __hip_atomic_fetch_add(ctr + k, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
@@ -459,11 +469,11 @@ MAPAD_HD void commit_child(const DevParams& P, const ReadInT<NL>& rd, ArenaT<NL>
                            const Node& nd, bool store, int owner) {
     if (st.n_hits > 0 && mb_reject_iterative(P, score, st.best_score)) return;
     if ((int)ngaps > P.max_num_gaps_open) return;
-    if (st.tree_next == st.tree_entries && st.tree_entries >= A.node_cap) { st.status = ST_ARENA_OVERFLOW; return; }  // cannot happen (search_step)
+    if (MAPAD_UNLIKELY(st.tree_next == st.tree_entries && st.tree_entries >= A.node_cap)) { st.status = ST_ARENA_OVERFLOW; return; }  // cannot happen (search_step)
     const uint32_t id = tree_alloc(A.nodes, st);
     if (store) A.nodes[id] = nd;
     count_event(rd.ctr, CTR_N_NODE);
-    if (len == rd.L) {  // rare: the state takes a round trip through memory only here, so it can live in registers otherwise
+    if (MAPAD_UNLIKELY(len == rd.L)) {  // rare: the state takes a round trip through memory only here, so it can live in registers otherwise
         Node u = nd;
 #if defined(__HIP_DEVICE_COMPILE__)
         if (LPR == 4) { u.w1 = quad_pick64(nd.w1, owner); u.w2 = quad_pick64(nd.w2, owner); u.w3 = quad_pick64(nd.w3, owner); }
@@ -475,7 +485,7 @@ MAPAD_HD void commit_child(const DevParams& P, const ReadInT<NL>& rd, ArenaT<NL>
         st = tmp;
         return;
     }
-    if (st.heap_len >= A.heap_cap) { st.status = ST_ARENA_OVERFLOW; return; }  // cannot happen (search_step)
+    if (MAPAD_UNLIKELY(st.heap_len >= A.heap_cap)) { st.status = ST_ARENA_OVERFLOW; return; }  // cannot happen (search_step)
     st.heap_len += 1;
     mm_bubble_up(A, st.heap_len - 1, HeapEntry{score, id});
     count_event(rd.ctr, CTR_N_PUSH);
@@ -511,7 +521,7 @@ MAPAD_RARE void search_init(uint64_t n_text, int alignment_start, const ReadInT<
 template <int LPR, bool CONT, bool NL, class Grow>
 MAPAD_HD bool search_step(const DevIndex& ix, const DevParams& P, const ReadInT<NL>& rd, ArenaT<NL>& A, SearchState& st, int w, const Grow& grow) {
     if (st.heap_len == 0 || st.status != ST_OK) return false;
-    if (st.tree_len + kStepNodes > A.node_cap || st.heap_len + kStepNodes > A.heap_cap) {
+    if (MAPAD_UNLIKELY(st.tree_len + kStepNodes > A.node_cap || st.heap_len + kStepNodes > A.heap_cap)) {
         const int g = grow(A, st);
         if (g == GROW_WAIT) return true;
         if (g == GROW_NEVER || st.tree_len + kStepNodes > A.node_cap || st.heap_len + kStepNodes > A.heap_cap) { st.status = ST_ARENA_OVERFLOW; return false; }
@@ -643,11 +653,11 @@ MAPAD_HD bool search_step(const DevIndex& ix, const DevParams& P, const ReadInT<
             commit_child<LPR>(P, rd, A, st, alignment_start, score, ngaps, len, make_child(t, k, xl, xr, xs), true, 0);
         }
     }
-    if (st.status != ST_OK) return false;
+    if (MAPAD_UNLIKELY(st.status != ST_OK)) return false;
     // :1348-1355
-    if (st.n_hits > 9 || (st.n_hits > 0 && st.best_size > 1)) return false;
+    if (MAPAD_UNLIKELY(st.n_hits > 9 || (st.n_hits > 0 && st.best_size > 1))) return false;
     // :1358-1380
-    if (st.heap_len > P.stack_limit || st.tree_len > P.edit_tree_limit) {
+    if (MAPAD_UNLIKELY(st.heap_len > P.stack_limit || st.tree_len > P.edit_tree_limit)) {
         if (P.stack_limit_abort) { st.status = ST_LIMIT_ABORT; return false; }
         const int64_t a = (int64_t)st.heap_len - (int64_t)P.stack_limit;
         const int64_t b = (int64_t)st.tree_len - (int64_t)P.edit_tree_limit;
