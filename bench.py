@@ -110,7 +110,7 @@ def main():
             return None
         from mapad_amd.distributed import gather_hit_records
         p_cnt, p_first, p_hits, p_ops, p_cur = ctx.device_result_ptrs()
-        cur = torch.as_tensor(DevArray(p_cur, (2,), "<u4"), device=dev).view(torch.int32).cpu()
+        cur = torch.as_tensor(DevArray(p_cur, (2,), "<i8"), device=dev).cpu()
         n_hits, n_ops = int(cur[0]), int(cur[1])
         cnt_first = torch.as_tensor(DevArray(p_cnt, (n_reads,), "<u4"), device=dev).view(torch.int32)
         first = torch.as_tensor(DevArray(p_first, (n_reads,), "<u4"), device=dev).view(torch.int32)
@@ -146,7 +146,7 @@ def main():
 
     # torch <-> library interop used by the multi-GPU gather: wrap the library's cursor words without a copy and cross-check them
     p_cur = ctx.device_result_ptrs()[4]
-    cur_view = torch.as_tensor(DevArray(p_cur, (2,), "<u4"), device=dev).view(torch.int32).cpu().numpy()
+    cur_view = torch.as_tensor(DevArray(p_cur, (2,), "<i8"), device=dev).cpu().numpy()
 
     # ---- roofline of the dominant kernel (rank 0) -------------------------------------------------------------------------
     res = ctx.fetch()

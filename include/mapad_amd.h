@@ -164,7 +164,7 @@ int mapad_map_batch_device(mapad_ctx_t* ctx, const void* d_seqs, const void* d_q
 /* after synchronising the stream: copy the last device batch's results to the host */
 int mapad_fetch_result(mapad_ctx_t* ctx, mapad_batch_result_t** out);
 /* device pointers of the last batch's raw result buffers (for the RCCL gather): per-read hit counts (u32[n_reads]),
- * per-read first-hit index (u32[n_reads]), hit pool (mapad_hit_t[]), ops pool (u32[]), 2 x u32 cursors {n_hits, n_ops} */
+ * per-read first-hit index (u32[n_reads]), hit pool (mapad_hit_t[]), ops pool (u32[]), 2 x u64 cursors {n_hits, n_ops} */
 int mapad_device_result_ptrs(mapad_ctx_t* ctx, void** d_hit_count, void** d_hit_first, void** d_hits, void** d_ops, void** d_cursors);
 /* sums of the per-read counters of the last batch (after a fetch or a stream sync): {e_search, e_darray, n_push, n_pop, n_node, n_hits} */
 int mapad_last_batch_counters(mapad_ctx_t* ctx, uint64_t out[6]);

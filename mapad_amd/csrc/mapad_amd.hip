@@ -42,8 +42,11 @@ constexpr int kTiers = 2;   // arena pools: growable base arenas, full-limit are
 constexpr int kStages = 4;  // launches over a batch: every read; two retries of reads that gave up waiting for an arena; full limits
 constexpr int kClasses = 10;  // grown arenas: 2x steps above the base arena (8 Ki nodes -> 16 Ki ... 4 Mi), the last one with the full limits
 constexpr int kKeyBins = kMaxReadLen + 2;
-// cursors: global bump allocators and work counters; per pass t: CUR_WORK + 2t = next work item, CUR_OVF + 2t = reads pass t handed on
-enum { CUR_HITS = 0, CUR_OPS = 1, CUR_POOL_OVF = 2, CUR_ERR = 3, CUR_WORK = 4, CUR_OVF = 5, CUR_GROWN = 4 + 2 * kStages, CUR_COUNT = 4 + 2 * kStages + 4 };
+// cursors (u32 words): global bump allocators and work counters; per pass t: CUR_WORK + 2t = next work item, CUR_OVF + 2t = reads pass t
+// handed on.  The two pool cursors are 64-bit (words 0-1 and 2-3): a batch may ask for more than 2^32 op words, which must show up as a pool
+// overflow, not wrap around.
+enum { CUR_HITS = 0, CUR_OPS = 2, CUR_POOL_OVF = 4, CUR_ERR = 5, CUR_WORK = 6, CUR_OVF = 7, CUR_GROWN = 6 + 2 * kStages, CUR_COUNT = 6 + 2 * kStages + 4 };
+inline uint64_t cur64(const uint32_t* cur, int k) { return (uint64_t)cur[k] | ((uint64_t)cur[k + 1] << 32); }
 
 struct BatchDev {
     const uint8_t* seqs;
@@ -262,21 +265,24 @@ __device__ MAPAD_FINALIZE_ATTR void finalize_read(const BatchDev B, const ReadIn
         return;
     }
     const uint32_t n = st.status == ST_ARENA_OVERFLOW ? 0u : st.n_hits, n_ops = st.status == ST_ARENA_OVERFLOW ? 0u : st.hit_ops_used;
-    uint32_t hbase = 0, obase = 0;
-    if (w == 0) { hbase = atomicAdd(&B.cursors[CUR_HITS], n); obase = atomicAdd(&B.cursors[CUR_OPS], n_ops); }
-    hbase = group_bcast<LPR>(hbase);
-    obase = group_bcast<LPR>(obase);
+    uint64_t hbase = 0, obase = 0;
+    if (w == 0) {
+        hbase = atomicAdd((unsigned long long*)(B.cursors + CUR_HITS), (unsigned long long)n);
+        obase = atomicAdd((unsigned long long*)(B.cursors + CUR_OPS), (unsigned long long)n_ops);
+    }
+    hbase = (uint64_t)group_bcast<LPR>((uint32_t)hbase) | ((uint64_t)group_bcast<LPR>((uint32_t)(hbase >> 32)) << 32);
+    obase = (uint64_t)group_bcast<LPR>((uint32_t)obase) | ((uint64_t)group_bcast<LPR>((uint32_t)(obase >> 32)) << 32);
     uint32_t status = st.status;
-    if ((uint64_t)hbase + n > B.hits_cap || (uint64_t)obase + n_ops > B.ops_cap) {
+    if (hbase + n > B.hits_cap || obase + n_ops > B.ops_cap) {  // caps are < 2^32, so everything stored below fits 32 bits
         status |= ST_POOL_OVERFLOW;
         if (w == 0) atomicOr(&B.cursors[CUR_POOL_OVF], 1u);
     } else {
-        for (uint32_t i = w; i < n; i += LPR) { HitRec h = A.hits[i]; h.ops_off += obase; B.hits_pool[hbase + i] = h; }
+        for (uint32_t i = w; i < n; i += LPR) { HitRec h = A.hits[i]; h.ops_off += (uint32_t)obase; B.hits_pool[hbase + i] = h; }
         for (uint32_t i = w; i < n_ops; i += LPR) B.ops_pool[obase + i] = A.hit_ops[i];
     }
     if (w == 0) {
         B.hit_count[read] = (status & ST_POOL_OVERFLOW) ? 0u : n;
-        B.hit_first[read] = hbase;
+        B.hit_first[read] = (uint32_t)hbase;
         B.status[read] = status;
         ReadCounters* c = B.counters + read;
         c->e_search = read_event(rd.ctr, CTR_E_SEARCH) / LPR; c->n_push = read_event(rd.ctr, CTR_N_PUSH) / LPR; c->n_pop = read_event(rd.ctr, CTR_N_POP) / LPR;
@@ -298,8 +304,12 @@ __device__ __forceinline__ uint32_t xcc_id() { return (uint32_t)__builtin_amdgcn
 template <int LPR>
 __device__ __forceinline__ void release_grown(const GrowPools* gp, uint32_t grown, int w) {
     const uint32_t cls = (grown >> kGrownShift) - 1;
-    if (gp->count[cls] >= kPartitionMin) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // stores have reached the (shared) L2
-    else __threadfence();  // every access to the arena has completed and is written back before another XCD may take it
+    // A partitioned pool's arena stays behind one L2, so no write-back is needed, but the old owner's stores must have COMPLETED (reached
+    // that L2) before the owner word is cleared: a workgroup-scope fence emits nothing on gfx950, hence the explicit wait.
+    // Shared pools: every access has completed and is written back before another XCD may take the arena; the explicit wait after the
+    // fence keeps the compiler from dropping the one that orders the owner word behind the write-back.
+    if (gp->count[cls] < kPartitionMin) __threadfence();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (w == 0) atomicExch(&gp->owner[cls][grown & ((1u << kGrownShift) - 1)], 0u);
 }
 
@@ -962,8 +972,8 @@ int mapad_fetch_result(mapad_ctx_t* ctx, mapad_batch_result_t** out) {
     if (cur[CUR_ERR] & ST_ARENA_OVERFLOW) { std::fprintf(stderr, "mapad_amd: arena overflow in the large-arena pass\n"); return MAPAD_ERR_NOMEM; }
     if (cur[CUR_POOL_OVF]) return MAPAD_ERR_NOMEM;  // mapad_map_batch retries with larger pools
     std::vector<uint32_t> cnt(n), first(n);
-    std::vector<HitRec> pool(cur[CUR_HITS]);
-    std::vector<uint32_t> ops_pool(cur[CUR_OPS]);
+    std::vector<HitRec> pool(cur64(cur, CUR_HITS));
+    std::vector<uint32_t> ops_pool(cur64(cur, CUR_OPS));
     r->status.resize(n); r->counters.resize(n);
     if (ctx->fetch_d) r->d_arrays.resize(ctx->last_total_bases);
     if (n) {
@@ -1036,8 +1046,12 @@ int mapad_map_batch(mapad_ctx_t* ctx, const uint8_t* seqs, const uint8_t* quals,
         uint32_t cur[CUR_COUNT];
         HIP_TRY(hipMemcpy(cur, ctx->d_cursors.p, sizeof cur, hipMemcpyDeviceToHost));
         if (!cur[CUR_POOL_OVF]) return rc;
-        if ((rc = ctx->d_hits.ensure((size_t)cur[CUR_HITS] + 1024))) return rc;
-        if ((rc = ctx->d_ops.ensure((size_t)cur[CUR_OPS] + 1024))) return rc;
+        if (cur64(cur, CUR_HITS) + 1024 > 0xFFFFFFFFull || cur64(cur, CUR_OPS) + 1024 > 0xFFFFFFFFull) {
+            std::fprintf(stderr, "mapad_amd: the batch produces more than 2^32 hit records or edit operations; split it\n");
+            return MAPAD_ERR_INVALID;
+        }
+        if ((rc = ctx->d_hits.ensure((size_t)cur64(cur, CUR_HITS) + 1024))) return rc;
+        if ((rc = ctx->d_ops.ensure((size_t)cur64(cur, CUR_OPS) + 1024))) return rc;
     }
     return MAPAD_ERR_NOMEM;
 }

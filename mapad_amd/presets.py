@@ -17,6 +17,12 @@ NO_DAMAGE = {"model": "simple_adna", "library": "single_stranded", "five_prime_o
              "penalty_gap_open": {"log2": 0.001}, "penalty_gap_extend": {"repr_mm_times": 1.0}, "gap_dist_ends": 5, "max_num_gaps_open": 2}
 # C3: README example, single-stranded library with 50 % overhang parameters (Readme.md:147-150)
 DAMAGE = dict(NO_DAMAGE, five_prime_overhang=0.5, three_prime_overhang=0.5, ds_deamination_rate=0.02, ss_deamination_rate=1.0)
+# `-c 0.2 -e 1.2` instead of `-p`: the Continuous bound (mismatch_bounds.rs:76-120; cutoff = -c, main.rs:463-475); 50^1.2 * -0.2 = -21.9
+CONTINUOUS = {k: v for k, v in dict(DAMAGE, bound="continuous", cutoff=-0.2, exponent=1.2).items() if k not in ("poisson_threshold", "base_error_rate")}
+# `-l double_stranded -f 0.5`: the 3' overhang parameter equals the 5' one (main.rs:427-437), G->A at the 3' end (sequence_difference_models.rs:125-144)
+DOUBLE_STRANDED = dict(DAMAGE, library="double_stranded")
+# `--ignore_base_quality`: one quality level (sequence_difference_models.rs:286-287)
+IGNORE_BQ = dict(DAMAGE, ignore_base_quality=1)
 
 
 def _log2f(x):

@@ -7,7 +7,7 @@ from mapad_amd import synth
 from oracle import binding as ob
 
 from kat_util import load, quals_for, resolve_params
-from parity_util import DAMAGE, NO_DAMAGE, assert_same_as_oracle, split_reads
+from parity_util import CONTINUOUS, DAMAGE, DOUBLE_STRANDED, IGNORE_BQ, NO_DAMAGE, assert_same_as_oracle, split_reads
 from test_oracle_kats import KATS, check_search_expectations, integration_reads
 
 pytestmark = pytest.mark.gpu
@@ -45,6 +45,11 @@ def test_search_kat_on_gpu(case):
     ("no_damage_q40", NO_DAMAGE, dict(qual=40)),
     ("damage_q20_40", DAMAGE, dict(qual_range=(20, 40), damage=dict(f=0.5, t=0.5, d=0.02, s=1.0))),
     ("mixed_len_indels", DAMAGE, dict(qual_range=(20, 40), len_range=(35, 100), indel_frac=0.05)),
+    # the kernel variants of the other plugin settings (mismatch_bounds.rs:76-120, sequence_difference_models.rs:125-144,286-287)
+    ("continuous_bound", CONTINUOUS, dict(qual_range=(20, 40), damage=dict(f=0.5, t=0.5, d=0.02, s=1.0))),
+    ("continuous_mixed_len", CONTINUOUS, dict(qual_range=(20, 40), len_range=(35, 70), indel_frac=0.05)),
+    ("double_stranded", DOUBLE_STRANDED, dict(qual_range=(20, 40), damage=dict(f=0.5, t=0.5, d=0.02, s=1.0))),
+    ("ignore_base_quality", IGNORE_BQ, dict(qual_range=(2, 40), damage=dict(f=0.5, t=0.5, d=0.02, s=1.0))),
 ])
 @pytest.mark.parametrize("lanes_per_read", ["4", "1"])
 def test_synthetic_batch_matches_oracle(name, prm, kw, lanes_per_read, monkeypatch):
@@ -104,6 +109,24 @@ def test_small_arena_growth_last_pass_and_limits(monkeypatch, class_counts):
         rp2 = dict(rp, **limits)
         res = _gpu_map(pidx, mapad_amd.make_params(rp2), seqs, quals, offsets)
         ores = oidx.map_batch(ob.make_params(rp2), reads, qs, n_threads=8, keep_d=True)
+        assert_same_as_oracle(ores, res, offsets)
+
+
+def test_arena_handoff_stress(monkeypatch):
+    """Partitioned (per-XCD) pools with tiny base arenas and few grown arenas per XCD: arenas change owners constantly, under uneven
+    load, and every word of every result is checked (a late store of an old owner landing in a new owner's arena would show here)."""
+    monkeypatch.setenv("MAPAD_TIER0_NODES", "32")
+    monkeypatch.setenv("MAPAD_CLASS_COUNTS", "128,128,128,64,64,64,64,64,64,16")  # >= 64: split per XCD, 8-16 arenas each
+    g = synth.genome(400_000, seed=77)
+    seqs, quals, offsets = synth.reads(g, 20000, 50, seed=13, qual_range=(20, 40), damage=dict(f=0.5, t=0.5, d=0.02, s=1.0))
+    rp = resolve_params(DAMAGE)
+    pidx = mapad_amd.Index.build([("chr1", g)])
+    oidx = ob.OracleIndex.from_bwt(pidx.bwt(), "$ACGTX", 128)
+    reads, qs = split_reads(seqs, quals, offsets)
+    ores = oidx.map_batch(ob.make_params(rp), reads, qs, n_threads=8, keep_d=True)
+    for _ in range(2):
+        res = _gpu_map(pidx, mapad_amd.make_params(rp), seqs, quals, offsets)
+        assert res.n_second_pass > 20000  # arena migrations: more than one per read
         assert_same_as_oracle(ores, res, offsets)
 
 
