@@ -85,6 +85,11 @@ typedef struct mapad_index mapad_index_t;
  * reference uses rand::StdRng(seed), whose stream is not reproduced), longer runs become 'X'; originals are kept. */
 int mapad_index_build(const char* const* names, const uint8_t* const* seqs, const uint64_t* lens, uint32_t n_contigs,
                       uint64_t seed, mapad_index_t** out);
+/* The same products (src/index/indexing.rs:163-195: suffix array -> BWT, SA sample, Less, rank structure) with the suffix sorting done on
+ * the MI355X `device_id` (prefix doubling over radix sorts, mapad_amd/csrc/index_gpu.hip); byte-identical to mapad_index_build for every
+ * input.  Texts up to 2^40 symbols; MAPAD_ERR_NO_DEVICE without a GPU (mapad_index_build is the host path of this offline step). */
+int mapad_index_build_gpu(const char* const* names, const uint8_t* const* seqs, const uint64_t* lens, uint32_t n_contigs,
+                          uint64_t seed, int device_id, mapad_index_t** out);
 /* load_index_from_path + load_suffix_array/.tpi/.tos (src/index/mod.rs:212-239): reads the 7 files <prefix>.{tbw,tle,toc,trt,tsa,tpi,tos} */
 int mapad_index_open(const char* prefix, mapad_index_t** out);
 /* writers of indexing.rs:110-208 (snappy frame stream of bincode 1.3, version byte 5) */

@@ -88,6 +88,7 @@ SYMBOLS = {
     "mapad_mb_reject_iterative": (_i32, [_PP, _f, _f]),
     "mapad_mb_remaining_frac_of_repr_mm": (_f, [_PP, _f, _u64]),
     "mapad_index_build": (_i32, [_vp, _vp, _vp, _u32, _u64, C.POINTER(_vp)]),
+    "mapad_index_build_gpu": (_i32, [_vp, _vp, _vp, _u32, _u64, _i32, C.POINTER(_vp)]),
     "mapad_index_open": (_i32, [C.c_char_p, C.POINTER(_vp)]),
     "mapad_index_save": (_i32, [_vp, C.c_char_p]),
     "mapad_index_free": (None, [_vp]),
@@ -226,15 +227,19 @@ class Index:
         self.h = handle
 
     @classmethod
-    def build(cls, contigs, seed=1234):
-        """contigs: list of (name: str, seq: bytes / uint8 array)"""
+    def build(cls, contigs, seed=1234, device=None):
+        """contigs: list of (name: str, seq: bytes / uint8 array).  device=None: suffix sorting on the host (SA-IS);
+        device=k: on GPU k (mapad_index_build_gpu) — same index, byte for byte."""
         n = len(contigs)
         names = (C.c_char_p * n)(*[c[0].encode() for c in contigs])
         bufs = [np.ascontiguousarray(np.frombuffer(c[1], dtype=np.uint8) if isinstance(c[1], (bytes, bytearray)) else c[1], dtype=np.uint8) for c in contigs]
         seqs = (C.c_void_p * n)(*[b.ctypes.data for b in bufs])
         lens = (C.c_uint64 * n)(*[b.size for b in bufs])
         out = C.c_void_p()
-        _check(lib().mapad_index_build(names, seqs, lens, n, seed, C.byref(out)), "mapad_index_build")
+        if device is None:
+            _check(lib().mapad_index_build(names, seqs, lens, n, seed, C.byref(out)), "mapad_index_build")
+        else:
+            _check(lib().mapad_index_build_gpu(names, seqs, lens, n, seed, int(device), C.byref(out)), "mapad_index_build_gpu")
         return cls(out)
 
     @classmethod
@@ -292,6 +297,11 @@ class Index:
         less, sent = np.zeros(8, np.uint64), np.zeros(2, np.uint64)
         _check(lib().mapad_index_device_view(self.h, C.byref(blocks), C.byref(nb), _ptr(less), _ptr(sent)), "mapad_index_device_view")
         return blocks.value, nb.value, less, sent
+
+    def blocks(self):
+        """the rank blocks (16 x u64 per 256 rows) as a numpy view of the index's host copy"""
+        ptr, nb, _, _ = self.device_view()
+        return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint64)), shape=(int(nb) * 16,))
 
 
 class Context:

@@ -6,7 +6,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmapad_amd.so")
-SOURCES = ["mapad_amd.hip"]
+SOURCES = ["mapad_amd.hip", "index_gpu.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math",
          # device code at -O2: fewer branches and scalar instructions in the search kernel than -O3 (measured 1-3 % faster on MI355X)

@@ -257,36 +257,56 @@ inline bool is_iupac(uint8_t c) {
     switch (c) { case 'A': case 'C': case 'G': case 'T': case 'U': case 'R': case 'Y': case 'K': case 'M': case 'S': case 'W': case 'B': case 'D': case 'H': case 'V': case 'N': return true; default: return false; }
 }
 
-// indexing.rs:43-212.  `fixed_replacement` != 0 forces every short-run replacement to that base (test hook).
-inline Index build_index(const std::vector<std::string>& names, const std::vector<std::vector<uint8_t>>& seqs, uint64_t seed, uint8_t fixed_replacement = 0) {
-    Index ix;
+// indexing.rs:43-160: contigs -> uppercase -> IUPAC check -> replacement of ambiguity codes -> text $ revcomp $ as ranks ($=0 A=1 C=2 G=3 T=4 X=5).
+// Fills ix.contigs, ix.original_symbols and ix.n.  `fixed_replacement` != 0 forces every short-run replacement to that base (test hook).
+inline std::vector<uint8_t> prepare_text(const std::vector<std::string>& names, const uint8_t* const* seqs, const uint64_t* lens, uint64_t seed, uint8_t fixed_replacement, Index& ix) {
     std::vector<uint8_t> text;
     uint64_t end = 0;
-    for (size_t c = 0; c < seqs.size(); ++c) {  // :115-137
-        for (uint8_t ch : seqs[c]) text.push_back((uint8_t)std::toupper(ch));
-        end += seqs[c].size();
-        ix.contigs.push_back({end - seqs[c].size(), end - 1, names[c]});
-    }
-    for (uint8_t ch : text) if (!is_iupac(ch)) throw std::runtime_error("Found non-IUPAC symbol in reference sequence");  // :71
-    SplitMix64 rng{seed};
-    auto pick = [&](const char* set) -> uint8_t { const size_t k = std::char_traits<char>::length(set); return (uint8_t)set[rng.next() % k]; };
-    auto replace = [&](uint8_t b) -> uint8_t {  // :78-92
-        if (b == 'U') return 'T';
-        if (fixed_replacement) return fixed_replacement;
-        switch (b) {
-            case 'R': return pick("AG"); case 'Y': return pick("CT"); case 'K': return pick("GT"); case 'M': return pick("AC");
-            case 'S': return pick("CG"); case 'W': return pick("AT"); case 'B': return pick("CGT"); case 'D': return pick("AGT");
-            case 'H': return pick("ACT"); case 'V': return pick("ACG"); default: return pick("ACGT");
+    for (size_t c = 0; c < names.size(); ++c) end += lens[c];
+    text.resize(end);
+    end = 0;
+    for (size_t c = 0; c < names.size(); ++c) {  // :115-137
+        uint8_t* dst = text.data() + end;
+        for (uint64_t i = 0; i < lens[c]; ++i) {
+            uint8_t ch = seqs[c][i];
+            if (ch >= 'a' && ch <= 'z') ch = (uint8_t)(ch - 'a' + 'A');
+            dst[i] = ch;
         }
-    };
-    run_apply(text, 20, replace, [](uint8_t) -> uint8_t { return 'X'; }, ix.original_symbols);  // :98-107
+        end += lens[c];
+        ix.contigs.push_back({end - lens[c], end - 1, names[c]});
+    }
+    bool ambiguous = false;
+    for (uint8_t ch : text) {
+        if (base_index(ch) <= 3) continue;
+        if (!is_iupac(ch)) throw std::runtime_error("Found non-IUPAC symbol in reference sequence");  // :71
+        ambiguous = true;
+    }
+    if (ambiguous) {
+        SplitMix64 rng{seed};
+        auto pick = [&](const char* set) -> uint8_t { const size_t k = std::char_traits<char>::length(set); return (uint8_t)set[rng.next() % k]; };
+        auto replace = [&](uint8_t b) -> uint8_t {  // :78-92
+            if (b == 'U') return 'T';
+            if (fixed_replacement) return fixed_replacement;
+            switch (b) {
+                case 'R': return pick("AG"); case 'Y': return pick("CT"); case 'K': return pick("GT"); case 'M': return pick("AC");
+                case 'S': return pick("CG"); case 'W': return pick("AT"); case 'B': return pick("CGT"); case 'D': return pick("AGT");
+                case 'H': return pick("ACT"); case 'V': return pick("ACG"); default: return pick("ACGT");
+            }
+        };
+        run_apply(text, 20, replace, [](uint8_t) -> uint8_t { return 'X'; }, ix.original_symbols);  // :98-107
+    }
     // :139-160 text $ revcomp $ -> ranks
     const size_t g = text.size();
     std::vector<uint8_t> t(2 * g + 2);
     auto rank = [](uint8_t c) -> uint8_t { return c == 'A' ? 1 : c == 'C' ? 2 : c == 'G' ? 3 : c == 'T' ? 4 : 5; };
-    for (size_t i = 0; i < g; ++i) { t[i] = rank(text[i]); t[g + 1 + i] = rank(complement(text[g - 1 - i])); }
+    for (size_t i = 0; i < g; ++i) { const uint8_t r = rank(text[i]); t[i] = r; t[2 * g - i] = (uint8_t)(r == 5 ? 5 : 5 - r); }  // complement of a rank: A<->T, C<->G, X stays
     t[g] = 0; t[2 * g + 1] = 0;
     ix.n = t.size();
+    return t;
+}
+
+// indexing.rs:163-195 on the host: suffix array (SA-IS) -> BWT, SA sample 1/32 + extra rows, Less, rank blocks.
+inline void finish_on_host(const std::vector<uint8_t>& t, Index& ix) {
     ix.bwt.resize(ix.n);
     auto finish = [&](auto* sa) {
         for (uint64_t i = 0; i < ix.n; ++i) {  // :166, :168-182
@@ -300,6 +320,12 @@ inline Index build_index(const std::vector<std::string>& names, const std::vecto
     if (ix.n < (1ull << 31) && !(force64 && force64[0] == '1')) { std::vector<int32_t> sa(ix.n); sais<uint8_t, int32_t>(t.data(), sa.data(), (int32_t)ix.n, 6); finish(sa.data()); }
     else { std::vector<int64_t> sa(ix.n); sais<uint8_t, int64_t>(t.data(), sa.data(), (int64_t)ix.n, 6); finish(sa.data()); }
     build_blocks(ix);
+}
+
+inline Index build_index(const std::vector<std::string>& names, const uint8_t* const* seqs, const uint64_t* lens, uint64_t seed, uint8_t fixed_replacement = 0) {
+    Index ix;
+    const std::vector<uint8_t> t = prepare_text(names, seqs, lens, seed, fixed_replacement, ix);
+    finish_on_host(t, ix);
     return ix;
 }
 

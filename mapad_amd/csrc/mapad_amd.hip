@@ -29,6 +29,8 @@
 
 using namespace mapad;
 
+namespace mapad { namespace gpuidx { void suffix_products(const uint8_t* t_host, host::Index& ix, int device, bool verbose); } }  // index_gpu.hip
+
 // ======================================================================================================================
 // device side
 // ======================================================================================================================
@@ -836,15 +838,33 @@ int mapad_index_build(const char* const* names, const uint8_t* const* seqs, cons
     if (!out || !names || !seqs || !lens || n_contigs == 0) return MAPAD_ERR_INVALID;
     try {
         std::vector<std::string> nm;
-        std::vector<std::vector<uint8_t>> sq;
-        for (uint32_t i = 0; i < n_contigs; ++i) { nm.emplace_back(names[i]); sq.emplace_back(seqs[i], seqs[i] + lens[i]); }
+        for (uint32_t i = 0; i < n_contigs; ++i) nm.emplace_back(names[i]);
         const char* fr = std::getenv("MAPAD_INDEX_FIXED_REPLACEMENT");  // test hook: pin the random IUPAC replacement
         auto idx = std::make_unique<mapad_index>();
-        idx->ix = host::build_index(nm, sq, seed, fr && fr[0] ? (uint8_t)fr[0] : 0);
+        idx->ix = host::build_index(nm, seqs, lens, seed, fr && fr[0] ? (uint8_t)fr[0] : 0);
         *out = idx.release();
         return MAPAD_OK;
     } catch (const std::bad_alloc&) { return MAPAD_ERR_NOMEM; } catch (const std::exception& e) {
         std::fprintf(stderr, "mapad_index_build: %s\n", e.what());
+        return MAPAD_ERR_PARSE;
+    }
+}
+int mapad_index_build_gpu(const char* const* names, const uint8_t* const* seqs, const uint64_t* lens, uint32_t n_contigs, uint64_t seed, int device_id, mapad_index_t** out) {
+    if (!out || !names || !seqs || !lens || n_contigs == 0) return MAPAD_ERR_INVALID;
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess || device_id < 0 || device_id >= n_dev) return MAPAD_ERR_NO_DEVICE;
+    try {
+        std::vector<std::string> nm;
+        for (uint32_t i = 0; i < n_contigs; ++i) nm.emplace_back(names[i]);
+        const char* fr = std::getenv("MAPAD_INDEX_FIXED_REPLACEMENT");
+        const char* vb = std::getenv("MAPAD_INDEX_VERBOSE");
+        auto idx = std::make_unique<mapad_index>();
+        std::vector<uint8_t> t = host::prepare_text(nm, seqs, lens, seed, fr && fr[0] ? (uint8_t)fr[0] : 0, idx->ix);
+        gpuidx::suffix_products(t.data(), idx->ix, device_id, vb && vb[0] == '1');
+        *out = idx.release();
+        return MAPAD_OK;
+    } catch (const std::bad_alloc&) { return MAPAD_ERR_NOMEM; } catch (const std::exception& e) {
+        std::fprintf(stderr, "mapad_index_build_gpu: %s\n", e.what());
         return MAPAD_ERR_PARSE;
     }
 }

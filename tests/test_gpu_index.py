@@ -1,0 +1,120 @@
+"""GPU suffix sorting (mapad_index_build_gpu, csrc/index_gpu.hip) vs the host SA-IS path: every product of `mapad index`
+(src/index/indexing.rs:163-195) byte for byte, on degenerate, repetitive, ambiguous and large texts; and the n > 2^32 index
+(the north-star's 3 Gbp class: 64-bit intervals, src/map/fmd_index.rs:185-189) mapped on the GPU against the oracle."""
+import os
+import time
+
+import numpy as np
+import pytest
+
+import mapad_amd
+from mapad_amd import synth
+from oracle import binding as ob
+
+from kat_util import resolve_params
+from parity_util import DAMAGE, NO_DAMAGE, assert_same_as_oracle, split_reads
+
+pytestmark = pytest.mark.gpu
+
+
+def assert_same_index(a, b):
+    assert len(a) == len(b)
+    assert np.array_equal(a.bwt(), b.bwt()), "BWT"
+    for x, y, what in zip(a.sampled_sa(), b.sampled_sa(), ("SA sample", "extra rows", "extra values")):
+        assert np.array_equal(x, y), what
+    (_, nba, la, sa_), (_, nbb, lb, sb) = a.device_view(), b.device_view()
+    assert nba == nbb and np.array_equal(la, lb) and np.array_equal(sa_, sb), "Less / sentinel rows"
+    assert np.array_equal(a.blocks(), b.blocks()), "rank blocks"
+    assert a.contigs() == b.contigs()
+
+
+def _texts():
+    rng = np.random.default_rng(99)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    out = []
+    for n in (3, 4, 5, 7, 8, 9, 31, 32, 33, 255, 256, 257, 1000, 4097):
+        out.append((f"uniform{n}", [("c", acgt[rng.integers(0, 4, n)].tobytes())]))
+    out.append(("polyA", [("c", b"A" * 70_000)]))                                   # one group of n/2 suffixes: 16 doubling rounds
+    out.append(("tandem", [("c", b"ACGTTGCA" * 20_000)]))                           # period-8 repeat + its own reverse complement
+    out.append(("two_copies", [("c", (synth.genome(150_000, seed=5).tobytes()) * 2)]))  # LCP 150 000
+    out.append(("palindrome", [("c", synth.genome(60_000, seed=6).tobytes() + synth.revcomp(synth.genome(60_000, seed=6)).tobytes())]))  # text == its revcomp
+    g = synth.genome(300_000, seed=7)
+    g[1000:1040] = ord("N"); g[5000:5019] = ord("N"); g[77] = ord("R"); g[200_000:200_500] = ord("N"); g[299_990:] = ord("N")
+    out.append(("ambiguous_multi_contig", [("chrA", g[:120_000].tobytes()), ("chrB", g[120_000:120_001].tobytes()), ("chrC", g[120_001:].tobytes().lower())]))
+    return out
+
+
+@pytest.mark.parametrize("name,contigs", _texts(), ids=[t[0] for t in _texts()])
+def test_gpu_index_equals_host_index(name, contigs):
+    host = mapad_amd.Index.build(contigs, seed=42)
+    dev = mapad_amd.Index.build(contigs, seed=42, device=0)
+    assert_same_index(host, dev)
+
+
+def test_gpu_index_equals_host_index_100mbp():
+    g = synth.genome(100_000_000, seed=1234)
+    t0 = time.time()
+    dev = mapad_amd.Index.build([("chr1", g)], device=0)
+    t1 = time.time()
+    host = mapad_amd.Index.build([("chr1", g)])
+    t2 = time.time()
+    print(f"\n100 Mbp (n = {len(dev)}): GPU build {t1 - t0:.1f} s, host SA-IS build {t2 - t1:.1f} s")
+    assert_same_index(host, dev)
+
+
+def test_index_beyond_2_pow_32_rows_maps_like_the_oracle(monkeypatch):
+    """2.2 Gbp text -> n = 4.4e9 > 2^32 rows: the index is built on the GPU, 100 K reads are mapped on the GPU and compared bit for bit
+    (hits, scores, edit tracks, D arrays, the six event counters) with the oracle running on its own structures over the same BWT;
+    SA positions located on the device are checked against the genome itself."""
+    monkeypatch.setenv("MAPAD_INDEX_VERBOSE", "1")
+    G = int(os.environ.get("MAPAD_TEST_BIG_GENOME", 2_200_000_000))
+    t0 = time.time()
+    g = synth.genome(G, seed=1234)
+    t1 = time.time()
+    pidx = mapad_amd.Index.build([("chr1", g)], device=0)
+    t2 = time.time()
+    n = len(pidx)
+    assert n == 2 * G + 2 and (G < 2_147_483_648 or n > 2 ** 32)
+    print(f"\ngenome {t1 - t0:.1f} s, GPU index of n = {n} rows {t2 - t1:.1f} s")
+    # the index against the text: unique 40-mers (exact matches) must be located where they were cut, on both strands
+    rng = np.random.default_rng(3)
+    pos = np.concatenate([rng.integers(0, G - 40, 2000), np.array([0, 1, G - 41, G - 40])])
+    rp = resolve_params(NO_DAMAGE)
+    params = mapad_amd.make_params(rp)
+    ctx = mapad_amd.Context(pidx, params, 0)
+    fwd = np.concatenate([g[p:p + 40] for p in pos])
+    rc = np.concatenate([synth.revcomp(g[p:p + 40]) for p in pos])
+    offs = (np.arange(len(pos) + 1) * 40).astype(np.uint64)
+    for seqs, strand in ((fwd, 0), (rc, 1)):
+        res = ctx.map_batch(seqs, np.full(len(seqs), 40, np.uint8), offs)
+        best = res.hit_begin[:-1].astype(np.int64)
+        assert (np.diff(res.hit_begin.astype(np.int64)) >= 1).all()
+        h = res.hits_arr[best]
+        assert (h["size"] == 1).all() and (h["score"] == 0.0).all()
+        located = ctx.sa_locate(h["lower"].astype(np.uint64)).astype(np.int64)
+        if strand == 0:
+            assert np.array_equal(located, pos)
+        else:  # the occurrence lies in the reverse-complement half of the text (mapping.rs:617-628)
+            assert np.array_equal(n - located - 40 - 1, pos)
+    # reads vs the oracle
+    n_reads = int(os.environ.get("MAPAD_TEST_BIG_READS", 100_000))
+    half = n_reads // 2
+    batches = [(NO_DAMAGE, synth.reads(g, half, 50, seed=4325, qual=40)),
+               (DAMAGE, synth.reads(g, n_reads - half, 50, seed=4326, qual_range=(20, 40), damage=dict(f=0.5, t=0.5, d=0.02, s=1.0)))]
+    t3 = time.time()
+    oidx = ob.OracleIndex.from_bwt(pidx.bwt(), "$ACGTX", 128)
+    t4 = time.time()
+    print(f"oracle structures (byte BWT + Occ k=128) {t4 - t3:.1f} s")
+    ctx.close()
+    for prm, (seqs, quals, offsets) in batches:
+        rp = resolve_params(prm)
+        ctx = mapad_amd.Context(pidx, mapad_amd.make_params(rp), 0)
+        res = ctx.map_batch(seqs, quals, offsets)
+        ctx.close()
+        reads, qs = split_reads(seqs, quals, offsets)
+        t5 = time.time()
+        ores = oidx.map_batch(ob.make_params(rp), reads, qs, n_threads=os.cpu_count() or 8, keep_d=True)
+        print(f"oracle mapped {len(reads)} reads in {time.time() - t5:.1f} s; hits above 2^32: {(res.hits_arr['lower'] >= 2 ** 32).sum()} of {res.n_hits}")
+        assert_same_as_oracle(ores, res, offsets)
+        if n > 2 ** 32:
+            assert (res.hits_arr["lower"] >= 2 ** 32).sum() > 0.2 * res.n_hits  # the 64-bit half of the interval arithmetic is exercised
