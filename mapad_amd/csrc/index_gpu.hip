@@ -223,14 +223,15 @@ __global__ void __launch_bounds__(256) gather_rows_kernel(const uint64_t* __rest
 // ---- step 4: products ------------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) bwt_kernel(const uint8_t* __restrict__ t, const uint64_t* __restrict__ sa, uint64_t n, uint32_t rate_shift, uint8_t* __restrict__ bwt, uint64_t* __restrict__ sample,
                                                   unsigned long long* __restrict__ extra /* [0] = count, then (row, value) pairs */) {
-    const uint64_t r = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-    if (r >= n) return;
-    const uint64_t p = sa[r];
-    const uint8_t c = p ? t[p - 1] : t[n - 1];  // indexing.rs:166
-    bwt[r] = c;
-    if ((r & ((1ull << rate_shift) - 1)) == 0) sample[r >> rate_shift] = p;  // :168-182
-    else if (c == 0) { const unsigned long long k = atomicAdd(&extra[0], 1ull); if (k < 4) { extra[1 + 2 * k] = r; extra[2 + 2 * k] = p; } }
-    if (c == 0) { const unsigned long long k = atomicAdd(&extra[16], 1ull); if (k < 4) extra[17 + k] = r; }  // '$' rows of the BWT
+    // grid-stride: a launch may not have 2^32 or more threads
+    for (uint64_t r = (uint64_t)blockIdx.x * 256 + threadIdx.x; r < n; r += (uint64_t)gridDim.x * 256) {
+        const uint64_t p = sa[r];
+        const uint8_t c = p ? t[p - 1] : t[n - 1];  // indexing.rs:166
+        bwt[r] = c;
+        if ((r & ((1ull << rate_shift) - 1)) == 0) sample[r >> rate_shift] = p;  // :168-182
+        else if (c == 0) { const unsigned long long k = atomicAdd(&extra[0], 1ull); if (k < 4) { extra[1 + 2 * k] = r; extra[2 + 2 * k] = p; } }
+        if (c == 0) { const unsigned long long k = atomicAdd(&extra[16], 1ull); if (k < 4) extra[17 + k] = r; }  // '$' rows of the BWT
+    }
 }
 // one thread per 256-row block: bit planes + symbol counts of the block
 __global__ void __launch_bounds__(256) block_planes_kernel(const uint8_t* __restrict__ bwt, uint64_t n, uint64_t n_blocks, uint64_t* __restrict__ blocks, uint32_t* __restrict__ counts /* [5][n_blocks] */) {
@@ -275,7 +276,10 @@ struct Scratch {  // temporary storage for rocPRIM calls, grown on demand
     void* get(size_t bytes) { if (bytes > b.n) b.alloc(bytes + bytes / 4 + 256); return b.p; }
 };
 
-inline uint32_t grid_for(uint64_t m, uint32_t block) { return (uint32_t)((m + block - 1) / block); }
+inline uint32_t grid_for(uint64_t m, uint32_t block) {  // one thread per element; callers keep m * 1 thread below 2^32 threads per launch
+    if (m >= (1ull << 32)) throw std::runtime_error("launch of 2^32 or more threads");
+    return (uint32_t)((m + block - 1) / block);
+}
 
 // Sorts one chunk [0, m) of (key, val) pairs — as a whole, or inside the groups marked by `seg_start` — and computes, per position,
 // the first position of its (new) group in `head`.  Input in key[0] / val[0]; returns the index of the buffers that hold the result.
@@ -504,7 +508,7 @@ void suffix_products(const uint8_t* t_host, host::Index& ix, int device, bool ve
     Buf<unsigned long long> d_extra(32);
     GI_TRY(hipMemsetAsync(d_extra.p, 0, 32 * 8, s));
     GI_TRY(hipMemsetAsync(d_bwt.p + n, 0, n_blocks * kBlockRows - n, s));
-    hipLaunchKernelGGL(bwt_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, d_t.p, d_sa.p, n, rate_shift, d_bwt.p, d_sample.p, d_extra.p);
+    hipLaunchKernelGGL(bwt_kernel, dim3((uint32_t)std::min<uint64_t>((n + 255) / 256, 1u << 22)), dim3(256), 0, s, d_t.p, d_sa.p, n, rate_shift, d_bwt.p, d_sample.p, d_extra.p);
     GI_TRY(hipGetLastError());
     unsigned long long extra[32];
     GI_TRY(hipMemcpyAsync(extra, d_extra.p, sizeof extra, hipMemcpyDeviceToHost, s));

@@ -63,11 +63,11 @@ def test_gpu_index_equals_host_index_100mbp():
 
 
 def test_index_beyond_2_pow_32_rows_maps_like_the_oracle(monkeypatch):
-    """2.2 Gbp text -> n = 4.4e9 > 2^32 rows: the index is built on the GPU, 100 K reads are mapped on the GPU and compared bit for bit
+    """3 Gbp text (the genome of BASELINE.json's C4/C5) -> n = 6e9 > 2^32 rows: the index is built on the GPU, 100 K reads are mapped on the GPU and compared bit for bit
     (hits, scores, edit tracks, D arrays, the six event counters) with the oracle running on its own structures over the same BWT;
     SA positions located on the device are checked against the genome itself."""
     monkeypatch.setenv("MAPAD_INDEX_VERBOSE", "1")
-    G = int(os.environ.get("MAPAD_TEST_BIG_GENOME", 2_200_000_000))
+    G = int(os.environ.get("MAPAD_TEST_BIG_GENOME", 3_000_000_000))
     t0 = time.time()
     g = synth.genome(G, seed=1234)
     t1 = time.time()
@@ -117,4 +117,4 @@ def test_index_beyond_2_pow_32_rows_maps_like_the_oracle(monkeypatch):
         print(f"oracle mapped {len(reads)} reads in {time.time() - t5:.1f} s; hits above 2^32: {(res.hits_arr['lower'] >= 2 ** 32).sum()} of {res.n_hits}")
         assert_same_as_oracle(ores, res, offsets)
         if n > 2 ** 32:
-            assert (res.hits_arr["lower"] >= 2 ** 32).sum() > 0.2 * res.n_hits  # the 64-bit half of the interval arithmetic is exercised
+            assert (res.hits_arr["lower"] >= 2 ** 32).sum() > 0.15 * res.n_hits  # the 64-bit half of the interval arithmetic is exercised
