@@ -1,25 +1,35 @@
 #!/usr/bin/env python3
 """bench.py — mapped reads/s of the mapAD hot path on MI355X (BASELINE.json metric), one JSON line on rank 0.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--genome-bp G] [--reads R] [--config c2|c3]
-  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--config c1|c2|c3|c4|c5] [--genome-bp G] [--reads R]
 
-Workload (BASELINE.json configs[1] "C2"): synthetic chr21-size genome (48 Mbp, i.i.d. ACGT, splitmix64 seed 1234),
-1 M synthetic 50 bp reads per GPU (90 % endogenous with 2 % substitutions, 10 % exogenous, Phred 40), `-p 0.03`, no-damage
-model (-l single_stranded -f 0 -t 0 -d 0 -s 0 -D 0.02 -i 0.001 -x 1.0), gap_dist_ends 5, max_num_gaps_open 2.
-One "step" = one pass of the hot path (D-array kernel + search kernel + large-arena pass) over the batch; reads, index and
-score tables are resident in HBM before the timed region.  With N > 1 every rank holds a replica of the index, maps its own
-shard of reads (weak scaling: 1 M reads per GPU) and the hit records are gathered on rank 0 over RCCL inside each step.
+`--gpus N` (N > 1) without a torchrun environment starts the N ranks itself (torch.distributed.run as a child process, before
+anything touches the GPU); under the driver's torchrun it reads RANK / LOCAL_RANK / WORLD_SIZE.  A world size that differs from
+--gpus, or fewer visible devices than ranks, is an error, never a silent 1-GPU run.
 
-Also reported on the same line:
-  roofline     — dominant kernel, algorithmic bytes (SURVEY §8d formula from the kernels' event counters) / HIP-event time
-  cpu_baseline — the C++ oracle (oracle/, a restatement of the reference algorithm; the Rust reference cannot be built
-                 here) on all host cores over a bounded sample of the same reads; its hits must equal the GPU's.
+Workloads (synthetic genome = i.i.d. ACGT from splitmix64(1234), reads 90 % endogenous with 2 % substitutions, 10 % exogenous;
+`-p 0.03 -D 0.02 -i 0.001 -x 1.0`, gap_dist_ends 5, max_num_gaps_open 2; the index is built on the GPU in the setup phase):
+  c1  5 386 bp genome (phiX174-size), 1 k x 50 bp, no-damage model, Phred 40 — with the single-thread oracle figure
+  c2  48 Mbp genome (chr21-size), 1 M x 50 bp per GPU, no-damage model, Phred 40            [default: BASELINE.json configs[1]]
+  c3  the same genome, single-stranded library f = t = 0.5, d = 0.02, s = 1.0, Phred 20-40
+  c4  3 Gbp genome (hg19-size, n = 6e9 rows > 2^32), 10 M x 50 bp per GPU, no-damage model, Phred 40
+  c5  the read mix of C5 (35-100 bp, 5 % of the reads with an indel, damage model) on the 48 Mbp genome
+One "step" = one pass of the hot path (D-array kernel, ordering, search kernel + its retry / full-limit launches) over the batch;
+reads, index and score tables are resident in HBM before the timed region.  With N > 1 every rank holds a replica of the index, maps
+its own shard (weak scaling) and, inside every step, lays its hits out in read order on the device and sends them to rank 0 (RCCL
+point-to-point over xGMI); after the timed region rank 0 merges the shards and checks them against every rank's own result.
+
+Also on the line: `roofline` (dominant kernel: algorithmic bytes from the kernels' event counters / HIP-event time), `cpu_baseline`
+(the C++ oracle on the host cores over a bounded sample, N = 1 only; its hits must equal the GPU's), `e2e` (host buffers in, host
+results out: H2D + kernels + device-side collect + D2H), `sa_locate` and `post_search` (the next rows of the path).
 """
 import argparse
 import ctypes
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -29,6 +39,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s
+
+CONFIGS = {  # genome bp, reads per GPU
+    "c1": (5_386, 1_000), "c2": (48_000_000, 1_000_000), "c3": (48_000_000, 1_000_000), "c4": (3_000_000_000, 10_000_000), "c5": (48_000_000, 250_000),
+}
 
 
 def log(*a):
@@ -42,61 +56,108 @@ class DevArray:
         self.__cuda_array_interface__ = {"shape": shape, "typestr": typestr, "data": (int(ptr), False), "version": 2}
 
 
+def spawn_ranks(n):
+    """Start n ranks as children of this (GPU-free) process and exit with their status."""
+    import torch
+    have = torch.cuda.device_count()  # does not initialise the GPU
+    if have < n:
+        log(f"bench.py: --gpus {n} but only {have} device(s) visible")
+        sys.exit(2)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.abspath(__file__)] + sys.argv[1:]
+    sys.exit(subprocess.call(cmd))
+
+
+def digest(*arrays):
+    h = hashlib.sha256()
+    for a in arrays:
+        h.update(np.ascontiguousarray(a).tobytes())
+    return h.hexdigest()
+
+
+def make_reads(synth, genome, n_reads, seed, **kw):
+    """synth.reads in chunks of 1 M reads (bounded host memory at 10 M reads)."""
+    chunk = 1_000_000
+    if n_reads <= 2 * chunk:
+        return synth.reads(genome, n_reads, 50, seed=seed, **kw)
+    parts, base = [], 0
+    for k, lo in enumerate(range(0, n_reads, chunk)):
+        s, q, o = synth.reads(genome, min(chunk, n_reads - lo), 50, seed=seed + 7919 * k, **kw)
+        parts.append((s, q, o[:-1] + np.uint64(base)))
+        base += int(o[-1])
+    return np.concatenate([p[0] for p in parts]), np.concatenate([p[1] for p in parts]), np.concatenate([p[2] for p in parts] + [np.array([base], np.uint64)])
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--genome-bp", type=int, default=48_000_000)
-    ap.add_argument("--reads", type=int, default=1_000_000, help="reads per GPU")
-    ap.add_argument("--config", default="c2", choices=["c2", "c3", "c5"])
+    ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
+    ap.add_argument("--genome-bp", type=int, default=None)
+    ap.add_argument("--reads", type=int, default=None, help="reads per GPU")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target wall time of the CPU baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the e2e / sa_locate / post_search legs")
     args = ap.parse_args()
+    genome_bp = args.genome_bp or CONFIGS[args.config][0]
+    n_reads = args.reads or CONFIGS[args.config][1]
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        spawn_ranks(args.gpus)  # never returns
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        log(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}")
-    n_gpus = world
+    if world != args.gpus:
+        log(f"bench.py: --gpus {args.gpus} but WORLD_SIZE {world}")
+        sys.exit(2)
 
     import torch
     import torch.distributed as dist
 
     import mapad_amd
     from mapad_amd import synth
+    from mapad_amd.distributed import gather_hit_records, merge_gathered
     from mapad_amd.presets import DAMAGE, NO_DAMAGE, resolve as resolve_params
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: there is no CPU path in mapad_amd")
+    if torch.cuda.device_count() <= local_rank:
+        raise SystemExit(f"bench.py: rank {rank} has no device {local_rank}")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         dist.init_process_group("nccl", device_id=dev)
+        assert dist.get_world_size() == world == args.gpus
 
     # ---- workload --------------------------------------------------------------------------------------------------------
     t0 = time.time()
-    genome = synth.genome(args.genome_bp, seed=1234)
-    index = mapad_amd.Index.build([("chr1", genome)], seed=1234)
+    genome = synth.genome(genome_bp, seed=1234)
+    t_genome = time.time() - t0
+    t0 = time.time()
+    index = mapad_amd.Index.build([("chr1", genome)], seed=1234, device=local_rank)  # suffix sorting on the GPU (csrc/index_gpu.hip)
     t_index = time.time() - t0
-    if args.config == "c2":
-        prm, kw, cfg_id = NO_DAMAGE, dict(qual=40), 2
+    if args.config in ("c1", "c2", "c4"):
+        prm, kw = NO_DAMAGE, dict(qual=40)
     elif args.config == "c3":
-        prm, kw, cfg_id = DAMAGE, dict(qual_range=(20, 40), damage=dict(f=0.5, t=0.5, d=0.02, s=1.0)), 3
-    else:  # the read mix of C5 (35-100 bp, 5 % of the reads with an indel, damage model) on this genome
-        prm, kw, cfg_id = DAMAGE, dict(qual_range=(20, 40), damage=dict(f=0.5, t=0.5, d=0.02, s=1.0), len_range=(35, 100), indel_frac=0.05), 5
+        prm, kw = DAMAGE, dict(qual_range=(20, 40), damage=dict(f=0.5, t=0.5, d=0.02, s=1.0))
+    else:
+        prm, kw = DAMAGE, dict(qual_range=(20, 40), damage=dict(f=0.5, t=0.5, d=0.02, s=1.0), len_range=(35, 100), indel_frac=0.05)
+    cfg_id = int(args.config[1])
     rp = resolve_params(prm)
     params = mapad_amd.make_params(rp)
-    seqs, quals, offsets = synth.reads(genome, args.reads, 50, seed=4321 + cfg_id + 1000 * rank, **kw)
-    n_reads = args.reads
-    log(f"[rank {rank}] genome {args.genome_bp} bp, index built in {t_index:.1f}s, {n_reads} reads")
+    seqs, quals, offsets = make_reads(synth, genome, n_reads, 4321 + cfg_id + 1000 * rank, **kw)
+    log(f"[rank {rank}] genome {genome_bp} bp in {t_genome:.1f}s, index (n = {len(index)}) built in {t_index:.1f}s, {n_reads} reads")
 
     stream = torch.cuda.current_stream(dev)
     ctx = mapad_amd.Context(index, params, local_rank)
     ctx.set_stream(ctypes.c_void_p(stream.cuda_stream))
-    max_len = int(np.diff(offsets.astype(np.int64)).max())
-    ctx.prepare_lengths(sorted(set(np.diff(offsets.astype(np.int64)).tolist())))
+    lens = np.diff(offsets.astype(np.int64))
+    max_len = int(lens.max())
+    ctx.prepare_lengths(sorted(set(lens.tolist())))
     ctx.set_fetch_d_arrays(False)
     d_seqs = torch.from_numpy(seqs).to(dev)
     d_quals = torch.from_numpy(quals).to(dev)
@@ -104,19 +165,14 @@ def main():
     torch.cuda.synchronize(dev)
 
     def gather_hits():
-        """Final gather of the hit records on rank 0 (the only exchange of the path): per-read hit count + first-hit index,
-        hit pool (10 x u32 per hit) and edit-operation pool, straight out of the library's HBM buffers."""
+        """The only exchange of the path: every rank's read-ordered hit records (device-side collect) go to rank 0."""
         if world == 1:
             return None
-        from mapad_amd.distributed import gather_hit_records
-        p_cnt, p_first, p_hits, p_ops, p_cur = ctx.device_result_ptrs()
-        cur = torch.as_tensor(DevArray(p_cur, (2,), "<i8"), device=dev).cpu()
-        n_hits, n_ops = int(cur[0]), int(cur[1])
-        cnt_first = torch.as_tensor(DevArray(p_cnt, (n_reads,), "<u4"), device=dev).view(torch.int32)
-        first = torch.as_tensor(DevArray(p_first, (n_reads,), "<u4"), device=dev).view(torch.int32)
-        hits = torch.as_tensor(DevArray(p_hits, (max(n_hits, 1) * 10,), "<u4"), device=dev).view(torch.int32)[:n_hits * 10]
-        ops = torch.as_tensor(DevArray(p_ops, (max(n_ops, 1),), "<u4"), device=dev).view(torch.int32)[:n_ops]
-        return gather_hit_records(torch.cat([cnt_first, first]), hits, ops, rank, world, device=dev)
+        p_begin, p_hits, p_ops, n_hits, n_ops = ctx.compact_device()
+        begin = torch.as_tensor(DevArray(p_begin, (n_reads + 1,), "<i8"), device=dev).view(torch.int32)
+        hits = torch.as_tensor(DevArray(p_hits, (max(n_hits, 1) * 10,), "<i4"), device=dev)[:n_hits * 10]
+        ops = torch.as_tensor(DevArray(p_ops, (max(n_ops, 1),), "<i4"), device=dev)[:n_ops]
+        return gather_hit_records(begin, hits, ops, rank, world, device=dev)
 
     def step():
         ctx.map_batch_device(d_seqs.data_ptr(), d_quals.data_ptr(), d_offsets.data_ptr(), n_reads, max_len)
@@ -144,14 +200,24 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    # torch <-> library interop used by the multi-GPU gather: wrap the library's cursor words without a copy and cross-check them
-    p_cur = ctx.device_result_ptrs()[4]
-    cur_view = torch.as_tensor(DevArray(p_cur, (2,), "<i8"), device=dev).cpu().numpy()
-
-    # ---- roofline of the dominant kernel (rank 0) -------------------------------------------------------------------------
     res = ctx.fetch()
     counters = ctx.last_counters()
-    assert int(cur_view[0]) == res.n_hits and int(cur_view[1]) == res.n_ops, "device-pointer interop check failed"
+
+    # ---- N > 1: rank 0 rebuilds the read-ordered hit list of the whole chunk and checks it against every rank's own result ---------
+    gather_check = None
+    if world > 1:
+        own = digest(res.hit_begin, res.hits_arr, res.ops)
+        all_own = [None] * world
+        dist.all_gather_object(all_own, own)
+        if rank == 0:
+            hb, hits, ops, per_rank = merge_gathered(gathered)
+            ok = [per_rank[r] == all_own[r] for r in range(world)]
+            gather_check = {"world_size_seen": dist.get_world_size(), "ranks_identical_to_own_fetch": int(sum(ok)), "merged_reads": int(len(hb) - 1),
+                            "merged_hits": int(hits.shape[0]), "merged_ops": int(ops.size)}
+            if not all(ok):
+                log("GATHER FAILURE: a rank's gathered records differ from its own result")
+
+    # ---- roofline of the dominant kernel (rank 0) -------------------------------------------------------------------------
     e_search, e_darray, n_push, n_pop, n_node, n_hit_events = [int(x) for x in counters]
     total_bases = int(offsets[-1])
     bytes_darray = 256 * e_darray + 6 * total_bases                      # 2 x 128-B index blocks per extension + read/qual in, D out
@@ -165,9 +231,7 @@ def main():
     tp = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tp):
         try:
-            tj = json.load(open(tp))
-            key = f"{args.config}:{args.genome_bp}:{args.reads}"
-            traffic = tj.get(key, {}).get(dominant)
+            traffic = json.load(open(tp)).get(f"{args.config}:{genome_bp}:{n_reads}", {}).get(dominant)
         except Exception:
             traffic = None
     roofline = {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
@@ -181,12 +245,12 @@ def main():
                 "index_lines_per_s": {"search_kernel": round(2 * e_search / (ms_search * 1e-3), 1), "darray_kernel": round(2 * e_darray / (ms_darray * 1e-3), 1)},
                 "events": {"E_search": e_search, "E_darray": e_darray, "N_push": n_push, "N_pop": n_pop, "N_node": n_node}}
 
-    # ---- CPU baseline + parity on a bounded sample (rank 0) ------------------------------------------------------------------
+    # ---- CPU baseline + parity on a bounded sample (rank 0, N = 1) -------------------------------------------------------------
     cpu = None
     parity = None
-    if rank == 0 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import binding as ob  # the checker / CPU baseline: only ever used in this leg
-        cores = os.cpu_count() or 1
+        cores = 1 if args.config == "c1" else (os.cpu_count() or 1)  # C1 is the single-thread figure
         oidx = ob.OracleIndex.from_bwt(index.bwt(), "$ACGTX", 128)  # byte BWT + Occ k = 128 like the reference (indexing.rs:188)
         op = ob.make_params(rp)
 
@@ -204,22 +268,47 @@ def main():
         ores, dt = run(n_sample)
         cpu = {"value": round(n_sample / dt, 1), "unit": "reads/s", "cores": cores, "kind": "port",
                "sample": f"first {n_sample} reads of the same batch, {dt:.1f} s wall, C++ oracle (restatement of the reference algorithm: byte BWT, "
-                         f"Occ k=128, min-max heap, slab tree), {cores} threads"}
+                         f"Occ k=128, min-max heap, slab tree), {cores} thread(s)"}
         # parity of the GPU result on that sample: hit counts, intervals, f32 score bits, edit tracks
         hb = res.hit_begin[:n_sample + 1]
         nh = int(hb[-1])
         ok = (np.array_equal(hb, ores.hit_offsets) and np.array_equal(res.hits_arr["lower"][:nh], ores.intervals[:, 0])
+              and np.array_equal(res.hits_arr["lower_rev"][:nh], ores.intervals[:, 1])
               and np.array_equal(res.hits_arr["size"][:nh], ores.intervals[:, 2])
               and np.array_equal(res.hits_arr["score"][:nh].view(np.uint32), ores.scores.view(np.uint32)))
         n_ops = int(ores.op_offsets[-1])
         ok = ok and np.array_equal(res.ops[:n_ops], ores.ops)
-        parity = {"reads_checked": n_sample, "bit_identical_hits": bool(ok)}
-        if not ok:
+        c = res.counters[:n_sample]
+        got = np.stack([c["e_search"], c["e_darray"], c["n_push"], c["n_pop"], c["n_node"], c["n_hits"]], axis=1).astype(np.uint64)
+        ok_c = bool(np.array_equal(got, ores.counters))
+        parity = {"reads_checked": n_sample, "bit_identical_hits": bool(ok), "identical_event_counters": ok_c,
+                  "hit_intervals_at_or_above_2^32": int((res.hits_arr["lower"][:nh] >= 2 ** 32).sum())}
+        if not (ok and ok_c):
             log("PARITY FAILURE: GPU hits differ from the oracle on the sample")
+        del oidx
+
+    extras = rank == 0 and world == 1 and not args.no_extras
+    # ---- end to end through the host entry point: pageable host buffers in, host result out --------------------------------------
+    e2e = None
+    if extras:
+        ctx.set_stream(None)
+        ts = []
+        for _ in range(3):
+            t = time.perf_counter()
+            r2 = ctx.map_batch(seqs, quals, offsets)
+            ts.append(time.perf_counter() - t)
+        same = r2.n_hits == res.n_hits and digest(r2.hit_begin, r2.hits_arr, r2.ops) == digest(res.hit_begin, res.hits_arr, res.ops)
+        dt = min(ts[1:])
+        h2d = 2 * total_bases + 8 * (n_reads + 1)
+        d2h = 8 * (n_reads + 1) + 40 * r2.n_hits + 4 * r2.n_ops + 28 * n_reads
+        e2e = {"reads_per_s": round(n_reads / dt, 1), "ms_per_batch": round(dt * 1e3, 2), "h2d_bytes": h2d, "d2h_bytes": d2h, "identical_to_device_path": bool(same),
+               "what": "mapad_map_batch: host reads in (H2D), D arrays + ordering + search, device-side collect, hit records + edit tracks + counters out (D2H)"}
+        r2.close()
+        ctx.set_stream(ctypes.c_void_p(stream.cuda_stream))
 
     # ---- the next row of the path, outside the timed region: SA locate of the hits' rows on the device -------------
     locate = None
-    if rank == 0:
+    if extras:
         small = res.hits_arr["size"] <= 8
         lo, sz = res.hits_arr["lower"][small].astype(np.uint64), res.hits_arr["size"][small].astype(np.uint64)
         rows = np.unique(np.concatenate([(lo + np.uint64(k))[sz > k] for k in range(8)]))
@@ -240,7 +329,7 @@ def main():
 
     # ---- hits -> record fields (intervals_to_bam minus BAM encoding; rows a14-a17 of SURVEY 8a), outside the timed region ----------
     post = None
-    if rank == 0:
+    if extras:
         from mapad_amd import binding as mb
         import ctypes as C
 
@@ -251,36 +340,31 @@ def main():
                                                     offsets.ctypes.data_as(C.c_void_p), None, 0, C.byref(out))
             dt = time.perf_counter() - t
             assert rc == 0
-            n_mapped = sum(1 for i in range(0, int(out.contents.n), max(1, int(out.contents.n) // 1000)) if out.contents.recs[i].mapped)
             mb.lib().mapad_records_free(out)
-            return dt, n_mapped
+            return dt
 
-        dt_all, _ = records_call()
+        dt_all = records_call()
         post = {"reads_per_s": round(n_reads / dt_all, 1), "wall_s": round(dt_all, 3), "host_threads": min(os.cpu_count() or 1, 64),
                 "what": "mapad_hits_to_records_gpu: SA locate kernel + coordinates, MAPQ, CIGAR/MD/XA strings on host threads"}
-        if not args.no_cpu_baseline:
-            os.environ["MAPAD_POSTPROC_THREADS"] = "1"
-            dt_one, _ = records_call()
-            del os.environ["MAPAD_POSTPROC_THREADS"]
-            post["one_host_thread_reads_per_s"] = round(n_reads / dt_one, 1)
 
     if rank == 0:
-        total_reads = n_reads * n_gpus * args.steps
+        total_reads = n_reads * world * args.steps
+        model = "no-damage" if args.config in ("c1", "c2", "c4") else "ss 50% deamination"
         line = {
             "metric": "mapped reads/sec (50 bp, -p 0.03)", "value": round(total_reads / elapsed, 1), "unit": "reads/s",
-            "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64+f32", "data": "synthetic",
-            "config": {"workload": f"{args.config.upper()}: synthetic genome ({args.genome_bp} bp, n = {len(index)}), "
+            "config": {"workload": f"{args.config.upper()}: synthetic genome ({genome_bp} bp, n = {len(index)} BWT rows), "
                                    f"{n_reads} x {'50' if args.config != 'c5' else '35-100'} bp reads per GPU, -p 0.03, "
-                                   f"{'no-damage' if args.config == 'c2' else 'ss 50% deamination'} model{', 5 % of the reads with an indel' if args.config == 'c5' else ''}",
-                       "reads_per_gpu": n_reads, "genome_bp": args.genome_bp, "index_bytes_hbm": int((len(index) + 255) // 256 * 128),
-                       "parallelism": f"reads sharded over {n_gpus} GPU(s), index replicated, hit records gathered on rank 0" if n_gpus > 1 else "1 GPU",
+                                   f"{model} model{', 5 % of the reads with an indel' if args.config == 'c5' else ''}",
+                       "reads_per_gpu": n_reads, "genome_bp": genome_bp, "index_bytes_hbm": int((len(index) + 255) // 256 * 128),
+                       "parallelism": f"reads sharded over {world} GPUs, index replicated, read-ordered hit records gathered on rank 0 (RCCL p2p)" if world > 1 else "1 GPU",
                        "mapped_fraction": round(float((np.diff(res.hit_begin.astype(np.int64)) > 0).mean()), 4),
-                       "index_build_s": round(t_index, 1)},
-            "roofline": roofline, "cpu_baseline": cpu, "parity": parity, "sa_locate": locate, "post_search": post,
+                       "index_build_s": round(t_index, 1), "index_build": "GPU suffix sorting (prefix doubling over radix sorts) + host text preparation"},
+            "roofline": roofline, "cpu_baseline": cpu, "parity": parity, "e2e": e2e, "sa_locate": locate, "post_search": post,
         }
-        if gathered is not None:
-            line["config"]["gathered_hit_records"] = int(sum(int(g[1].numel()) // 10 for g in gathered))
+        if gather_check is not None:
+            line["gather"] = gather_check
         print(json.dumps(line), flush=True)
     ctx.close()
     if world > 1:

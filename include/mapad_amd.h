@@ -168,6 +168,11 @@ int mapad_map_batch_device(mapad_ctx_t* ctx, const void* d_seqs, const void* d_q
                            uint32_t max_read_len);
 /* after synchronising the stream: copy the last device batch's results to the host */
 int mapad_fetch_result(mapad_ctx_t* ctx, mapad_batch_result_t** out);
+/* Order-preserving collect (src/map/mapping.rs:288) on the device: lays the last batch's hits and edit operations out in read order and
+ * returns device pointers to hit_begin (u64[n_reads + 1], exclusive prefix sums), the hit records (mapad_hit_t[n_hits], ops_offset into
+ * the ops array) and the ops (u32[n_ops]) — the arrays mapad_fetch_result copies out and the multi-GPU gather sends to rank 0.
+ * Valid until the next batch.  Launches on the context's stream; returns without waiting for it. */
+int mapad_compact_result_device(mapad_ctx_t* ctx, void** d_hit_begin, void** d_hits, void** d_ops, uint64_t* n_hits, uint64_t* n_ops);
 /* device pointers of the last batch's raw result buffers (for the RCCL gather): per-read hit counts (u32[n_reads]),
  * per-read first-hit index (u32[n_reads]), hit pool (mapad_hit_t[]), ops pool (u32[]), 2 x u64 cursors {n_hits, n_ops} */
 int mapad_device_result_ptrs(mapad_ctx_t* ctx, void** d_hit_count, void** d_hit_first, void** d_hits, void** d_ops, void** d_cursors);

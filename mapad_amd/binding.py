@@ -111,6 +111,7 @@ SYMBOLS = {
     "mapad_batch_result_free": (None, [C.POINTER(BatchResultC)]),
     "mapad_map_batch_device": (_i32, [_vp, _vp, _vp, _vp, _u64, _u32]),
     "mapad_fetch_result": (_i32, [_vp, C.POINTER(C.POINTER(BatchResultC))]),
+    "mapad_compact_result_device": (_i32, [_vp, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_u64), C.POINTER(_u64)]),
     "mapad_device_result_ptrs": (_i32, [_vp, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp)]),
     "mapad_last_batch_counters": (_i32, [_vp, _vp]),
     "mapad_last_kernel_ms": (_i32, [_vp, _vp]),
@@ -349,6 +350,13 @@ class Context:
         out = C.POINTER(BatchResultC)()
         _check(lib().mapad_fetch_result(self.h, C.byref(out)), "mapad_fetch_result")
         return BatchResult(out, lib().mapad_batch_result_free)
+
+    def compact_device(self):
+        """device-side order-preserving collect of the last batch: (d_hit_begin, d_hits, d_ops, n_hits, n_ops)"""
+        p = [C.c_void_p() for _ in range(3)]
+        nh, no = C.c_uint64(), C.c_uint64()
+        _check(lib().mapad_compact_result_device(self.h, C.byref(p[0]), C.byref(p[1]), C.byref(p[2]), C.byref(nh), C.byref(no)), "mapad_compact_result_device")
+        return p[0].value, p[1].value, p[2].value, int(nh.value), int(no.value)
 
     def device_result_ptrs(self):
         p = [C.c_void_p() for _ in range(5)]

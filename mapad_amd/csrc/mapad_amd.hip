@@ -466,6 +466,95 @@ __global__ void __launch_bounds__(64, MAPAD_MIN_WAVES) search_kernel(DevIndex ix
     }
 }
 
+// ---- order-preserving collect (mapping.rs:288) on the device ------------------------------------------------------------------
+// The search writes a read's hits wherever the bump cursors stood when the read finished.  These three kernels lay hits and edit
+// operations out in read order (hit_begin / ops_begin = exclusive prefix sums over the reads), so that results leave the GPU — to
+// the host or to rank 0 — as dense arrays that concatenate across shards.
+constexpr int kScanTile = 1024;  // reads per block, 4 per thread
+struct CompactDev {
+    const uint32_t* hit_count; const uint32_t* hit_first; const HitRec* pool; const uint32_t* ops_pool;
+    uint64_t n_reads;
+    uint64_t* hit_begin; uint64_t* ops_begin;  // [n_reads + 1]
+    unsigned long long* tile_hits; unsigned long long* tile_ops;  // [n_tiles]
+    HitRec* hits_out; uint32_t* ops_out;
+};
+__device__ __forceinline__ uint32_t read_ops(const CompactDev& Q, uint64_t r) {
+    uint32_t s = 0;
+    const uint32_t c = Q.hit_count[r], f = Q.hit_first[r];
+    for (uint32_t k = 0; k < c; ++k) s += Q.pool[f + k].n_ops;
+    return s;
+}
+__global__ void __launch_bounds__(256) compact_sums_kernel(CompactDev Q) {
+    __shared__ unsigned long long sh[2];
+    if (threadIdx.x == 0) { sh[0] = 0; sh[1] = 0; }
+    __syncthreads();
+    unsigned long long h = 0, o = 0;
+    for (int q = 0; q < 4; ++q) {
+        const uint64_t r = (uint64_t)blockIdx.x * kScanTile + q * 256 + threadIdx.x;
+        if (r < Q.n_reads) { h += Q.hit_count[r]; o += read_ops(Q, r); }
+    }
+    for (int d = 32; d; d >>= 1) { h += __shfl_xor(h, d); o += __shfl_xor(o, d); }
+    if ((threadIdx.x & 63) == 0) { atomicAdd(&sh[0], h); atomicAdd(&sh[1], o); }
+    __syncthreads();
+    if (threadIdx.x == 0) { Q.tile_hits[blockIdx.x] = sh[0]; Q.tile_ops[blockIdx.x] = sh[1]; }
+}
+__global__ void __launch_bounds__(1024) compact_scan_tiles_kernel(CompactDev Q, uint64_t n_tiles) {  // one block: exclusive scan of the tile sums
+    __shared__ unsigned long long sh[2][1024];
+    unsigned long long carry_h = 0, carry_o = 0;
+    for (uint64_t base = 0; base < n_tiles; base += 1024) {
+        const uint64_t i = base + threadIdx.x;
+        const unsigned long long vh = i < n_tiles ? Q.tile_hits[i] : 0, vo = i < n_tiles ? Q.tile_ops[i] : 0;
+        sh[0][threadIdx.x] = vh; sh[1][threadIdx.x] = vo;
+        __syncthreads();
+        for (int d = 1; d < 1024; d <<= 1) {
+            const unsigned long long ah = threadIdx.x >= (unsigned)d ? sh[0][threadIdx.x - d] : 0, ao = threadIdx.x >= (unsigned)d ? sh[1][threadIdx.x - d] : 0;
+            __syncthreads();
+            sh[0][threadIdx.x] += ah; sh[1][threadIdx.x] += ao;
+            __syncthreads();
+        }
+        if (i < n_tiles) { Q.tile_hits[i] = carry_h + sh[0][threadIdx.x] - vh; Q.tile_ops[i] = carry_o + sh[1][threadIdx.x] - vo; }
+        carry_h += sh[0][1023]; carry_o += sh[1][1023];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { Q.hit_begin[Q.n_reads] = carry_h; Q.ops_begin[Q.n_reads] = carry_o; }
+}
+__global__ void __launch_bounds__(256) compact_move_kernel(CompactDev Q) {
+    __shared__ unsigned long long sh[2][256];
+    // tile-local exclusive scan: thread t owns reads 4t .. 4t+3 of the tile
+    const uint64_t r0 = (uint64_t)blockIdx.x * kScanTile + 4 * threadIdx.x;
+    uint32_t c[4], o[4];
+    unsigned long long th = 0, to = 0;
+    for (int q = 0; q < 4; ++q) {
+        const uint64_t r = r0 + q;
+        c[q] = r < Q.n_reads ? Q.hit_count[r] : 0; o[q] = r < Q.n_reads ? read_ops(Q, r) : 0;
+        th += c[q]; to += o[q];
+    }
+    sh[0][threadIdx.x] = th; sh[1][threadIdx.x] = to;
+    __syncthreads();
+    for (int d = 1; d < 256; d <<= 1) {
+        const unsigned long long ah = threadIdx.x >= (unsigned)d ? sh[0][threadIdx.x - d] : 0, ao = threadIdx.x >= (unsigned)d ? sh[1][threadIdx.x - d] : 0;
+        __syncthreads();
+        sh[0][threadIdx.x] += ah; sh[1][threadIdx.x] += ao;
+        __syncthreads();
+    }
+    unsigned long long hb = Q.tile_hits[blockIdx.x] + sh[0][threadIdx.x] - th, ob = Q.tile_ops[blockIdx.x] + sh[1][threadIdx.x] - to;
+    for (int q = 0; q < 4; ++q) {
+        const uint64_t r = r0 + q;
+        if (r >= Q.n_reads) break;
+        Q.hit_begin[r] = hb; Q.ops_begin[r] = ob;
+        const uint32_t f = Q.hit_first[r];
+        for (uint32_t k = 0; k < c[q]; ++k) {
+            HitRec h = Q.pool[f + k];
+            const uint32_t* src = Q.ops_pool + h.ops_off;
+            for (uint32_t i = 0; i < h.n_ops; ++i) Q.ops_out[ob + i] = src[i];
+            h.ops_off = (uint32_t)ob;
+            Q.hits_out[hb + k] = h;
+            ob += h.n_ops;
+        }
+        hb += c[q];
+    }
+}
+
 }  // namespace
 
 // ======================================================================================================================
@@ -551,6 +640,13 @@ struct mapad_ctx {
     DevBuf<uint32_t> d_owner[kClasses];
     DevBuf<GrowPools> d_grow;
     GrowPools grow{};
+    // read-ordered results (compact_* kernels)
+    DevBuf<uint64_t> d_c_hit_begin, d_c_ops_begin;
+    DevBuf<unsigned long long> d_c_tiles;
+    DevBuf<HitRec> d_c_hits;
+    DevBuf<uint32_t> d_c_ops;
+    uint64_t c_n_hits = 0, c_n_ops = 0;
+    bool compacted = false;
     // SA locate
     DevBuf<uint64_t> d_sa, d_xc, d_rows, d_pos;
     DevBuf<unsigned long long> d_steps;
@@ -580,6 +676,7 @@ struct mapad_ctx {
         for (auto& a : d_owner) a.release();
         d_grow.release();
         d_sa.release(); d_xc.release(); d_rows.release(); d_pos.release(); d_steps.release();
+        d_c_hit_begin.release(); d_c_ops_begin.release(); d_c_tiles.release(); d_c_hits.release(); d_c_ops.release();
         for (auto& e : lev) if (e) (void)hipEventDestroy(e);
         for (auto& e : ev) if (e) (void)hipEventDestroy(e);
     }
@@ -733,7 +830,7 @@ int launch_batch(mapad_ctx* c, const uint8_t* d_seqs, const uint8_t* d_quals, co
     B.cursors = c->d_cursors.p; B.overflow_list = c->d_overflow.p;
     B.sort_key = ordered ? c->d_sort_key.p : nullptr; B.key_hist = ordered ? c->d_key_hist.p : nullptr; B.order = ordered ? c->d_order.p : nullptr;
     B.order_shift = order_shift;
-    c->last = B; c->last_total_bases = total_bases; c->last_lmax = lmax;
+    c->last = B; c->last_total_bases = total_bases; c->last_lmax = lmax; c->compacted = false;
     if (n_reads == 0) return MAPAD_OK;
     const uint32_t lds_lmax = std::max<uint32_t>(lmax, 1);
     const size_t lds_bytes = (size_t)16 * lds_lmax * sizeof(float);
@@ -781,6 +878,35 @@ int launch_batch(mapad_ctx* c, const uint8_t* d_seqs, const uint8_t* d_quals, co
     c->launch_info[0] = grid_d; c->launch_info[1] = 64; c->launch_info[2] = (uint32_t)lds_bytes;
     c->launch_info[3] = grid_s; c->launch_info[4] = 64; c->launch_info[5] = c->slots[1] / rpw;
     c->launch_info[6] = c->pool[0].node_cap; c->launch_info[7] = (uint32_t)(c->pool[0].stride >> 10);
+    return MAPAD_OK;
+}
+
+// Lays the last batch's hits out in read order on the device (no-op if already done).  Reports pool overflow / kernel errors like the fetch.
+int compact_last(mapad_ctx* c) {
+    if (c->compacted) return MAPAD_OK;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    const BatchDev& B = c->last;
+    const uint64_t n = B.n_reads;
+    uint32_t cur[CUR_COUNT] = {0};
+    if (n) HIP_TRY(hipMemcpy(cur, B.cursors, sizeof cur, hipMemcpyDeviceToHost));
+    if (cur[CUR_ERR] & ST_NO_TABLE) { std::fprintf(stderr, "mapad_amd: a read length had no score table (call mapad_ctx_prepare_lengths)\n"); return MAPAD_ERR_INVALID; }
+    if (cur[CUR_ERR] & ST_ARENA_OVERFLOW) { std::fprintf(stderr, "mapad_amd: arena overflow in the large-arena pass\n"); return MAPAD_ERR_NOMEM; }
+    if (cur[CUR_POOL_OVF]) return MAPAD_ERR_NOMEM;  // mapad_map_batch retries with larger pools
+    c->c_n_hits = cur64(cur, CUR_HITS); c->c_n_ops = cur64(cur, CUR_OPS);
+    int rc;
+    const uint64_t n_tiles = (n + kScanTile - 1) / kScanTile;
+    if ((rc = c->d_c_hit_begin.ensure(n + 1))) return rc;
+    if ((rc = c->d_c_ops_begin.ensure(n + 1))) return rc;
+    if ((rc = c->d_c_tiles.ensure(2 * std::max<uint64_t>(n_tiles, 1)))) return rc;
+    if ((rc = c->d_c_hits.ensure(std::max<uint64_t>(c->c_n_hits, 1)))) return rc;
+    if ((rc = c->d_c_ops.ensure(std::max<uint64_t>(c->c_n_ops, 1)))) return rc;
+    if (n == 0) { HIP_TRY(hipMemsetAsync(c->d_c_hit_begin.p, 0, 8, c->stream)); HIP_TRY(hipMemsetAsync(c->d_c_ops_begin.p, 0, 8, c->stream)); c->compacted = true; return MAPAD_OK; }
+    CompactDev Q{B.hit_count, B.hit_first, B.hits_pool, B.ops_pool, n, c->d_c_hit_begin.p, c->d_c_ops_begin.p, c->d_c_tiles.p, c->d_c_tiles.p + n_tiles, c->d_c_hits.p, c->d_c_ops.p};
+    hipLaunchKernelGGL(compact_sums_kernel, dim3((uint32_t)n_tiles), dim3(256), 0, c->stream, Q);
+    hipLaunchKernelGGL(compact_scan_tiles_kernel, dim3(1), dim3(1024), 0, c->stream, Q, n_tiles);
+    hipLaunchKernelGGL(compact_move_kernel, dim3((uint32_t)n_tiles), dim3(256), 0, c->stream, Q);
+    HIP_TRY(hipGetLastError());
+    c->compacted = true;
     return MAPAD_OK;
 }
 
@@ -982,42 +1108,32 @@ int mapad_map_batch_device(mapad_ctx_t* ctx, const void* d_seqs, const void* d_q
 int mapad_fetch_result(mapad_ctx_t* ctx, mapad_batch_result_t** out) {
     if (!ctx || !out) return MAPAD_ERR_INVALID;
     if (hipSetDevice(ctx->device) != hipSuccess) return MAPAD_ERR_NO_DEVICE;
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    int rc;
+    if ((rc = compact_last(ctx))) return rc;
     const BatchDev& B = ctx->last;
     const uint64_t n = B.n_reads;
     auto r = std::make_unique<HostResult>();
     uint32_t cur[CUR_COUNT] = {0};
-    if (n) HIP_TRY(hipMemcpy(cur, B.cursors, sizeof cur, hipMemcpyDeviceToHost));
-    if (cur[CUR_ERR] & ST_NO_TABLE) { std::fprintf(stderr, "mapad_amd: a read length had no score table (call mapad_ctx_prepare_lengths)\n"); return MAPAD_ERR_INVALID; }
-    if (cur[CUR_ERR] & ST_ARENA_OVERFLOW) { std::fprintf(stderr, "mapad_amd: arena overflow in the large-arena pass\n"); return MAPAD_ERR_NOMEM; }
-    if (cur[CUR_POOL_OVF]) return MAPAD_ERR_NOMEM;  // mapad_map_batch retries with larger pools
-    std::vector<uint32_t> cnt(n), first(n);
-    std::vector<HitRec> pool(cur64(cur, CUR_HITS));
-    std::vector<uint32_t> ops_pool(cur64(cur, CUR_OPS));
+    if (n) HIP_TRY(hipMemcpyAsync(cur, B.cursors, sizeof cur, hipMemcpyDeviceToHost, ctx->stream));
     r->status.resize(n); r->counters.resize(n);
     if (ctx->fetch_d) r->d_arrays.resize(ctx->last_total_bases);
-    if (n) {
-        HIP_TRY(hipMemcpy(cnt.data(), B.hit_count, n * 4, hipMemcpyDeviceToHost));
-        HIP_TRY(hipMemcpy(first.data(), B.hit_first, n * 4, hipMemcpyDeviceToHost));
-        HIP_TRY(hipMemcpy(r->status.data(), B.status, n * 4, hipMemcpyDeviceToHost));
-        HIP_TRY(hipMemcpy(r->counters.data(), B.counters, n * sizeof(ReadCounters), hipMemcpyDeviceToHost));
-        if (!pool.empty()) HIP_TRY(hipMemcpy(pool.data(), B.hits_pool, pool.size() * sizeof(HitRec), hipMemcpyDeviceToHost));
-        if (!ops_pool.empty()) HIP_TRY(hipMemcpy(ops_pool.data(), B.ops_pool, ops_pool.size() * 4, hipMemcpyDeviceToHost));
-        if (ctx->fetch_d && ctx->last_total_bases) HIP_TRY(hipMemcpy(r->d_arrays.data(), B.d_arrays, ctx->last_total_bases * 4, hipMemcpyDeviceToHost));
-    }
-    // order-preserving collect (mapping.rs:288): hits in read order, BinaryHeap array order inside a read
+    // order-preserving collect (mapping.rs:288): hits in read order, BinaryHeap array order inside a read — laid out by the device
     r->hit_begin.assign(n + 1, 0);
-    for (uint64_t i = 0; i < n; ++i) r->hit_begin[i + 1] = r->hit_begin[i] + cnt[i];
-    r->hits.resize(r->hit_begin[n]);
-    r->ops.reserve(ops_pool.size());
+    r->hits.resize(ctx->c_n_hits);
+    r->ops.resize(ctx->c_n_ops);
+    static_assert(sizeof(mapad_hit_t) == sizeof(HitRec), "hit records are copied as they are");
+    if (n) {
+        HIP_TRY(hipMemcpyAsync(r->hit_begin.data(), ctx->d_c_hit_begin.p, (n + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipMemcpyAsync(r->status.data(), B.status, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipMemcpyAsync(r->counters.data(), B.counters, n * sizeof(ReadCounters), hipMemcpyDeviceToHost, ctx->stream));
+        if (!r->hits.empty()) HIP_TRY(hipMemcpyAsync(r->hits.data(), ctx->d_c_hits.p, r->hits.size() * sizeof(HitRec), hipMemcpyDeviceToHost, ctx->stream));
+        if (!r->ops.empty()) HIP_TRY(hipMemcpyAsync(r->ops.data(), ctx->d_c_ops.p, r->ops.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
+        if (ctx->fetch_d && ctx->last_total_bases) HIP_TRY(hipMemcpyAsync(r->d_arrays.data(), B.d_arrays, ctx->last_total_bases * 4, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (r->hit_begin[n] != r->hits.size()) { std::fprintf(stderr, "mapad_amd: compacted hit count does not match the pool cursor\n"); return MAPAD_ERR_DEVICE; }
     uint64_t sums[6] = {0, 0, 0, 0, 0, 0};
     for (uint64_t i = 0; i < n; ++i) {
-        for (uint32_t k = 0; k < cnt[i]; ++k) {
-            const HitRec& h = pool[first[i] + k];
-            mapad_hit_t o{h.lower, h.lower_rev, h.size, h.score, h.n_ops, (uint32_t)r->ops.size(), 0};
-            r->ops.insert(r->ops.end(), ops_pool.begin() + h.ops_off, ops_pool.begin() + h.ops_off + h.n_ops);
-            r->hits[r->hit_begin[i] + k] = o;
-        }
         const auto& c = r->counters[i];
         sums[0] += c.e_search; sums[1] += c.e_darray; sums[2] += c.n_push; sums[3] += c.n_pop; sums[4] += c.n_node; sums[5] += c.n_hits;
     }
@@ -1029,6 +1145,18 @@ int mapad_fetch_result(mapad_ctx_t* ctx, mapad_batch_result_t** out) {
     if (cur[CUR_GROWN + 1] && std::getenv("MAPAD_DEBUG")) std::fprintf(stderr, "mapad_amd: size-class pools that ran dry (bit per class): 0x%x, waits: %u, reads restarted: %u, re-run with full limits: %u\n", cur[CUR_GROWN + 1], cur[CUR_GROWN + 2], cur[CUR_OVF], cur[CUR_OVF + 2 * (kStages - 2)]);
     r->pub.n_third_pass = cur[CUR_OVF + 2 * (kStages - 2)];  // reads re-run by the full-limit pass
     *out = &r.release()->pub;
+    return MAPAD_OK;
+}
+int mapad_compact_result_device(mapad_ctx_t* ctx, void** d_hit_begin, void** d_hits, void** d_ops, uint64_t* n_hits, uint64_t* n_ops) {
+    if (!ctx) return MAPAD_ERR_INVALID;
+    if (hipSetDevice(ctx->device) != hipSuccess) return MAPAD_ERR_NO_DEVICE;
+    const int rc = compact_last(ctx);
+    if (rc) return rc;
+    if (d_hit_begin) *d_hit_begin = ctx->d_c_hit_begin.p;
+    if (d_hits) *d_hits = ctx->d_c_hits.p;
+    if (d_ops) *d_ops = ctx->d_c_ops.p;
+    if (n_hits) *n_hits = ctx->c_n_hits;
+    if (n_ops) *n_ops = ctx->c_n_ops;
     return MAPAD_OK;
 }
 void mapad_batch_result_free(mapad_batch_result_t* r) {

@@ -16,7 +16,7 @@ def shard_bounds(n_reads, world, rank):
 
 
 def gather_hit_records(hit_count, hits, ops, rank, world, device=None):
-    """Gathers (hit_count int32[n_reads_local], hits int32[n_hits_local * 10], ops int32[n_ops_local]) on rank 0.
+    """Gathers (hit_begin as int32 view of uint64[n_reads_local + 1], hits int32[n_hits_local * 10], ops int32[n_ops_local]) on rank 0.
 
     Tensors may live on the GPU (nccl/RCCL) or the CPU (gloo).  Returns on rank 0 a list, indexed by source rank, of
     (hit_count, hits, ops) tensors; None elsewhere.  Sizes are exchanged first (all_gather of three int64), then every peer
@@ -49,18 +49,49 @@ def gather_hit_records(hit_count, hits, ops, rank, world, device=None):
     return None
 
 
+def collect_in_read_order(hit_count, hit_first, pool, ops_pool):
+    """numpy restatement of the device-side collect (compact_* kernels of csrc/mapad_amd.hip) for the CPU tests of the N > 1 path:
+    per-read (count, first index) into a completion-ordered hit pool -> hit_begin (uint64[n+1]), hits in read order (n_hits x 10 int32,
+    word 8 = offset into the returned ops) and ops in read order."""
+    hit_count = np.asarray(hit_count, dtype=np.int64)
+    pool = np.asarray(pool).reshape(-1, 10)
+    hit_begin = np.zeros(len(hit_count) + 1, dtype=np.uint64)
+    hit_begin[1:] = np.cumsum(hit_count)
+    hits = np.zeros((int(hit_begin[-1]), 10), dtype=np.int32)
+    ops, k, base = [], 0, 0
+    for r in range(len(hit_count)):
+        for j in range(int(hit_count[r])):
+            h = pool[int(hit_first[r]) + j].copy()
+            n_ops, off = int(h[7]), int(h[8])
+            ops.append(np.asarray(ops_pool[off:off + n_ops]))
+            h[8] = base
+            base += n_ops
+            hits[k] = h
+            k += 1
+    return hit_begin, hits, (np.concatenate(ops) if ops else np.zeros(0, np.int32)).astype(np.int32)
+
+
 def merge_gathered(parts):
-    """rank-ordered (hit_count, hits[10 x int32 per hit], ops) -> global hit_begin (uint64[n+1]), hits (n_hits x 10 int32) and ops, with
-    every hit's ops_offset (word 8) rebased into the concatenated ops array.  Hits inside a rank's pool may be stored in any
-    order; `hit_first` is not needed here because per-rank pools are first compacted into read order by the caller."""
-    counts = np.concatenate([np.asarray(p[0].cpu()) for p in parts]).astype(np.uint64)
-    hit_begin = np.zeros(len(counts) + 1, dtype=np.uint64)
-    hit_begin[1:] = np.cumsum(counts)
-    hits, ops, base = [], [], 0
-    for _, h, o in parts:
-        h = np.asarray(h.cpu()).reshape(-1, 10).copy()
-        h[:, 8] += base
-        base += int(o.numel())
+    """rank-ordered (hit_begin as int32 view of uint64[n_r + 1], hits[10 x int32 per hit], ops) of read-ordered shards -> the chunk's
+    hit_begin (uint64[n+1]), hits (n_hits x 10 int32), ops — every hit's ops offset (word 8) rebased into the concatenated ops array —
+    and the sha256 of each rank's part, which must equal the digest of that rank's own fetched result."""
+    import hashlib
+    begins, hits, ops, digests = [np.zeros(1, np.uint64)], [], [], []
+    hit_base = ops_base = 0
+    for b, h, o in parts:
+        b = np.ascontiguousarray(np.asarray(b.cpu())).view(np.uint64)
+        h = np.ascontiguousarray(np.asarray(h.cpu())).reshape(-1, 10)
+        o = np.ascontiguousarray(np.asarray(o.cpu()))
+        dg = hashlib.sha256()
+        for a in (b, h, o):
+            dg.update(a.tobytes())
+        digests.append(dg.hexdigest())
+        assert int(b[-1]) == h.shape[0], "a shard's hit_begin does not match its hit records"
+        begins.append(b[1:] + np.uint64(hit_base))
+        h = h.copy()
+        h[:, 8] += ops_base
+        hit_base += h.shape[0]
+        ops_base += int(o.size)
         hits.append(h)
-        ops.append(np.asarray(o.cpu()))
-    return hit_begin, np.concatenate(hits), np.concatenate(ops)
+        ops.append(o)
+    return np.concatenate(begins), np.concatenate(hits), np.concatenate(ops), digests

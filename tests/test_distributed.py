@@ -32,21 +32,45 @@ def _map_slice(lo, hi):
     sub_off = offsets[lo:hi + 1] - offsets[lo]
     s, e = int(offsets[lo]), int(offsets[hi])
     res = emu_util.map_batch(idx, mapad_amd.make_params(presets.resolve(presets.DAMAGE)), seqs[s:e], quals[s:e], sub_off)
-    counts = np.diff(res.hit_begin.astype(np.int64)).astype(np.int32)
     hits = res.hits_arr.view(np.int32).reshape(-1, 10).copy() if res.n_hits else np.zeros((0, 10), np.int32)
-    return counts, hits, res.ops.view(np.int32).copy()
+    return res.hit_begin.copy(), hits, res.ops.view(np.int32).copy()
+
+
+def _as_completion_ordered_pools(hit_begin, hits, ops, seed):
+    """What the search kernel leaves behind: reads finish in any order, each appending its hits / ops at the bump cursors."""
+    rng = np.random.default_rng(seed)
+    n = len(hit_begin) - 1
+    count = np.diff(hit_begin.astype(np.int64)).astype(np.int32)
+    first = np.zeros(n, np.int32)
+    pool, ops_pool, ops_base = [], [], 0
+    for r in rng.permutation(n):
+        first[r] = len(pool)
+        for h in hits[int(hit_begin[r]):int(hit_begin[r + 1])]:
+            h = h.copy()
+            ops_pool.append(ops[int(h[8]):int(h[8]) + int(h[7])])
+            h[8] = ops_base
+            ops_base += int(h[7])
+            pool.append(h)
+    return count, first, (np.stack(pool) if pool else np.zeros((0, 10), np.int32)), (np.concatenate(ops_pool) if ops_pool else np.zeros(0, np.int32))
 
 
 def _worker(rank, world, port, out_path):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     sys.path.insert(0, ROOT)
-    from mapad_amd.distributed import gather_hit_records, merge_gathered, shard_bounds
+    import hashlib
+    from mapad_amd.distributed import collect_in_read_order, gather_hit_records, merge_gathered, shard_bounds
     lo, hi = shard_bounds(101, world, rank)
-    counts, hits, ops = _map_slice(lo, hi)
-    parts = gather_hit_records(torch.from_numpy(counts), torch.from_numpy(hits.reshape(-1)), torch.from_numpy(ops), rank, world)
+    own = _map_slice(lo, hi)
+    own_digest = hashlib.sha256(b"".join(np.ascontiguousarray(a).tobytes() for a in own)).hexdigest()
+    # the rank's raw result is completion-ordered; the collect (device kernels on the GPU) lays it out in read order before the gather
+    hit_begin, hits, ops = collect_in_read_order(*_as_completion_ordered_pools(*own, seed=100 + rank))
+    parts = gather_hit_records(torch.from_numpy(hit_begin.view(np.int32)), torch.from_numpy(hits.reshape(-1)), torch.from_numpy(ops), rank, world)
+    digests = [None] * world
+    dist.all_gather_object(digests, own_digest)
     if rank == 0:
-        hb, h, o = merge_gathered(parts)
+        hb, h, o, per_rank = merge_gathered(parts)
+        assert per_rank == digests  # every shard arrived as the rank's own result
         np.savez(out_path, hit_begin=hb, hits=h, ops=o)
     else:
         assert parts is None
@@ -65,9 +89,7 @@ def test_two_rank_sharding_and_gather_matches_single_process(tmp_path):
     out = str(tmp_path / "merged.npz")
     mp.spawn(_worker, args=(2, _free_port(), out), nprocs=2, join=True)
     got = np.load(out)
-    counts, hits, ops = _map_slice(0, 101)
-    hb = np.zeros(102, dtype=np.uint64)
-    hb[1:] = np.cumsum(counts)
+    hb, hits, ops = _map_slice(0, 101)
     assert np.array_equal(got["hit_begin"], hb)
     assert np.array_equal(got["hits"], hits) and np.array_equal(got["ops"], ops)  # incl. rebased ops offsets
     assert hb[-1] > 50
