@@ -166,6 +166,20 @@ void mapad_batch_result_free(mapad_batch_result_t* r);
  * in the context's device buffers until fetched.  Asynchronous on the context's stream. */
 int mapad_map_batch_device(mapad_ctx_t* ctx, const void* d_seqs, const void* d_quals, const void* d_offsets, uint64_t n_reads,
                            uint32_t max_read_len);
+/* Batches in flight.  With depth d > 1 the context keeps d sets of batch buffers and streams of its own: mapad_map_batch_device rotates
+ * through them and returns as soon as the batch is enqueued (it waits only for the batch that used the same set d calls ago), so the serial
+ * tail of batch k — its few heaviest reads, each a chain of dependent memory accesses — runs beside the bulk of batch k + 1, the way the
+ * reference's worker threads start the next chunk while stragglers finish (src/map/mapping.rs:151-156).  Inputs are ordered behind the
+ * context's stream (mapad_ctx_set_stream) at submission.  Default 1 (MAPAD_PIPELINE_DEPTH overrides): everything runs on the context's stream.
+ * Changing the depth waits for all batches and drops their results. */
+int mapad_ctx_set_pipeline_depth(mapad_ctx_t* ctx, int depth);
+/* result accessors (fetch, compact, counters, kernel times, device pointers) read the batch submitted `age` calls before the most recent
+ * one (0 = most recent; reset to 0 by every submission) */
+int mapad_ctx_select_batch(mapad_ctx_t* ctx, int age);
+/* HIP-event time stamps of every launch since the last call (waits for all batches): 4 floats per launch = ms from the start of the first
+ * launch to {start of the D-array kernel, end of D arrays + ordering, end of the growable search stages, end of the full-limit stage}.
+ * Returns the number of launches in *n (at most `cap` are written). */
+int mapad_kernel_history(mapad_ctx_t* ctx, float* out, uint32_t cap, uint32_t* n);
 /* after synchronising the stream: copy the last device batch's results to the host */
 int mapad_fetch_result(mapad_ctx_t* ctx, mapad_batch_result_t** out);
 /* Order-preserving collect (src/map/mapping.rs:288) on the device: lays the last batch's hits and edit operations out in read order and

@@ -111,6 +111,9 @@ SYMBOLS = {
     "mapad_batch_result_free": (None, [C.POINTER(BatchResultC)]),
     "mapad_map_batch_device": (_i32, [_vp, _vp, _vp, _vp, _u64, _u32]),
     "mapad_fetch_result": (_i32, [_vp, C.POINTER(C.POINTER(BatchResultC))]),
+    "mapad_ctx_set_pipeline_depth": (_i32, [_vp, _i32]),
+    "mapad_ctx_select_batch": (_i32, [_vp, _i32]),
+    "mapad_kernel_history": (_i32, [_vp, _vp, _u32, C.POINTER(_u32)]),
     "mapad_compact_result_device": (_i32, [_vp, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_u64), C.POINTER(_u64)]),
     "mapad_device_result_ptrs": (_i32, [_vp, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp)]),
     "mapad_last_batch_counters": (_i32, [_vp, _vp]),
@@ -350,6 +353,19 @@ class Context:
         out = C.POINTER(BatchResultC)()
         _check(lib().mapad_fetch_result(self.h, C.byref(out)), "mapad_fetch_result")
         return BatchResult(out, lib().mapad_batch_result_free)
+
+    def set_pipeline_depth(self, depth):
+        _check(lib().mapad_ctx_set_pipeline_depth(self.h, int(depth)), "mapad_ctx_set_pipeline_depth")
+
+    def select_batch(self, age):
+        _check(lib().mapad_ctx_select_batch(self.h, int(age)), "mapad_ctx_select_batch")
+
+    def kernel_history(self, cap=4096):
+        """(n_launches, 4) float32: ms from the first launch's start to each launch's four event marks; clears the history"""
+        out = np.zeros((cap, 4), np.float32)
+        n = C.c_uint32()
+        _check(lib().mapad_kernel_history(self.h, _ptr(out), cap, C.byref(n)), "mapad_kernel_history")
+        return out[:min(cap, int(n.value))].copy()
 
     def compact_device(self):
         """device-side order-preserving collect of the last batch: (d_hit_begin, d_hits, d_ops, n_hits, n_ops)"""

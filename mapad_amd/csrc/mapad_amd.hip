@@ -396,7 +396,7 @@ struct DeviceGrow {
 #define MAPAD_MIN_WAVES 4
 #endif
 template <int LPR, bool CONT, int PASS, bool NL>
-__global__ void __launch_bounds__(64, MAPAD_MIN_WAVES) search_kernel(DevIndex ix, DevParams P, BatchDev B, ArenaPool AP, const GrowPools* GP, uint32_t near_stride, uint32_t near_lmax, int stage) {
+__global__ void __launch_bounds__(64, (LPR == 1 && NL) ? 1 : MAPAD_MIN_WAVES) search_kernel(DevIndex ix, DevParams P, BatchDev B, ArenaPool AP, const GrowPools* GP, uint32_t near_stride, uint32_t near_lmax, int stage) {
     const int lane = threadIdx.x & 63, w = lane & (LPR - 1);
     const int tier = stage;
     const uint32_t slot = blockIdx.x * (64 / LPR) + (lane / LPR);
@@ -611,9 +611,52 @@ ArenaPool make_pool_layout(uint32_t heap_cap, uint32_t node_cap, uint32_t hit_op
 
 }  // namespace
 
+// Everything one batch in flight owns: its stream, result and scratch buffers, per-read-slot base arenas.  A context keeps `depth` of
+// them so that the serial tail of batch k (its few heaviest reads) runs beside the bulk of batch k + 1; the size-class pools the read
+// slots grow into are shared (arenas are claimed through owner words, whichever launch asks).
+constexpr int kMaxDepth = 4;
+struct BatchSlot {
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};  // around D arrays + ordering / growable search stages / full-limit stage
+    hipEvent_t ev_in = nullptr;                                // the caller's stream at submission: inputs are ready behind it
+    DevBuf<uint8_t> d_seqs, d_quals;
+    DevBuf<uint64_t> d_offsets;
+    DevBuf<float> d_darr;
+    DevBuf<ReadCounters> d_counters;
+    DevBuf<uint32_t> d_status, d_hit_count, d_hit_first, d_ops, d_cursors, d_overflow, d_sort_key, d_key_hist, d_order;
+    DevBuf<HitRec> d_hits;
+    DevBuf<uint8_t> d_arena[kTiers];
+    // read-ordered results (compact_* kernels)
+    DevBuf<uint64_t> d_c_hit_begin, d_c_ops_begin;
+    DevBuf<unsigned long long> d_c_tiles;
+    DevBuf<HitRec> d_c_hits;
+    DevBuf<uint32_t> d_c_ops;
+    uint64_t c_n_hits = 0, c_n_ops = 0;
+    bool compacted = false;
+    // the batch
+    BatchDev last{};
+    uint64_t last_total_bases = 0;
+    uint32_t last_lmax = 0;
+    uint32_t launch_info[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    bool ev_valid = false, timed = true;  // timed: its event times are already in the context's history
+
+    void release() {
+        d_seqs.release(); d_quals.release(); d_offsets.release(); d_darr.release(); d_counters.release(); d_status.release(); d_hit_count.release();
+        d_hit_first.release(); d_ops.release(); d_cursors.release(); d_overflow.release(); d_sort_key.release(); d_key_hist.release(); d_order.release();
+        d_hits.release();
+        for (auto& a : d_arena) a.release();
+        d_c_hit_begin.release(); d_c_ops_begin.release(); d_c_tiles.release(); d_c_hits.release(); d_c_ops.release();
+        for (auto& e : ev) if (e) { (void)hipEventDestroy(e); e = nullptr; }
+        if (ev_in) { (void)hipEventDestroy(ev_in); ev_in = nullptr; }
+        if (own_stream && stream) (void)hipStreamDestroy(stream);
+        stream = nullptr; own_stream = false;
+    }
+};
+
 struct mapad_ctx {
     int device = 0;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;  // the caller's stream: inputs are ordered behind it, results are consumed on it
     mapad_params_t params{};
     const mapad_index* index = nullptr;
     host::HostTables tables;
@@ -624,15 +667,13 @@ struct mapad_ctx {
     DevBuf<int32_t> d_base;
     DevIndex dix{};
     DevParams dprm{};
-    // batch buffers
-    DevBuf<uint8_t> d_seqs, d_quals;
-    DevBuf<uint64_t> d_offsets;
-    DevBuf<float> d_darr;
     bool fetch_d = true;
-    DevBuf<ReadCounters> d_counters;
-    DevBuf<uint32_t> d_status, d_hit_count, d_hit_first, d_ops, d_cursors, d_overflow, d_sort_key, d_key_hist, d_order;
-    DevBuf<HitRec> d_hits;
-    DevBuf<uint8_t> d_arena[kTiers];
+    // batches in flight
+    BatchSlot bs[kMaxDepth];
+    int depth = 1, cur = 0, view = 0;  // cur: slot of the most recent batch; view: slot the result accessors read (cur unless selected otherwise)
+    hipEvent_t ev_ref = nullptr;       // start of the first launch of the current timing history
+    std::vector<float> history;        // 4 floats per finished launch: ms from ev_ref to its ev[0..3]
+    // arenas
     ArenaPool pool[kTiers] = {};
     uint32_t slots[kTiers] = {0, 0}, arena_lmax = 0;
     uint64_t arena_reads = 0;
@@ -640,13 +681,6 @@ struct mapad_ctx {
     DevBuf<uint32_t> d_owner[kClasses];
     DevBuf<GrowPools> d_grow;
     GrowPools grow{};
-    // read-ordered results (compact_* kernels)
-    DevBuf<uint64_t> d_c_hit_begin, d_c_ops_begin;
-    DevBuf<unsigned long long> d_c_tiles;
-    DevBuf<HitRec> d_c_hits;
-    DevBuf<uint32_t> d_c_ops;
-    uint64_t c_n_hits = 0, c_n_ops = 0;
-    bool compacted = false;
     // SA locate
     DevBuf<uint64_t> d_sa, d_xc, d_rows, d_pos;
     DevBuf<unsigned long long> d_steps;
@@ -656,37 +690,32 @@ struct mapad_ctx {
     uint64_t last_locate_rows = 0;
     int lpr = 4;  // lanes per read in the search kernel (MAPAD_LANES_PER_READ = 4 | 1)
     int n_cu = 256;
-    // last batch
-    BatchDev last{};
-    uint64_t last_total_bases = 0;
-    uint32_t last_lmax = 0;
-    bool last_owned_inputs = false;
-    uint32_t launch_info[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     uint64_t counter_sums[6] = {0, 0, 0, 0, 0, 0};
-    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};  // around D arrays + ordering / growable search stages / full-limit stage, on `stream`
-    bool ev_valid = false;
 
     ~mapad_ctx() {
         (void)hipSetDevice(device);
-        d_blocks.release(); d_sdm.release(); d_thr.release(); d_base.release(); d_seqs.release(); d_quals.release(); d_offsets.release();
-        d_darr.release(); d_counters.release(); d_status.release(); d_hit_count.release(); d_hit_first.release(); d_ops.release();
-        d_cursors.release(); d_overflow.release(); d_hits.release(); d_sort_key.release(); d_key_hist.release(); d_order.release();
-        for (auto& a : d_arena) a.release();
+        for (auto& b : bs) { if (b.stream) (void)hipStreamSynchronize(b.stream); b.release(); }
+        d_blocks.release(); d_sdm.release(); d_thr.release(); d_base.release();
         for (auto& a : d_class) a.release();
         for (auto& a : d_owner) a.release();
         d_grow.release();
         d_sa.release(); d_xc.release(); d_rows.release(); d_pos.release(); d_steps.release();
-        d_c_hit_begin.release(); d_c_ops_begin.release(); d_c_tiles.release(); d_c_hits.release(); d_c_ops.release();
         for (auto& e : lev) if (e) (void)hipEventDestroy(e);
-        for (auto& e : ev) if (e) (void)hipEventDestroy(e);
+        if (ev_ref) (void)hipEventDestroy(ev_ref);
     }
 };
 
 namespace {
 
+int sync_all_slots(mapad_ctx* c) {
+    for (auto& b : c->bs) if (b.ev_valid) HIP_TRY(hipStreamSynchronize(b.stream));
+    return MAPAD_OK;
+}
+
 int upload_tables(mapad_ctx* c) {
     if (!c->tables_dirty) return MAPAD_OK;
     int rc;
+    if ((rc = sync_all_slots(c))) return rc;  // launches in flight read the old tables
     if ((rc = c->d_sdm.ensure(std::max<size_t>(c->tables.sdm.size(), 4)))) return rc;
     if ((rc = c->d_base.ensure(c->tables.table_base.size()))) return rc;
     if ((rc = c->d_thr.ensure(c->tables.reject_thr.size()))) return rc;
@@ -716,29 +745,32 @@ uint32_t env_u32(const char* name, uint32_t dflt) {
 // Pass 0: one base arena per read slot (MAPAD_TIER0_NODES nodes) plus size-class pools the slots grow into (x4 per class).
 // Pass 1: arenas with the reference's full limits (STACK_LIMIT + 9 frames, EDIT_TREE_LIMIT + 9 nodes: mapping.rs:52-54,147-148) for
 // the reads pass 0 could not finish (a size-class pool ran dry).  Semantic limits are the same everywhere.
-int ensure_arenas(mapad_ctx* c, uint32_t lmax, uint64_t n_reads) {
-    if (c->d_arena[0].p && lmax <= c->arena_lmax && n_reads <= c->arena_reads) return MAPAD_OK;
+int ensure_arenas(mapad_ctx* c, BatchSlot& S, uint32_t lmax, uint64_t n_reads) {
+    int rc;
+    if (c->pool[0].stride && lmax <= c->arena_lmax && n_reads <= c->arena_reads) {  // layouts and pools stand: only this slot's own arenas may be missing
+        for (int t = 0; t < kTiers; ++t) if ((rc = S.d_arena[t].ensure((size_t)c->slots[t] * c->pool[t].stride, true))) return rc;
+        return MAPAD_OK;
+    }
+    if ((rc = sync_all_slots(c))) return rc;  // the layouts change: nothing may be in flight
+    for (auto& b : c->bs) for (auto& a : b.d_arena) a.release();
     n_reads = std::max<uint64_t>(n_reads, c->arena_reads);  // pools never shrink; a batch cannot use more arenas than it has reads
     c->lpr = env_u32("MAPAD_LANES_PER_READ", 4) == 1 ? 1 : 4;
-    const uint32_t lm = std::max<uint32_t>(lmax, 128);
+    const uint32_t lm = std::max<uint32_t>(std::max<uint32_t>(lmax, c->arena_lmax), 128);
     const uint64_t stack_cap = (uint64_t)c->dprm.stack_limit + 10, tree_cap = (uint64_t)c->dprm.edit_tree_limit + 10;
     const uint32_t hit_ops_cap = kMaxHits * (lm + 32);
     const uint32_t rpw = 64 / c->lpr;
-    int rc;
     {   // pass 0 base arenas
         const uint32_t nodes = env_u32("MAPAD_TIER0_NODES", 8192);
         c->pool[0] = make_pool_layout((uint32_t)std::min<uint64_t>(nodes, stack_cap), (uint32_t)std::min<uint64_t>(nodes, tree_cap), hit_ops_cap, lm);
         c->slots[0] = env_u32("MAPAD_TIER0_WAVES_PER_CU", c->lpr == 4 ? 16 : 8) * (uint32_t)c->n_cu * rpw;
         c->slots[0] = (uint32_t)std::min<uint64_t>(c->slots[0], (std::max<uint64_t>(n_reads, 1) + rpw - 1) / rpw * rpw);
-        if ((rc = c->d_arena[0].ensure((size_t)c->slots[0] * c->pool[0].stride, true))) return rc;
-        c->pool[0].base = c->d_arena[0].p;
     }
     {   // pass 1: full limits
         c->pool[1] = make_pool_layout((uint32_t)stack_cap, (uint32_t)tree_cap, hit_ops_cap, lm);
         c->slots[1] = std::max<uint32_t>(env_u32("MAPAD_LAST_PASS_WAVES", 1), 1) * rpw;
-        if ((rc = c->d_arena[1].ensure((size_t)c->slots[1] * c->pool[1].stride, true))) return rc;
-        c->pool[1].base = c->d_arena[1].p;
     }
+    for (int t = 0; t < kTiers; ++t) if ((rc = S.d_arena[t].ensure((size_t)c->slots[t] * c->pool[t].stride, true))) return rc;
+    const uint64_t other_slots_bytes = (uint64_t)(c->depth - 1) * ((uint64_t)c->slots[0] * c->pool[0].stride + (uint64_t)c->slots[1] * c->pool[1].stride);
     // size classes: 2x steps; the last one holds the reference's full limits so that its owners never have to grow (no wait cycles)
     uint32_t counts[kClasses] = {c->slots[0] / 2, c->slots[0] / 4, c->slots[0] / 8, c->slots[0] / 16, 1024, 256, 64, 32, 16, 16};
     for (int k = 0; k < kClasses; ++k) counts[k] = std::max<uint32_t>(counts[k], 16);
@@ -764,7 +796,7 @@ int ensure_arenas(mapad_ctx* c, uint32_t lmax, uint64_t n_reads) {
         for (auto& a : c->d_class) a.release();
         size_t free_b = 0, total_b = 0;
         HIP_TRY(hipMemGetInfo(&free_b, &total_b));
-        const uint64_t reserve = std::min<uint64_t>(16ull << 30, free_b / 4);
+        const uint64_t reserve = std::min<uint64_t>(16ull << 30, free_b / 4) + other_slots_bytes;  // batch buffers + the base arenas of the other batches in flight
         uint64_t budget = free_b > reserve ? free_b - reserve : 0;
         if (const uint32_t gb = env_u32("MAPAD_POOL_BUDGET_GB", 0)) budget = std::min<uint64_t>(budget, (uint64_t)gb << 30);
         for (;;) {
@@ -779,134 +811,165 @@ int ensure_arenas(mapad_ctx* c, uint32_t lmax, uint64_t n_reads) {
     for (int k = 0; k < kClasses; ++k) {
         if ((rc = c->d_class[k].ensure(std::max<size_t>((size_t)g.count[k] * g.stride[k], 128), true))) return rc;
         if ((rc = c->d_owner[k].ensure(std::max<size_t>(g.count[k], 1)))) return rc;
-        HIP_TRY(hipMemsetAsync(c->d_owner[k].p, 0, std::max<size_t>(g.count[k], 1) * 4, c->stream));
+        HIP_TRY(hipMemsetAsync(c->d_owner[k].p, 0, std::max<size_t>(g.count[k], 1) * 4, S.stream));
         g.base[k] = c->d_class[k].p;
         g.owner[k] = c->d_owner[k].p;
     }
     g.max_waits = env_u32("MAPAD_MAX_WAITS", 64);
     if ((rc = c->d_grow.ensure(1))) return rc;
-    HIP_TRY(hipMemcpyAsync(c->d_grow.p, &c->grow, sizeof(GrowPools), hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipMemcpyAsync(c->d_grow.p, &c->grow, sizeof(GrowPools), hipMemcpyHostToDevice, S.stream));
+    HIP_TRY(hipStreamSynchronize(S.stream));
     c->arena_lmax = lm;
     c->arena_reads = n_reads;
     return MAPAD_OK;
 }
 
-int launch_batch(mapad_ctx* c, const uint8_t* d_seqs, const uint8_t* d_quals, const uint64_t* d_offsets, uint64_t n_reads, uint64_t total_bases,
+// time stamps of a finished launch -> the context's history (ms since ev_ref)
+int record_times(mapad_ctx* c, BatchSlot& S) {
+    if (S.timed || !S.ev_valid || !c->ev_ref) return MAPAD_OK;
+    HIP_TRY(hipEventSynchronize(S.ev[3]));
+    for (int i = 0; i < 4; ++i) { float ms = 0.0f; HIP_TRY(hipEventElapsedTime(&ms, c->ev_ref, S.ev[i])); c->history.push_back(ms); }
+    S.timed = true;
+    return MAPAD_OK;
+}
+
+// Makes slot `k` ready for a new batch: its previous batch has finished, its stream exists and waits for the caller's stream.
+int acquire_slot(mapad_ctx* c, int k) {
+    BatchSlot& S = c->bs[k];
+    if (c->depth == 1) S.stream = S.stream;  // one batch at a time: everything runs on the caller's stream
+    else if (!S.stream) { HIP_TRY(hipStreamCreateWithFlags(&S.stream, hipStreamNonBlocking)); S.own_stream = true; }
+    if (S.ev_valid) { HIP_TRY(hipStreamSynchronize(S.stream)); int rc = record_times(c, S); if (rc) return rc; }
+    if (c->depth > 1) {
+        if (!S.ev_in) HIP_TRY(hipEventCreateWithFlags(&S.ev_in, hipEventDisableTiming));
+        HIP_TRY(hipEventRecord(S.ev_in, S.stream));
+        HIP_TRY(hipStreamWaitEvent(S.stream, S.ev_in, 0));
+    }
+    c->cur = k; c->view = k;
+    return MAPAD_OK;
+}
+
+int launch_batch(mapad_ctx* c, BatchSlot& S, const uint8_t* d_seqs, const uint8_t* d_quals, const uint64_t* d_offsets, uint64_t n_reads, uint64_t total_bases,
                  uint32_t lmax) {
     int rc;
     if ((rc = upload_tables(c))) return rc;
-    if ((rc = ensure_arenas(c, lmax, n_reads))) return rc;
+    if ((rc = ensure_arenas(c, S, lmax, n_reads))) return rc;
     const size_t nr = std::max<uint64_t>(n_reads, 1);
-    if ((rc = c->d_darr.ensure(std::max<uint64_t>(total_bases, 1)))) return rc;
-    if ((rc = c->d_counters.ensure(nr))) return rc;
-    if ((rc = c->d_status.ensure(nr))) return rc;
-    if ((rc = c->d_hit_count.ensure(nr))) return rc;
-    if ((rc = c->d_hit_first.ensure(nr))) return rc;
-    if ((rc = c->d_overflow.ensure(nr * kStages))) return rc;
+    if ((rc = S.d_darr.ensure(std::max<uint64_t>(total_bases, 1)))) return rc;
+    if ((rc = S.d_counters.ensure(nr))) return rc;
+    if ((rc = S.d_status.ensure(nr))) return rc;
+    if ((rc = S.d_hit_count.ensure(nr))) return rc;
+    if ((rc = S.d_hit_first.ensure(nr))) return rc;
+    if ((rc = S.d_overflow.ensure(nr * kStages))) return rc;
     const bool ordered = env_u32("MAPAD_ORDER", 1) != 0;
     const uint32_t order_shift = std::min<uint32_t>(std::max<uint32_t>(env_u32("MAPAD_ORDER_CHUNK_LOG2", 20), 10), 31);
     const uint32_t n_chunks = (uint32_t)((nr + (1ull << order_shift) - 1) >> order_shift);
     if (ordered) {
-        if ((rc = c->d_sort_key.ensure(nr))) return rc;
-        if ((rc = c->d_order.ensure(nr))) return rc;
-        if ((rc = c->d_key_hist.ensure((size_t)n_chunks * kKeyBins))) return rc;
-        HIP_TRY(hipMemsetAsync(c->d_key_hist.p, 0, (size_t)n_chunks * kKeyBins * 4, c->stream));
+        if ((rc = S.d_sort_key.ensure(nr))) return rc;
+        if ((rc = S.d_order.ensure(nr))) return rc;
+        if ((rc = S.d_key_hist.ensure((size_t)n_chunks * kKeyBins))) return rc;
+        HIP_TRY(hipMemsetAsync(S.d_key_hist.p, 0, (size_t)n_chunks * kKeyBins * 4, S.stream));
     }
-    if ((rc = c->d_cursors.ensure(CUR_COUNT))) return rc;
+    if ((rc = S.d_cursors.ensure(CUR_COUNT))) return rc;
     // 2 hits per read on average + slack; MAPAD_HIT_POOL (test hook) starts smaller so that the retry of mapad_map_batch is exercised
-    const size_t hits_cap = std::max(c->d_hits.cap, (size_t)env_u32("MAPAD_HIT_POOL", (uint32_t)std::min<size_t>(2 * nr + 1024, 0xFFFFFFFFu)));
-    const size_t ops_cap = std::max(c->d_ops.cap, hits_cap * (size_t)(std::min<uint32_t>(lmax, 256) + 8));
-    if ((rc = c->d_hits.ensure(hits_cap))) return rc;
-    if ((rc = c->d_ops.ensure(ops_cap))) return rc;
-    HIP_TRY(hipMemsetAsync(c->d_cursors.p, 0, CUR_COUNT * 4, c->stream));
-    HIP_TRY(hipMemsetAsync(c->d_status.p, 0, nr * 4, c->stream));
+    const size_t hits_cap = std::max(S.d_hits.cap, (size_t)env_u32("MAPAD_HIT_POOL", (uint32_t)std::min<size_t>(2 * nr + 1024, 0xFFFFFFFFu)));
+    const size_t ops_cap = std::max(S.d_ops.cap, hits_cap * (size_t)(std::min<uint32_t>(lmax, 256) + 8));
+    if ((rc = S.d_hits.ensure(hits_cap))) return rc;
+    if ((rc = S.d_ops.ensure(ops_cap))) return rc;
+    HIP_TRY(hipMemsetAsync(S.d_cursors.p, 0, CUR_COUNT * 4, S.stream));
+    HIP_TRY(hipMemsetAsync(S.d_status.p, 0, nr * 4, S.stream));
     BatchDev B{};
     B.seqs = d_seqs; B.quals = d_quals; B.offsets = d_offsets; B.n_reads = (uint32_t)n_reads;
-    B.d_arrays = c->d_darr.p; B.counters = c->d_counters.p; B.status = c->d_status.p;
-    B.hit_count = c->d_hit_count.p; B.hit_first = c->d_hit_first.p;
-    B.hits_pool = c->d_hits.p; B.ops_pool = c->d_ops.p;
-    B.hits_cap = (uint32_t)std::min<size_t>(c->d_hits.cap, 0xFFFFFFFFu); B.ops_cap = (uint32_t)std::min<size_t>(c->d_ops.cap, 0xFFFFFFFFu);
-    B.cursors = c->d_cursors.p; B.overflow_list = c->d_overflow.p;
-    B.sort_key = ordered ? c->d_sort_key.p : nullptr; B.key_hist = ordered ? c->d_key_hist.p : nullptr; B.order = ordered ? c->d_order.p : nullptr;
+    B.d_arrays = S.d_darr.p; B.counters = S.d_counters.p; B.status = S.d_status.p;
+    B.hit_count = S.d_hit_count.p; B.hit_first = S.d_hit_first.p;
+    B.hits_pool = S.d_hits.p; B.ops_pool = S.d_ops.p;
+    B.hits_cap = (uint32_t)std::min<size_t>(S.d_hits.cap, 0xFFFFFFFFu); B.ops_cap = (uint32_t)std::min<size_t>(S.d_ops.cap, 0xFFFFFFFFu);
+    B.cursors = S.d_cursors.p; B.overflow_list = S.d_overflow.p;
+    B.sort_key = ordered ? S.d_sort_key.p : nullptr; B.key_hist = ordered ? S.d_key_hist.p : nullptr; B.order = ordered ? S.d_order.p : nullptr;
     B.order_shift = order_shift;
-    c->last = B; c->last_total_bases = total_bases; c->last_lmax = lmax; c->compacted = false;
+    S.last = B; S.last_total_bases = total_bases; S.last_lmax = lmax; S.compacted = false;
     if (n_reads == 0) return MAPAD_OK;
     const uint32_t lds_lmax = std::max<uint32_t>(lmax, 1);
     const size_t lds_bytes = (size_t)16 * lds_lmax * sizeof(float);
     const uint32_t grid_d = (uint32_t)std::min<uint64_t>(n_reads, (uint64_t)c->n_cu * 32);
-    for (auto& e : c->ev) if (!e) HIP_TRY(hipEventCreate(&e));
-    HIP_TRY(hipEventRecord(c->ev[0], c->stream));
-    hipLaunchKernelGGL(darray_kernel, dim3(grid_d), dim3(64), lds_bytes, c->stream, c->dix, c->dprm, B, (int)lds_lmax);
+    for (auto& e : S.ev) if (!e) HIP_TRY(hipEventCreate(&e));
+    if (!c->ev_ref) { HIP_TRY(hipEventCreate(&c->ev_ref)); HIP_TRY(hipEventRecord(c->ev_ref, S.stream)); c->history.clear(); }
+    HIP_TRY(hipEventRecord(S.ev[0], S.stream));
+    hipLaunchKernelGGL(darray_kernel, dim3(grid_d), dim3(64), lds_bytes, S.stream, c->dix, c->dprm, B, (int)lds_lmax);
     HIP_TRY(hipGetLastError());
     if (ordered) {
-        hipLaunchKernelGGL(order_scan_kernel, dim3(1), dim3(64), 0, c->stream, c->d_key_hist.p, n_chunks);
-        hipLaunchKernelGGL(order_scatter_kernel, dim3((uint32_t)((n_reads + 1023) / 1024)), dim3(1024), 0, c->stream, B);
+        hipLaunchKernelGGL(order_scan_kernel, dim3(1), dim3(64), 0, S.stream, S.d_key_hist.p, n_chunks);
+        hipLaunchKernelGGL(order_scatter_kernel, dim3((uint32_t)((n_reads + 1023) / 1024)), dim3(1024), 0, S.stream, B);
         HIP_TRY(hipGetLastError());
     }
-    HIP_TRY(hipEventRecord(c->ev[1], c->stream));
+    HIP_TRY(hipEventRecord(S.ev[1], S.stream));
     const uint32_t rpw = 64 / c->lpr;  // reads per wavefront
     // near data in LDS (16 read slots per wavefront) unless the batch has very long reads or every lane owns a read
     const uint32_t near_lmax = std::max<uint32_t>(lmax, 1);
-    const uint32_t near_stride = (c->lpr == 4 && near_lmax <= kMaxLdsReadLen && env_u32("MAPAD_NEAR_LDS", 1)) ? near_bytes(near_lmax) : 0;
+    // lanes-per-read 1: 64 read slots per wavefront, near data in LDS while it fits the 64 KB a launch may ask for without an opt-in
+    const bool near_fits = c->lpr == 4 ? near_lmax <= kMaxLdsReadLen : (size_t)near_bytes(near_lmax) * 64 <= 65536;
+    const uint32_t near_stride = (near_fits && env_u32("MAPAD_NEAR_LDS", 1)) ? near_bytes(near_lmax) : 0;
     const size_t lds = (size_t)near_stride * rpw;
     const bool cont = c->dprm.bound_kind == BOUND_CONTINUOUS;
-#define MAPAD_LAUNCH(L, C, P, N) hipLaunchKernelGGL((search_kernel<L, C, P, N>), dim3(grid), dim3(64), lds, c->stream, c->dix, c->dprm, B, ap, c->d_grow.p, near_stride, near_lmax, stage)
+#define MAPAD_LAUNCH(L, C, P, N) hipLaunchKernelGGL((search_kernel<L, C, P, N>), dim3(grid), dim3(64), lds, S.stream, c->dix, c->dprm, B, ap, c->d_grow.p, near_stride, near_lmax, stage)
 #define MAPAD_LAUNCH_PASS(P)                                                                                      \
     if (c->lpr == 4 && near_stride) { if (!cont) MAPAD_LAUNCH(4, false, P, true); else MAPAD_LAUNCH(4, true, P, true); }   \
     else if (c->lpr == 4) { if (!cont) MAPAD_LAUNCH(4, false, P, false); else MAPAD_LAUNCH(4, true, P, false); }          \
+    else if (near_stride) { if (!cont) MAPAD_LAUNCH(1, false, P, true); else MAPAD_LAUNCH(1, true, P, true); }              \
     else { if (!cont) MAPAD_LAUNCH(1, false, P, false); else MAPAD_LAUNCH(1, true, P, false); }
     const uint32_t grid_s = (uint32_t)std::min<uint64_t>((n_reads + rpw - 1) / rpw, c->slots[0] / rpw);
     for (int stage = 0; stage + 1 < kStages; ++stage) {  // every read, then the reads that gave up waiting (normally none: the launch exits at once)
         const uint32_t grid = grid_s;
-        const ArenaPool& ap = c->pool[0];
+        ArenaPool ap = c->pool[0];
+        ap.base = S.d_arena[0].p;
         if (stage == 0) { MAPAD_LAUNCH_PASS(0) } else { MAPAD_LAUNCH_PASS(2) }  // PASS 2 = PASS 0 under its own symbol, so that profiles keep the passes apart
         HIP_TRY(hipGetLastError());
     }
-    HIP_TRY(hipEventRecord(c->ev[2], c->stream));
+    HIP_TRY(hipEventRecord(S.ev[2], S.stream));
     {   // leftovers with the reference's full limits
         const int stage = kStages - 1;
         const uint32_t grid = (uint32_t)std::min<uint64_t>((n_reads + rpw - 1) / rpw, c->slots[1] / rpw);
-        const ArenaPool& ap = c->pool[1];
+        ArenaPool ap = c->pool[1];
+        ap.base = S.d_arena[1].p;
         MAPAD_LAUNCH_PASS(1)
         HIP_TRY(hipGetLastError());
     }
 #undef MAPAD_LAUNCH_PASS
 #undef MAPAD_LAUNCH
-    HIP_TRY(hipEventRecord(c->ev[3], c->stream));
-    c->ev_valid = true;
-    c->launch_info[0] = grid_d; c->launch_info[1] = 64; c->launch_info[2] = (uint32_t)lds_bytes;
-    c->launch_info[3] = grid_s; c->launch_info[4] = 64; c->launch_info[5] = c->slots[1] / rpw;
-    c->launch_info[6] = c->pool[0].node_cap; c->launch_info[7] = (uint32_t)(c->pool[0].stride >> 10);
+    HIP_TRY(hipEventRecord(S.ev[3], S.stream));
+    S.ev_valid = true; S.timed = false;
+    S.launch_info[0] = grid_d; S.launch_info[1] = 64; S.launch_info[2] = (uint32_t)lds_bytes;
+    S.launch_info[3] = grid_s; S.launch_info[4] = 64; S.launch_info[5] = c->slots[1] / rpw;
+    S.launch_info[6] = c->pool[0].node_cap; S.launch_info[7] = (uint32_t)(c->pool[0].stride >> 10);
     return MAPAD_OK;
 }
 
 // Lays the last batch's hits out in read order on the device (no-op if already done).  Reports pool overflow / kernel errors like the fetch.
 int compact_last(mapad_ctx* c) {
-    if (c->compacted) return MAPAD_OK;
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    const BatchDev& B = c->last;
+    BatchSlot& S = c->bs[c->view];
+    if (S.compacted) return MAPAD_OK;
+    HIP_TRY(hipStreamSynchronize(S.stream));
+    const BatchDev& B = S.last;
     const uint64_t n = B.n_reads;
     uint32_t cur[CUR_COUNT] = {0};
     if (n) HIP_TRY(hipMemcpy(cur, B.cursors, sizeof cur, hipMemcpyDeviceToHost));
     if (cur[CUR_ERR] & ST_NO_TABLE) { std::fprintf(stderr, "mapad_amd: a read length had no score table (call mapad_ctx_prepare_lengths)\n"); return MAPAD_ERR_INVALID; }
     if (cur[CUR_ERR] & ST_ARENA_OVERFLOW) { std::fprintf(stderr, "mapad_amd: arena overflow in the large-arena pass\n"); return MAPAD_ERR_NOMEM; }
     if (cur[CUR_POOL_OVF]) return MAPAD_ERR_NOMEM;  // mapad_map_batch retries with larger pools
-    c->c_n_hits = cur64(cur, CUR_HITS); c->c_n_ops = cur64(cur, CUR_OPS);
+    S.c_n_hits = cur64(cur, CUR_HITS); S.c_n_ops = cur64(cur, CUR_OPS);
     int rc;
     const uint64_t n_tiles = (n + kScanTile - 1) / kScanTile;
-    if ((rc = c->d_c_hit_begin.ensure(n + 1))) return rc;
-    if ((rc = c->d_c_ops_begin.ensure(n + 1))) return rc;
-    if ((rc = c->d_c_tiles.ensure(2 * std::max<uint64_t>(n_tiles, 1)))) return rc;
-    if ((rc = c->d_c_hits.ensure(std::max<uint64_t>(c->c_n_hits, 1)))) return rc;
-    if ((rc = c->d_c_ops.ensure(std::max<uint64_t>(c->c_n_ops, 1)))) return rc;
-    if (n == 0) { HIP_TRY(hipMemsetAsync(c->d_c_hit_begin.p, 0, 8, c->stream)); HIP_TRY(hipMemsetAsync(c->d_c_ops_begin.p, 0, 8, c->stream)); c->compacted = true; return MAPAD_OK; }
-    CompactDev Q{B.hit_count, B.hit_first, B.hits_pool, B.ops_pool, n, c->d_c_hit_begin.p, c->d_c_ops_begin.p, c->d_c_tiles.p, c->d_c_tiles.p + n_tiles, c->d_c_hits.p, c->d_c_ops.p};
-    hipLaunchKernelGGL(compact_sums_kernel, dim3((uint32_t)n_tiles), dim3(256), 0, c->stream, Q);
-    hipLaunchKernelGGL(compact_scan_tiles_kernel, dim3(1), dim3(1024), 0, c->stream, Q, n_tiles);
-    hipLaunchKernelGGL(compact_move_kernel, dim3((uint32_t)n_tiles), dim3(256), 0, c->stream, Q);
+    if ((rc = S.d_c_hit_begin.ensure(n + 1))) return rc;
+    if ((rc = S.d_c_ops_begin.ensure(n + 1))) return rc;
+    if ((rc = S.d_c_tiles.ensure(2 * std::max<uint64_t>(n_tiles, 1)))) return rc;
+    if ((rc = S.d_c_hits.ensure(std::max<uint64_t>(S.c_n_hits, 1)))) return rc;
+    if ((rc = S.d_c_ops.ensure(std::max<uint64_t>(S.c_n_ops, 1)))) return rc;
+    if (n == 0) { HIP_TRY(hipMemsetAsync(S.d_c_hit_begin.p, 0, 8, S.stream)); HIP_TRY(hipMemsetAsync(S.d_c_ops_begin.p, 0, 8, S.stream)); S.compacted = true; return MAPAD_OK; }
+    CompactDev Q{B.hit_count, B.hit_first, B.hits_pool, B.ops_pool, n, S.d_c_hit_begin.p, S.d_c_ops_begin.p, S.d_c_tiles.p, S.d_c_tiles.p + n_tiles, S.d_c_hits.p, S.d_c_ops.p};
+    hipLaunchKernelGGL(compact_sums_kernel, dim3((uint32_t)n_tiles), dim3(256), 0, S.stream, Q);
+    hipLaunchKernelGGL(compact_scan_tiles_kernel, dim3(1), dim3(1024), 0, S.stream, Q, n_tiles);
+    hipLaunchKernelGGL(compact_move_kernel, dim3((uint32_t)n_tiles), dim3(256), 0, S.stream, Q);
     HIP_TRY(hipGetLastError());
-    c->compacted = true;
+    S.compacted = true;
     return MAPAD_OK;
 }
 
@@ -1070,6 +1133,7 @@ int mapad_ctx_create(const mapad_index_t* idx, const mapad_params_t* params, int
     auto c = std::make_unique<mapad_ctx>();
     c->device = device_id; c->params = *params; c->index = idx; c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     c->tables = host::make_tables(*params);
+    c->depth = (int)std::min<uint32_t>(std::max<uint32_t>(env_u32("MAPAD_PIPELINE_DEPTH", 1), 1), kMaxDepth);
     int rc;
     if ((rc = c->d_blocks.ensure(idx->ix.blocks.size()))) return rc;
     HIP_TRY(hipMemcpy(c->d_blocks.p, idx->ix.blocks.data(), idx->ix.blocks.size() * 8, hipMemcpyHostToDevice));
@@ -1101,8 +1165,9 @@ int mapad_map_batch_device(mapad_ctx_t* ctx, const void* d_seqs, const void* d_q
     uint64_t total = 0;
     if (n_reads) HIP_TRY(hipMemcpyAsync(&total, (const uint64_t*)d_offsets + n_reads, 8, hipMemcpyDeviceToHost, ctx->stream));
     if (n_reads) HIP_TRY(hipStreamSynchronize(ctx->stream));
-    ctx->last_owned_inputs = false;
-    return launch_batch(ctx, (const uint8_t*)d_seqs, (const uint8_t*)d_quals, (const uint64_t*)d_offsets, n_reads, total, max_read_len);
+    int rc;
+    if ((rc = acquire_slot(ctx, (ctx->cur + 1) % ctx->depth))) return rc;  // batches rotate through the slots: this one runs beside the previous one's tail
+    return launch_batch(ctx, ctx->bs[ctx->cur], (const uint8_t*)d_seqs, (const uint8_t*)d_quals, (const uint64_t*)d_offsets, n_reads, total, max_read_len);
 }
 
 int mapad_fetch_result(mapad_ctx_t* ctx, mapad_batch_result_t** out) {
@@ -1110,27 +1175,28 @@ int mapad_fetch_result(mapad_ctx_t* ctx, mapad_batch_result_t** out) {
     if (hipSetDevice(ctx->device) != hipSuccess) return MAPAD_ERR_NO_DEVICE;
     int rc;
     if ((rc = compact_last(ctx))) return rc;
-    const BatchDev& B = ctx->last;
+    BatchSlot& S = ctx->bs[ctx->view];
+    const BatchDev& B = S.last;
     const uint64_t n = B.n_reads;
     auto r = std::make_unique<HostResult>();
     uint32_t cur[CUR_COUNT] = {0};
-    if (n) HIP_TRY(hipMemcpyAsync(cur, B.cursors, sizeof cur, hipMemcpyDeviceToHost, ctx->stream));
+    if (n) HIP_TRY(hipMemcpyAsync(cur, B.cursors, sizeof cur, hipMemcpyDeviceToHost, S.stream));
     r->status.resize(n); r->counters.resize(n);
-    if (ctx->fetch_d) r->d_arrays.resize(ctx->last_total_bases);
+    if (ctx->fetch_d) r->d_arrays.resize(S.last_total_bases);
     // order-preserving collect (mapping.rs:288): hits in read order, BinaryHeap array order inside a read — laid out by the device
     r->hit_begin.assign(n + 1, 0);
-    r->hits.resize(ctx->c_n_hits);
-    r->ops.resize(ctx->c_n_ops);
+    r->hits.resize(S.c_n_hits);
+    r->ops.resize(S.c_n_ops);
     static_assert(sizeof(mapad_hit_t) == sizeof(HitRec), "hit records are copied as they are");
     if (n) {
-        HIP_TRY(hipMemcpyAsync(r->hit_begin.data(), ctx->d_c_hit_begin.p, (n + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
-        HIP_TRY(hipMemcpyAsync(r->status.data(), B.status, n * 4, hipMemcpyDeviceToHost, ctx->stream));
-        HIP_TRY(hipMemcpyAsync(r->counters.data(), B.counters, n * sizeof(ReadCounters), hipMemcpyDeviceToHost, ctx->stream));
-        if (!r->hits.empty()) HIP_TRY(hipMemcpyAsync(r->hits.data(), ctx->d_c_hits.p, r->hits.size() * sizeof(HitRec), hipMemcpyDeviceToHost, ctx->stream));
-        if (!r->ops.empty()) HIP_TRY(hipMemcpyAsync(r->ops.data(), ctx->d_c_ops.p, r->ops.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
-        if (ctx->fetch_d && ctx->last_total_bases) HIP_TRY(hipMemcpyAsync(r->d_arrays.data(), B.d_arrays, ctx->last_total_bases * 4, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipMemcpyAsync(r->hit_begin.data(), S.d_c_hit_begin.p, (n + 1) * 8, hipMemcpyDeviceToHost, S.stream));
+        HIP_TRY(hipMemcpyAsync(r->status.data(), B.status, n * 4, hipMemcpyDeviceToHost, S.stream));
+        HIP_TRY(hipMemcpyAsync(r->counters.data(), B.counters, n * sizeof(ReadCounters), hipMemcpyDeviceToHost, S.stream));
+        if (!r->hits.empty()) HIP_TRY(hipMemcpyAsync(r->hits.data(), S.d_c_hits.p, r->hits.size() * sizeof(HitRec), hipMemcpyDeviceToHost, S.stream));
+        if (!r->ops.empty()) HIP_TRY(hipMemcpyAsync(r->ops.data(), S.d_c_ops.p, r->ops.size() * 4, hipMemcpyDeviceToHost, S.stream));
+        if (ctx->fetch_d && S.last_total_bases) HIP_TRY(hipMemcpyAsync(r->d_arrays.data(), B.d_arrays, S.last_total_bases * 4, hipMemcpyDeviceToHost, S.stream));
     }
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(hipStreamSynchronize(S.stream));
     if (r->hit_begin[n] != r->hits.size()) { std::fprintf(stderr, "mapad_amd: compacted hit count does not match the pool cursor\n"); return MAPAD_ERR_DEVICE; }
     uint64_t sums[6] = {0, 0, 0, 0, 0, 0};
     for (uint64_t i = 0; i < n; ++i) {
@@ -1152,11 +1218,17 @@ int mapad_compact_result_device(mapad_ctx_t* ctx, void** d_hit_begin, void** d_h
     if (hipSetDevice(ctx->device) != hipSuccess) return MAPAD_ERR_NO_DEVICE;
     const int rc = compact_last(ctx);
     if (rc) return rc;
-    if (d_hit_begin) *d_hit_begin = ctx->d_c_hit_begin.p;
-    if (d_hits) *d_hits = ctx->d_c_hits.p;
-    if (d_ops) *d_ops = ctx->d_c_ops.p;
-    if (n_hits) *n_hits = ctx->c_n_hits;
-    if (n_ops) *n_ops = ctx->c_n_ops;
+    BatchSlot& S = ctx->bs[ctx->view];
+    if (S.stream != ctx->stream) {  // the caller consumes the arrays on its own stream: order it behind the collect
+        if (!S.ev_in) HIP_TRY(hipEventCreateWithFlags(&S.ev_in, hipEventDisableTiming));
+        HIP_TRY(hipEventRecord(S.ev_in, S.stream));
+        HIP_TRY(hipStreamWaitEvent(ctx->stream, S.ev_in, 0));
+    }
+    if (d_hit_begin) *d_hit_begin = S.d_c_hit_begin.p;
+    if (d_hits) *d_hits = S.d_c_hits.p;
+    if (d_ops) *d_ops = S.d_c_ops.p;
+    if (n_hits) *n_hits = S.c_n_hits;
+    if (n_ops) *n_ops = S.c_n_ops;
     return MAPAD_OK;
 }
 void mapad_batch_result_free(mapad_batch_result_t* r) {
@@ -1177,49 +1249,50 @@ int mapad_map_batch(mapad_ctx_t* ctx, const uint8_t* seqs, const uint8_t* quals,
     std::vector<uint32_t> lv(lens.begin(), lens.end());
     int rc;
     if ((rc = mapad_ctx_prepare_lengths(ctx, lv.data(), (uint32_t)lv.size()))) return rc;
-    if ((rc = ctx->d_seqs.ensure(std::max<uint64_t>(total, 1)))) return rc;
-    if ((rc = ctx->d_quals.ensure(std::max<uint64_t>(total, 1)))) return rc;
-    if ((rc = ctx->d_offsets.ensure(n_reads + 1))) return rc;
+    if ((rc = acquire_slot(ctx, ctx->cur))) return rc;  // synchronous entry point: no rotation, one slot's buffers
+    BatchSlot& S = ctx->bs[ctx->cur];
+    if ((rc = S.d_seqs.ensure(std::max<uint64_t>(total, 1)))) return rc;
+    if ((rc = S.d_quals.ensure(std::max<uint64_t>(total, 1)))) return rc;
+    if ((rc = S.d_offsets.ensure(n_reads + 1))) return rc;
     if (n_reads) {
-        HIP_TRY(hipMemcpyAsync(ctx->d_seqs.p, seqs, total, hipMemcpyHostToDevice, ctx->stream));
-        HIP_TRY(hipMemcpyAsync(ctx->d_quals.p, quals, total, hipMemcpyHostToDevice, ctx->stream));
-        HIP_TRY(hipMemcpyAsync(ctx->d_offsets.p, offsets, (n_reads + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(hipMemcpyAsync(S.d_seqs.p, seqs, total, hipMemcpyHostToDevice, S.stream));
+        HIP_TRY(hipMemcpyAsync(S.d_quals.p, quals, total, hipMemcpyHostToDevice, S.stream));
+        HIP_TRY(hipMemcpyAsync(S.d_offsets.p, offsets, (n_reads + 1) * 8, hipMemcpyHostToDevice, S.stream));
     }
-    ctx->last_owned_inputs = true;
     for (int attempt = 0; attempt < 6; ++attempt) {
-        if ((rc = launch_batch(ctx, ctx->d_seqs.p, ctx->d_quals.p, ctx->d_offsets.p, n_reads, total, lmax))) return rc;
+        if ((rc = launch_batch(ctx, S, S.d_seqs.p, S.d_quals.p, S.d_offsets.p, n_reads, total, lmax))) return rc;
         rc = mapad_fetch_result(ctx, out);
         if (rc != MAPAD_ERR_NOMEM) return rc;
         // pools too small for this batch: quadruple and retry (rare: needs > 2 hits per read on average)
         uint32_t cur[CUR_COUNT];
-        HIP_TRY(hipMemcpy(cur, ctx->d_cursors.p, sizeof cur, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(cur, S.d_cursors.p, sizeof cur, hipMemcpyDeviceToHost));
         if (!cur[CUR_POOL_OVF]) return rc;
         if (cur64(cur, CUR_HITS) + 1024 > 0xFFFFFFFFull || cur64(cur, CUR_OPS) + 1024 > 0xFFFFFFFFull) {
             std::fprintf(stderr, "mapad_amd: the batch produces more than 2^32 hit records or edit operations; split it\n");
             return MAPAD_ERR_INVALID;
         }
-        if ((rc = ctx->d_hits.ensure((size_t)cur64(cur, CUR_HITS) + 1024))) return rc;
-        if ((rc = ctx->d_ops.ensure((size_t)cur64(cur, CUR_OPS) + 1024))) return rc;
+        if ((rc = S.d_hits.ensure((size_t)cur64(cur, CUR_HITS) + 1024))) return rc;
+        if ((rc = S.d_ops.ensure((size_t)cur64(cur, CUR_OPS) + 1024))) return rc;
     }
     return MAPAD_ERR_NOMEM;
 }
 
 int mapad_device_result_ptrs(mapad_ctx_t* ctx, void** d_hit_count, void** d_hit_first, void** d_hits, void** d_ops, void** d_cursors) {
     if (!ctx) return MAPAD_ERR_INVALID;
-    if (d_hit_count) *d_hit_count = ctx->last.hit_count;
-    if (d_hit_first) *d_hit_first = ctx->last.hit_first;
-    if (d_hits) *d_hits = ctx->last.hits_pool;
-    if (d_ops) *d_ops = ctx->last.ops_pool;
-    if (d_cursors) *d_cursors = ctx->last.cursors;
+    if (d_hit_count) *d_hit_count = ctx->bs[ctx->view].last.hit_count;
+    if (d_hit_first) *d_hit_first = ctx->bs[ctx->view].last.hit_first;
+    if (d_hits) *d_hits = ctx->bs[ctx->view].last.hits_pool;
+    if (d_ops) *d_ops = ctx->bs[ctx->view].last.ops_pool;
+    if (d_cursors) *d_cursors = ctx->bs[ctx->view].last.cursors;
     return MAPAD_OK;
 }
 int mapad_last_batch_counters(mapad_ctx_t* ctx, uint64_t out[6]) {
     if (!ctx || !out) return MAPAD_ERR_INVALID;
     if (hipSetDevice(ctx->device) != hipSuccess) return MAPAD_ERR_NO_DEVICE;
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
-    const uint64_t n = ctx->last.n_reads;
+    HIP_TRY(hipStreamSynchronize(ctx->bs[ctx->view].stream));
+    const uint64_t n = ctx->bs[ctx->view].last.n_reads;
     std::vector<ReadCounters> c(n);
-    if (n) HIP_TRY(hipMemcpy(c.data(), ctx->last.counters, n * sizeof(ReadCounters), hipMemcpyDeviceToHost));
+    if (n) HIP_TRY(hipMemcpy(c.data(), ctx->bs[ctx->view].last.counters, n * sizeof(ReadCounters), hipMemcpyDeviceToHost));
     uint64_t s[6] = {0, 0, 0, 0, 0, 0};
     for (auto& x : c) { s[0] += x.e_search; s[1] += x.e_darray; s[2] += x.n_push; s[3] += x.n_pop; s[4] += x.n_node; s[5] += x.n_hits; }
     std::memcpy(out, s, sizeof s);
@@ -1227,18 +1300,48 @@ int mapad_last_batch_counters(mapad_ctx_t* ctx, uint64_t out[6]) {
 }
 int mapad_last_kernel_ms(mapad_ctx_t* ctx, float out[3]) {
     if (!ctx || !out) return MAPAD_ERR_INVALID;
-    if (!ctx->ev_valid) return MAPAD_ERR_INVALID;
+    BatchSlot& S = ctx->bs[ctx->view];
+    if (!S.ev_valid) return MAPAD_ERR_INVALID;
     if (hipSetDevice(ctx->device) != hipSuccess) return MAPAD_ERR_NO_DEVICE;
-    HIP_TRY(hipEventSynchronize(ctx->ev[3]));
-    for (int i = 0; i < 3; ++i) HIP_TRY(hipEventElapsedTime(&out[i], ctx->ev[i], ctx->ev[i + 1]));
+    HIP_TRY(hipEventSynchronize(S.ev[3]));
+    for (int i = 0; i < 3; ++i) HIP_TRY(hipEventElapsedTime(&out[i], S.ev[i], S.ev[i + 1]));
     return MAPAD_OK;
 }
 int mapad_last_launch_info(mapad_ctx_t* ctx, uint32_t out[8]) {
     if (!ctx || !out) return MAPAD_ERR_INVALID;
-    std::memcpy(out, ctx->launch_info, sizeof ctx->launch_info);
+    std::memcpy(out, ctx->bs[ctx->view].launch_info, sizeof ctx->bs[ctx->view].launch_info);
     return MAPAD_OK;
 }
 
+int mapad_ctx_set_pipeline_depth(mapad_ctx_t* ctx, int depth) {
+    if (!ctx || depth < 1 || depth > kMaxDepth) return MAPAD_ERR_INVALID;
+    if (hipSetDevice(ctx->device) != hipSuccess) return MAPAD_ERR_NO_DEVICE;
+    int rc;
+    if ((rc = sync_all_slots(ctx))) return rc;
+    for (auto& b : ctx->bs) { if ((rc = record_times(ctx, b))) return rc; b.release(); b.ev_valid = false; b.compacted = false; }
+    ctx->depth = depth; ctx->cur = 0; ctx->view = 0;
+    ctx->arena_reads = 0; ctx->arena_lmax = 0; ctx->pool[0].stride = 0;  // pools are re-sized around the base arenas of `depth` batches
+    return MAPAD_OK;
+}
+int mapad_ctx_select_batch(mapad_ctx_t* ctx, int age) {
+    if (!ctx || age < 0 || age >= ctx->depth) return MAPAD_ERR_INVALID;
+    ctx->view = ((ctx->cur - age) % ctx->depth + ctx->depth) % ctx->depth;
+    return ctx->bs[ctx->view].ev_valid ? MAPAD_OK : MAPAD_ERR_INVALID;
+}
+int mapad_kernel_history(mapad_ctx_t* ctx, float* out, uint32_t cap, uint32_t* n) {
+    if (!ctx || !n || (cap && !out)) return MAPAD_ERR_INVALID;
+    if (hipSetDevice(ctx->device) != hipSuccess) return MAPAD_ERR_NO_DEVICE;
+    int rc;
+    if ((rc = sync_all_slots(ctx))) return rc;
+    // launches finish in submission order per slot; slots are visited in submission order: cur + 1, ..., cur
+    for (int k = 1; k <= ctx->depth; ++k) if ((rc = record_times(ctx, ctx->bs[(ctx->cur + k) % ctx->depth]))) return rc;
+    const uint32_t have = (uint32_t)(ctx->history.size() / 4);
+    *n = have;
+    for (uint32_t i = 0; i < have && i < cap; ++i) std::memcpy(out + 4 * i, ctx->history.data() + 4 * i, 16);
+    ctx->history.clear();
+    if (ctx->ev_ref) { (void)hipEventDestroy(ctx->ev_ref); ctx->ev_ref = nullptr; }
+    return MAPAD_OK;
+}
 }  // extern "C"
 
 // ---- SA locate on the device ---------------------------------------------------------------------------------------------

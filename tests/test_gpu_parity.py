@@ -130,6 +130,51 @@ def test_arena_handoff_stress(monkeypatch):
         assert_same_as_oracle(ores, res, offsets)
 
 
+@pytest.mark.parametrize("depth,tiny", [(2, False), (3, True)])
+def test_batches_in_flight_do_not_change_results(depth, tiny, monkeypatch):
+    """mapad_ctx_set_pipeline_depth: batch k + 1 is submitted while batch k is still running (own streams and buffers, shared size-class
+    pools); every batch must come out exactly as it does alone."""
+    import ctypes as C
+    hip = C.CDLL("libamdhip64.so")  # the runtime the library itself uses: device-resident inputs without torch
+
+    def to_device(a):
+        a = np.ascontiguousarray(a)
+        p = C.c_void_p()
+        assert hip.hipMalloc(C.byref(p), C.c_size_t(max(a.nbytes, 8))) == 0
+        assert hip.hipMemcpy(p, a.ctypes.data_as(C.c_void_p), C.c_size_t(a.nbytes), 1) == 0  # hipMemcpyHostToDevice
+        return p.value
+
+    if tiny:  # reads migrate constantly and the concurrent launches compete for the same few arenas
+        monkeypatch.setenv("MAPAD_TIER0_NODES", "64")
+        monkeypatch.setenv("MAPAD_CLASS_COUNTS", "256,128,64,64,64,64,64,16,16,16")
+    g = synth.genome(300_000, seed=31)
+    rp = resolve_params(DAMAGE)
+    pidx = mapad_amd.Index.build([("chr1", g)], device=0)
+    oidx = ob.OracleIndex.from_bwt(pidx.bwt(), "$ACGTX", 128)
+    batches = [synth.reads(g, n, 50, seed=40 + i, qual_range=(20, 40), damage=dict(f=0.5, t=0.5, d=0.02, s=1.0)) for i, n in enumerate((6000, 1500, 9000, 3000, 4500, 700))]
+    want = []
+    for seqs, quals, offsets in batches:
+        reads, qs = split_reads(seqs, quals, offsets)
+        want.append(oidx.map_batch(ob.make_params(rp), reads, qs, n_threads=8, keep_d=True))
+    ctx = mapad_amd.Context(pidx, mapad_amd.make_params(rp), 0)
+    on_dev = [tuple(to_device(a) for a in b) for b in batches]
+    ctx.set_pipeline_depth(depth)
+    ctx.prepare_lengths([50])
+    for lo in range(0, len(batches), depth):
+        group = list(range(lo, min(lo + depth, len(batches))))
+        for i in group:  # submitted back to back, nothing fetched in between
+            ctx.map_batch_device(on_dev[i][0], on_dev[i][1], on_dev[i][2], len(batches[i][2]) - 1, 50)
+        for i in group:
+            ctx.select_batch(group[-1] - i)
+            assert_same_as_oracle(want[i], ctx.fetch(), batches[i][2])
+    hist = ctx.kernel_history()
+    assert hist.shape == (len(batches), 4) and (np.diff(hist, axis=1) >= 0).all()
+    ctx.close()
+    for b in on_dev:
+        for p in b:
+            hip.hipFree(C.c_void_p(p))
+
+
 def test_integration_expectation_on_gpu(monkeypatch):
     """tests/integration_tests.rs: FASTA -> index -> 17 reads -> record fields, all through the C ABI with the GPU search."""
     k = load("integration")
