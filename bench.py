@@ -102,7 +102,7 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target wall time of the CPU baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the e2e / sa_locate / post_search legs")
-    ap.add_argument("--depth", type=int, default=2, help="batches in flight (1 = every step runs alone on the stream)")
+    ap.add_argument("--depth", type=int, default=3, help="batches in flight (1 = every step runs alone on the stream)")
     args = ap.parse_args()
     genome_bp = args.genome_bp or CONFIGS[args.config][0]
     n_reads = args.reads or CONFIGS[args.config][1]
@@ -161,6 +161,7 @@ def main():
     max_len = int(lens.max())
     ctx.prepare_lengths(sorted(set(lens.tolist())))
     ctx.set_fetch_d_arrays(False)
+    ctx.reserve(n_reads, int(offsets[-1]), max_len)  # every batch slot's buffers up front: an allocation inside the pipeline would wait for running kernels
     d_seqs = torch.from_numpy(seqs).to(dev)
     d_quals = torch.from_numpy(quals).to(dev)
     d_offsets = torch.from_numpy(offsets.view(np.int64)).to(dev)
@@ -269,8 +270,9 @@ def main():
                 "algorithmic_bytes_per_launch": dom_bytes, "kernel_ms": round(float(dom_ms), 4),
                 "kernel_ms_is": "union of the K launches' HIP-event intervals / K" + (f" ({args.depth} batches in flight: launch k+1 runs beside the tail of launch k)" if args.depth > 1 else ""),
                 "search_kernel_ms_per_launch_overlapped": round(per_launch_search, 4),
+                "launch_marks_ms": [[round(float(x), 2) for x in row] for row in hist],  # per launch: D-array start, search start, search end, last-pass end
                 "solo_launch": {"darray_ms": round(solo_ms[0], 4), "search_ms": round(solo_ms[1], 4), "search_GB/s": round(bytes_search / (solo_ms[1] * 1e-3) / 1e9, 2),
-                                "frac": round(bytes_search / (solo_ms[1] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5), "what": "one launch alone on the chip (what rocprofv3 --stats sees with MAPAD_PIPELINE_DEPTH=1)"},
+                                "frac": round(bytes_search / (solo_ms[1] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5), "what": "one launch alone on the chip, nothing else in flight (what rocprofv3 --stats sees with --depth 1)"},
                 "all_kernels": {"darray_kernel": {"ms": round(float(ms_darray), 4), "bytes": bytes_darray, "GB/s": round(bytes_darray / (ms_darray * 1e-3) / 1e9, 2)},
                                 "search_kernel": {"ms": round(float(ms_search), 4), "bytes": bytes_search, "GB/s": round(bytes_search / (ms_search * 1e-3) / 1e9, 2)},
                                 "search_kernel_last_pass": {"ms": round(float(ms_pass2), 4), "arena_migrations": res.n_second_pass, "reads": res.n_third_pass}},
@@ -326,11 +328,16 @@ def main():
     e2e = None
     if extras:
         ctx.set_stream(None)
+        from mapad_amd import binding as mb
+        import ctypes as C
         ts = []
         for _ in range(3):
+            out = C.POINTER(mb.BatchResultC)()
             t = time.perf_counter()
-            r2 = ctx.map_batch(seqs, quals, offsets)
-            ts.append(time.perf_counter() - t)
+            rc = mb.lib().mapad_map_batch(ctx.h, seqs.ctypes.data_as(C.c_void_p), quals.ctypes.data_as(C.c_void_p), offsets.ctypes.data_as(C.c_void_p), n_reads, C.byref(out))
+            ts.append(time.perf_counter() - t)  # the C call: results are in (page-locked) host memory when it returns
+            assert rc == 0
+            r2 = mb.BatchResult(out, mb.lib().mapad_batch_result_free)
         same = r2.n_hits == res.n_hits and digest(r2.hit_begin, r2.hits_arr, r2.ops) == digest(res.hit_begin, res.hits_arr, res.ops)
         dt = min(ts[1:])
         h2d = 2 * total_bases + 8 * (n_reads + 1)
@@ -339,6 +346,44 @@ def main():
                "what": "mapad_map_batch: host reads in (H2D), D arrays + ordering + search, device-side collect, hit records + edit tracks + counters out (D2H)"}
         r2.close()
         ctx.set_stream(ctypes.c_void_p(stream.cuda_stream))
+
+    # ---- the command line end to end: FASTQ in, BAM out (reader, GPU mapping, records, BAM encoding + BGZF, all overlapped) -----------------
+    cli = None
+    if extras and args.config in ("c2", "c3") and n_reads <= 2_000_000:
+        import re
+        import shutil
+        import tempfile
+        from mapad_amd import build as mbuild
+        tmp = tempfile.mkdtemp(prefix="mapad_cli_")
+        try:
+            fa, fq, bam = os.path.join(tmp, "ref.fa"), os.path.join(tmp, "reads.fastq"), os.path.join(tmp, "out.bam")
+            with open(fa, "wb") as f:
+                f.write(b">chr1\n")
+                f.write(genome.tobytes())
+                f.write(b"\n")
+            rec = np.empty((n_reads, 114), np.uint8)  # "@rNNNNNNN\n" + 50 bases + "\n+\n" + 50 qualities + "\n"
+            rec[:, 0] = ord("@"); rec[:, 1] = ord("r")
+            ids = np.arange(n_reads)
+            for k in range(7):
+                rec[:, 8 - k] = 48 + (ids // 10 ** k) % 10
+            rec[:, 9] = 10; rec[:, 10:60] = seqs.reshape(n_reads, 50); rec[:, 60] = 10; rec[:, 61] = ord("+"); rec[:, 62] = 10
+            rec[:, 63:113] = quals.reshape(n_reads, 50) + 33; rec[:, 113] = 10
+            rec.tofile(fq)
+            exe = mbuild.build_cli()
+            t = time.perf_counter()
+            subprocess.check_call([exe, "index", "-g", fa], stderr=subprocess.DEVNULL)
+            t_idx = time.perf_counter() - t
+            model = ["-f", "0", "-t", "0", "-d", "0", "-s", "0"] if args.config == "c2" else ["-f", "0.5", "-t", "0.5", "-d", "0.02", "-s", "1.0"]
+            t = time.perf_counter()
+            pr = subprocess.run([exe, "map", "-r", fq, "-g", fa, "-o", bam, "-l", "single_stranded", "-p", "0.03", "-D", "0.02", "-i", "0.001", "-x", "1.0",
+                                 "--batch_size", "250000", "--force_overwrite"] + model, stderr=subprocess.PIPE, text=True, check=True)
+            t_map = time.perf_counter() - t
+            m = re.search(r"(\d+) reads, (\d+) mapped; (\d+) device\(s\); index \+ contexts ([0-9.]+) s, mapping ([0-9.]+) s", pr.stderr)
+            cli = {"reads_per_s": round(n_reads / float(m.group(5)), 1), "mapping_s": float(m.group(5)), "index_load_and_contexts_s": float(m.group(4)),
+                   "process_wall_s": round(t_map, 2), "mapped": int(m.group(2)), "bam_bytes": os.path.getsize(bam), "index_cmd_s": round(t_idx, 2),
+                   "what": "mapad-amd map: FASTQ -> BAM, --batch_size 250000 (the reference's default), chunks pipelined 2 deep on one GPU; reader, records and BGZF on host threads"}
+        finally:
+            shutil.rmtree(tmp, ignore_errors=True)
 
     # ---- the next row of the path, outside the timed region: SA locate of the hits' rows on the device -------------
     locate = None
@@ -396,7 +441,7 @@ def main():
                        "parallelism": f"reads sharded over {world} GPUs, index replicated, read-ordered hit records gathered on rank 0 (RCCL p2p)" if world > 1 else "1 GPU",
                        "mapped_fraction": round(float((np.diff(res.hit_begin.astype(np.int64)) > 0).mean()), 4),
                        "index_build_s": round(t_index, 1), "index_build": "GPU suffix sorting (prefix doubling over radix sorts) + host text preparation"},
-            "roofline": roofline, "cpu_baseline": cpu, "parity": parity, "e2e": e2e, "sa_locate": locate, "post_search": post,
+            "roofline": roofline, "cpu_baseline": cpu, "parity": parity, "e2e": e2e, "cli": cli, "sa_locate": locate, "post_search": post,
         }
         if gather_check is not None:
             line["gather"] = gather_check

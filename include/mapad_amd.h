@@ -162,6 +162,15 @@ int mapad_map_batch(mapad_ctx_t* ctx, const uint8_t* seqs, const uint8_t* quals,
                     mapad_batch_result_t** out);
 void mapad_batch_result_free(mapad_batch_result_t* r);
 
+/* Asynchronous variant for a chunk loop that keeps the GPU busy (run_inner's loop, src/map/mapping.rs:151-294, with the next chunk
+ * submitted before the previous one is collected): stages the reads (the host buffers may be reused on return), launches on the next of the
+ * context's batch slots (mapad_ctx_set_pipeline_depth) and returns.  Collect with mapad_ctx_select_batch + mapad_fetch_result; a fetch that
+ * returns MAPAD_ERR_NOMEM (hit pools too small for that chunk) is repaired by running the chunk through mapad_map_batch. */
+int mapad_submit_batch(mapad_ctx_t* ctx, const uint8_t* seqs, const uint8_t* quals, const uint64_t* offsets, uint64_t n_reads);
+/* page-locked host memory: reads placed here reach the GPU by DMA at link speed (pageable memory goes through the driver's staging copies) */
+void* mapad_host_alloc(size_t bytes);
+void mapad_host_free(void* p);
+
 /* Device-resident variant used by bench.py and the multi-GPU driver: inputs already in HBM (device pointers), results stay
  * in the context's device buffers until fetched.  Asynchronous on the context's stream. */
 int mapad_map_batch_device(mapad_ctx_t* ctx, const void* d_seqs, const void* d_quals, const void* d_offsets, uint64_t n_reads,
@@ -173,6 +182,10 @@ int mapad_map_batch_device(mapad_ctx_t* ctx, const void* d_seqs, const void* d_q
  * context's stream (mapad_ctx_set_stream) at submission.  Default 1 (MAPAD_PIPELINE_DEPTH overrides): everything runs on the context's stream.
  * Changing the depth waits for all batches and drops their results. */
 int mapad_ctx_set_pipeline_depth(mapad_ctx_t* ctx, int depth);
+/* Allocates, for every batch slot, the device buffers of batches of up to n_reads reads / total_bases bases / reads up to max_read_len long
+ * (host_inputs != 0: also the staging buffers of mapad_map_batch / mapad_submit_batch).  Optional: buffers grow on demand, but an allocation in
+ * the middle of a pipeline waits for the kernels that are running. */
+int mapad_ctx_reserve(mapad_ctx_t* ctx, uint64_t n_reads, uint64_t total_bases, uint32_t max_read_len, int host_inputs);
 /* result accessors (fetch, compact, counters, kernel times, device pointers) read the batch submitted `age` calls before the most recent
  * one (0 = most recent; reset to 0 by every submission) */
 int mapad_ctx_select_batch(mapad_ctx_t* ctx, int age);
@@ -223,6 +236,9 @@ typedef struct mapad_records {
 int mapad_hits_to_records(const mapad_index_t* idx, const mapad_params_t* params, const mapad_batch_result_t* res, const uint8_t* seqs,
                           const uint8_t* quals, const uint64_t* offsets, const uint16_t* in_flags, uint64_t seed, mapad_records_t** out);
 void mapad_records_free(mapad_records_t* r);
+/* The seed to pass for a slice of a chunk that starts at read `first_read_index`, such that every read draws the same stand-in for
+ * rng.next_u32() (src/map/mapping.rs:605-607) as it would if the whole chunk were converted by one call with `seed`. */
+uint64_t mapad_records_seed_at(uint64_t seed, uint64_t first_read_index);
 
 /* ---- SA locate on the device ---------------------------------------------------------------------------
  * SampledSuffixArray::get (src/index/mod.rs:160-187) for a batch of BWT rows: LF walk to the next sampled row (or '$' row) in a

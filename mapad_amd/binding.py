@@ -109,10 +109,14 @@ SYMBOLS = {
     "mapad_ctx_prepare_lengths": (_i32, [_vp, _vp, _u32]),
     "mapad_map_batch": (_i32, [_vp, _vp, _vp, _vp, _u64, C.POINTER(C.POINTER(BatchResultC))]),
     "mapad_batch_result_free": (None, [C.POINTER(BatchResultC)]),
+    "mapad_submit_batch": (_i32, [_vp, _vp, _vp, _vp, _u64]),
+    "mapad_host_alloc": (_vp, [C.c_size_t]),
+    "mapad_host_free": (None, [_vp]),
     "mapad_map_batch_device": (_i32, [_vp, _vp, _vp, _vp, _u64, _u32]),
     "mapad_fetch_result": (_i32, [_vp, C.POINTER(C.POINTER(BatchResultC))]),
     "mapad_ctx_set_pipeline_depth": (_i32, [_vp, _i32]),
     "mapad_ctx_select_batch": (_i32, [_vp, _i32]),
+    "mapad_ctx_reserve": (_i32, [_vp, _u64, _u64, _u32, _i32]),
     "mapad_kernel_history": (_i32, [_vp, _vp, _u32, C.POINTER(_u32)]),
     "mapad_compact_result_device": (_i32, [_vp, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_u64), C.POINTER(_u64)]),
     "mapad_device_result_ptrs": (_i32, [_vp, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp)]),
@@ -121,6 +125,7 @@ SYMBOLS = {
     "mapad_last_launch_info": (_i32, [_vp, _vp]),
     "mapad_hits_to_records": (_i32, [_vp, _PP, C.POINTER(BatchResultC), _vp, _vp, _vp, _vp, _u64, C.POINTER(C.POINTER(RecordsC))]),
     "mapad_records_free": (None, [C.POINTER(RecordsC)]),
+    "mapad_records_seed_at": (_u64, [_u64, _u64]),
     "mapad_sa_locate": (_i32, [_vp, _vp, _u64, _vp]),
     "mapad_last_locate_info": (_i32, [_vp, C.POINTER(C.c_float), C.POINTER(_u64), C.POINTER(_u64)]),
     "mapad_hits_to_records_gpu": (_i32, [_vp, C.POINTER(BatchResultC), _vp, _vp, _vp, _vp, _u64, C.POINTER(C.POINTER(RecordsC))]),
@@ -346,6 +351,13 @@ class Context:
         _check(lib().mapad_map_batch(self.h, _ptr(seqs), _ptr(quals), _ptr(offsets), offsets.size - 1, C.byref(out)), "mapad_map_batch")
         return BatchResult(out, lib().mapad_batch_result_free)
 
+    def submit_batch(self, seqs, quals, offsets):
+        """asynchronous map_batch: returns once the reads are staged and the kernels are enqueued (collect with select_batch + fetch)"""
+        seqs = np.ascontiguousarray(seqs, dtype=np.uint8)
+        quals = np.ascontiguousarray(quals, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        _check(lib().mapad_submit_batch(self.h, _ptr(seqs), _ptr(quals), _ptr(offsets), offsets.size - 1), "mapad_submit_batch")
+
     def map_batch_device(self, d_seqs, d_quals, d_offsets, n_reads, max_read_len):
         _check(lib().mapad_map_batch_device(self.h, d_seqs, d_quals, d_offsets, n_reads, max_read_len), "mapad_map_batch_device")
 
@@ -356,6 +368,9 @@ class Context:
 
     def set_pipeline_depth(self, depth):
         _check(lib().mapad_ctx_set_pipeline_depth(self.h, int(depth)), "mapad_ctx_set_pipeline_depth")
+
+    def reserve(self, n_reads, total_bases, max_read_len, host_inputs=False):
+        _check(lib().mapad_ctx_reserve(self.h, int(n_reads), int(total_bases), int(max_read_len), int(host_inputs)), "mapad_ctx_reserve")
 
     def select_batch(self, age):
         _check(lib().mapad_ctx_select_batch(self.h, int(age)), "mapad_ctx_select_batch")

@@ -13,6 +13,7 @@
 #include <cstring>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <vector>
 
 namespace mapad {
@@ -35,6 +36,27 @@ public:
             if (buf_.size() == kBlock) flush_block();
         }
     }
+    // the same stream as write(), with the full blocks of a large buffer deflated by `threads` threads (BGZF blocks are independent)
+    void write_parallel(const void* p, size_t n, unsigned threads) {
+        const uint8_t* b = (const uint8_t*)p;
+        if (!buf_.empty()) {  // complete the block that is open
+            const size_t k = std::min(n, kBlock - buf_.size());
+            write(b, k);
+            b += k; n -= k;
+        }
+        const size_t n_blocks = n / kBlock;
+        if (n_blocks >= 2 && threads > 1) {
+            std::vector<std::vector<uint8_t>> outs(n_blocks);
+            threads = (unsigned)std::min<size_t>(threads, n_blocks);
+            std::vector<std::thread> pool;
+            for (unsigned t = 0; t < threads; ++t)
+                pool.emplace_back([&, t] { for (size_t i = t; i < n_blocks; i += threads) outs[i] = deflate_block(b + i * kBlock, kBlock); });
+            for (auto& th : pool) th.join();
+            for (auto& o : outs) if (std::fwrite(o.data(), 1, o.size(), f_) != o.size()) throw std::runtime_error("write failed");
+            b += n_blocks * kBlock; n -= n_blocks * kBlock;
+        }
+        write(b, n);
+    }
     void close() {
         if (!f_) return;
         if (!buf_.empty()) flush_block();
@@ -48,11 +70,11 @@ private:
     static constexpr size_t kBlock = 0xff00;
     FILE* f_ = nullptr;
     std::vector<uint8_t> buf_;
-    void flush_block() {
+    static std::vector<uint8_t> deflate_block(const uint8_t* data, size_t len) {
         std::vector<uint8_t> out(kBlock + 1024);
         z_stream zs{};
         if (deflateInit2(&zs, 6, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) throw std::runtime_error("deflateInit2");
-        zs.next_in = buf_.data(); zs.avail_in = (uInt)buf_.size();
+        zs.next_in = const_cast<uint8_t*>(data); zs.avail_in = (uInt)len;
         zs.next_out = out.data() + 18; zs.avail_out = (uInt)(out.size() - 18 - 8);
         if (deflate(&zs, Z_FINISH) != Z_STREAM_END) throw std::runtime_error("deflate");
         const size_t clen = zs.total_out;
@@ -60,10 +82,15 @@ private:
         const size_t bsize = clen + 18 + 8;
         const uint8_t hdr[18] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0, (uint8_t)((bsize - 1) & 0xff), (uint8_t)((bsize - 1) >> 8)};
         std::memcpy(out.data(), hdr, 18);
-        const uint32_t crc = (uint32_t)crc32(crc32(0, nullptr, 0), buf_.data(), (uInt)buf_.size()), isize = (uint32_t)buf_.size();
+        const uint32_t crc = (uint32_t)crc32(crc32(0, nullptr, 0), data, (uInt)len), isize = (uint32_t)len;
         std::memcpy(out.data() + 18 + clen, &crc, 4);
         std::memcpy(out.data() + 18 + clen + 4, &isize, 4);
-        if (std::fwrite(out.data(), 1, bsize, f_) != bsize) throw std::runtime_error("write failed");
+        out.resize(bsize);
+        return out;
+    }
+    void flush_block() {
+        const std::vector<uint8_t> out = deflate_block(buf_.data(), buf_.size());
+        if (std::fwrite(out.data(), 1, out.size(), f_) != out.size()) throw std::runtime_error("write failed");
         buf_.clear();
     }
 };

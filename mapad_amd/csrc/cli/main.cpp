@@ -2,17 +2,25 @@
 // (include/mapad_amd.h).  Everything a Rust `mapad` would do around the hot path is done here through the same extern "C"
 // calls a Rust caller would bind: index open/build, parameters, mapad_map_batch (GPU), mapad_hits_to_records_gpu (SA locate on the GPU), BAM output.
 //
-//   mapad-amd [--seed N] [--device K] index -g ref.fa
-//   mapad-amd [--seed N] [--device K] map -r reads.{bam,fastq,fastq.gz} -g ref.fa -o out.bam -l single_stranded|double_stranded
+//   mapad-amd [--seed N] [--devices K] index -g ref.fa
+//   mapad-amd [--seed N] [--devices 0-7 | 0,1,...] map -r reads.{bam,fastq,fastq.gz} -g ref.fa -o out.bam -l single_stranded|double_stranded
 //             -p 0.03 | (-c CUTOFF [-e EXP]) -f F -t T -d D -s S [-D 0.02] -i I [-x 1.0] [--batch_size 250000] [--ignore_base_quality]
 //             [--gap_dist_ends 5] [--max_num_gaps_open 2] [--no_search_limit_recovery] [--force_overwrite] [-R ID]
+#include <atomic>
 #include <chrono>
 #include <cmath>
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
+#include <deque>
 #include <fstream>
+#include <functional>
 #include <map>
+#include <memory>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../../include/mapad_amd.h"
@@ -81,7 +89,7 @@ std::string make_header(const std::string& src, const mapad_index_t* idx, const 
     return out;
 }
 
-int cmd_index(const Args& a, uint64_t seed) {
+int cmd_index(const Args& a, uint64_t seed, int device) {
     const std::string ref = a.get("reference");
     if (ref.empty()) die("index: -g/--reference is required");
     std::vector<std::string> names;
@@ -92,13 +100,113 @@ int cmd_index(const Args& a, uint64_t seed) {
     std::vector<uint64_t> lens;
     for (size_t i = 0; i < names.size(); ++i) { np.push_back(names[i].c_str()); sp.push_back(seqs[i].data()); lens.push_back(seqs[i].size()); }
     mapad_index_t* idx = nullptr;
-    check(mapad_index_build(np.data(), sp.data(), lens.data(), (uint32_t)names.size(), seed, &idx), "mapad_index_build");
+    // suffix sorting on the GPU when there is one (seconds for a 3 Gbp genome); the host SA-IS path builds the same files without a GPU
+    int rc = a.flag("host_index") ? MAPAD_ERR_NO_DEVICE : mapad_index_build_gpu(np.data(), sp.data(), lens.data(), (uint32_t)names.size(), seed, device, &idx);
+    if (rc == MAPAD_ERR_NO_DEVICE) rc = mapad_index_build(np.data(), sp.data(), lens.data(), (uint32_t)names.size(), seed, &idx);
+    check(rc, "mapad_index_build");
     check(mapad_index_save(idx, ref.c_str()), "mapad_index_save");  // files are named <reference>.{tbw,...} (indexing.rs:110-208)
     mapad_index_free(idx);
     return 0;
 }
 
-int cmd_map(const Args& a, uint64_t seed, int device, const std::string& cmdline) {
+// ---- `map`: a three-stage pipeline over chunks (run_inner's loop, src/map/mapping.rs:151-294) -------------------------------------------
+//   reader  : parses the next chunk of input records into page-locked buffers
+//   devices : one worker thread and one context per GPU; a chunk is cut into contiguous slices, one per device (the reference's rayon map over
+//             the chunk, order-preserving, mapping.rs:153-156,288).  A worker submits its slice of chunk k + 1 before it collects chunk k, so the
+//             GPU maps while the host turns the previous chunk's hits into records (SA locate on the same GPU, strings on host threads).
+//   writer  : encodes and BGZF-compresses the records of a finished chunk on several threads, writes them in input order.
+// Results reach the writer through page-locked host memory, each GPU over its own PCIe link; there is no GPU-to-GPU hop in a single process.
+template <class T>
+class BoundedQueue {
+public:
+    explicit BoundedQueue(size_t cap) : cap_(cap) {}
+    void push(T v) {
+        std::unique_lock<std::mutex> l(mu_);
+        not_full_.wait(l, [&] { return q_.size() < cap_; });
+        q_.push_back(std::move(v));
+        not_empty_.notify_all();
+    }
+    bool pop(T& out) {  // false: closed and drained
+        std::unique_lock<std::mutex> l(mu_);
+        not_empty_.wait(l, [&] { return !q_.empty() || closed_; });
+        if (q_.empty()) return false;
+        out = std::move(q_.front());
+        q_.pop_front();
+        not_full_.notify_all();
+        return true;
+    }
+    void close() { std::lock_guard<std::mutex> l(mu_); closed_ = true; not_empty_.notify_all(); }
+private:
+    size_t cap_;
+    std::deque<T> q_;
+    std::mutex mu_;
+    std::condition_variable not_full_, not_empty_;
+    bool closed_ = false;
+};
+
+struct PinnedBytes {  // page-locked byte buffer from the library (DMA at link speed)
+    uint8_t* p = nullptr;
+    size_t n = 0, cap = 0;
+    void append(const void* src, size_t k) {
+        if (n + k > cap) {
+            const size_t want = std::max<size_t>((n + k) * 2, 1 << 20);
+            uint8_t* q = (uint8_t*)mapad_host_alloc(want);
+            if (!q) die("out of page-locked host memory");
+            if (n) std::memcpy(q, p, n);
+            mapad_host_free(p);
+            p = q; cap = want;
+        }
+        if (k) std::memcpy(p + n, src, k);
+        n += k;
+    }
+    ~PinnedBytes() { mapad_host_free(p); }
+};
+
+struct Slice {
+    uint64_t lo = 0, hi = 0;  // reads [lo, hi) of the chunk's mappable reads
+    std::vector<uint64_t> offsets;  // rebased to the slice
+    mapad_batch_result_t* res = nullptr;
+    mapad_records_t* recs = nullptr;
+};
+struct Chunk {
+    uint64_t no = 0;
+    std::vector<InRecord> in;        // every input record, in input order
+    std::vector<int64_t> read_of;    // per input record: its index among the mapped reads, -1 if it cannot be mapped (empty / longer than the device limit)
+    PinnedBytes seqs, quals;         // mapped reads, concatenated
+    std::vector<uint64_t> offsets;
+    std::vector<uint16_t> flags;
+    std::vector<Slice> slices;
+    std::atomic<int> pending{0};
+    std::chrono::steady_clock::time_point t_submit;
+    float per_read_s = 0.0f;
+};
+using ChunkPtr = std::shared_ptr<Chunk>;
+
+std::vector<int> parse_devices(const std::string& spec) {  // "0", "0,2,3", "0-7"
+    std::vector<int> out;
+    size_t i = 0;
+    while (i < spec.size()) {
+        size_t j = i;
+        while (j < spec.size() && spec[j] != ',') ++j;
+        const std::string tok = spec.substr(i, j - i);
+        const size_t dash = tok.find('-');
+        if (dash != std::string::npos && dash > 0) { for (int d = std::atoi(tok.substr(0, dash).c_str()); d <= std::atoi(tok.substr(dash + 1).c_str()); ++d) out.push_back(d); }
+        else if (!tok.empty()) out.push_back(std::atoi(tok.c_str()));
+        i = j + 1;
+    }
+    if (out.empty()) die("--devices: empty device list");
+    return out;
+}
+
+void parallel_for(size_t n, unsigned threads, const std::function<void(size_t, size_t, unsigned)>& fn) {  // contiguous ranges
+    threads = (unsigned)std::max<size_t>(1, std::min<size_t>(threads, n));
+    if (threads == 1) { fn(0, n, 0); return; }
+    std::vector<std::thread> pool;
+    for (unsigned t = 0; t < threads; ++t) pool.emplace_back([&, t] { fn(n * t / threads, n * (t + 1) / threads, t); });
+    for (auto& th : pool) th.join();
+}
+
+int cmd_map(const Args& a, uint64_t seed, const std::vector<int>& devices, const std::string& cmdline) {
     for (const char* req : {"reads", "reference", "output", "library", "five_prime_overhang", "ds_deamination_rate", "ss_deamination_rate", "indel_rate"})
         if (!a.has(req)) die(std::string("map: --") + req + " is required");
     if (!a.has("poisson_prob") && !a.has("as_cutoff")) die("map: either -p or -c is required");
@@ -112,11 +220,19 @@ int cmd_map(const Args& a, uint64_t seed, int device, const std::string& cmdline
                                 a.f("gap_extension_penalty", 1.0f), std::atoi(a.get("gap_dist_ends", "5").c_str()), std::atoi(a.get("max_num_gaps_open", "2").c_str()),
                                 a.flag("ignore_base_quality"), a.flag("no_search_limit_recovery"), std::strtoull(a.get("chunk_size", "250000").c_str(), nullptr, 10)),
           "mapad_params_from_cli");
+    const auto t_start = std::chrono::steady_clock::now();
     mapad_index_t* idx = nullptr;
     check(mapad_index_open(a.get("reference").c_str(), &idx), "mapad_index_open");
-    mapad_ctx_t* ctx = nullptr;
-    check(mapad_ctx_create(idx, &prm, device, &ctx), "mapad_ctx_create");
-    check(mapad_ctx_set_fetch_d_arrays(ctx, 0), "mapad_ctx_set_fetch_d_arrays");
+    const size_t n_dev = devices.size();
+    std::vector<mapad_ctx_t*> ctxs(n_dev, nullptr);
+    for (size_t d = 0; d < n_dev; ++d) {  // the read-only index is replicated into every GPU's HBM
+        check(mapad_ctx_create(idx, &prm, devices[d], &ctxs[d]), "mapad_ctx_create");
+        check(mapad_ctx_set_fetch_d_arrays(ctxs[d], 0), "mapad_ctx_set_fetch_d_arrays");
+        check(mapad_ctx_set_pipeline_depth(ctxs[d], 2), "mapad_ctx_set_pipeline_depth");
+        const uint64_t per_dev = (prm.chunk_size + n_dev - 1) / n_dev;  // both batch slots' buffers up front (typical short reads; longer ones grow them)
+        check(mapad_ctx_reserve(ctxs[d], per_dev, per_dev * 64, 128, 1), "mapad_ctx_reserve");
+    }
+    const double t_load = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
     ReadSource src(a.get("reads"));
     const std::string rg = a.get("read_group");
     BgzfWriter out(a.get("output"), a.flag("force_overwrite"));
@@ -137,50 +253,159 @@ int cmd_map(const Args& a, uint64_t seed, int device, const std::string& cmdline
         }
         out.write(h.data(), h.size());
     }
-    uint64_t n_total = 0, n_mapped = 0, chunk_no = 0;
-    std::vector<InRecord> chunk;
-    std::vector<uint8_t> seqs, quals, enc;
-    std::vector<uint64_t> offsets;
-    std::vector<uint16_t> flags;
-    bool more = true;
-    while (more) {  // run_inner's chunk loop (mapping.rs:151-294): map a chunk, write it in input order
-        chunk.clear(); seqs.clear(); quals.clear(); offsets.assign(1, 0); flags.clear();
-        InRecord r;
-        while (chunk.size() < prm.chunk_size && (more = src.next(r))) {
-            if (r.seq.size() > MAPAD_MAX_READ_LEN) { std::fprintf(stderr, "Skip record due to an error: read \"%s\" is longer than %d bp\n", r.name.c_str(), MAPAD_MAX_READ_LEN); continue; }
-            seqs.insert(seqs.end(), r.seq.begin(), r.seq.end());
-            quals.insert(quals.end(), r.qual.begin(), r.qual.end());
-            offsets.push_back(seqs.size());
-            flags.push_back(r.flags);
-            chunk.push_back(std::move(r));
-        }
-        if (chunk.empty()) break;
-        const auto t0 = std::chrono::steady_clock::now();
-        mapad_batch_result_t* res = nullptr;
-        check(mapad_map_batch(ctx, seqs.data(), quals.data(), offsets.data(), chunk.size(), &res), "mapad_map_batch");
-        const float per_read_s = std::chrono::duration<float>(std::chrono::steady_clock::now() - t0).count() / (float)chunk.size();
-        mapad_records_t* recs = nullptr;
-        check(mapad_hits_to_records_gpu(ctx, res, seqs.data(), quals.data(), offsets.data(), flags.data(), seed + chunk_no, &recs), "mapad_hits_to_records_gpu");
-        enc.clear();
-        for (size_t i = 0; i < chunk.size(); ++i) {
-            const mapad_record_t& c = recs->recs[i];
-            OutFields f;
-            f.mapped = c.mapped; f.reverse = c.reverse; f.flags = c.flags; f.tid = c.tid; f.pos = c.pos; f.mapq = c.mapq;
-            f.cigar.assign(recs->text + c.cigar_off, c.cigar_len); f.md.assign(recs->text + c.md_off, c.md_len); f.xa.assign(recs->text + c.xa_off, c.xa_len);
-            f.as = c.as_score; f.xs = c.xs_score; f.nm = c.nm; f.x0 = c.x0; f.x1 = c.x1; f.has_xs = c.has_xs; f.has_alt = c.mapped; f.xt = c.xt;
-            f.xd = per_read_s;  // the reference stores the wall time of each read's search (mapping.rs:912-918); here: chunk time / reads
-            encode_bam_record(chunk[i], f, rg, enc);
-            n_mapped += c.mapped;
-        }
-        out.write(enc.data(), enc.size());
-        n_total += chunk.size();
-        chunk_no += 1;
-        mapad_records_free(recs);
-        mapad_batch_result_free(res);
-    }
+    const unsigned host_threads = std::max(1u, std::min(std::thread::hardware_concurrency(), 32u));
+    std::vector<std::unique_ptr<BoundedQueue<ChunkPtr>>> dev_q;
+    for (size_t d = 0; d < n_dev; ++d) dev_q.emplace_back(new BoundedQueue<ChunkPtr>(2));
+    BoundedQueue<ChunkPtr> done_q(4);
+    std::atomic<bool> failed{false};
+    std::string fail_msg;
+    std::mutex fail_mu;
+    auto fail = [&](const std::string& m) { std::lock_guard<std::mutex> l(fail_mu); if (!failed.exchange(true)) fail_msg = m; };
+
+    // ---- reader ----
+    std::thread reader([&] {
+        try {
+            uint64_t chunk_no = 0;
+            bool more = true;
+            while (more && !failed) {
+                auto c = std::make_shared<Chunk>();
+                c->no = chunk_no;
+                c->offsets.assign(1, 0);
+                size_t bases = 0;
+                InRecord r;
+                while (c->in.size() < prm.chunk_size && (more = src.next(r))) {
+                    // Reads the device cannot take (longer than MAPAD_MAX_READ_LEN; the reference's limit is i16::MAX, src/map/record.rs:144-150) and empty
+                    // reads stay in the output as unmapped records, so that input and output hold the same number of records.
+                    const bool mappable = !r.seq.empty() && r.seq.size() <= MAPAD_MAX_READ_LEN;
+                    if (!mappable) std::fprintf(stderr, "mapad-amd: read \"%s\" (%zu bp) is %s; written as unmapped\n", r.name.c_str(), r.seq.size(), r.seq.empty() ? "empty" : "longer than the device limit");
+                    c->read_of.push_back(mappable ? (int64_t)(c->offsets.size() - 1) : -1);
+                    if (mappable) {
+                        c->seqs.append(r.seq.data(), r.seq.size()); c->quals.append(r.qual.data(), r.seq.size());
+                        bases += r.seq.size();
+                        c->offsets.push_back(bases);
+                        c->flags.push_back(r.flags);
+                    }
+                    c->in.push_back(std::move(r));
+                }
+                if (c->in.empty()) break;
+                const uint64_t n_reads = c->offsets.size() - 1;
+                c->slices.resize(n_dev);
+                for (size_t d = 0; d < n_dev; ++d) {  // contiguous slices: concatenation in device order = input order
+                    Slice& sl = c->slices[d];
+                    const uint64_t base = n_reads / n_dev, extra = n_reads % n_dev;
+                    sl.lo = d * base + std::min<uint64_t>(d, extra); sl.hi = sl.lo + base + (d < extra ? 1 : 0);
+                    sl.offsets.resize(sl.hi - sl.lo + 1);
+                    for (uint64_t i = sl.lo; i <= sl.hi; ++i) sl.offsets[i - sl.lo] = c->offsets[i] - c->offsets[sl.lo];
+                }
+                c->pending = (int)n_dev;
+                c->t_submit = std::chrono::steady_clock::now();
+                for (size_t d = 0; d < n_dev; ++d) dev_q[d]->push(c);
+                chunk_no += 1;
+            }
+        } catch (const std::exception& e) { fail(e.what()); }
+        for (auto& q : dev_q) q->close();
+    });
+
+    // ---- device workers ----
+    auto worker = [&](size_t d) {
+        mapad_ctx_t* ctx = ctxs[d];
+        auto submit = [&](const ChunkPtr& c) {
+            const Slice& sl = c->slices[d];
+            const uint64_t b0 = c->offsets[sl.lo];
+            check(mapad_submit_batch(ctx, c->seqs.p + b0, c->quals.p + b0, sl.offsets.data(), sl.hi - sl.lo), "mapad_submit_batch");
+        };
+        auto records = [&](const ChunkPtr& c) {
+            Slice& sl = c->slices[d];
+            const uint64_t b0 = c->offsets[sl.lo];
+            // one seed per read of the run, whichever device maps it: the chunk's seed advanced to the slice's first read
+            check(mapad_hits_to_records_gpu(ctx, sl.res, c->seqs.p + b0, c->quals.p + b0, sl.offsets.data(), c->flags.data() + sl.lo,
+                                            mapad_records_seed_at(seed + c->no, sl.lo), &sl.recs), "mapad_hits_to_records_gpu");
+            if (--c->pending == 0) {
+                c->per_read_s = std::chrono::duration<float>(std::chrono::steady_clock::now() - c->t_submit).count() / (float)std::max<size_t>(c->in.size(), 1);
+                done_q.push(c);
+            }
+        };
+        auto collect = [&](const ChunkPtr& c, int age) -> bool {  // false: the hit pools were too small for this slice
+            check(mapad_ctx_select_batch(ctx, age), "mapad_ctx_select_batch");
+            const int rc = mapad_fetch_result(ctx, &c->slices[d].res);
+            if (rc == MAPAD_ERR_NOMEM) return false;
+            check(rc, "mapad_fetch_result");
+            return true;
+        };
+        auto rerun = [&](const ChunkPtr& c) {  // synchronous path that grows the pools
+            const Slice& sl = c->slices[d];
+            const uint64_t b0 = c->offsets[sl.lo];
+            check(mapad_map_batch(ctx, c->seqs.p + b0, c->quals.p + b0, sl.offsets.data(), sl.hi - sl.lo, &c->slices[d].res), "mapad_map_batch");
+        };
+        try {
+            ChunkPtr prev, c;
+            while (dev_q[d]->pop(c)) {
+                if (failed) continue;
+                submit(c);                       // the GPU starts on chunk k + 1 ...
+                if (prev) {                      // ... while chunk k is collected and turned into records
+                    if (collect(prev, 1)) records(prev);
+                    else {                       // rare: finish the newer batch first, then repair the older one synchronously
+                        const bool ok = collect(c, 0);
+                        rerun(prev); records(prev);
+                        if (!ok) rerun(c);
+                        records(c);
+                        c.reset();
+                    }
+                }
+                prev = c;
+            }
+            if (prev && !failed) { if (!collect(prev, 0)) rerun(prev); records(prev); }
+        } catch (const std::exception& e) { fail(e.what()); }
+    };
+    std::vector<std::thread> workers;
+    for (size_t d = 0; d < n_dev; ++d) workers.emplace_back(worker, d);
+
+    // ---- writer ----
+    uint64_t n_total = 0, n_mapped = 0;
+    std::thread writer([&] {
+        try {
+            ChunkPtr c;
+            while (done_q.pop(c)) {
+                if (failed) continue;
+                const size_t n = c->in.size();
+                std::vector<std::vector<uint8_t>> enc(host_threads);
+                std::vector<uint64_t> mapped(host_threads, 0);
+                parallel_for(n, host_threads, [&](size_t lo, size_t hi, unsigned t) {
+                    size_t d = 0;
+                    for (size_t i = lo; i < hi; ++i) {
+                        OutFields f;
+                        const int64_t r = c->read_of[i];
+                        if (r < 0) f.flags = (uint16_t)((c->in[i].flags & ~(0x8 | 0x20 | 0x2 | 0x100 | 0x800 | 0x10)) | 0x4);  // unmapped (mapping.rs:748-776)
+                        else {
+                            while ((uint64_t)r >= c->slices[d].hi) ++d;
+                            const mapad_records_t* recs = c->slices[d].recs;
+                            const mapad_record_t& m = recs->recs[(uint64_t)r - c->slices[d].lo];
+                            f.mapped = m.mapped; f.reverse = m.reverse; f.flags = m.flags; f.tid = m.tid; f.pos = m.pos; f.mapq = m.mapq;
+                            f.cigar.assign(recs->text + m.cigar_off, m.cigar_len); f.md.assign(recs->text + m.md_off, m.md_len); f.xa.assign(recs->text + m.xa_off, m.xa_len);
+                            f.as = m.as_score; f.xs = m.xs_score; f.nm = m.nm; f.x0 = m.x0; f.x1 = m.x1; f.has_xs = m.has_xs; f.has_alt = m.mapped; f.xt = m.xt;
+                            mapped[t] += m.mapped;
+                        }
+                        f.xd = c->per_read_s;  // the reference stores the wall time of each read's search (mapping.rs:912-918); here: chunk time / reads
+                        encode_bam_record(c->in[i], f, rg, enc[t]);
+                    }
+                });
+                for (unsigned t = 0; t < host_threads; ++t) { out.write_parallel(enc[t].data(), enc[t].size(), host_threads); n_mapped += mapped[t]; }
+                n_total += n;
+                for (auto& sl : c->slices) { mapad_records_free(sl.recs); mapad_batch_result_free(sl.res); sl.recs = nullptr; sl.res = nullptr; }
+            }
+        } catch (const std::exception& e) { fail(e.what()); }
+    });
+
+    reader.join();
+    for (auto& w : workers) w.join();
+    done_q.close();
+    writer.join();
+    if (failed) die(fail_msg);
     out.close();
-    std::fprintf(stderr, "mapad-amd: %llu reads, %llu mapped\n", (unsigned long long)n_total, (unsigned long long)n_mapped);
-    mapad_ctx_destroy(ctx);
+    const double t_all = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
+    std::fprintf(stderr, "mapad-amd: %llu reads, %llu mapped; %zu device(s); index + contexts %.2f s, mapping %.2f s (%.0f reads/s)\n", (unsigned long long)n_total,
+                 (unsigned long long)n_mapped, n_dev, t_load, t_all - t_load, (double)n_total / std::max(t_all - t_load, 1e-9));
+    for (auto* c : ctxs) mapad_ctx_destroy(c);
     mapad_index_free(idx);
     return 0;
 }
@@ -216,7 +441,7 @@ int main(int argc, char** argv) {
         {"-g", "reference"}, {"-r", "reads"}, {"-o", "output"}, {"-p", "poisson_prob"}, {"-c", "as_cutoff"}, {"-e", "as_cutoff_exponent"}, {"-l", "library"},
         {"-f", "five_prime_overhang"}, {"-t", "three_prime_overhang"}, {"-d", "ds_deamination_rate"}, {"-s", "ss_deamination_rate"}, {"-D", "divergence"},
         {"-i", "indel_rate"}, {"-x", "gap_extension_penalty"}, {"-R", "read_group"}};
-    static const std::vector<std::string> bool_flags = {"ignore_base_quality", "no_search_limit_recovery", "force_overwrite"};
+    static const std::vector<std::string> bool_flags = {"ignore_base_quality", "no_search_limit_recovery", "force_overwrite", "host_index"};
     std::string cmdline, sub;
     for (int i = 0; i < argc; ++i) cmdline += std::string(i ? " " : "") + argv[i];
     Args a;
@@ -235,11 +460,11 @@ int main(int argc, char** argv) {
         else { if (i + 1 >= argc) die("missing value for " + k); a.kv[key] = argv[++i]; }
     }
     const uint64_t seed = std::strtoull(a.get("seed", "1234").c_str(), nullptr, 10);
-    const int device = std::atoi(a.get("device", "0").c_str());
+    const std::vector<int> devices = parse_devices(a.get("devices", a.get("device", "0")));
     try {
-        if (sub == "index") return cmd_index(a, seed);
-        if (sub == "map") return cmd_map(a, seed, device, cmdline);
+        if (sub == "index") return cmd_index(a, seed, devices[0]);
+        if (sub == "map") return cmd_map(a, seed, devices, cmdline);
         if (sub == "recode") return cmd_recode(a);
-        die("usage: mapad-amd [--seed N] [--device K] index|map ...");
+        die("usage: mapad-amd [--seed N] [--devices 0[,1,...|-7]] index|map ...");
     } catch (const std::exception& e) { die(e.what()); }
 }

@@ -13,7 +13,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <memory>
+#include <mutex>
 #include <new>
 #include <set>
 #include <string>
@@ -848,26 +850,30 @@ int acquire_slot(mapad_ctx* c, int k) {
     return MAPAD_OK;
 }
 
-int launch_batch(mapad_ctx* c, BatchSlot& S, const uint8_t* d_seqs, const uint8_t* d_quals, const uint64_t* d_offsets, uint64_t n_reads, uint64_t total_bases,
-                 uint32_t lmax) {
+// Device buffers of a batch of n_reads reads / total_bases bases / reads up to lmax long in slot S (allocation only; hipMalloc may wait
+// for running kernels, so a pipelined caller reserves every slot up front: mapad_ctx_reserve).
+int ensure_batch_buffers(mapad_ctx* c, BatchSlot& S, uint64_t n_reads, uint64_t total_bases, uint32_t lmax, bool host_inputs) {
     int rc;
     if ((rc = upload_tables(c))) return rc;
     if ((rc = ensure_arenas(c, S, lmax, n_reads))) return rc;
     const size_t nr = std::max<uint64_t>(n_reads, 1);
+    if (host_inputs) {
+        if ((rc = S.d_seqs.ensure(std::max<uint64_t>(total_bases, 1)))) return rc;
+        if ((rc = S.d_quals.ensure(std::max<uint64_t>(total_bases, 1)))) return rc;
+        if ((rc = S.d_offsets.ensure(n_reads + 1))) return rc;
+    }
     if ((rc = S.d_darr.ensure(std::max<uint64_t>(total_bases, 1)))) return rc;
     if ((rc = S.d_counters.ensure(nr))) return rc;
     if ((rc = S.d_status.ensure(nr))) return rc;
     if ((rc = S.d_hit_count.ensure(nr))) return rc;
     if ((rc = S.d_hit_first.ensure(nr))) return rc;
     if ((rc = S.d_overflow.ensure(nr * kStages))) return rc;
-    const bool ordered = env_u32("MAPAD_ORDER", 1) != 0;
     const uint32_t order_shift = std::min<uint32_t>(std::max<uint32_t>(env_u32("MAPAD_ORDER_CHUNK_LOG2", 20), 10), 31);
     const uint32_t n_chunks = (uint32_t)((nr + (1ull << order_shift) - 1) >> order_shift);
-    if (ordered) {
+    if (env_u32("MAPAD_ORDER", 1) != 0) {
         if ((rc = S.d_sort_key.ensure(nr))) return rc;
         if ((rc = S.d_order.ensure(nr))) return rc;
         if ((rc = S.d_key_hist.ensure((size_t)n_chunks * kKeyBins))) return rc;
-        HIP_TRY(hipMemsetAsync(S.d_key_hist.p, 0, (size_t)n_chunks * kKeyBins * 4, S.stream));
     }
     if ((rc = S.d_cursors.ensure(CUR_COUNT))) return rc;
     // 2 hits per read on average + slack; MAPAD_HIT_POOL (test hook) starts smaller so that the retry of mapad_map_batch is exercised
@@ -875,6 +881,20 @@ int launch_batch(mapad_ctx* c, BatchSlot& S, const uint8_t* d_seqs, const uint8_
     const size_t ops_cap = std::max(S.d_ops.cap, hits_cap * (size_t)(std::min<uint32_t>(lmax, 256) + 8));
     if ((rc = S.d_hits.ensure(hits_cap))) return rc;
     if ((rc = S.d_ops.ensure(ops_cap))) return rc;
+    return MAPAD_OK;
+}
+
+// warm: an empty launch of the search kernels only (mapad_ctx_reserve): the first dispatch on a stream that needs scratch memory sets up the
+// queue's scratch ring, which waits for kernels running on other queues — better paid before the pipeline starts.
+int launch_batch(mapad_ctx* c, BatchSlot& S, const uint8_t* d_seqs, const uint8_t* d_quals, const uint64_t* d_offsets, uint64_t n_reads, uint64_t total_bases,
+                 uint32_t lmax, bool warm = false) {
+    int rc;
+    if ((rc = ensure_batch_buffers(c, S, n_reads, total_bases, lmax, false))) return rc;
+    const size_t nr = std::max<uint64_t>(n_reads, 1);
+    const bool ordered = env_u32("MAPAD_ORDER", 1) != 0;
+    const uint32_t order_shift = std::min<uint32_t>(std::max<uint32_t>(env_u32("MAPAD_ORDER_CHUNK_LOG2", 20), 10), 31);
+    const uint32_t n_chunks = (uint32_t)((nr + (1ull << order_shift) - 1) >> order_shift);
+    if (ordered) HIP_TRY(hipMemsetAsync(S.d_key_hist.p, 0, (size_t)n_chunks * kKeyBins * 4, S.stream));
     HIP_TRY(hipMemsetAsync(S.d_cursors.p, 0, CUR_COUNT * 4, S.stream));
     HIP_TRY(hipMemsetAsync(S.d_status.p, 0, nr * 4, S.stream));
     BatchDev B{};
@@ -887,21 +907,23 @@ int launch_batch(mapad_ctx* c, BatchSlot& S, const uint8_t* d_seqs, const uint8_
     B.sort_key = ordered ? S.d_sort_key.p : nullptr; B.key_hist = ordered ? S.d_key_hist.p : nullptr; B.order = ordered ? S.d_order.p : nullptr;
     B.order_shift = order_shift;
     S.last = B; S.last_total_bases = total_bases; S.last_lmax = lmax; S.compacted = false;
-    if (n_reads == 0) return MAPAD_OK;
+    if (n_reads == 0 && !warm) return MAPAD_OK;
     const uint32_t lds_lmax = std::max<uint32_t>(lmax, 1);
     const size_t lds_bytes = (size_t)16 * lds_lmax * sizeof(float);
     const uint32_t grid_d = (uint32_t)std::min<uint64_t>(n_reads, (uint64_t)c->n_cu * 32);
     for (auto& e : S.ev) if (!e) HIP_TRY(hipEventCreate(&e));
-    if (!c->ev_ref) { HIP_TRY(hipEventCreate(&c->ev_ref)); HIP_TRY(hipEventRecord(c->ev_ref, S.stream)); c->history.clear(); }
-    HIP_TRY(hipEventRecord(S.ev[0], S.stream));
-    hipLaunchKernelGGL(darray_kernel, dim3(grid_d), dim3(64), lds_bytes, S.stream, c->dix, c->dprm, B, (int)lds_lmax);
-    HIP_TRY(hipGetLastError());
-    if (ordered) {
+    if (!warm) {
+        if (!c->ev_ref) { HIP_TRY(hipEventCreate(&c->ev_ref)); HIP_TRY(hipEventRecord(c->ev_ref, S.stream)); c->history.clear(); }
+        HIP_TRY(hipEventRecord(S.ev[0], S.stream));
+        hipLaunchKernelGGL(darray_kernel, dim3(grid_d), dim3(64), lds_bytes, S.stream, c->dix, c->dprm, B, (int)lds_lmax);
+        HIP_TRY(hipGetLastError());
+    }
+    if (ordered && !warm) {
         hipLaunchKernelGGL(order_scan_kernel, dim3(1), dim3(64), 0, S.stream, S.d_key_hist.p, n_chunks);
         hipLaunchKernelGGL(order_scatter_kernel, dim3((uint32_t)((n_reads + 1023) / 1024)), dim3(1024), 0, S.stream, B);
         HIP_TRY(hipGetLastError());
     }
-    HIP_TRY(hipEventRecord(S.ev[1], S.stream));
+    if (!warm) HIP_TRY(hipEventRecord(S.ev[1], S.stream));
     const uint32_t rpw = 64 / c->lpr;  // reads per wavefront
     // near data in LDS (16 read slots per wavefront) unless the batch has very long reads or every lane owns a read
     const uint32_t near_lmax = std::max<uint32_t>(lmax, 1);
@@ -916,7 +938,13 @@ int launch_batch(mapad_ctx* c, BatchSlot& S, const uint8_t* d_seqs, const uint8_
     else if (c->lpr == 4) { if (!cont) MAPAD_LAUNCH(4, false, P, false); else MAPAD_LAUNCH(4, true, P, false); }          \
     else if (near_stride) { if (!cont) MAPAD_LAUNCH(1, false, P, true); else MAPAD_LAUNCH(1, true, P, true); }              \
     else { if (!cont) MAPAD_LAUNCH(1, false, P, false); else MAPAD_LAUNCH(1, true, P, false); }
-    const uint32_t grid_s = (uint32_t)std::min<uint64_t>((n_reads + rpw - 1) / rpw, c->slots[0] / rpw);
+    // A launch alone on the chip fills it (16 wavefronts per CU at 128 VGPRs).  While another batch is still running, a launch takes half: two
+    // bulks then share the chip all the time and a launch that is down to its tail does not hold the next one back (measured, C2, per 1 M reads:
+    // 16 per CU x 2 batches in flight 273 ms, 8 x 2 247 ms, 8 x 3 252 ms; C3: 8 x 2 589 ms, 8 x 3 529 ms).
+    bool others_running = false;
+    for (auto& o : c->bs) if (&o != &S && o.ev_valid && hipEventQuery(o.ev[3]) == hipErrorNotReady) others_running = true;
+    const uint32_t full_waves = c->slots[0] / rpw, shared_waves = std::max<uint32_t>(1, std::min<uint32_t>(full_waves, env_u32("MAPAD_SHARED_WAVES_PER_CU", 8) * (uint32_t)c->n_cu));
+    const uint32_t grid_s = warm ? 1u : (uint32_t)std::min<uint64_t>((n_reads + rpw - 1) / rpw, others_running ? shared_waves : full_waves);
     for (int stage = 0; stage + 1 < kStages; ++stage) {  // every read, then the reads that gave up waiting (normally none: the launch exits at once)
         const uint32_t grid = grid_s;
         ArenaPool ap = c->pool[0];
@@ -924,10 +952,10 @@ int launch_batch(mapad_ctx* c, BatchSlot& S, const uint8_t* d_seqs, const uint8_
         if (stage == 0) { MAPAD_LAUNCH_PASS(0) } else { MAPAD_LAUNCH_PASS(2) }  // PASS 2 = PASS 0 under its own symbol, so that profiles keep the passes apart
         HIP_TRY(hipGetLastError());
     }
-    HIP_TRY(hipEventRecord(S.ev[2], S.stream));
+    if (!warm) HIP_TRY(hipEventRecord(S.ev[2], S.stream));
     {   // leftovers with the reference's full limits
         const int stage = kStages - 1;
-        const uint32_t grid = (uint32_t)std::min<uint64_t>((n_reads + rpw - 1) / rpw, c->slots[1] / rpw);
+        const uint32_t grid = warm ? 1u : (uint32_t)std::min<uint64_t>((n_reads + rpw - 1) / rpw, c->slots[1] / rpw);
         ArenaPool ap = c->pool[1];
         ap.base = S.d_arena[1].p;
         MAPAD_LAUNCH_PASS(1)
@@ -935,6 +963,7 @@ int launch_batch(mapad_ctx* c, BatchSlot& S, const uint8_t* d_seqs, const uint8_
     }
 #undef MAPAD_LAUNCH_PASS
 #undef MAPAD_LAUNCH
+    if (warm) return MAPAD_OK;
     HIP_TRY(hipEventRecord(S.ev[3], S.stream));
     S.ev_valid = true; S.timed = false;
     S.launch_info[0] = grid_d; S.launch_info[1] = 64; S.launch_info[2] = (uint32_t)lds_bytes;
@@ -973,13 +1002,68 @@ int compact_last(mapad_ctx* c) {
     return MAPAD_OK;
 }
 
+// Page-locked host memory for everything that crosses PCIe (results out, staged inputs in): DMA at link speed instead of the driver's
+// staged copies of pageable memory.  Pinning is slow (the pages are locked one by one), so blocks are recycled: power-of-two sizes, a few
+// kept per size, process-wide (results may outlive the context they came from).
+class PinnedPool {
+public:
+    static PinnedPool& instance() { static PinnedPool p; return p; }
+    void* take(size_t bytes, size_t& got) {
+        size_t cap = 1 << 16;
+        while (cap < bytes) cap <<= 1;
+        got = cap;
+        {
+            std::lock_guard<std::mutex> g(mu_);
+            auto& fl = free_[cap];
+            if (!fl.empty()) { void* p = fl.back(); fl.pop_back(); return p; }
+        }
+        void* p = nullptr;
+        if (hipHostMalloc(&p, cap, hipHostMallocPortable) != hipSuccess) return nullptr;
+        return p;
+    }
+    void give(void* p, size_t cap) {
+        if (!p) return;
+        {
+            std::lock_guard<std::mutex> g(mu_);
+            auto& fl = free_[cap];
+            if (fl.size() < 6) { fl.push_back(p); return; }
+        }
+        (void)hipHostFree(p);
+    }
+private:
+    std::mutex mu_;
+    std::map<size_t, std::vector<void*>> free_;
+};
+template <class T>
+struct PinnedBuf {
+    T* p = nullptr;
+    size_t n = 0, cap_bytes = 0;
+    PinnedBuf() = default;
+    PinnedBuf(const PinnedBuf&) = delete;
+    PinnedBuf& operator=(const PinnedBuf&) = delete;
+    bool resize(size_t count) {
+        if (count * sizeof(T) > cap_bytes) {
+            PinnedPool::instance().give(p, cap_bytes);
+            p = (T*)PinnedPool::instance().take(std::max<size_t>(count * sizeof(T), 1), cap_bytes);
+            if (!p) { cap_bytes = 0; n = 0; return false; }
+        }
+        n = count;
+        return true;
+    }
+    T* data() { return p; }
+    size_t size() const { return n; }
+    bool empty() const { return n == 0; }
+    T& operator[](size_t i) { return p[i]; }
+    ~PinnedBuf() { PinnedPool::instance().give(p, cap_bytes); }
+};
+
 struct HostResult {
     mapad_batch_result_t pub{};
-    std::vector<uint64_t> hit_begin;
-    std::vector<mapad_hit_t> hits;
-    std::vector<uint32_t> ops, status;
-    std::vector<mapad_read_counters_t> counters;
-    std::vector<float> d_arrays;
+    PinnedBuf<uint64_t> hit_begin;
+    PinnedBuf<mapad_hit_t> hits;
+    PinnedBuf<uint32_t> ops, status;
+    PinnedBuf<mapad_read_counters_t> counters;
+    PinnedBuf<float> d_arrays;
 };
 static_assert(sizeof(mapad_hit_t) == sizeof(HitRec), "public hit record == device hit record");
 static_assert(sizeof(mapad_read_counters_t) == sizeof(ReadCounters), "counter layout");
@@ -1162,11 +1246,13 @@ int mapad_map_batch_device(mapad_ctx_t* ctx, const void* d_seqs, const void* d_q
     if (max_read_len > MAPAD_MAX_READ_LEN) return MAPAD_ERR_READ_TOO_LONG;
     if (n_reads >= 0xFFFFFFF0ull) return MAPAD_ERR_INVALID;
     if (hipSetDevice(ctx->device) != hipSuccess) return MAPAD_ERR_NO_DEVICE;
-    uint64_t total = 0;
-    if (n_reads) HIP_TRY(hipMemcpyAsync(&total, (const uint64_t*)d_offsets + n_reads, 8, hipMemcpyDeviceToHost, ctx->stream));
-    if (n_reads) HIP_TRY(hipStreamSynchronize(ctx->stream));
     int rc;
     if ((rc = acquire_slot(ctx, (ctx->cur + 1) % ctx->depth))) return rc;  // batches rotate through the slots: this one runs beside the previous one's tail
+    // the batch's base count, read on the slot's own (idle) stream: a copy on the caller's stream would wait for whatever that stream orders
+    // itself behind (the legacy default stream: every blocking stream)
+    uint64_t total = 0;
+    if (n_reads) HIP_TRY(hipMemcpyAsync(&total, (const uint64_t*)d_offsets + n_reads, 8, hipMemcpyDeviceToHost, ctx->bs[ctx->cur].stream));
+    if (n_reads) HIP_TRY(hipStreamSynchronize(ctx->bs[ctx->cur].stream));
     return launch_batch(ctx, ctx->bs[ctx->cur], (const uint8_t*)d_seqs, (const uint8_t*)d_quals, (const uint64_t*)d_offsets, n_reads, total, max_read_len);
 }
 
@@ -1181,12 +1267,11 @@ int mapad_fetch_result(mapad_ctx_t* ctx, mapad_batch_result_t** out) {
     auto r = std::make_unique<HostResult>();
     uint32_t cur[CUR_COUNT] = {0};
     if (n) HIP_TRY(hipMemcpyAsync(cur, B.cursors, sizeof cur, hipMemcpyDeviceToHost, S.stream));
-    r->status.resize(n); r->counters.resize(n);
-    if (ctx->fetch_d) r->d_arrays.resize(S.last_total_bases);
     // order-preserving collect (mapping.rs:288): hits in read order, BinaryHeap array order inside a read — laid out by the device
-    r->hit_begin.assign(n + 1, 0);
-    r->hits.resize(S.c_n_hits);
-    r->ops.resize(S.c_n_ops);
+    bool ok = r->status.resize(n) && r->counters.resize(n) && r->hit_begin.resize(n + 1) && r->hits.resize(S.c_n_hits) && r->ops.resize(S.c_n_ops);
+    if (ctx->fetch_d) ok = ok && r->d_arrays.resize(S.last_total_bases);
+    if (!ok) return MAPAD_ERR_NOMEM;
+    r->hit_begin[0] = 0;
     static_assert(sizeof(mapad_hit_t) == sizeof(HitRec), "hit records are copied as they are");
     if (n) {
         HIP_TRY(hipMemcpyAsync(r->hit_begin.data(), S.d_c_hit_begin.p, (n + 1) * 8, hipMemcpyDeviceToHost, S.stream));
@@ -1235,30 +1320,46 @@ void mapad_batch_result_free(mapad_batch_result_t* r) {
     if (r) delete reinterpret_cast<HostResult*>(r);  // pub is the first member
 }
 
-int mapad_map_batch(mapad_ctx_t* ctx, const uint8_t* seqs, const uint8_t* quals, const uint64_t* offsets, uint64_t n_reads, mapad_batch_result_t** out) {
-    if (!ctx || !out || (n_reads && (!seqs || !quals || !offsets))) return MAPAD_ERR_INVALID;
-    if (hipSetDevice(ctx->device) != hipSuccess) return MAPAD_ERR_NO_DEVICE;
-    const uint64_t total = n_reads ? offsets[n_reads] : 0;
-    std::set<uint32_t> lens;
-    uint32_t lmax = 0;
+namespace {
+// host reads -> a slot's device buffers (+ the score tables of their lengths); returns once the inputs have left the host buffers
+int stage_host_batch(mapad_ctx_t* ctx, BatchSlot& S, const uint8_t* seqs, const uint8_t* quals, const uint64_t* offsets, uint64_t n_reads, uint64_t& total, uint32_t& lmax) {
+    total = n_reads ? offsets[n_reads] : 0;
+    bool seen[MAPAD_MAX_READ_LEN + 1] = {false};
+    std::vector<uint32_t> lv;
+    lmax = 0;
     for (uint64_t i = 0; i < n_reads; ++i) {
         const uint64_t l = offsets[i + 1] - offsets[i];
         if (l > MAPAD_MAX_READ_LEN) return MAPAD_ERR_READ_TOO_LONG;
-        lens.insert((uint32_t)l); lmax = std::max<uint32_t>(lmax, (uint32_t)l);
+        if (!seen[l]) { seen[l] = true; lv.push_back((uint32_t)l); }
+        lmax = std::max<uint32_t>(lmax, (uint32_t)l);
     }
-    std::vector<uint32_t> lv(lens.begin(), lens.end());
     int rc;
     if ((rc = mapad_ctx_prepare_lengths(ctx, lv.data(), (uint32_t)lv.size()))) return rc;
-    if ((rc = acquire_slot(ctx, ctx->cur))) return rc;  // synchronous entry point: no rotation, one slot's buffers
-    BatchSlot& S = ctx->bs[ctx->cur];
     if ((rc = S.d_seqs.ensure(std::max<uint64_t>(total, 1)))) return rc;
     if ((rc = S.d_quals.ensure(std::max<uint64_t>(total, 1)))) return rc;
     if ((rc = S.d_offsets.ensure(n_reads + 1))) return rc;
-    if (n_reads) {
+    if (n_reads) {  // pinned sources (mapad_host_alloc) go by DMA at link speed, pageable ones through the driver's staging buffers
         HIP_TRY(hipMemcpyAsync(S.d_seqs.p, seqs, total, hipMemcpyHostToDevice, S.stream));
         HIP_TRY(hipMemcpyAsync(S.d_quals.p, quals, total, hipMemcpyHostToDevice, S.stream));
         HIP_TRY(hipMemcpyAsync(S.d_offsets.p, offsets, (n_reads + 1) * 8, hipMemcpyHostToDevice, S.stream));
+        if (!S.ev_in) HIP_TRY(hipEventCreateWithFlags(&S.ev_in, hipEventDisableTiming));
+        HIP_TRY(hipEventRecord(S.ev_in, S.stream));
+        HIP_TRY(hipEventSynchronize(S.ev_in));
     }
+    return MAPAD_OK;
+}
+}  // namespace
+
+int mapad_map_batch(mapad_ctx_t* ctx, const uint8_t* seqs, const uint8_t* quals, const uint64_t* offsets, uint64_t n_reads, mapad_batch_result_t** out) {
+    if (!ctx || !out || (n_reads && (!seqs || !quals || !offsets))) return MAPAD_ERR_INVALID;
+    if (n_reads >= 0xFFFFFFF0ull) return MAPAD_ERR_INVALID;
+    if (hipSetDevice(ctx->device) != hipSuccess) return MAPAD_ERR_NO_DEVICE;
+    int rc;
+    if ((rc = acquire_slot(ctx, ctx->cur))) return rc;  // synchronous entry point: no rotation, one slot's buffers
+    BatchSlot& S = ctx->bs[ctx->cur];
+    uint64_t total = 0;
+    uint32_t lmax = 0;
+    if ((rc = stage_host_batch(ctx, S, seqs, quals, offsets, n_reads, total, lmax))) return rc;
     for (int attempt = 0; attempt < 6; ++attempt) {
         if ((rc = launch_batch(ctx, S, S.d_seqs.p, S.d_quals.p, S.d_offsets.p, n_reads, total, lmax))) return rc;
         rc = mapad_fetch_result(ctx, out);
@@ -1276,6 +1377,25 @@ int mapad_map_batch(mapad_ctx_t* ctx, const uint8_t* seqs, const uint8_t* quals,
     }
     return MAPAD_ERR_NOMEM;
 }
+
+int mapad_submit_batch(mapad_ctx_t* ctx, const uint8_t* seqs, const uint8_t* quals, const uint64_t* offsets, uint64_t n_reads) {
+    if (!ctx || (n_reads && (!seqs || !quals || !offsets))) return MAPAD_ERR_INVALID;
+    if (n_reads >= 0xFFFFFFF0ull) return MAPAD_ERR_INVALID;
+    if (hipSetDevice(ctx->device) != hipSuccess) return MAPAD_ERR_NO_DEVICE;
+    int rc;
+    if ((rc = acquire_slot(ctx, (ctx->cur + 1) % ctx->depth))) return rc;
+    BatchSlot& S = ctx->bs[ctx->cur];
+    uint64_t total = 0;
+    uint32_t lmax = 0;
+    if ((rc = stage_host_batch(ctx, S, seqs, quals, offsets, n_reads, total, lmax))) return rc;
+    return launch_batch(ctx, S, S.d_seqs.p, S.d_quals.p, S.d_offsets.p, n_reads, total, lmax);
+}
+void* mapad_host_alloc(size_t bytes) {
+    void* p = nullptr;
+    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocPortable) != hipSuccess) return nullptr;
+    return p;
+}
+void mapad_host_free(void* p) { if (p) (void)hipHostFree(p); }
 
 int mapad_device_result_ptrs(mapad_ctx_t* ctx, void** d_hit_count, void** d_hit_first, void** d_hits, void** d_ops, void** d_cursors) {
     if (!ctx) return MAPAD_ERR_INVALID;
@@ -1321,6 +1441,31 @@ int mapad_ctx_set_pipeline_depth(mapad_ctx_t* ctx, int depth) {
     for (auto& b : ctx->bs) { if ((rc = record_times(ctx, b))) return rc; b.release(); b.ev_valid = false; b.compacted = false; }
     ctx->depth = depth; ctx->cur = 0; ctx->view = 0;
     ctx->arena_reads = 0; ctx->arena_lmax = 0; ctx->pool[0].stride = 0;  // pools are re-sized around the base arenas of `depth` batches
+    return MAPAD_OK;
+}
+int mapad_ctx_reserve(mapad_ctx_t* ctx, uint64_t n_reads, uint64_t total_bases, uint32_t max_read_len, int host_inputs) {
+    if (!ctx || max_read_len > MAPAD_MAX_READ_LEN) return MAPAD_ERR_INVALID;
+    if (hipSetDevice(ctx->device) != hipSuccess) return MAPAD_ERR_NO_DEVICE;
+    int rc;
+    if ((rc = sync_all_slots(ctx))) return rc;
+    for (int k = 0; k < ctx->depth; ++k) {
+        BatchSlot& S = ctx->bs[k];
+        if (ctx->depth == 1) S.stream = ctx->stream;
+        else if (!S.stream) { HIP_TRY(hipStreamCreateWithFlags(&S.stream, hipStreamNonBlocking)); S.own_stream = true; }
+        if ((rc = ensure_batch_buffers(ctx, S, n_reads, total_bases, max_read_len, host_inputs != 0))) return rc;
+        // the collect's outputs: ~1 hit per read, one op per base + indels (grown on demand if a batch needs more)
+        if ((rc = S.d_c_hit_begin.ensure(n_reads + 1))) return rc;
+        if ((rc = S.d_c_ops_begin.ensure(n_reads + 1))) return rc;
+        if ((rc = S.d_c_tiles.ensure(2 * std::max<uint64_t>((n_reads + kScanTile - 1) / kScanTile, 1)))) return rc;
+        if ((rc = S.d_c_hits.ensure(n_reads + n_reads / 4 + 1024))) return rc;
+        if ((rc = S.d_c_ops.ensure(total_bases + total_bases / 4 + 1024))) return rc;
+        // first use of a stream sets up its hardware queue and scratch ring, which waits for a busy GPU: do it now, with an empty launch
+        if (!S.ev_in) HIP_TRY(hipEventCreateWithFlags(&S.ev_in, hipEventDisableTiming));
+        HIP_TRY(hipEventRecord(S.ev_in, S.stream));
+        if ((rc = launch_batch(ctx, S, nullptr, nullptr, nullptr, 0, 0, max_read_len, true))) return rc;
+        HIP_TRY(hipStreamSynchronize(S.stream));
+        S.compacted = false;
+    }
     return MAPAD_OK;
 }
 int mapad_ctx_select_batch(mapad_ctx_t* ctx, int age) {
@@ -1438,5 +1583,7 @@ int mapad_hits_to_records(const mapad_index_t* idx, const mapad_params_t* params
     }
 }
 void mapad_records_free(mapad_records_t* r) { host::free_records(r); }
+// host_postproc.hpp: seed_for(seed, read_idx, call) advances by one golden-ratio step per read
+uint64_t mapad_records_seed_at(uint64_t seed, uint64_t first_read_index) { return seed + first_read_index * 0x9E3779B97F4A7C15ull; }
 
 }  // extern "C"

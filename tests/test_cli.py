@@ -122,3 +122,51 @@ def test_cli_map_matches_integration_expectation(tmp_path, monkeypatch):
             assert g["tags"].keys() <= {"XI", "YI", "FF", "RG", "XD"}
         assert g["tag_order"][:len(r["tags"])] == [x[0] for x in r["tags"]]  # input tags first
     assert n_mapped >= 14
+
+
+def _decoded(path):
+    """decoded records without the wall-time tag XD (SURVEY §8c parity definition: compare decoded records, ignore XD and @PG CL)"""
+    text, refs, recs = read_bam(path)
+    out = []
+    for r in recs:
+        tags = {k: v for k, v in r["tags"].items() if k != "XD"}
+        out.append((r["name"], r["flags"], r["tid"], r["pos"], r["mapq"], r["cigar"], r["seq"], r["qual"], tuple(sorted(tags.items())), tuple(x for x in r["tag_order"] if x != "XD")))
+    return refs, out
+
+
+@pytest.mark.gpu
+def test_cli_map_devices_chunks_and_unmappable_reads(tmp_path):
+    """`--devices 0,0` (two contexts and worker threads, contiguous slices of every chunk) and small chunks (a pipeline of many batches)
+    must write the same records as one device and one chunk; empty and over-length reads come out unmapped, in place."""
+    g = synth.genome(120_000, seed=17)
+    fa, fq = str(tmp_path / "ref.fa"), str(tmp_path / "reads.fastq")
+    _write_fasta(fa, [("chr1", g[:70_000].tobytes().decode()), ("chr2", g[70_000:].tobytes().decode())])
+    seqs, quals, offsets = synth.reads(g, 4000, 50, seed=23, qual_range=(20, 40), damage=dict(f=0.5, t=0.5, d=0.02, s=1.0), len_range=(30, 80))
+    long_read = g[1000:2500].tobytes().decode()  # 1500 bp > MAPAD_MAX_READ_LEN
+    with open(fq, "w") as f:
+        for i in range(4000):
+            s, e = int(offsets[i]), int(offsets[i + 1])
+            f.write(f"@r{i}\n{seqs[s:e].tobytes().decode()}\n+\n{''.join(chr(33 + q) for q in quals[s:e])}\n")
+            if i == 777:
+                f.write(f"@too_long\n{long_read}\n+\n{'I' * len(long_read)}\n")
+            if i == 2500:
+                f.write("@empty\n\n+\n\n")
+    subprocess.check_call([_cli(), "index", "-g", fa])
+    base = [_cli(), "map", "-r", fq, "-g", fa, "-l", "single_stranded", "-p", "0.03", "-f", "0.5", "-t", "0.5", "-d", "0.02", "-s", "1.0", "-i", "0.001", "--seed", "7"]
+    outs = {}
+    for tag, extra in (("one", ["--devices", "0", "--batch_size", "250000"]), ("two", ["--devices", "0,0", "--batch_size", "250000"]),
+                       ("chunks", ["--devices", "0", "--batch_size", "301"])):
+        out = str(tmp_path / f"{tag}.bam")
+        subprocess.check_call(base + ["-o", out] + extra)
+        outs[tag] = _decoded(out)
+    refs, one = outs["one"]
+    assert refs == [("chr1", 70_000), ("chr2", 50_000)]
+    assert len(one) == 4002 and [r[0] for r in one][778] == "too_long" and [r[0] for r in one][2502] == "empty"
+    for name in ("too_long", "empty"):
+        r = next(x for x in one if x[0] == name)
+        assert r[1] & 0x4 and r[2] == -1 and r[3] == -1 and r[5] == ""
+    assert sum(1 for r in one if not (r[1] & 0x4)) > 3000
+    assert outs["two"][1] == one  # identical BAM records whichever device mapped a read
+    # chunk boundaries change the per-chunk seed (seed + chunk_no, like one rng per rayon chunk): positions of multi-row hits may differ, nothing else
+    for a_, b_ in zip(outs["chunks"][1], one):
+        assert a_[:3] == b_[:3] and a_[4:8] == b_[4:8]
