@@ -138,9 +138,11 @@ def lib():
     """Loads libmapad_amd.so (building it in-tree if the sources are newer).  Raises if it cannot be loaded."""
     global _lib
     if _lib is None:
-        path = _build.LIB
-        if _build.needs_build():
-            path = _build.build()
+        path = os.environ.get("MAPAD_AMD_LIB")  # an alternative build of the library (profiling / A-B variants)
+        if not path:
+            path = _build.LIB
+            if _build.needs_build():
+                path = _build.build()
         L = C.CDLL(path)
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(L, name)  # AttributeError = the library does not export what the header declares

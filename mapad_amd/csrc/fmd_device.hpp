@@ -165,6 +165,31 @@ __device__ __forceinline__ uint64_t quad_pick64(uint64_t v, int k) {  // value o
     const uint64_t a = quad_bcast64<0>(v), b = quad_bcast64<1>(v), c = quad_bcast64<2>(v), d = quad_bcast64<3>(v);
     return k == 0 ? a : k == 1 ? b : k == 2 ? c : d;
 }
+// The same in two halves, so that a caller can put other memory traffic (the repair of the heap) between issuing the four loads and using them.
+struct ExtLoads { OccLoads lo, hi; };
+__device__ __forceinline__ ExtLoads ext4_quad_issue(const DevIndex& ix, uint64_t lower, uint64_t size, int w) {
+    const uint64_t r_lo = lower == 0 ? 0 : lower - 1, r_hi = lower + size - 1;
+    ExtLoads l;
+    l.lo = quad_occ_issue(ix, r_lo, w);
+    l.hi = quad_occ_issue(ix, r_hi, w);
+    return l;
+}
+__device__ __forceinline__ void ext4_quad_lane_finish(const DevIndex& ix, const ExtLoads& l, uint64_t lower, uint64_t lower_rev, uint64_t size, int w, ExtLane& out) {
+    const uint64_t r_lo = lower == 0 ? 0 : lower - 1, r_hi = lower + size - 1;
+    const uint64_t occ_lo = quad_occ_finish(l.lo, r_lo, w);
+    const uint64_t my_hi = quad_occ_finish(l.hi, r_hi, w);
+    const uint64_t my_lo = lower == 0 ? 0 : occ_lo;
+    const uint64_t my_size = my_hi - my_lo;
+    const uint64_t s0 = quad_bcast64<0>(my_size), s1 = quad_bcast64<1>(my_size), s2 = quad_bcast64<2>(my_size), s3 = quad_bcast64<3>(my_size);
+    const uint64_t o_s = lower == 0 ? 0 : sentinel_le(ix, lower - 1);
+    const uint64_t sent = sentinel_le(ix, lower + size - 1) - o_s;  // '$' rows inside the interval
+    const uint64_t above = w == 3 ? 0 : w == 2 ? s3 : w == 1 ? s3 + s2 : s3 + s2 + s1;
+    const uint64_t less = w == 0 ? ix.less[1] : w == 1 ? ix.less[2] : w == 2 ? ix.less[3] : ix.less[4];
+    out.lower = less + my_lo;
+    out.lower_rev = lower_rev + sent + above;
+    out.size = my_size;
+    out.nonempty = (s0 >= 1 ? 1u : 0u) | (s1 >= 1 ? 2u : 0u) | (s2 >= 1 ? 4u : 0u) | (s3 >= 1 ? 8u : 0u);
+}
 __device__ __forceinline__ void ext4_quad_lane(const DevIndex& ix, uint64_t lower, uint64_t lower_rev, uint64_t size, int w, ExtLane& out) {
     // both rank queries unconditionally, so that their four loads are in flight together (lower == 0: the result is discarded)
     const uint64_t r_lo = lower == 0 ? 0 : lower - 1, r_hi = lower + size - 1;

@@ -71,6 +71,7 @@ struct BatchDev {
     uint32_t* key_hist;       // [n_chunks][kKeyBins] reads per (chunk, cost class), then the running scatter cursors
     uint32_t order_shift;     // log2 of the chunk size: reads are ordered inside chunks of 2^order_shift consecutive reads
     uint32_t* order;          // [n_reads] read ids, most expensive class first (nullptr: in input order)
+    unsigned long long* prof; // -DMAPAD_PROFILE_SECTIONS builds: section cycle sums (else nullptr)
 };
 
 struct ArenaPool {
@@ -289,8 +290,7 @@ __device__ MAPAD_FINALIZE_ATTR void finalize_read(const BatchDev B, const ReadIn
         B.hit_first[read] = (uint32_t)hbase;
         B.status[read] = status;
         ReadCounters* c = B.counters + read;
-        c->e_search = read_event(rd.ctr, CTR_E_SEARCH) / LPR; c->n_push = read_event(rd.ctr, CTR_N_PUSH) / LPR; c->n_pop = read_event(rd.ctr, CTR_N_POP) / LPR;
-        c->n_node = read_event(rd.ctr, CTR_N_NODE) / LPR; c->n_hits = read_event(rd.ctr, CTR_N_HITS) / LPR;  // every lane of the group counted
+        c->e_search = st.c_esearch; c->n_push = st.c_push; c->n_pop = st.c_pop; c->n_node = st.c_node; c->n_hits = st.c_hits;
         if (status == ST_ARENA_OVERFLOW) atomicOr(&B.cursors[CUR_ERR], ST_ARENA_OVERFLOW);  // cannot happen: the last stage holds the reference's limits
     }
 }
@@ -395,7 +395,7 @@ struct DeviceGrow {
 // NL: the near data (heap top, position data) of every read slot is in LDS and addressed with ds_* instructions; otherwise it
 // lives in the slot's HBM arena (reads longer than kMaxLdsReadLen, lanes-per-read 1).
 #if !defined(MAPAD_MIN_WAVES)
-#define MAPAD_MIN_WAVES 4
+#define MAPAD_MIN_WAVES 3  // 12 wavefronts per CU: 168 VGPRs (no SGPR spills into VGPR lanes) and 853 B of LDS per read slot (heap levels 0-5)
 #endif
 template <int LPR, bool CONT, int PASS, bool NL>
 __global__ void __launch_bounds__(64, (LPR == 1 && NL) ? 1 : MAPAD_MIN_WAVES) search_kernel(DevIndex ix, DevParams P, BatchDev B, ArenaPool AP, const GrowPools* GP, uint32_t near_stride, uint32_t near_lmax, int stage) {
@@ -403,7 +403,7 @@ __global__ void __launch_bounds__(64, (LPR == 1 && NL) ? 1 : MAPAD_MIN_WAVES) se
     const int tier = stage;
     const uint32_t slot = blockIdx.x * (64 / LPR) + (lane / LPR);
     ArenaT<NL> A = carve<NL>(AP, slot);
-    // near data of this read slot: [32 heap slots][2*lmax bytes class/quality][lmax floats D][event counters]
+    // near data of this read slot: [kTop + 1 heap slots][2*lmax bytes class/quality][lmax floats D]
     extern __shared__ __attribute__((aligned(16))) uint8_t near_lds[];
     using NearBytes = typename near_ptr<uint8_t, NL>::type;
     NearBytes near;
@@ -418,15 +418,20 @@ __global__ void __launch_bounds__(64, (LPR == 1 && NL) ? 1 : MAPAD_MIN_WAVES) se
     // reads of the first stages give up after kMaxWaits fruitless waits for an arena and are restarted by the next stage, when the
     // pools are quiet; the last growable stage waits as long as it takes
     const DeviceGrow<LPR, NL> grow{GP, &B.cursors[CUR_GROWN], slot, w, stage + 2 < kStages};
+#if defined(MAPAD_PROFILE_SECTIONS)
+    if (lane < 2 * PROF_N + 2) g_prof_lds[lane] = 0;
+    g_prof_hist[lane] = 0;
+    if (lane == 0) g_prof_lds[2 * PROF_N] = __builtin_amdgcn_s_memtime();
+#endif
     bool have = false, done = false;
 #if defined(MAPAD_ACTIVE_QUADS)
     if ((lane / LPR) >= MAPAD_ACTIVE_QUADS) done = true;  // experiment: fewer reads per wavefront
 #endif
-    const typename near_ptr<uint32_t, NL>::type near_ctr = (typename near_ptr<uint32_t, NL>::type)((NearBytes)near_d + ((4 * near_lmax + 15) & ~15u));
-    ReadInT<NL> rd{near_qc, near_d, 0, 0.0f, 0, near_ctr};
+    ReadInT<NL> rd{near_qc, near_d, 0, 0.0f, 0};
     SearchState st;
     uint32_t read = 0;
     for (;;) {
+        MAPAD_MARK(PROF_LOOP);
         if (!have && !done) {
             uint32_t item = 0;
             if (w == 0) item = atomicAdd(work, 1u);
@@ -447,14 +452,17 @@ __global__ void __launch_bounds__(64, (LPR == 1 && NL) ? 1 : MAPAD_MIN_WAVES) se
                     search_init(ix.n, alignment_start_of(P, rd.L), rd, A, tmp);
                     st = tmp;
                     have = true;
+                    drain_memory();  // rare path of the step loop (search_core.hpp: drain_memory)
                 }
             }
         }
+        MAPAD_MARK(PROF_SETUP);
         if (__all(done)) break;
         if (have) {
             bool cont;
             if constexpr (PASS != 1) cont = search_step<LPR, CONT, NL>(ix, P, rd, A, st, w, grow);
             else cont = search_step<LPR, CONT, NL>(ix, P, rd, A, st, w, NoGrow());
+            MAPAD_MARK(PROF_TAIL);
             if (!cont) {
                 finalize_read<LPR, NL>(B, rd, A, st, read, w, tier);
                 if (PASS != 1 && A.grown) {  // give the grown arena back; the next read starts in the base arena again
@@ -463,9 +471,16 @@ __global__ void __launch_bounds__(64, (LPR == 1 && NL) ? 1 : MAPAD_MIN_WAVES) se
                     A.heap = base.heap; A.nodes = base.nodes; A.heap_cap = base.heap_cap; A.node_cap = base.node_cap; A.grown = 0;
                 }
                 have = false;
+                drain_memory();
+                MAPAD_MARK(PROF_FINALIZE);
             }
         }
     }
+#if defined(MAPAD_PROFILE_SECTIONS)
+    __syncthreads();
+    if (PASS == 0 && lane < 2 * PROF_N && B.prof) atomicAdd(&B.prof[lane], g_prof_lds[lane]);
+    if (PASS == 0 && B.prof) atomicAdd(&B.prof[2 * PROF_N + lane], (unsigned long long)g_prof_hist[lane]);
+#endif
 }
 
 // ---- order-preserving collect (mapping.rs:288) on the device ------------------------------------------------------------------
@@ -594,7 +609,7 @@ struct DevBuf {
 };
 
 // bytes of "near" data per read slot: heap top (32 physical slots), 2 bytes + 4 bytes per read position
-uint32_t near_bytes(uint32_t lmax) { return (kTop + 1) * 8 + ((2 * lmax + 15) & ~15u) + ((4 * lmax + 15) & ~15u) + CTR_COUNT * 4; }
+uint32_t near_bytes(uint32_t lmax) { return (kTop + 1) * 8 + ((2 * lmax + 15) & ~15u) + ((4 * lmax + 15) & ~15u); }
 constexpr uint32_t kMaxLdsReadLen = 256;  // longer reads keep their near data in the HBM arena instead of LDS
 
 ArenaPool make_pool_layout(uint32_t heap_cap, uint32_t node_cap, uint32_t hit_ops_cap, uint32_t lmax) {
@@ -693,6 +708,7 @@ struct mapad_ctx {
     int lpr = 4;  // lanes per read in the search kernel (MAPAD_LANES_PER_READ = 4 | 1)
     int n_cu = 256;
     uint64_t counter_sums[6] = {0, 0, 0, 0, 0, 0};
+    DevBuf<unsigned long long> d_prof;  // -DMAPAD_PROFILE_SECTIONS builds
 
     ~mapad_ctx() {
         (void)hipSetDevice(device);
@@ -764,7 +780,7 @@ int ensure_arenas(mapad_ctx* c, BatchSlot& S, uint32_t lmax, uint64_t n_reads) {
     {   // pass 0 base arenas
         const uint32_t nodes = env_u32("MAPAD_TIER0_NODES", 8192);
         c->pool[0] = make_pool_layout((uint32_t)std::min<uint64_t>(nodes, stack_cap), (uint32_t)std::min<uint64_t>(nodes, tree_cap), hit_ops_cap, lm);
-        c->slots[0] = env_u32("MAPAD_TIER0_WAVES_PER_CU", c->lpr == 4 ? 16 : 8) * (uint32_t)c->n_cu * rpw;
+        c->slots[0] = env_u32("MAPAD_TIER0_WAVES_PER_CU", c->lpr == 4 ? 4 * MAPAD_MIN_WAVES : 8) * (uint32_t)c->n_cu * rpw;
         c->slots[0] = (uint32_t)std::min<uint64_t>(c->slots[0], (std::max<uint64_t>(n_reads, 1) + rpw - 1) / rpw * rpw);
     }
     {   // pass 1: full limits
@@ -906,6 +922,11 @@ int launch_batch(mapad_ctx* c, BatchSlot& S, const uint8_t* d_seqs, const uint8_
     B.cursors = S.d_cursors.p; B.overflow_list = S.d_overflow.p;
     B.sort_key = ordered ? S.d_sort_key.p : nullptr; B.key_hist = ordered ? S.d_key_hist.p : nullptr; B.order = ordered ? S.d_order.p : nullptr;
     B.order_shift = order_shift;
+#if defined(MAPAD_PROFILE_SECTIONS)
+    if ((rc = c->d_prof.ensure(2 * PROF_N + 64))) return rc;
+    HIP_TRY(hipMemsetAsync(c->d_prof.p, 0, (2 * PROF_N + 64) * 8, S.stream));
+    B.prof = c->d_prof.p;
+#endif
     S.last = B; S.last_total_bases = total_bases; S.last_lmax = lmax; S.compacted = false;
     if (n_reads == 0 && !warm) return MAPAD_OK;
     const uint32_t lds_lmax = std::max<uint32_t>(lmax, 1);
@@ -943,7 +964,7 @@ int launch_batch(mapad_ctx* c, BatchSlot& S, const uint8_t* d_seqs, const uint8_
     // 16 per CU x 2 batches in flight 273 ms, 8 x 2 247 ms, 8 x 3 252 ms; C3: 8 x 2 589 ms, 8 x 3 529 ms).
     bool others_running = false;
     for (auto& o : c->bs) if (&o != &S && o.ev_valid && hipEventQuery(o.ev[3]) == hipErrorNotReady) others_running = true;
-    const uint32_t full_waves = c->slots[0] / rpw, shared_waves = std::max<uint32_t>(1, std::min<uint32_t>(full_waves, env_u32("MAPAD_SHARED_WAVES_PER_CU", 8) * (uint32_t)c->n_cu));
+    const uint32_t full_waves = c->slots[0] / rpw, shared_waves = std::max<uint32_t>(1, std::min<uint32_t>(full_waves, env_u32("MAPAD_SHARED_WAVES_PER_CU", 2 * MAPAD_MIN_WAVES) * (uint32_t)c->n_cu));
     const uint32_t grid_s = warm ? 1u : (uint32_t)std::min<uint64_t>((n_reads + rpw - 1) / rpw, others_running ? shared_waves : full_waves);
     for (int stage = 0; stage + 1 < kStages; ++stage) {  // every read, then the reads that gave up waiting (normally none: the launch exits at once)
         const uint32_t grid = grid_s;
@@ -1295,6 +1316,27 @@ int mapad_fetch_result(mapad_ctx_t* ctx, mapad_batch_result_t** out) {
     r->pub.n_second_pass = cur[CUR_GROWN];  // arena migrations in pass 0
     if (cur[CUR_GROWN + 1] && std::getenv("MAPAD_DEBUG")) std::fprintf(stderr, "mapad_amd: size-class pools that ran dry (bit per class): 0x%x, waits: %u, reads restarted: %u, re-run with full limits: %u\n", cur[CUR_GROWN + 1], cur[CUR_GROWN + 2], cur[CUR_OVF], cur[CUR_OVF + 2 * (kStages - 2)]);
     r->pub.n_third_pass = cur[CUR_OVF + 2 * (kStages - 2)];  // reads re-run by the full-limit pass
+#if defined(MAPAD_PROFILE_SECTIONS)
+    {
+        unsigned long long pv[2 * PROF_N + 64];
+        HIP_TRY(hipMemcpy(pv, ctx->d_prof.p, sizeof pv, hipMemcpyDeviceToHost));
+        const unsigned long long* hv = pv + 2 * PROF_N;
+        auto row = [&](const char* what, int lo, int n) {
+            double tot = 0; for (int i = 0; i < n; ++i) tot += (double)hv[lo + i];
+            std::fprintf(stderr, "[sections] %s:", what);
+            for (int i = 0; i < n; ++i) std::fprintf(stderr, " %d:%.1f%%", i, 100.0 * hv[lo + i] / std::max(tot, 1.0));
+            std::fprintf(stderr, "\n");
+        };
+        row("log2(heap_len) at pop", 0, 24); row("children committed per pop", 24, 12); row("commit-loop trips per wave step", 36, 12);
+        static const char* names[PROF_N] = {"pop+sift", "node/row/D", "rank ext", "gates+kids", "commit loop", "step tail", "read setup", "finalize", "grow", "record hit", "loop head", "commit: pre", "commit: wait", "-"};
+        double tw = 0, tl = 0;
+        for (int k = 0; k < PROF_N; ++k) { tw += (double)pv[k]; tl += (double)pv[PROF_N + k]; }
+        std::fprintf(stderr, "[sections] wave-cycles %.3e, lane-cycles %.3e (mean active lanes %.1f)\n", tw, tl, tl / std::max(tw, 1.0));
+        for (int k = 0; k < PROF_N - 1; ++k)
+            std::fprintf(stderr, "[sections] %-12s wave %5.1f %%   lanes %5.1f %%   active lanes %4.1f\n", names[k], 100.0 * pv[k] / std::max(tw, 1.0), 100.0 * pv[PROF_N + k] / std::max(tl, 1.0),
+                         (double)pv[PROF_N + k] / std::max<double>((double)pv[k], 1.0));
+    }
+#endif
     *out = &r.release()->pub;
     return MAPAD_OK;
 }

@@ -26,7 +26,46 @@
 #define MAPAD_RARE inline
 #endif
 
+// -DMAPAD_PROFILE_SECTIONS: wave time and lane time per section of the search loop (s_memtime deltas accumulated in LDS, dumped by the kernel).
+// A diagnostic build: the marks cost a few percent and the numbers are relative.
+#if defined(MAPAD_PROFILE_SECTIONS) && defined(__HIPCC__)
+enum { PROF_POP = 0, PROF_NODE = 1, PROF_EXT = 2, PROF_GATES = 3, PROF_COMMIT = 4, PROF_TAIL = 5, PROF_SETUP = 6, PROF_FINALIZE = 7, PROF_GROW = 8, PROF_HIT = 9, PROF_LOOP = 10, PROF_C_PRE = 11, PROF_C_LOAD = 12, PROF_N = 14 };
+__shared__ unsigned long long g_prof_lds[2 * PROF_N + 2];  // [k] wave cycles, [PROF_N + k] lane cycles, [2 PROF_N] last stamp
+__shared__ unsigned int g_prof_hist[64];  // [0..23] log2(heap_len) at pop, [24..35] children committed by a pop, [36..47] commit-loop trips of a wave step, [48..63] trickle levels
+__device__ __forceinline__ void prof_mark(int k) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const unsigned long long t = __builtin_amdgcn_s_memtime();
+    const unsigned long long act = __ballot(1);
+    if ((int)__builtin_amdgcn_mbcnt_hi((unsigned)(act >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)act, 0)) == 0) {  // first active lane
+        const unsigned long long dt = t - g_prof_lds[2 * PROF_N];
+        g_prof_lds[2 * PROF_N] = t;
+        g_prof_lds[k] += dt;
+        g_prof_lds[PROF_N + k] += dt * (unsigned long long)__popcll(act);
+    }
+#else
+    (void)k;
+#endif
+}
+#if defined(__HIP_DEVICE_COMPILE__)
+#define MAPAD_MARK(k) prof_mark(k)
+#else
+#define MAPAD_MARK(k) ((void)0)
+#endif
+#else
+#define MAPAD_MARK(k) ((void)0)
+#endif
+
 namespace mapad {
+
+// The compiler's wait-count pass is not path sensitive: a load or store issued on a RARE path of the search loop counts as "possibly still in
+// flight" at the join, and the common path then carries a full `s_waitcnt vmcnt(0)` — a drain of every store in flight — in front of the
+// next instruction that touches one of the registers involved.  Rare paths therefore end with an explicit wait of their own, which the pass
+// does model: behind it nothing is pending and the common path keeps only the waits it needs.
+MAPAD_HD void drain_memory() {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __builtin_amdgcn_s_waitcnt(0);  // vmcnt(0) expcnt(0) lgkmcnt(0)
+#endif
+}
 
 enum : uint32_t { GAP_INS = 0, GAP_DEL = 1, GAP_CLOSED = 2 };  // src/map/mod.rs:93-98
 
@@ -66,6 +105,13 @@ MAPAD_HD Frame unpack_frame(const Node& n) {
     f.size = n.w3;
     return f;
 }
+// word-wise selects: a conditional expression on whole structs selects an ADDRESS and copies from it, which pins all three nodes in scratch memory
+MAPAD_HD Node pick_node(bool first, bool second, const Node& a, const Node& b, const Node& c) {
+    Node n;
+    n.w0 = first ? a.w0 : second ? b.w0 : c.w0; n.w1 = first ? a.w1 : second ? b.w1 : c.w1;
+    n.w2 = first ? a.w2 : second ? b.w2 : c.w2; n.w3 = first ? a.w3 : second ? b.w3 : c.w3;
+    return n;
+}
 MAPAD_HD uint32_t node_op(const Node& n) { return (uint32_t)n.w0; }
 MAPAD_HD uint32_t node_parent(const Node& n) { return (uint32_t)(n.w0 >> 32); }
 MAPAD_HD bool node_occupied(const Node& n) { return (n.w2 >> 52) & 1; }
@@ -83,9 +129,9 @@ static_assert(sizeof(HitRec) == 40, "hit record is 40 bytes");
 //   qc[2j] = read-base class (0..3 = ACGT, 4 otherwise), qc[2j+1] = Phred quality  -> one shared score-table row per pop
 //   d[j]   = BiDArray::d_composite[j] (written by darray_kernel)
 #if !defined(MAPAD_KTOP)
-#define MAPAD_KTOP 31
+#define MAPAD_KTOP 63
 #endif
-constexpr int kTop = MAPAD_KTOP;  // logical heap slots 0..kTop-1 (31: levels 0-4) live in the `top` array (LDS on the device)
+constexpr int kTop = MAPAD_KTOP;  // logical heap slots 0..kTop-1 (63: levels 0-5) live in the `top` array (LDS on the device); must be 2^k - 1
 
 constexpr int kMaxHits = 20;  // a pop adds <= 9 hits and the search returns once more than 9 exist (mapping.rs:1348)
 
@@ -131,27 +177,7 @@ struct ReadInT {
     int L;
     float thr;          // DevParams::reject_thr[L]
     int32_t table;      // DevParams::table_base[L]
-    typename near_ptr<uint32_t, NL>::type ctr;  // event counters of the read, kCtr* below (near data: they would cost five registers)
 };
-enum : int { CTR_E_SEARCH = 0, CTR_N_PUSH = 1, CTR_N_POP = 2, CTR_N_NODE = 3, CTR_N_HITS = 4, CTR_COUNT = 8 };
-// Every lane of the read's lane group counts (LPR increments per event on the device, one atomic-add instruction without a return
-// value); the reader divides by the group size.
-// reads a counter back (device: at agent scope, so that a copy of the line in the CU's L1 cannot hide the atomic adds when the near
-// data lives in HBM)
-template <class P> MAPAD_HD uint32_t read_event(P ctr, int k) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    return __hip_atomic_load(ctr + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#else
-    return ctr[k];
-#endif
-}
-template <class P> MAPAD_HD void count_event(P ctr, int k) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    __hip_atomic_fetch_add(ctr + k, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-#else
-    ctr[k] += 1;
-#endif
-}
 using ReadIn = ReadInT<false>;
 
 struct alignas(16) HeapPair { HeapEntry a, b; };
@@ -198,6 +224,7 @@ template <bool NL> MAPAD_HD void hp_set(const ArenaT<NL>& A, uint32_t i, const H
 template <bool NL> MAPAD_HD HeapPair hp_pair(const ArenaT<NL>& A, uint32_t i) { if (i < (uint32_t)kTop) return load_pair(A.top + i); return load_pair(A.heap + i); }
 
 struct SearchState {
+    uint32_t c_esearch, c_push, c_pop, c_node, c_hits;  // event counters of the read (identical on the oracle: itself a parity check)
     uint32_t heap_len;
     uint32_t tree_entries, tree_next, tree_len;  // slab: backing length, free-list head, occupied count
     uint32_t n_hits, hit_ops_used;
@@ -235,45 +262,155 @@ struct Ancestors { HeapEntry e1, e2, e3; };  // parent, grandparent of pos, gran
 template <bool NL>
 MAPAD_HD Ancestors load_ancestors(const ArenaT<NL>& A, uint32_t pos) {
     const uint32_t i1 = pos > 0 ? (pos - 1) >> 1 : 0, i2 = pos > 2 ? (pos - 3) >> 2 : 0, i3 = i1 > 2 ? (i1 - 3) >> 2 : 0;
-    Ancestors a;  // i3 <= i2 <= i1: one branch per near/arena split, so that the arena loads of a case are in flight together
+    Ancestors a;  // i3 <= i2 <= i1
+#if defined(MAPAD_BRANCHY_HEAP)
+    // one branch per near/arena split, so that the arena loads of a case are in flight together
     if (i1 < (uint32_t)kTop) { a.e1 = load_entry(A.top + i1); a.e2 = load_entry(A.top + i2); a.e3 = load_entry(A.top + i3); }
     else if (i2 < (uint32_t)kTop) { a.e1 = load_entry(A.heap + i1); a.e2 = load_entry(A.top + i2); a.e3 = load_entry(A.top + i3); }
     else if (i3 < (uint32_t)kTop) { a.e1 = load_entry(A.heap + i1); a.e2 = load_entry(A.heap + i2); a.e3 = load_entry(A.top + i3); }
     else { a.e1 = load_entry(A.heap + i1); a.e2 = load_entry(A.heap + i2); a.e3 = load_entry(A.heap + i3); }
+#else
+    // The read slots of a wavefront are at different heap sizes: a four-way branch on where the three entries live runs its cases one after
+    // the other, each with its own wait for memory.  Here every slot reads the near array (index clamped into it) and only the arena loads
+    // are predicated, back to back, so that a wavefront waits for memory once.
+    const uint32_t k1 = i1 < (uint32_t)kTop ? i1 : 0, k2 = i2 < (uint32_t)kTop ? i2 : 0, k3 = i3 < (uint32_t)kTop ? i3 : 0;
+    const HeapEntry n1 = load_entry(A.top + k1), n2 = load_entry(A.top + k2), n3 = load_entry(A.top + k3);
+    HeapEntry g1 = HeapEntry{0.0f, 0u}, g2 = HeapEntry{0.0f, 0u}, g3 = HeapEntry{0.0f, 0u};
+    if (i1 >= (uint32_t)kTop) g1 = load_entry(A.heap + i1);
+    if (i2 >= (uint32_t)kTop) g2 = load_entry(A.heap + i2);
+    if (i3 >= (uint32_t)kTop) g3 = load_entry(A.heap + i3);
+    a.e1 = i1 < (uint32_t)kTop ? n1 : g1; a.e2 = i2 < (uint32_t)kTop ? n2 : g2; a.e3 = i3 < (uint32_t)kTop ? n3 : g3;
+#endif
     return a;
 }
 template <bool NL>
 MAPAD_HD void mm_bubble_up(const ArenaT<NL>& A, uint32_t pos, const HeapEntry elt, const Ancestors& an) {  // elt is the new element, destined for slot pos
-    if (pos > 0) {
-        const uint32_t i1 = (pos - 1) >> 1;                 // parent
-        const uint32_t i2 = pos > 2 ? (pos - 3) >> 2 : 0;   // grandparent of pos
-        const uint32_t i3 = i1 > 2 ? (i1 - 3) >> 2 : 0;     // grandparent of the parent
-        const HeapEntry e1 = an.e1, e2 = an.e2, e3 = an.e3;
-        bool greater;  // which grandparent chain to follow
-        bool moved;
-        if (mm_is_min_level(pos)) { moved = elt.score > e1.score; greater = moved; }
-        else { moved = elt.score < e1.score; greater = !moved; }
-        if (moved) { hp_set(A, pos, e1); pos = i1; }
-        if (pos > 2) {
-            const HeapEntry ge = moved ? e3 : e2;
-            const uint32_t gp = moved ? i3 : i2;
-            if (greater ? (elt.score > ge.score) : (elt.score < ge.score)) {
-                hp_set(A, pos, ge);
-                pos = gp;
-                while (pos > 2) {
-                    const uint32_t g2 = (pos - 3) >> 2;
-                    const HeapEntry g = hp_get(A, g2);
-                    if (!(greater ? (elt.score > g.score) : (elt.score < g.score))) break;
-                    hp_set(A, pos, g);
-                    pos = g2;
-                }
+    // Both compares are evaluated unconditionally (slots that do not exist compare as "stay"): the three entries are then consumed on the main
+    // path, where the compiler places the one wait for them, and the outcome is a store of elt plus at most two displaced entries.
+    const uint32_t i1 = pos > 0 ? (pos - 1) >> 1 : 0;   // parent
+    const uint32_t i2 = pos > 2 ? (pos - 3) >> 2 : 0;   // grandparent of pos
+    const uint32_t i3 = i1 > 2 ? (i1 - 3) >> 2 : 0;     // grandparent of the parent
+    const HeapEntry e1 = an.e1, e2 = an.e2, e3 = an.e3;
+    const bool min_level = mm_is_min_level(pos);
+    const bool moved = pos > 0 && (min_level ? elt.score > e1.score : elt.score < e1.score);
+    const bool greater = min_level ? moved : !moved;    // which grandparent chain to follow
+#if defined(MAPAD_PROFILE_SECTIONS) && defined(__HIP_DEVICE_COMPILE__)
+    if (__ballot(moved) != 0xFFFFFFFFFFFFFFFFull || e2.score != e3.score) MAPAD_MARK(PROF_C_LOAD);  // forces the wait for the three entries before the mark
+#endif
+    const uint32_t pos1 = moved ? i1 : pos;
+    const HeapEntry ge = moved ? e3 : e2;
+    const uint32_t gp = moved ? i3 : i2;
+    const bool moved2 = pos1 > 2 && (greater ? (elt.score > ge.score) : (elt.score < ge.score));
+    if (moved) hp_set(A, pos, e1);
+    if (moved2) {
+        hp_set(A, pos1, ge);
+        pos = gp;
+        if (MAPAD_UNLIKELY(pos > 2)) {  // 2 % of the pushes climb further
+            while (pos > 2) {
+                const uint32_t g2 = (pos - 3) >> 2;
+                const HeapEntry g = hp_get(A, g2);
+                if (!(greater ? (elt.score > g.score) : (elt.score < g.score))) break;
+                hp_set(A, pos, g);
+                pos = g2;
             }
+            drain_memory();
         }
-    }
+    } else pos = pos1;
     hp_set(A, pos, elt);
 }
 template <bool NL>
 MAPAD_HD void mm_bubble_up(const ArenaT<NL>& A, uint32_t pos, const HeapEntry elt) { mm_bubble_up(A, pos, elt, load_ancestors(A, pos)); }
+
+// The children of one popped frame are pushed to consecutive slots n0, n0 + 1, ...; their parents lie in three consecutive slots, their
+// grandparents and the grandparents of their parents in two each.  Loading that window once — right after the pop, so that the loads are in
+// flight during the rank queries — takes the memory round trip out of every push of the commit loop (it was the largest share of a step:
+// 44 % of the wave time, profiles/r02/sections_before.txt).  Pushes update the window as they store, so a later sibling sees what an earlier
+// one moved.  Used when the parents are beyond the near part of the heap (n0 >= kTop) and for the first kWinPushes pushes of a step.
+constexpr uint32_t kWinPushes = 4;
+// Entries are kept as packed 64-bit values and every access is a chain of value selects: field-wise conditional stores let the compiler
+// merge them into one store through a computed address, which pins the whole window in scratch memory.
+struct AncWindow {
+    uint64_t p0, p1, p2, g0, g1, h0, h1;  // slots pb .. pb + 2, gb .. gb + 1, hb .. hb + 1
+    uint32_t pb, gb, hb;
+    uint32_t n0;     // first slot the window serves
+    bool on;
+};
+MAPAD_HD uint64_t pack_entry(const HeapEntry e) {
+    uint32_t sb;
+    std::memcpy(&sb, &e.score, 4);
+    return (uint64_t)sb | ((uint64_t)e.node << 32);
+}
+MAPAD_HD HeapEntry unpack_entry(uint64_t v) {
+    HeapEntry e;
+    const uint32_t sb = (uint32_t)v;
+    std::memcpy(&e.score, &sb, 4);
+    e.node = (uint32_t)(v >> 32);
+    return e;
+}
+template <bool NL>
+MAPAD_HD AncWindow win_load(const ArenaT<NL>& A, uint32_t n0) {
+    AncWindow W;
+#if defined(MAPAD_ANCESTOR_WINDOW)
+    W.on = n0 >= (uint32_t)kTop;
+#else
+    W.on = false;  // measured on MI355X (C2): the window's seven loads per pop cost more than the round trips they save (336 vs 282 ms per 1 M reads)
+#endif
+    W.n0 = n0;
+    W.pb = n0 > 0 ? (n0 - 1) >> 1 : 0; W.gb = n0 > 2 ? (n0 - 3) >> 2 : 0; W.hb = W.pb > 2 ? (W.pb - 3) >> 2 : 0;
+    W.p0 = W.p1 = W.p2 = W.g0 = W.g1 = W.h0 = W.h1 = 0;
+    if (W.on) {  // slots past the current end of the heap are stale memory inside the arena (it has slack); they are never selected
+        W.p0 = pack_entry(hp_get(A, W.pb)); W.p1 = pack_entry(hp_get(A, W.pb + 1)); W.p2 = pack_entry(hp_get(A, W.pb + 2));
+        W.g0 = pack_entry(hp_get(A, W.gb)); W.g1 = pack_entry(hp_get(A, W.gb + 1));
+        W.h0 = pack_entry(hp_get(A, W.hb)); W.h1 = pack_entry(hp_get(A, W.hb + 1));
+    }
+    return W;
+}
+MAPAD_HD Ancestors win_ancestors(const AncWindow& W, uint32_t pos) {  // == load_ancestors(A, pos) for pos in [n0, n0 + kWinPushes)
+    const uint32_t i1 = (pos - 1) >> 1, i2 = (pos - 3) >> 2, i3 = (i1 - 3) >> 2;  // n0 >= kTop: all three exist
+    const uint32_t a = i1 - W.pb, b = i2 - W.gb, c = i3 - W.hb;
+    Ancestors r;
+    r.e1 = unpack_entry(a == 0 ? W.p0 : a == 1 ? W.p1 : W.p2);
+    r.e2 = unpack_entry(b == 0 ? W.g0 : W.g1);
+    r.e3 = unpack_entry(c == 0 ? W.h0 : W.h1);
+    return r;
+}
+// hp_set that keeps the window current
+template <bool NL>
+MAPAD_HD void hp_set_win(const ArenaT<NL>& A, AncWindow& W, uint32_t i, const HeapEntry e) {
+    hp_set(A, i, e);
+    const uint64_t v = pack_entry(e);
+    const uint32_t a = i - W.pb, b = i - W.gb, c = i - W.hb;
+    W.p0 = a == 0 ? v : W.p0; W.p1 = a == 1 ? v : W.p1; W.p2 = a == 2 ? v : W.p2;
+    W.g0 = b == 0 ? v : W.g0; W.g1 = b == 1 ? v : W.g1;
+    W.h0 = c == 0 ? v : W.h0; W.h1 = c == 1 ? v : W.h1;
+}
+// mm_bubble_up with the first two compares served by the window; every store goes through hp_set_win
+template <bool NL>
+MAPAD_HD void mm_bubble_up_win(const ArenaT<NL>& A, AncWindow& W, uint32_t pos, const HeapEntry elt) {
+    const Ancestors an = win_ancestors(W, pos);
+    const uint32_t i1 = (pos - 1) >> 1, i2 = (pos - 3) >> 2, i3 = (i1 - 3) >> 2;
+    const HeapEntry e1 = an.e1, e2 = an.e2, e3 = an.e3;
+    bool greater, moved;
+    if (mm_is_min_level(pos)) { moved = elt.score > e1.score; greater = moved; }
+    else { moved = elt.score < e1.score; greater = !moved; }
+    if (moved) { hp_set_win(A, W, pos, e1); pos = i1; }
+    {
+        const HeapEntry ge = moved ? e3 : e2;
+        const uint32_t gp = moved ? i3 : i2;
+        if (greater ? (elt.score > ge.score) : (elt.score < ge.score)) {
+            hp_set_win(A, W, pos, ge);
+            pos = gp;
+            while (pos > 2) {
+                const uint32_t g2 = (pos - 3) >> 2;
+                const HeapEntry g = hp_get(A, g2);
+                if (!(greater ? (elt.score > g.score) : (elt.score < g.score))) break;
+                hp_set_win(A, W, pos, g);
+                pos = g2;
+            }
+        }
+    }
+    hp_set_win(A, W, pos, elt);
+}
 
 // The heap array is stored shifted by one entry (logical index i lives in physical slot i + 1; `v` points at logical 0), so the
 // two children of a node (logical 2p+1, 2p+2) form one 16-byte aligned pair and its four grandchildren (4p+3 .. 4p+6) one
@@ -285,10 +422,22 @@ template <bool MAX, bool NL>
 MAPAD_HD void mm_trickle_down(const ArenaT<NL>& A, uint32_t n, uint32_t pos, HeapEntry elt) {
     while (2 * pos + 1 < n) {
         const uint32_t c1 = 2 * pos + 1, g1 = 2 * c1 + 1;
-        HeapPair c, ga, gb;  // a level is entirely near or entirely in the arena; one branch per split keeps a case's loads in flight together
+        HeapPair c, ga, gb;  // a level is entirely near or entirely in the arena
+#if defined(MAPAD_BRANCHY_HEAP)
         if (g1 + 3 < (uint32_t)kTop) { c = load_pair(A.top + c1); ga = load_pair(A.top + g1); gb = load_pair(A.top + g1 + 2); }
         else if (c1 < (uint32_t)kTop) { c = load_pair(A.top + c1); ga = load_pair(A.heap + g1); gb = load_pair(A.heap + g1 + 2); }
         else { c = load_pair(A.heap + c1); ga = load_pair(A.heap + g1); gb = load_pair(A.heap + g1 + 2); }
+#else
+        {   // near reads for every slot (clamped), arena loads predicated and back to back: one wait per level for the whole wavefront
+            const bool c_near = c1 < (uint32_t)kTop, g_near = g1 + 3 < (uint32_t)kTop;
+            const uint32_t kc = c_near ? c1 : 1u, kg = g_near ? g1 : 3u;  // clamped indices keep the 16-byte alignment of a pair (odd logical index)
+            const HeapPair nc = load_pair(A.top + kc), nga = load_pair(A.top + kg), ngb = load_pair(A.top + kg + 2);
+            HeapPair hc = HeapPair{}, hga = HeapPair{}, hgb = HeapPair{};
+            if (!c_near) hc = load_pair(A.heap + c1);
+            if (!g_near) { hga = load_pair(A.heap + g1); hgb = load_pair(A.heap + g1 + 2); }
+            c = c_near ? nc : hc; ga = g_near ? nga : hga; gb = g_near ? ngb : hgb;
+        }
+#endif
         uint32_t best = c1;
         HeapEntry be = c.a;
         if (c1 + 1 < n && (MAX ? (c.b.score > be.score) : (c.b.score < be.score))) { best = c1 + 1; be = c.b; }
@@ -342,11 +491,26 @@ MAPAD_HD uint32_t tree_insert(NP nodes, SearchState& st, const Node& nd) {
     return key;
 }
 // tree_insert without the store: the caller writes the node (one lane of the quad owns it, search_step)
+// The free list is only ever non-empty after an overflow eviction (mapping.rs:1371-1379).  On the device its load is wrapped in an asm block
+// that waits for itself: left to the compiler, the load's destination register is shared with the common path's `key + 1`, and the wait-count
+// pass then guards that register with a full `s_waitcnt vmcnt(0)` on EVERY allocation — a drain of all stores in flight per pushed child
+// (measured: 29 % of the wave time of a step sat in front of this wait).
+template <class NP>
+MAPAD_HD uint32_t free_list_next(NP nodes, uint32_t key) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint32_t r;
+    const MAPAD_GLOBAL Node* p = (const MAPAD_GLOBAL Node*)(nodes + key);
+    asm volatile("global_load_dword %0, %1, off offset:4\n\ts_waitcnt vmcnt(0)" : "=v"(r) : "v"(p) : "memory");
+    return r;
+#else
+    return node_parent(nodes[key]);
+#endif
+}
 template <class NP>
 MAPAD_HD uint32_t tree_alloc(NP nodes, SearchState& st) {
     const uint32_t key = st.tree_next;
-    if (key == st.tree_entries) { st.tree_entries += 1; st.tree_next = key + 1; }
-    else st.tree_next = node_parent(nodes[key]);
+    if (MAPAD_UNLIKELY(key != st.tree_entries)) st.tree_next = free_list_next(nodes, key);
+    else { st.tree_entries += 1; st.tree_next = key + 1; }
     st.tree_len += 1;
     return key;
 }
@@ -448,7 +612,7 @@ MAPAD_RARE void record_hit(const ReadInT<NL> rd, const ArenaT<NL> A, SearchState
     st.hit_ops_used += m;
     hits_push(A.hits, st.n_hits, h);
     if (st.n_hits == 1 || score > st.best_score) { st.best_score = score; st.best_size = size; }  // new BinaryHeap root
-    count_event(rd.ctr, CTR_N_HITS);
+    st.c_hits += 1;
 }
 
 // Before a step starts, an arena that cannot take the step's worst case (9 new nodes, 8 more frames) asks `grow` for a bigger one:
@@ -466,13 +630,19 @@ struct NoGrow {
 // `owner` is the owning lane (the frame of a finished alignment is fetched from it).  Everything else is quad-uniform.
 template <int LPR, bool NL>
 MAPAD_HD void commit_child(const DevParams& P, const ReadInT<NL>& rd, ArenaT<NL>& A, SearchState& st, int alignment_start, float score, uint32_t ngaps, int len,
-                           const Node& nd, bool store, int owner) {
+                           const Node& nd, bool store, int owner, AncWindow& W) {
     if (st.n_hits > 0 && mb_reject_iterative(P, score, st.best_score)) return;
     if ((int)ngaps > P.max_num_gaps_open) return;
     if (MAPAD_UNLIKELY(st.tree_next == st.tree_entries && st.tree_entries >= A.node_cap)) { st.status = ST_ARENA_OVERFLOW; return; }  // cannot happen (search_step)
     const uint32_t id = tree_alloc(A.nodes, st);
+    // the loads of a push go out before the stores of its node: the wait for them then leaves the stores in flight (vmcnt counts in order)
+    const bool pushes = len != rd.L;
+    const uint32_t pos = st.heap_len;
+    const bool use_win = W.on && pos - W.n0 < kWinPushes;
+    Ancestors an{};
+    if (pushes && !use_win) an = load_ancestors(A, pos);
     if (store) A.nodes[id] = nd;
-    count_event(rd.ctr, CTR_N_NODE);
+    st.c_node += 1;
     if (MAPAD_UNLIKELY(len == rd.L)) {  // rare: the state takes a round trip through memory only here, so it can live in registers otherwise
         Node u = nd;
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -481,14 +651,19 @@ MAPAD_HD void commit_child(const DevParams& P, const ReadInT<NL>& rd, ArenaT<NL>
         (void)owner;
         const Frame c = unpack_frame(u);
         SearchState tmp = st;
+        MAPAD_MARK(PROF_COMMIT);
         record_hit(rd, A, tmp, alignment_start, c.lower, c.lower_rev, c.size, score, id);
+        drain_memory();
+        MAPAD_MARK(PROF_HIT);
         st = tmp;
         return;
     }
     if (MAPAD_UNLIKELY(st.heap_len >= A.heap_cap)) { st.status = ST_ARENA_OVERFLOW; return; }  // cannot happen (search_step)
     st.heap_len += 1;
-    mm_bubble_up(A, st.heap_len - 1, HeapEntry{score, id});
-    count_event(rd.ctr, CTR_N_PUSH);
+    MAPAD_MARK(PROF_C_PRE);
+    if (use_win) mm_bubble_up_win(A, W, pos, HeapEntry{score, id});
+    else mm_bubble_up(A, pos, HeapEntry{score, id}, an);  // the ancestors were read from memory, which every earlier store of this step has reached
+    st.c_push += 1;
 }
 
 // Overflow recovery (mapping.rs:1371-1379): evict the worst frames and free their tree nodes.
@@ -505,7 +680,7 @@ MAPAD_RARE void evict_worst(const ArenaT<NL> A, SearchState& st, int64_t cnt) {
 // persistent quad can fetch its next read as soon as the current one finishes.  `w` = lane index inside the quad.
 template <bool NL>
 MAPAD_RARE void search_init(uint64_t n_text, int alignment_start, const ReadInT<NL> rd, const ArenaT<NL> A, SearchState& st) {
-    for (int k = 0; k < CTR_COUNT; ++k) rd.ctr[k] = 0;
+    st.c_esearch = 0; st.c_push = 0; st.c_pop = 0; st.c_node = 0; st.c_hits = 0;
     st.heap_len = 0; st.tree_entries = 0; st.tree_next = 0; st.tree_len = 0; st.n_hits = 0; st.hit_ops_used = 0; st.status = ST_OK;
     st.best_score = 0.0f; st.best_size = 0;
     Frame root;  // Tree::clear() -> id 0; root frame (mapping.rs:1045-1054)
@@ -514,7 +689,7 @@ MAPAD_RARE void search_init(uint64_t n_text, int alignment_start, const ReadInT<
     tree_insert(A.nodes, st, pack_node(pack_op(OP_MATCH, 0, 0), 0, root));
     A.top[0] = HeapEntry{0.0f, 0u};
     st.heap_len = 1;
-    count_event(rd.ctr, CTR_N_PUSH);
+    st.c_push += 1;
 }
 
 // One iteration of the `while let Some(stack_frame) = stack.pop_max()` loop.  Returns false when the search is over.
@@ -522,7 +697,10 @@ template <int LPR, bool CONT, bool NL, class Grow>
 MAPAD_HD bool search_step(const DevIndex& ix, const DevParams& P, const ReadInT<NL>& rd, ArenaT<NL>& A, SearchState& st, int w, const Grow& grow) {
     if (st.heap_len == 0 || st.status != ST_OK) return false;
     if (MAPAD_UNLIKELY(st.tree_len + kStepNodes > A.node_cap || st.heap_len + kStepNodes > A.heap_cap)) {
+        MAPAD_MARK(PROF_LOOP);
         const int g = grow(A, st);
+        drain_memory();
+        MAPAD_MARK(PROF_GROW);
         if (g == GROW_WAIT) return true;
         if (g == GROW_NEVER || st.tree_len + kStepNodes > A.node_cap || st.heap_len + kStepNodes > A.heap_cap) { st.status = ST_ARENA_OVERFLOW; return false; }
     }
@@ -530,10 +708,18 @@ MAPAD_HD bool search_step(const DevIndex& ix, const DevParams& P, const ReadInT<
     const int alignment_start = alignment_start_of(P, L);
     const float open_ext = P.gap_open + P.gap_extend;
     uint32_t top_idx;
+#if defined(MAPAD_PROFILE_SECTIONS) && defined(__HIP_DEVICE_COMPILE__)
+    if (w == 0) atomicAdd(&g_prof_hist[31 - __clz((int)st.heap_len)], 1u);
+    const uint32_t prof_nodes0 = st.tree_len;
+#endif
+    // Order of a step, chosen for the memory round trips it takes (each of them ~1-2 us when the chip is loaded):
+    //   1. {popped frame's node, the heap's last entry}      2. {score row, four index loads} issued as soon as the frame is known, and behind
+    //   them the repair of the heap (its round trips through the arena levels run while the index loads are in flight) and the window of
+    //   ancestors for this step's pushes      3. nothing: counts, gates, children and pushes work on what has arrived.
     const HeapEntry top = mm_find_max(A, st.heap_len, top_idx);
-    const Node top_node = A.nodes[top.node];  // in flight while the heap is repaired
-    mm_remove_at<true>(A, st.heap_len, top_idx);
-    count_event(rd.ctr, CTR_N_POP);
+    const Node top_node = A.nodes[top.node];
+    const HeapEntry last = hp_get(A, st.heap_len - 1);
+    st.c_pop += 1;
     const Frame f = unpack_frame(top_node);
     const float f_score = top.score;
     int j, d_k, d_l;
@@ -550,7 +736,8 @@ MAPAD_HD bool search_step(const DevIndex& ix, const DevParams& P, const ReadInT<
     const float deletion_score = (gap_side == GAP_DEL ? P.gap_extend : open_ext) + f_score;
     const uint32_t num_gaps_open = gap_side == GAP_CLOSED ? f.ngaps + 1 : f.ngaps;             // :1148-1152
     const float lower_bound = d_get(rd.d, L, alignment_start, d_k, d_l);                       // :1195
-    if (st.n_hits > 0 && mb_reject_iterative(P, f_score + lower_bound, st.best_score)) return false;  // :1201-1208
+    if (st.n_hits > 0 && mb_reject_iterative(P, f_score + lower_bound, st.best_score)) { st.heap_len -= 1; return false; }  // :1201-1208 (the frame was popped; the search is over)
+    MAPAD_MARK(PROF_NODE);
 
     // Extension (:1245); forward extension works on the swapped interval.  Device quads: lane w keeps the extension by base w only.
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -558,20 +745,36 @@ MAPAD_HD bool search_step(const DevIndex& ix, const DevParams& P, const ReadInT<
 #else
     constexpr bool kLaneKids = false;
 #endif
+    const uint64_t x_lower = forward ? f.lower_rev : f.lower, x_lower_rev = forward ? f.lower : f.lower_rev;
+#if defined(__HIP_DEVICE_COMPILE__)
+    ExtLoads ext_loads{};
+#if !defined(MAPAD_LATE_EXT)
+    if constexpr (kLaneKids) ext_loads = ext4_quad_issue(ix, x_lower, f.size, w);  // one call site: forward and backward quads of a wavefront share the round trip
+#endif
+#endif
+    // pop_max of the crate, second half: the last entry takes the place of the maximum and trickles down
+    st.heap_len -= 1;
+    if (top_idx < st.heap_len) mm_trickle_down<true>(A, st.heap_len, top_idx, last);
+#if defined(MAPAD_LATE_EXT) && defined(__HIP_DEVICE_COMPILE__)
+    if constexpr (kLaneKids) ext_loads = ext4_quad_issue(ix, x_lower, f.size, w);
+#endif
+    AncWindow W = win_load(A, st.heap_len);
+    MAPAD_MARK(PROF_POP);
     Ext4 e;
     uint64_t my_lower = 0, my_lower_rev = 0, my_size = 0;  // kLaneKids: extension by base w
     uint32_t nonempty;
     if constexpr (kLaneKids) {
 #if defined(__HIP_DEVICE_COMPILE__)
-        ExtLane x;  // one call site: the rank queries of forward and backward quads of a wavefront share their memory round trip
-        ext4_quad_lane(ix, forward ? f.lower_rev : f.lower, forward ? f.lower : f.lower_rev, f.size, w, x);
+        ExtLane x;
+        ext4_quad_lane_finish(ix, ext_loads, x_lower, x_lower_rev, f.size, w, x);
         my_lower = x.lower; my_lower_rev = x.lower_rev; my_size = x.size; nonempty = x.nonempty;
 #endif
     } else {
-        ext4_any<LPR>(ix, forward ? f.lower_rev : f.lower, forward ? f.lower : f.lower_rev, f.size, w, e);
+        ext4_any<LPR>(ix, x_lower, x_lower_rev, f.size, w, e);
         nonempty = (e.size[0] >= 1 ? 1u : 0u) | (e.size[1] >= 1 ? 2u : 0u) | (e.size[2] >= 1 ? 4u : 0u) | (e.size[3] >= 1 ? 8u : 0u);
     }
-    count_event(rd.ctr, CTR_E_SEARCH);
+    st.c_esearch += 1;
+    MAPAD_MARK(PROF_EXT);
 
     // Static gates of the <= 9 children in commit order: Ins; then for k = T,G,C,A: Del(k), Match/Mismatch(k).
     // bit 0 = Ins, bit 1+2i = Del, bit 2+2i = M/MM with i = 0..3 <-> k = 3..0.
@@ -630,6 +833,61 @@ MAPAD_HD bool search_step(const DevIndex& ix, const DevParams& P, const ReadInT<
         nd_del = make_child(1 + 2 * (3 - w), w, my_lower, my_lower_rev, my_size);
         nd_mm = make_child(2 + 2 * (3 - w), w, my_lower, my_lower_rev, my_size);
     }
+    MAPAD_MARK(PROF_GATES);
+#if defined(MAPAD_PROFILE_SECTIONS) && defined(__HIP_DEVICE_COMPILE__)
+    {   // trips of this wave step = max candidates over the active quads
+        uint32_t m = (uint32_t)__popc(cand);
+        for (int d = 32; d; d >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, d));
+        if ((threadIdx.x & 63) == (unsigned)(__ffsll((long long)__ballot(1)) - 1)) atomicAdd(&g_prof_hist[36 + min(m, 11u)], 1u);
+    }
+#endif
+    // Fast path of the commit loop: when no child can complete the read (len + 1 < L) and the slab has no free list, nothing a sibling does
+    // changes the gates of the next one — reject_iterative compares against a best hit that cannot change within the step, the gap limit is
+    // static — so both fold into the candidate mask and the loop body is: slab key, arena loads of the push, node store, bubble-up.  (The
+    // general loop below pays ~350 instructions per child for the checks, the selects around them and the hit path; children are 2.4 loop
+    // trips per wavefront step and were half of a step's instructions.)
+#if !defined(MAPAD_NO_FAST_COMMIT)
+    if (f.len + 1 < L && st.tree_next == st.tree_entries) {
+        if ((int)num_gaps_open > P.max_num_gaps_open) cand &= 0x154u;  // Ins and Del children open or extend a gap; M/MM children keep the frame's count
+        if (st.n_hits > 0 && P.bound_kind != BOUND_TEST) {             // mb_reject_iterative (commit_child)
+            const float lim = st.best_score + P.repr_mm;
+            if (insertion_score < lim) cand &= ~1u;
+            if (deletion_score < lim) cand &= ~0xAAu;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) if (mm[i] < lim) cand &= ~(4u << (2 * i));
+        }
+        while (cand != 0) {
+#if defined(__HIP_DEVICE_COMPILE__)
+            const int t = __ffs((int)cand) - 1;
+#else
+            const int t = __builtin_ctz(cand);
+#endif
+            cand &= cand - 1;
+            const bool is_ins = t == 0, is_del = (t & 1) != 0;
+            const int i = is_ins ? 0 : (t - 1) >> 1, k = 3 - i;
+            const float score = is_ins ? insertion_score : is_del ? deletion_score : (i == 0 ? mm[0] : i == 1 ? mm[1] : i == 2 ? mm[2] : mm[3]);
+            const uint32_t id = st.tree_next;  // == tree_entries: the slab grows at its end
+            st.tree_next = id + 1; st.tree_entries = id + 1; st.tree_len += 1;
+            const uint32_t pos = st.heap_len;
+            st.heap_len = pos + 1;
+            const bool use_win = W.on && pos - W.n0 < kWinPushes;
+            Ancestors an{};
+            if (!use_win) an = load_ancestors(A, pos);  // before the node store: the wait for these loads then leaves the stores in flight
+            if constexpr (kLaneKids) {
+                const Node nd = pick_node(is_ins, is_del, nd_ins, nd_del, nd_mm);
+                if (w == (is_ins ? 0 : k)) A.nodes[id] = nd;
+            } else {
+                const uint64_t xl = k == 0 ? e.lower[0] : k == 1 ? e.lower[1] : k == 2 ? e.lower[2] : e.lower[3];
+                const uint64_t xr = k == 0 ? e.lower_rev[0] : k == 1 ? e.lower_rev[1] : k == 2 ? e.lower_rev[2] : e.lower_rev[3];
+                const uint64_t xs = k == 0 ? e.size[0] : k == 1 ? e.size[1] : k == 2 ? e.size[2] : e.size[3];
+                A.nodes[id] = make_child(t, k, xl, xr, xs);
+            }
+            if (use_win) mm_bubble_up_win(A, W, pos, HeapEntry{score, id});
+            else mm_bubble_up(A, pos, HeapEntry{score, id}, an);
+            st.c_node += 1; st.c_push += 1;
+        }
+    }
+#endif
     while (cand != 0 && st.status == ST_OK) {
 #if defined(__HIP_DEVICE_COMPILE__)
         const int t = __ffs((int)cand) - 1;
@@ -643,16 +901,20 @@ MAPAD_HD bool search_step(const DevIndex& ix, const DevParams& P, const ReadInT<
         const uint32_t ngaps = (is_ins || is_del) ? num_gaps_open : f.ngaps;
         const int len = is_del ? f.len : f.len + 1;
         if constexpr (kLaneKids) {
-            const Node nd = is_ins ? nd_ins : is_del ? nd_del : nd_mm;
+            const Node nd = pick_node(is_ins, is_del, nd_ins, nd_del, nd_mm);
             const int owner = is_ins ? 0 : k;
-            commit_child<LPR>(P, rd, A, st, alignment_start, score, ngaps, len, nd, w == owner, owner);
+            commit_child<LPR>(P, rd, A, st, alignment_start, score, ngaps, len, nd, w == owner, owner, W);
         } else {
             const uint64_t xl = k == 0 ? e.lower[0] : k == 1 ? e.lower[1] : k == 2 ? e.lower[2] : e.lower[3];
             const uint64_t xr = k == 0 ? e.lower_rev[0] : k == 1 ? e.lower_rev[1] : k == 2 ? e.lower_rev[2] : e.lower_rev[3];
             const uint64_t xs = k == 0 ? e.size[0] : k == 1 ? e.size[1] : k == 2 ? e.size[2] : e.size[3];
-            commit_child<LPR>(P, rd, A, st, alignment_start, score, ngaps, len, make_child(t, k, xl, xr, xs), true, 0);
+            commit_child<LPR>(P, rd, A, st, alignment_start, score, ngaps, len, make_child(t, k, xl, xr, xs), true, 0, W);
         }
     }
+    MAPAD_MARK(PROF_COMMIT);
+#if defined(MAPAD_PROFILE_SECTIONS) && defined(__HIP_DEVICE_COMPILE__)
+    if (w == 0) atomicAdd(&g_prof_hist[24 + min(st.tree_len - prof_nodes0, 11u)], 1u);
+#endif
     if (MAPAD_UNLIKELY(st.status != ST_OK)) return false;
     // :1348-1355
     if (MAPAD_UNLIKELY(st.n_hits > 9 || (st.n_hits > 0 && st.best_size > 1))) return false;
@@ -663,6 +925,7 @@ MAPAD_HD bool search_step(const DevIndex& ix, const DevParams& P, const ReadInT<
         const int64_t b = (int64_t)st.tree_len - (int64_t)P.edit_tree_limit;
         SearchState tmp = st;
         evict_worst(A, tmp, a > b ? a : b);
+        drain_memory();
         st = tmp;
     }
     return st.heap_len > 0;

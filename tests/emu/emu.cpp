@@ -49,7 +49,7 @@ mapad_batch_result_t* emu_map_batch(const uint64_t* blocks, uint64_t n_blocks, u
     auto* r = new EmuResult();
     r->hit_begin.assign(n_reads + 1, 0); r->status.resize(n_reads); r->counters.resize(n_reads);
     r->d_arrays.resize(n_reads ? offsets[n_reads] : 0);
-    std::vector<HeapEntry> top(32);
+    std::vector<HeapEntry> top(kTop + 1 + 8);  // logical slots [0, kTop) shifted by one, plus slack for pair loads
     std::vector<uint8_t> qc(2 * (lmax + 1));
     std::vector<float> dnear(lmax + 1);
     std::vector<float> pen(lmax + 1), chain(lmax + 1);
@@ -87,7 +87,6 @@ mapad_batch_result_t* emu_map_batch(const uint64_t* blocks, uint64_t n_blocks, u
         ctr.e_darray = d_array_scalar(ix, P, seqs + off, quals + off, L, pen.data(), chain.data(), d);
         read_setup(seqs + off, quals + off, d, L, qc.data(), dnear.data(), 0, 1);
         SearchState st;
-        uint32_t last_ev[CTR_COUNT] = {0};
         for (int pass = 0; pass < 2; ++pass) {
             const uint32_t hc = pass == 0 ? heap_cap : P.stack_limit + 10, nc = pass == 0 ? node_cap : P.edit_tree_limit + 10;
             // lazily grown backing stores keep the host emulation cheap even with the reference's 2M / 10M limits
@@ -96,14 +95,14 @@ mapad_batch_result_t* emu_map_batch(const uint64_t* blocks, uint64_t n_blocks, u
             nodes.assign(std::min<uint32_t>(nc, 1u << 22), Node{});
             A.top = top.data() + 1; A.heap = heap.data() + 1; A.nodes = nodes.data(); A.hits = hits.data(); A.hit_ops = hit_ops.data(); A.scratch = scratch.data();
             A.heap_cap = (uint32_t)heap.size() - 16; A.node_cap = (uint32_t)nodes.size(); A.hit_ops_cap = (uint32_t)hit_ops.size();
-            ReadIn rd{qc.data(), dnear.data(), L, P.reject_thr[L], P.table_base[L], last_ev};
+            ReadIn rd{qc.data(), dnear.data(), L, P.reject_thr[L], P.table_base[L]};
             if (pass == 0) search_read(ix, P, rd, A, st, 0, grow);
             else search_read(ix, P, rd, A, st, 0);
             if (st.status != ST_ARENA_OVERFLOW) break;
             if (pass == 0) second += 1;
         }
         r->status[i] = st.status;
-        ctr.e_search = last_ev[CTR_E_SEARCH]; ctr.n_push = last_ev[CTR_N_PUSH]; ctr.n_pop = last_ev[CTR_N_POP]; ctr.n_node = last_ev[CTR_N_NODE]; ctr.n_hits = last_ev[CTR_N_HITS];
+        ctr.e_search = st.c_esearch; ctr.n_push = st.c_push; ctr.n_pop = st.c_pop; ctr.n_node = st.c_node; ctr.n_hits = st.c_hits;
         std::memcpy(&r->counters[i], &ctr, sizeof ctr);
         for (uint32_t k = 0; k < st.n_hits; ++k) {
             const HitRec& h = hits[k];
