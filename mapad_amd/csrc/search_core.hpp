@@ -529,8 +529,8 @@ MAPAD_HD void tree_remove(NP nodes, SearchState& st, uint32_t key) {  // backtra
 // Walk leaf -> root (root excluded, stop at a vacant slot), bucket by read position ascending; a bucket keeps walk order
 // if its position is left of the alignment start, else it is reversed.  Counting sort over positions 0..L.
 template <class NP, class SP, class OP>
-MAPAD_RARE uint32_t extract_ops(NP nodes, uint32_t end_node, int alignment_start, int L, SP scratch, OP out,
-                              uint32_t out_cap) {
+MAPAD_RARE uint32_t extract_ops_general(NP nodes, uint32_t end_node, int alignment_start, int L, SP scratch, OP out,
+                                      uint32_t out_cap) {
     SP cnt = scratch;           // [L + 1]
     SP fill = scratch + L + 1;  // [L + 1]
     for (int i = 0; i <= L; ++i) { cnt[i] = 0; fill[i] = 0; }
@@ -556,6 +556,30 @@ MAPAD_RARE uint32_t extract_ops(NP nodes, uint32_t end_node, int alignment_start
         s = node_parent(nd);
     }
     return m;
+}
+// The walk is a chain of dependent loads (one arena round trip per edit operation) during which the other read slots of the wavefront
+// idle, so it is done once where that is enough: with the production model the alignment starts at the 3' end (every position is left of
+// the alignment start) and the search only moves backward, so positions do not decrease from leaf to root and the bucket order of
+// record.rs:491-496 IS the walk order.  The walk checks exactly that while it writes; anything else (the bidirectional test models)
+// falls back to the counting sort.  `dense`: the slab has no vacant entries, so the occupancy word of a node need not be loaded.
+template <class NP, class SP, class OP>
+MAPAD_RARE uint32_t extract_ops(NP nodes, uint32_t end_node, int alignment_start, int L, SP scratch, OP out, uint32_t out_cap, bool dense) {
+    if (dense) {
+        uint32_t m = 0, prev = 0;
+        bool in_order = true;
+        for (uint32_t s = end_node; s != 0;) {
+            const uint64_t w0 = nodes[s].w0;
+            const uint32_t op = (uint32_t)w0, p = op & 0xFFFFu;
+            in_order = in_order && p >= prev && (int)p < alignment_start;
+            prev = p;
+            if (m < out_cap) out[m] = op;
+            m += 1;
+            s = (uint32_t)(w0 >> 32);
+        }
+        if (m > out_cap) return 0xFFFFFFFFu;
+        if (in_order) return m;
+    }
+    return extract_ops_general(nodes, end_node, alignment_start, L, scratch, out, out_cap);
 }
 
 // ---- hit list: Rust BinaryHeap::push (sift_up moves while strictly greater than the parent) -----------------------------------
@@ -606,7 +630,7 @@ MAPAD_RARE void record_hit(const ReadInT<NL> rd, const ArenaT<NL> A, SearchState
     HitRec h;
     h.lower = lower; h.lower_rev = lower_rev; h.size = size; h.score = score; h.pad = 0;
     h.ops_off = st.hit_ops_used;
-    const uint32_t m = extract_ops(A.nodes, id, alignment_start, rd.L, A.scratch, A.hit_ops + st.hit_ops_used, A.hit_ops_cap - st.hit_ops_used);
+    const uint32_t m = extract_ops(A.nodes, id, alignment_start, rd.L, A.scratch, A.hit_ops + st.hit_ops_used, A.hit_ops_cap - st.hit_ops_used, st.tree_len == st.tree_entries);
     if (m == 0xFFFFFFFFu) { st.status = ST_ARENA_OVERFLOW; return; }
     h.n_ops = m;
     st.hit_ops_used += m;
@@ -856,6 +880,7 @@ MAPAD_HD bool search_step(const DevIndex& ix, const DevParams& P, const ReadInT<
 #pragma unroll
             for (int i = 0; i < 4; ++i) if (mm[i] < lim) cand &= ~(4u << (2 * i));
         }
+        const uint32_t cand0 = cand, id0 = st.tree_next;  // == tree_entries: the slab grows at its end, child t gets key id0 + (children before t)
         while (cand != 0) {
 #if defined(__HIP_DEVICE_COMPILE__)
             const int t = __ffs((int)cand) - 1;
@@ -866,17 +891,14 @@ MAPAD_HD bool search_step(const DevIndex& ix, const DevParams& P, const ReadInT<
             const bool is_ins = t == 0, is_del = (t & 1) != 0;
             const int i = is_ins ? 0 : (t - 1) >> 1, k = 3 - i;
             const float score = is_ins ? insertion_score : is_del ? deletion_score : (i == 0 ? mm[0] : i == 1 ? mm[1] : i == 2 ? mm[2] : mm[3]);
-            const uint32_t id = st.tree_next;  // == tree_entries: the slab grows at its end
+            const uint32_t id = st.tree_next;
             st.tree_next = id + 1; st.tree_entries = id + 1; st.tree_len += 1;
             const uint32_t pos = st.heap_len;
             st.heap_len = pos + 1;
             const bool use_win = W.on && pos - W.n0 < kWinPushes;
             Ancestors an{};
-            if (!use_win) an = load_ancestors(A, pos);  // before the node store: the wait for these loads then leaves the stores in flight
-            if constexpr (kLaneKids) {
-                const Node nd = pick_node(is_ins, is_del, nd_ins, nd_del, nd_mm);
-                if (w == (is_ins ? 0 : k)) A.nodes[id] = nd;
-            } else {
+            if (!use_win) an = load_ancestors(A, pos);
+            if constexpr (!kLaneKids) {
                 const uint64_t xl = k == 0 ? e.lower[0] : k == 1 ? e.lower[1] : k == 2 ? e.lower[2] : e.lower[3];
                 const uint64_t xr = k == 0 ? e.lower_rev[0] : k == 1 ? e.lower_rev[1] : k == 2 ? e.lower_rev[2] : e.lower_rev[3];
                 const uint64_t xs = k == 0 ? e.size[0] : k == 1 ? e.size[1] : k == 2 ? e.size[2] : e.size[3];
@@ -885,6 +907,17 @@ MAPAD_HD bool search_step(const DevIndex& ix, const DevParams& P, const ReadInT<
             if (use_win) mm_bubble_up_win(A, W, pos, HeapEntry{score, id});
             else mm_bubble_up(A, pos, HeapEntry{score, id}, an);
             st.c_node += 1; st.c_push += 1;
+        }
+        if constexpr (kLaneKids) {
+            // The nodes of all children in three store groups behind the pushes (a node is only read when its frame is popped, at the earliest
+            // in the next step): lane w stores the match/mismatch and the deletion child of base w, lane 0 the insertion child.  Inside the loop
+            // the stores sat between a push's loads and its wait, which then had to cover them as well.
+            const uint32_t t_mm = 2u + 2u * (3u - (uint32_t)w), t_del = t_mm - 1u;
+#if defined(__HIP_DEVICE_COMPILE__)
+            if ((cand0 >> t_mm) & 1u) A.nodes[id0 + (uint32_t)__popc(cand0 & ((1u << t_mm) - 1u))] = nd_mm;
+            if ((cand0 >> t_del) & 1u) A.nodes[id0 + (uint32_t)__popc(cand0 & ((1u << t_del) - 1u))] = nd_del;
+#endif
+            if ((cand0 & 1u) && w == 0) A.nodes[id0] = nd_ins;
         }
     }
 #endif
