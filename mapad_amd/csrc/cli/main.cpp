@@ -258,6 +258,8 @@ int cmd_map(const Args& a, uint64_t seed, const std::vector<int>& devices, const
     for (size_t d = 0; d < n_dev; ++d) dev_q.emplace_back(new BoundedQueue<ChunkPtr>(2));
     BoundedQueue<ChunkPtr> done_q(4);
     std::atomic<bool> failed{false};
+    std::atomic<uint64_t> us_reader{0}, us_device{0}, us_writer{0};  // busy time of the three stages (the slowest one sets the throughput)
+    auto now_us = [] { return (uint64_t)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     std::string fail_msg;
     std::mutex fail_mu;
     auto fail = [&](const std::string& m) { std::lock_guard<std::mutex> l(fail_mu); if (!failed.exchange(true)) fail_msg = m; };
@@ -268,6 +270,7 @@ int cmd_map(const Args& a, uint64_t seed, const std::vector<int>& devices, const
             uint64_t chunk_no = 0;
             bool more = true;
             while (more && !failed) {
+                const uint64_t t_r0 = now_us();
                 auto c = std::make_shared<Chunk>();
                 c->no = chunk_no;
                 c->offsets.assign(1, 0);
@@ -298,6 +301,7 @@ int cmd_map(const Args& a, uint64_t seed, const std::vector<int>& devices, const
                     for (uint64_t i = sl.lo; i <= sl.hi; ++i) sl.offsets[i - sl.lo] = c->offsets[i] - c->offsets[sl.lo];
                 }
                 c->pending = (int)n_dev;
+                us_reader += now_us() - t_r0;
                 c->t_submit = std::chrono::steady_clock::now();
                 for (size_t d = 0; d < n_dev; ++d) dev_q[d]->push(c);
                 chunk_no += 1;
@@ -341,6 +345,7 @@ int cmd_map(const Args& a, uint64_t seed, const std::vector<int>& devices, const
             ChunkPtr prev, c;
             while (dev_q[d]->pop(c)) {
                 if (failed) continue;
+                const uint64_t t_d0 = now_us();
                 submit(c);                       // the GPU starts on chunk k + 1 ...
                 if (prev) {                      // ... while chunk k is collected and turned into records
                     if (collect(prev, 1)) records(prev);
@@ -353,8 +358,11 @@ int cmd_map(const Args& a, uint64_t seed, const std::vector<int>& devices, const
                     }
                 }
                 prev = c;
+                if (d == 0) us_device += now_us() - t_d0;
             }
+            const uint64_t t_d1 = now_us();
             if (prev && !failed) { if (!collect(prev, 0)) rerun(prev); records(prev); }
+            if (d == 0) us_device += now_us() - t_d1;
         } catch (const std::exception& e) { fail(e.what()); }
     };
     std::vector<std::thread> workers;
@@ -367,6 +375,7 @@ int cmd_map(const Args& a, uint64_t seed, const std::vector<int>& devices, const
             ChunkPtr c;
             while (done_q.pop(c)) {
                 if (failed) continue;
+                const uint64_t t_w0 = now_us();
                 const size_t n = c->in.size();
                 std::vector<std::vector<uint8_t>> enc(host_threads);
                 std::vector<uint64_t> mapped(host_threads, 0);
@@ -392,6 +401,7 @@ int cmd_map(const Args& a, uint64_t seed, const std::vector<int>& devices, const
                 for (unsigned t = 0; t < host_threads; ++t) { out.write_parallel(enc[t].data(), enc[t].size(), host_threads); n_mapped += mapped[t]; }
                 n_total += n;
                 for (auto& sl : c->slices) { mapad_records_free(sl.recs); mapad_batch_result_free(sl.res); sl.recs = nullptr; sl.res = nullptr; }
+                us_writer += now_us() - t_w0;
             }
         } catch (const std::exception& e) { fail(e.what()); }
     });
@@ -405,6 +415,7 @@ int cmd_map(const Args& a, uint64_t seed, const std::vector<int>& devices, const
     const double t_all = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
     std::fprintf(stderr, "mapad-amd: %llu reads, %llu mapped; %zu device(s); index + contexts %.2f s, mapping %.2f s (%.0f reads/s)\n", (unsigned long long)n_total,
                  (unsigned long long)n_mapped, n_dev, t_load, t_all - t_load, (double)n_total / std::max(t_all - t_load, 1e-9));
+    std::fprintf(stderr, "mapad-amd: stage busy time: reader %.2f s, device worker 0 %.2f s, writer %.2f s\n", us_reader.load() * 1e-6, us_device.load() * 1e-6, us_writer.load() * 1e-6);
     for (auto* c : ctxs) mapad_ctx_destroy(c);
     mapad_index_free(idx);
     return 0;

@@ -8,9 +8,11 @@
 #include <algorithm>
 #include <cstdint>
 #include <cstdlib>
+#include <functional>
 #include <map>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "fmd_device.hpp"
@@ -200,30 +202,48 @@ inline void build_blocks(Index& ix) {
     ix.blocks.assign(n_blocks * 16, 0);
     ix.x_counts.clear();
     static const int CODE[6] = {0, 4, 5, 6, 7, 1};  // rank -> device symbol code
-    uint64_t cnt[4] = {0, 0, 0, 0}, xcnt = 0;
-    bool any_x = false;
+    // pass 1 (threads over block ranges): bit planes + the block's own symbol counts, parked in the count words
+    const unsigned T = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(std::min<unsigned>(std::thread::hardware_concurrency(), 32u), n_blocks / 4096 + 1));
     std::vector<uint64_t> xs(n_blocks, 0);
-    int nsent = 0;
+    std::vector<std::vector<uint64_t>> sent(T);
+    std::vector<int> bad(T, 0);
+    auto work = [&](unsigned t) {
+        const uint64_t b0 = n_blocks * t / T, b1 = n_blocks * (t + 1) / T;
+        for (uint64_t b = b0; b < b1; ++b) {
+            uint64_t* blk = ix.blocks.data() + b * 16;
+            uint64_t cnt[4] = {0, 0, 0, 0}, xcnt = 0;
+            const uint64_t r0 = b * kBlockRows;
+            for (uint64_t r = r0; r < std::min(n, r0 + kBlockRows); ++r) {
+                const uint8_t a = ix.bwt[r];
+                if (a > 5) { bad[t] = 1; continue; }
+                const int code = CODE[a];
+                const int w = (int)((r - r0) >> 6), bit = (int)((r - r0) & 63);
+                if (code & 1) blk[4 * w + 1] |= 1ull << bit;
+                if (code & 2) blk[4 * w + 2] |= 1ull << bit;
+                if (code & 4) blk[4 * w + 3] |= 1ull << bit;
+                if (a >= 1 && a <= 4) cnt[a - 1] += 1;
+                else if (a == 5) xcnt += 1;
+                else if (sent[t].size() < 4) sent[t].push_back(r);
+            }
+            for (int w = 0; w < 4; ++w) blk[4 * w] = cnt[w];
+            xs[b] = xcnt;
+        }
+    };
+    if (T == 1) work(0);
+    else { std::vector<std::thread> pool; for (unsigned t = 0; t < T; ++t) pool.emplace_back(work, t); for (auto& th : pool) th.join(); }
+    for (unsigned t = 0; t < T; ++t) if (bad[t]) throw std::runtime_error("BWT symbol out of range");
+    // pass 2: exclusive prefix sums over the blocks
+    uint64_t cnt[4] = {0, 0, 0, 0}, xcnt = 0;
     for (uint64_t b = 0; b < n_blocks; ++b) {
         uint64_t* blk = ix.blocks.data() + b * 16;
-        for (int w = 0; w < 4; ++w) blk[4 * w] = cnt[w];
-        xs[b] = xcnt;
-        const uint64_t r0 = b * kBlockRows;
-        for (uint64_t r = r0; r < std::min(n, r0 + kBlockRows); ++r) {
-            const uint8_t a = ix.bwt[r];
-            if (a > 5) throw std::runtime_error("BWT symbol out of range");
-            const int code = CODE[a];
-            const int w = (int)((r - r0) >> 6), bit = (int)((r - r0) & 63);
-            if (code & 1) blk[4 * w + 1] |= 1ull << bit;
-            if (code & 2) blk[4 * w + 2] |= 1ull << bit;
-            if (code & 4) blk[4 * w + 3] |= 1ull << bit;
-            if (a >= 1 && a <= 4) cnt[a - 1] += 1;
-            else if (a == 5) { xcnt += 1; any_x = true; }
-            else { if (nsent < 2) ix.sentinel[nsent] = r; nsent += 1; }
-        }
+        for (int w = 0; w < 4; ++w) { const uint64_t c = blk[4 * w]; blk[4 * w] = cnt[w]; cnt[w] += c; }
+        const uint64_t x = xs[b]; xs[b] = xcnt; xcnt += x;
     }
-    if (nsent != 2) throw std::runtime_error("BWT must contain exactly two sentinels");
-    if (any_x) ix.x_counts = std::move(xs);
+    std::vector<uint64_t> all_sent;
+    for (auto& v : sent) all_sent.insert(all_sent.end(), v.begin(), v.end());
+    if (all_sent.size() != 2) throw std::runtime_error("BWT must contain exactly two sentinels");
+    ix.sentinel[0] = std::min(all_sent[0], all_sent[1]); ix.sentinel[1] = std::max(all_sent[0], all_sent[1]);
+    if (xcnt) ix.x_counts = std::move(xs);
     // Less: less[c] = number of symbols < c
     uint64_t per[6] = {2, cnt[0], cnt[1], cnt[2], cnt[3], xcnt};
     uint64_t acc = 0;
@@ -264,23 +284,32 @@ inline std::vector<uint8_t> prepare_text(const std::vector<std::string>& names, 
     uint64_t end = 0;
     for (size_t c = 0; c < names.size(); ++c) end += lens[c];
     text.resize(end);
+    const unsigned T = (unsigned)std::max<size_t>(1, std::min<size_t>(std::min<unsigned>(std::thread::hardware_concurrency(), 32u), text.size() / (1u << 22) + 1));
+    auto parallel = [&](const std::function<void(size_t, size_t, unsigned)>& fn, size_t total) {
+        if (T == 1) { fn(0, total, 0); return; }
+        std::vector<std::thread> pool;
+        for (unsigned t = 0; t < T; ++t) pool.emplace_back([&, t] { fn(total * t / T, total * (t + 1) / T, t); });
+        for (auto& th : pool) th.join();
+    };
     end = 0;
     for (size_t c = 0; c < names.size(); ++c) {  // :115-137
         uint8_t* dst = text.data() + end;
-        for (uint64_t i = 0; i < lens[c]; ++i) {
-            uint8_t ch = seqs[c][i];
-            if (ch >= 'a' && ch <= 'z') ch = (uint8_t)(ch - 'a' + 'A');
-            dst[i] = ch;
-        }
+        const uint8_t* src = seqs[c];
+        auto upper = [&](size_t lo, size_t hi, unsigned) {
+            for (size_t i = lo; i < hi; ++i) { uint8_t ch = src[i]; if (ch >= 'a' && ch <= 'z') ch = (uint8_t)(ch - 'a' + 'A'); dst[i] = ch; }
+        };
+        if (lens[c] >= (1u << 22)) parallel(upper, lens[c]); else upper(0, lens[c], 0);  // no thread launches for scaffold-sized contigs
         end += lens[c];
         ix.contigs.push_back({end - lens[c], end - 1, names[c]});
     }
+    std::vector<int> flag(T, 0);  // 1 ambiguous, 2 non-IUPAC
+    parallel([&](size_t lo, size_t hi, unsigned t) {
+        int fl = 0;
+        for (size_t i = lo; i < hi; ++i) { const uint8_t ch = text[i]; if (base_index(ch) <= 3) continue; fl |= is_iupac(ch) ? 1 : 2; }
+        flag[t] = fl;
+    }, text.size());
     bool ambiguous = false;
-    for (uint8_t ch : text) {
-        if (base_index(ch) <= 3) continue;
-        if (!is_iupac(ch)) throw std::runtime_error("Found non-IUPAC symbol in reference sequence");  // :71
-        ambiguous = true;
-    }
+    for (int fl : flag) { if (fl & 2) throw std::runtime_error("Found non-IUPAC symbol in reference sequence"); ambiguous |= (fl & 1) != 0; }  // :71
     if (ambiguous) {
         SplitMix64 rng{seed};
         auto pick = [&](const char* set) -> uint8_t { const size_t k = std::char_traits<char>::length(set); return (uint8_t)set[rng.next() % k]; };
@@ -299,7 +328,9 @@ inline std::vector<uint8_t> prepare_text(const std::vector<std::string>& names, 
     const size_t g = text.size();
     std::vector<uint8_t> t(2 * g + 2);
     auto rank = [](uint8_t c) -> uint8_t { return c == 'A' ? 1 : c == 'C' ? 2 : c == 'G' ? 3 : c == 'T' ? 4 : 5; };
-    for (size_t i = 0; i < g; ++i) { const uint8_t r = rank(text[i]); t[i] = r; t[2 * g - i] = (uint8_t)(r == 5 ? 5 : 5 - r); }  // complement of a rank: A<->T, C<->G, X stays
+    parallel([&](size_t lo, size_t hi, unsigned) {
+        for (size_t i = lo; i < hi; ++i) { const uint8_t r = rank(text[i]); t[i] = r; t[2 * g - i] = (uint8_t)(r == 5 ? 5 : 5 - r); }  // complement of a rank: A<->T, C<->G, X stays
+    }, g);
     t[g] = 0; t[2 * g + 1] = 0;
     ix.n = t.size();
     return t;

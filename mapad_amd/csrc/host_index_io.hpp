@@ -8,7 +8,8 @@
 //
 // Reading accepts compressed and uncompressed snappy chunks; writing emits uncompressed chunks (valid frame format,
 // readable by snap::read::FrameDecoder).  The fork's Occ byte layout is unpinned: .toc is only validated
-// (outer length, k) and otherwise ignored — ranks are answered from the block layout rebuilt from .tbw.
+// (outer length, inner lengths, k) and its counts are skipped — ranks are answered from the block layout rebuilt from .tbw.
+// The large files (.tbw, .toc, .tsa) are streamed chunk by chunk in both directions; nothing is held twice.
 #pragma once
 #include <cstdint>
 #include <cstdio>
@@ -24,16 +25,31 @@ namespace mapad {
 namespace host {
 namespace io {
 
-inline uint32_t crc32c(const uint8_t* p, size_t n) {
+inline uint32_t crc32c_table(uint32_t c, const uint8_t* p, size_t n) {
     static uint32_t table[256];
     static bool init = false;
     if (!init) {
-        for (uint32_t i = 0; i < 256; ++i) { uint32_t c = i; for (int k = 0; k < 8; ++k) c = (c & 1) ? (c >> 1) ^ 0x82F63B78u : c >> 1; table[i] = c; }
+        for (uint32_t i = 0; i < 256; ++i) { uint32_t v = i; for (int k = 0; k < 8; ++k) v = (v & 1) ? (v >> 1) ^ 0x82F63B78u : v >> 1; table[i] = v; }
         init = true;
     }
-    uint32_t c = 0xFFFFFFFFu;
     for (size_t i = 0; i < n; ++i) c = table[(c ^ p[i]) & 0xFF] ^ (c >> 8);
-    return c ^ 0xFFFFFFFFu;
+    return c;
+}
+#if defined(__x86_64__)
+__attribute__((target("sse4.2"))) inline uint32_t crc32c_hw(uint32_t c, const uint8_t* p, size_t n) {
+    uint64_t c64 = c;
+    while (n >= 8) { uint64_t v; std::memcpy(&v, p, 8); c64 = __builtin_ia32_crc32di(c64, v); p += 8; n -= 8; }
+    c = (uint32_t)c64;
+    while (n--) c = __builtin_ia32_crc32qi(c, *p++);
+    return c;
+}
+#endif
+inline uint32_t crc32c(const uint8_t* p, size_t n) {  // a 6 GB .tbw is checked at memory speed with the CPU's CRC32C instruction
+#if defined(__x86_64__)
+    static const bool hw = __builtin_cpu_supports("sse4.2");
+    if (hw) return crc32c_hw(0xFFFFFFFFu, p, n) ^ 0xFFFFFFFFu;
+#endif
+    return crc32c_table(0xFFFFFFFFu, p, n) ^ 0xFFFFFFFFu;
 }
 inline uint32_t masked_crc(const uint8_t* p, size_t n) { const uint32_t c = crc32c(p, n); return ((c >> 15) | (c << 17)) + 0xA282EAD8u; }
 
@@ -64,44 +80,117 @@ inline bool snappy_uncompress(const uint8_t* in, size_t n, std::vector<uint8_t>&
     return out.size() - base == ulen;
 }
 
-inline int read_frames(const std::string& path, std::vector<uint8_t>& out) {
-    std::ifstream f(path, std::ios::binary);
-    if (!f) return MAPAD_ERR_IO;
-    std::vector<uint8_t> raw((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
-    size_t i = 0;
-    while (i + 4 <= raw.size()) {
-        const uint8_t type = raw[i];
-        const size_t len = raw[i + 1] | ((size_t)raw[i + 2] << 8) | ((size_t)raw[i + 3] << 16);
-        i += 4;
-        if (i + len > raw.size()) return MAPAD_ERR_PARSE;
-        if (type == 0xFF) { if (len != 6 || std::memcmp(&raw[i], "sNaPpY", 6) != 0) return MAPAD_ERR_PARSE; }
-        else if (type == 0x00 || type == 0x01) {
-            if (len < 4) return MAPAD_ERR_PARSE;
-            const uint32_t want = raw[i] | (raw[i + 1] << 8) | (raw[i + 2] << 16) | ((uint32_t)raw[i + 3] << 24);
-            const size_t before = out.size();
-            if (type == 0x01) out.insert(out.end(), raw.begin() + i + 4, raw.begin() + i + len);
-            else if (!snappy_uncompress(&raw[i + 4], len - 4, out)) return MAPAD_ERR_PARSE;
-            if (masked_crc(out.data() + before, out.size() - before) != want) return MAPAD_ERR_PARSE;
-        } else if (type >= 0x02 && type <= 0x7F) return MAPAD_ERR_PARSE;  // reserved unskippable
-        i += len;
+// Decoded byte stream of a snappy frame file, one chunk (<= 64 KiB of payload) in memory at a time: a 6 GB .tbw is copied straight into its
+// destination and the 2.25 GB .toc is skipped without being materialised.
+class FrameStream {
+public:
+    explicit FrameStream(const std::string& path) : f_(std::fopen(path.c_str(), "rb")) { if (f_) std::setvbuf(f_, nullptr, _IOFBF, 1 << 22); }
+    ~FrameStream() { if (f_) std::fclose(f_); }
+    bool is_open() const { return f_ != nullptr; }
+    int error() const { return err_; }
+    bool read(void* dst, size_t n) {
+        uint8_t* d = (uint8_t*)dst;
+        while (n) {
+            if (pos_ == chunk_.size() && !next_chunk()) { if (!err_) err_ = MAPAD_ERR_PARSE; return false; }
+            const size_t k = std::min(n, chunk_.size() - pos_);
+            if (d) { std::memcpy(d, chunk_.data() + pos_, k); d += k; }
+            pos_ += k; n -= k;
+        }
+        return true;
     }
-    return i == raw.size() ? MAPAD_OK : MAPAD_ERR_PARSE;
+    bool skip(size_t n) { return read(nullptr, n); }
+    uint8_t u8() { uint8_t v = 0; read(&v, 1); return v; }
+    uint32_t u32() { uint32_t v = 0; read(&v, 4); return v; }
+    uint64_t u64() { uint64_t v = 0; read(&v, 8); return v; }
+    bool at_end() { return pos_ == chunk_.size() && !next_chunk() && err_ == MAPAD_OK; }
+
+private:
+    FILE* f_;
+    std::vector<uint8_t> raw_, chunk_;
+    size_t pos_ = 0;
+    int err_ = MAPAD_OK;
+    bool next_chunk() {  // false at end of file or on error (err_)
+        for (;;) {
+            uint8_t h[4];
+            const size_t got = std::fread(h, 1, 4, f_);
+            if (got == 0) return false;
+            if (got != 4) { err_ = MAPAD_ERR_PARSE; return false; }
+            const uint8_t type = h[0];
+            const size_t len = h[1] | ((size_t)h[2] << 8) | ((size_t)h[3] << 16);
+            raw_.resize(len);
+            if (len && std::fread(raw_.data(), 1, len, f_) != len) { err_ = MAPAD_ERR_PARSE; return false; }
+            if (type == 0xFF) { if (len != 6 || std::memcmp(raw_.data(), "sNaPpY", 6) != 0) { err_ = MAPAD_ERR_PARSE; return false; } continue; }
+            if (type == 0x00 || type == 0x01) {
+                if (len < 4) { err_ = MAPAD_ERR_PARSE; return false; }
+                const uint32_t want = raw_[0] | (raw_[1] << 8) | (raw_[2] << 16) | ((uint32_t)raw_[3] << 24);
+                chunk_.clear(); pos_ = 0;
+                if (type == 0x01) chunk_.assign(raw_.begin() + 4, raw_.end());
+                else if (!snappy_uncompress(raw_.data() + 4, len - 4, chunk_)) { err_ = MAPAD_ERR_PARSE; return false; }
+                if (masked_crc(chunk_.data(), chunk_.size()) != want) { err_ = MAPAD_ERR_PARSE; return false; }
+                if (chunk_.empty()) continue;
+                return true;
+            }
+            if (type >= 0x02 && type <= 0x7F) { err_ = MAPAD_ERR_PARSE; return false; }  // reserved unskippable
+            // 0x80..0xFE: skippable
+        }
+    }
+};
+inline int read_frames(const std::string& path, std::vector<uint8_t>& out) {  // small files
+    FrameStream fs(path);
+    if (!fs.is_open()) return MAPAD_ERR_IO;
+    uint8_t buf[4096];
+    for (;;) {
+        if (fs.at_end()) break;
+        size_t k = 0;
+        while (k < sizeof buf && !fs.at_end()) { if (!fs.read(buf + k, 1)) return fs.error() ? fs.error() : MAPAD_ERR_PARSE; ++k; }
+        out.insert(out.end(), buf, buf + k);
+    }
+    return fs.error();
 }
-inline int write_frames(const std::string& path, const std::vector<uint8_t>& data) {
-    std::ofstream f(path, std::ios::binary | std::ios::trunc);
-    if (!f) return MAPAD_ERR_IO;
-    static const uint8_t ident[10] = {0xFF, 0x06, 0x00, 0x00, 's', 'N', 'a', 'P', 'p', 'Y'};
-    f.write((const char*)ident, 10);
-    for (size_t i = 0; i < data.size() || (i == 0 && data.empty()); i += 65536) {
-        const size_t n = std::min<size_t>(65536, data.size() - i);
-        if (n == 0) break;
-        const uint32_t crc = masked_crc(data.data() + i, n);
+// frame writer: uncompressed chunks, fed incrementally
+class FrameWriter {
+public:
+    explicit FrameWriter(const std::string& path) : f_(std::fopen(path.c_str(), "wb")) {
+        if (f_) { std::setvbuf(f_, nullptr, _IOFBF, 1 << 22); static const uint8_t ident[10] = {0xFF, 0x06, 0x00, 0x00, 's', 'N', 'a', 'P', 'p', 'Y'}; ok_ = std::fwrite(ident, 1, 10, f_) == 10; }
+        buf_.reserve(65536);
+    }
+    ~FrameWriter() { if (f_) std::fclose(f_); }
+    void bytes(const void* p, size_t n) {
+        const uint8_t* b = (const uint8_t*)p;
+        while (n) {
+            const size_t k = std::min(n, (size_t)65536 - buf_.size());
+            buf_.insert(buf_.end(), b, b + k);
+            b += k; n -= k;
+            if (buf_.size() == 65536) flush();
+        }
+    }
+    void u8(uint8_t v) { bytes(&v, 1); }
+    void u32(uint32_t v) { bytes(&v, 4); }
+    void u64(uint64_t v) { bytes(&v, 8); }
+    int close() {
+        if (!f_) return MAPAD_ERR_IO;
+        if (!buf_.empty()) flush();
+        const bool good = ok_ && std::fclose(f_) == 0;
+        f_ = nullptr;
+        return good ? MAPAD_OK : MAPAD_ERR_IO;
+    }
+private:
+    FILE* f_;
+    bool ok_ = false;
+    std::vector<uint8_t> buf_;
+    void flush() {
+        const size_t n = buf_.size();
+        const uint32_t crc = masked_crc(buf_.data(), n);
         const size_t len = n + 4;
         const uint8_t hdr[8] = {0x01, (uint8_t)len, (uint8_t)(len >> 8), (uint8_t)(len >> 16), (uint8_t)crc, (uint8_t)(crc >> 8), (uint8_t)(crc >> 16), (uint8_t)(crc >> 24)};
-        f.write((const char*)hdr, 8);
-        f.write((const char*)data.data() + i, (std::streamsize)n);
+        ok_ = ok_ && std::fwrite(hdr, 1, 8, f_) == 8 && std::fwrite(buf_.data(), 1, n, f_) == n;
+        buf_.clear();
     }
-    return f ? MAPAD_OK : MAPAD_ERR_IO;
+};
+inline int write_frames(const std::string& path, const std::vector<uint8_t>& data) {
+    FrameWriter w(path);
+    w.bytes(data.data(), data.size());
+    return w.close();
 }
 
 struct Reader {
@@ -135,12 +224,20 @@ inline int load_index(const std::string& prefix, Index& ix) {
         return MAPAD_OK;
     };
     ix = Index();
-    {   // .tbw
-        if ((rc = open(".tbw"))) return rc;
-        Reader r(buf); r.u8();
-        const uint64_t n = r.u64(); const uint8_t* p;
-        if (!r.bytes(n, p) || r.i != buf.size()) return MAPAD_ERR_PARSE;
-        ix.bwt.assign(p, p + n); ix.n = n;
+    auto open_stream = [&](FrameStream& fs, const char* ext) -> int {
+        if (!fs.is_open()) return MAPAD_ERR_IO;
+        const uint8_t version = fs.u8();
+        if (fs.error()) return fs.error();
+        if (version != kIndexVersion) { std::fprintf(stderr, "mapad_amd: index version mismatch in %s%s: on disk %u, expected %u\n", prefix.c_str(), ext, version, kIndexVersion); return MAPAD_ERR_INDEX_VERSION; }
+        return MAPAD_OK;
+    };
+    {   // .tbw: streamed straight into the BWT vector
+        FrameStream fs(prefix + ".tbw");
+        if ((rc = open_stream(fs, ".tbw"))) return rc;
+        const uint64_t n = fs.u64();
+        if (fs.error() || n >= (1ull << 40)) return MAPAD_ERR_PARSE;
+        ix.bwt.resize(n); ix.n = n;
+        if (!fs.read(ix.bwt.data(), n) || !fs.at_end()) return MAPAD_ERR_PARSE;
     }
     std::vector<uint64_t> less_disk;
     {   // .tle
@@ -151,14 +248,21 @@ inline int load_index(const std::string& prefix, Index& ix) {
         for (uint64_t i = 0; i < n; ++i) less_disk.push_back(r.u64());
         if (!r.ok) return MAPAD_ERR_PARSE;
     }
-    {   // .toc — validated, not used
-        if ((rc = open(".toc"))) return rc;
-        Reader r(buf); r.u8();
-        const uint64_t outer = r.u64();
-        if (!r.ok || outer == 0 || outer > 256) return MAPAD_ERR_PARSE;
-        for (uint64_t s = 0; s < outer; ++s) { const uint64_t inner = r.u64(); const uint8_t* p; if (!r.ok || !r.bytes(inner * 8, p)) return MAPAD_ERR_PARSE; }
-        const uint32_t k = r.u32();
-        if (!r.ok || k == 0) return MAPAD_ERR_PARSE;
+    {   // .toc — shape validated (outer length, inner lengths against n / k, k), counts skipped: ranks are answered from the blocks rebuilt from .tbw
+        FrameStream fs(prefix + ".toc");
+        if ((rc = open_stream(fs, ".toc"))) return rc;
+        const uint64_t outer = fs.u64();
+        if (fs.error() || outer == 0 || outer > 256) return MAPAD_ERR_PARSE;
+        uint64_t inner0 = 0;
+        for (uint64_t sidx = 0; sidx < outer; ++sidx) {
+            const uint64_t inner = fs.u64();
+            if (fs.error() || inner > ix.n + 1 || (sidx && inner != inner0)) return MAPAD_ERR_PARSE;
+            inner0 = inner;
+            if (!fs.skip(inner * 8)) return MAPAD_ERR_PARSE;
+        }
+        const uint32_t k = fs.u32();
+        if (fs.error() || k == 0 || !fs.at_end()) return MAPAD_ERR_PARSE;
+        if (inner0 != (ix.n + k - 1) / k) return MAPAD_ERR_PARSE;  // one checkpoint per k rows
     }
     {   // .trt — must be the $ACGTX (or $ACGT) rank transform
         if ((rc = open(".trt"))) return rc;
@@ -168,17 +272,19 @@ inline int load_index(const std::string& prefix, Index& ix) {
         if (n < 5 || n > 6) return MAPAD_ERR_PARSE;
         for (uint64_t i = 0; i < n; ++i) { const uint64_t key = r.u64(); const uint8_t val = r.u8(); if (!r.ok || key != (uint64_t)expect[i] || val != i) return MAPAD_ERR_PARSE; }
     }
-    {   // .tsa
-        if ((rc = open(".tsa"))) return rc;
-        Reader r(buf); r.u8();
-        const uint64_t n = r.u64(); const uint8_t* p;
-        if (!r.bytes(n * 8, p)) return MAPAD_ERR_PARSE;
-        ix.sa_sample.resize(n); std::memcpy(ix.sa_sample.data(), p, n * 8);
-        ix.sa_rate = r.u64();
-        const uint64_t m = r.u64();
-        for (uint64_t i = 0; i < m && r.ok; ++i) { const uint64_t k = r.u64(), v = r.u64(); ix.extra_rows[k] = v; }
-        const uint8_t sentinel = r.u8();
-        if (!r.ok || ix.sa_rate == 0 || sentinel != 0) return MAPAD_ERR_PARSE;
+    {   // .tsa: the sample array is streamed into place
+        FrameStream fs(prefix + ".tsa");
+        if ((rc = open_stream(fs, ".tsa"))) return rc;
+        const uint64_t n = fs.u64();
+        if (fs.error() || n > ix.n + 1) return MAPAD_ERR_PARSE;
+        ix.sa_sample.resize(n);
+        if (!fs.read(ix.sa_sample.data(), n * 8)) return MAPAD_ERR_PARSE;
+        ix.sa_rate = fs.u64();
+        const uint64_t m = fs.u64();
+        if (fs.error() || m > 1024) return MAPAD_ERR_PARSE;
+        for (uint64_t i = 0; i < m; ++i) { const uint64_t k = fs.u64(), v = fs.u64(); ix.extra_rows[k] = v; }
+        const uint8_t sentinel = fs.u8();
+        if (fs.error() || ix.sa_rate == 0 || sentinel != 0 || !fs.at_end()) return MAPAD_ERR_PARSE;
     }
     {   // .tpi
         if ((rc = open(".tpi"))) return rc;
@@ -209,24 +315,27 @@ inline int load_index(const std::string& prefix, Index& ix) {
 inline int save_index(const std::string& prefix, const Index& ix) {
     using namespace io;
     int rc;
-    {   Writer w; w.u8(kIndexVersion); w.u64(ix.bwt.size()); w.bytes(ix.bwt.data(), ix.bwt.size());
-        if ((rc = write_frames(prefix + ".tbw", w.b))) return rc; }
+    {   FrameWriter w(prefix + ".tbw"); w.u8(kIndexVersion); w.u64(ix.bwt.size()); w.bytes(ix.bwt.data(), ix.bwt.size());
+        if ((rc = w.close())) return rc; }
     {   Writer w; w.u8(kIndexVersion); w.u64(7); for (int c = 0; c < 7; ++c) w.u64(ix.less[c]);  // less: max_symbol + 2 entries
         if ((rc = write_frames(prefix + ".tle", w.b))) return rc; }
-    {   // Occ::new(bwt, 128, alphabet 0..6) (indexing.rs:188)
+    {   // Occ::new(bwt, 128, alphabet 0..6) (indexing.rs:188): per symbol, the inclusive count at every row i with i % k == 0
         const uint32_t k = 128;
-        std::vector<std::vector<uint64_t>> occ(6);
-        uint64_t cur[6] = {0, 0, 0, 0, 0, 0};
-        for (uint64_t i = 0; i < ix.n; ++i) { cur[ix.bwt[i]] += 1; if (i % k == 0) for (int s = 0; s < 6; ++s) occ[s].push_back(cur[s]); }
-        Writer w; w.u8(kIndexVersion); w.u64(6);
-        for (int s = 0; s < 6; ++s) { w.u64(occ[s].size()); w.bytes(occ[s].data(), occ[s].size() * 8); }
+        const uint64_t n_cp = (ix.n + k - 1) / k;
+        FrameWriter w(prefix + ".toc"); w.u8(kIndexVersion); w.u64(6);
+        std::vector<uint64_t> col(n_cp);
+        for (int sym = 0; sym < 6; ++sym) {  // one pass per symbol keeps the memory at one column (n / 128 x 8 B)
+            uint64_t cur = 0;
+            for (uint64_t i = 0; i < ix.n; ++i) { cur += ix.bwt[i] == sym; if (i % k == 0) col[i / k] = cur; }
+            w.u64(n_cp); w.bytes(col.data(), n_cp * 8);
+        }
         w.u32(k);
-        if ((rc = write_frames(prefix + ".toc", w.b))) return rc; }
+        if ((rc = w.close())) return rc; }
     {   Writer w; w.u8(kIndexVersion); w.u64(6); static const char sym[] = "$ACGTX"; for (int i = 0; i < 6; ++i) { w.u64((uint64_t)sym[i]); w.u8((uint8_t)i); }
         if ((rc = write_frames(prefix + ".trt", w.b))) return rc; }
-    {   Writer w; w.u8(kIndexVersion); w.u64(ix.sa_sample.size()); w.bytes(ix.sa_sample.data(), ix.sa_sample.size() * 8); w.u64(ix.sa_rate);
+    {   FrameWriter w(prefix + ".tsa"); w.u8(kIndexVersion); w.u64(ix.sa_sample.size()); w.bytes(ix.sa_sample.data(), ix.sa_sample.size() * 8); w.u64(ix.sa_rate);
         w.u64(ix.extra_rows.size()); for (auto& kv : ix.extra_rows) { w.u64(kv.first); w.u64(kv.second); } w.u8(0);
-        if ((rc = write_frames(prefix + ".tsa", w.b))) return rc; }
+        if ((rc = w.close())) return rc; }
     {   Writer w; w.u8(kIndexVersion); w.u64(ix.contigs.size());
         for (auto& c : ix.contigs) { w.u64(c.start); w.u64(c.end); w.u64(c.name.size()); w.bytes(c.name.data(), c.name.size()); }
         if ((rc = write_frames(prefix + ".tpi", w.b))) return rc; }

@@ -292,15 +292,16 @@ MAPAD_HD void mm_bubble_up(const ArenaT<NL>& A, uint32_t pos, const HeapEntry el
     const uint32_t i3 = i1 > 2 ? (i1 - 3) >> 2 : 0;     // grandparent of the parent
     const HeapEntry e1 = an.e1, e2 = an.e2, e3 = an.e3;
     const bool min_level = mm_is_min_level(pos);
-    const bool moved = pos > 0 && (min_level ? elt.score > e1.score : elt.score < e1.score);
-    const bool greater = min_level ? moved : !moved;    // which grandparent chain to follow
+    // (bitwise on purpose: short-circuit forms of these predicates come out as nested branches on the device)
+    const bool moved = (pos > 0) & ((min_level & (elt.score > e1.score)) | (!min_level & (elt.score < e1.score)));
+    const bool greater = min_level == moved;            // which grandparent chain to follow
 #if defined(MAPAD_PROFILE_SECTIONS) && defined(__HIP_DEVICE_COMPILE__)
     if (__ballot(moved) != 0xFFFFFFFFFFFFFFFFull || e2.score != e3.score) MAPAD_MARK(PROF_C_LOAD);  // forces the wait for the three entries before the mark
 #endif
     const uint32_t pos1 = moved ? i1 : pos;
     const HeapEntry ge = moved ? e3 : e2;
     const uint32_t gp = moved ? i3 : i2;
-    const bool moved2 = pos1 > 2 && (greater ? (elt.score > ge.score) : (elt.score < ge.score));
+    const bool moved2 = (pos1 > 2) & ((greater & (elt.score > ge.score)) | (!greater & (elt.score < ge.score)));
     if (moved) hp_set(A, pos, e1);
     if (moved2) {
         hp_set(A, pos1, ge);
@@ -890,7 +891,9 @@ MAPAD_HD bool search_step(const DevIndex& ix, const DevParams& P, const ReadInT<
             cand &= cand - 1;
             const bool is_ins = t == 0, is_del = (t & 1) != 0;
             const int i = is_ins ? 0 : (t - 1) >> 1, k = 3 - i;
-            const float score = is_ins ? insertion_score : is_del ? deletion_score : (i == 0 ? mm[0] : i == 1 ? mm[1] : i == 2 ? mm[2] : mm[3]);
+            float score = mm[3];  // a chain of plain selects (nested conditionals on floats come out as nested branches)
+            score = i == 2 ? mm[2] : score; score = i == 1 ? mm[1] : score; score = i == 0 ? mm[0] : score;
+            score = is_del ? deletion_score : score; score = is_ins ? insertion_score : score;
             const uint32_t id = st.tree_next;
             st.tree_next = id + 1; st.tree_entries = id + 1; st.tree_len += 1;
             const uint32_t pos = st.heap_len;

@@ -30,4 +30,5 @@ json.dump({"note": "rocprofv3 --pmc passes of `bench.py --steps 1 --warmup 0 --d
 for k, d in res.items():
     if "search_kernel<4, false, 0" in k or "search_kernel<4, 0, 0" in k: print(k, json.dumps(d))
 PY
+mkdir -p "$ROOT/gpurun_out/profiles_out"; cp "$ROOT"/profiles/${TAG}_sq_summary.json "$ROOT/gpurun_out/profiles_out/" 2>/dev/null
 rm -rf "$OUT"  # raw counter CSVs are large; the summary is what is kept

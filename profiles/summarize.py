@@ -9,7 +9,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 out = sys.argv[1]
-tag = sys.argv[2] if len(sys.argv) > 2 else "r01"
+tag = sys.argv[2] if len(sys.argv) > 2 else "r02"
 key = sys.argv[3] if len(sys.argv) > 3 else "c2:48000000:1000000"
 
 
@@ -23,9 +23,32 @@ def short(name):
     return None
 
 
-st = glob.glob(os.path.join(out, "stats", "**", "*kernel_stats.csv"), recursive=True)
-if st:
-    shutil.copy(max(st, key=os.path.getmtime), os.path.join(ROOT, "profiles", f"{tag}_kernel_stats.csv"))
+for sub, suffix in (("stats", "kernel_stats"), ("stats_d1", "kernel_stats_depth1")):
+    st = glob.glob(os.path.join(out, sub, "**", "*kernel_stats.csv"), recursive=True)
+    if st:
+        shutil.copy(max(st, key=os.path.getmtime), os.path.join(ROOT, "profiles", f"{tag}_{suffix}.csv"))
+# pipelined launches overlap: the effective duration of a launch is the union of the launches' intervals divided by their number
+# (what bench.py reports as roofline.kernel_ms); computed here from the kernel trace of the default command
+tr = glob.glob(os.path.join(out, "stats", "**", "*kernel_trace.csv"), recursive=True)
+overlap = {}
+if tr:
+    iv = collections.defaultdict(list)
+    for r in csv.DictReader(open(max(tr, key=os.path.getmtime))):
+        k = short(r["Kernel_Name"])
+        if k:
+            iv[k].append((int(r["Start_Timestamp"]), int(r["End_Timestamp"])))
+    for k, lst in iv.items():
+        lst.sort()
+        total, end = 0, -1
+        for lo, hi in lst:
+            if hi > end:
+                total += hi - max(lo, end)
+                end = hi
+        overlap[k] = {"launches": len(lst), "mean_duration_ms": sum(h - l for l, h in lst) / len(lst) / 1e6, "union_ms": total / 1e6,
+                      "union_per_launch_ms": total / len(lst) / 1e6}
+    json.dump({"note": "kernel trace of the default bench command (batches pipelined): per kernel, mean duration of a launch, union of all launches' intervals, "
+                       "and union / launches = the effective per-launch time bench.py uses for the roofline (first launch = warm-up included)",
+               "kernels": overlap}, open(os.path.join(ROOT, "profiles", f"{tag}_kernel_overlap.json"), "w"), indent=1)
 counters = collections.defaultdict(lambda: collections.defaultdict(float))
 launches = collections.defaultdict(lambda: collections.defaultdict(set))
 for d in ("pmc_fetch", "pmc_write", "pmc_tcc"):
