@@ -86,7 +86,7 @@ MAPAD_HD float f32_min(float a, float b) { return a < b ? a : b; }
 constexpr float kF32Min = -3.402823466e+38f;  // Rust f32::MIN
 
 struct Float4 { float a, c, g, t; };
-MAPAD_HD float f4_get(const Float4& f, int i) { return i == 0 ? f.a : i == 1 ? f.c : i == 2 ? f.g : f.t; }
+MAPAD_HD float f4_get(const Float4& f, int i) { float r = f.t; r = i == 2 ? f.g : r; r = i == 1 ? f.c : r; r = i == 0 ? f.a : r; return r; }
 
 // `base` = DevParams::table_base[L] of the read (looked up once per read: it is a dependent load otherwise)
 MAPAD_HD Float4 sdm_row_at(const DevParams& p, int32_t base, int i, int q, int to_class) {

@@ -441,17 +441,18 @@ MAPAD_HD void mm_trickle_down(const ArenaT<NL>& A, uint32_t n, uint32_t pos, Hea
 #endif
         uint32_t best = c1;
         HeapEntry be = c.a;
-        if (c1 + 1 < n && (MAX ? (c.b.score > be.score) : (c.b.score < be.score))) { best = c1 + 1; be = c.b; }
-        if (g1 < n && (MAX ? (ga.a.score > be.score) : (ga.a.score < be.score))) { best = g1; be = ga.a; }
-        if (g1 + 1 < n && (MAX ? (ga.b.score > be.score) : (ga.b.score < be.score))) { best = g1 + 1; be = ga.b; }
-        if (g1 + 2 < n && (MAX ? (gb.a.score > be.score) : (gb.a.score < be.score))) { best = g1 + 2; be = gb.a; }
-        if (g1 + 3 < n && (MAX ? (gb.b.score > be.score) : (gb.b.score < be.score))) { best = g1 + 3; be = gb.b; }
+        auto consider = [&](uint32_t idx, const HeapEntry cand) {  // a later candidate wins only if strictly better; plain selects
+            const bool take = (idx < n) & (MAX ? (cand.score > be.score) : (cand.score < be.score));
+            best = take ? idx : best; be.score = take ? cand.score : be.score; be.node = take ? cand.node : be.node;
+        };
+        consider(c1 + 1, c.b); consider(g1, ga.a); consider(g1 + 1, ga.b); consider(g1 + 2, gb.a); consider(g1 + 3, gb.b);
         if (!(MAX ? (be.score > elt.score) : (be.score < elt.score))) break;
         hp_set(A, pos, be);
         pos = best;
         if (best < g1) break;  // moved to a child: done
         const uint32_t parent = (pos - 1) >> 1;
-        const HeapEntry pe = parent == c1 ? c.a : c.b;  // the parent of a grandchild is one of the two children just loaded
+        HeapEntry pe;  // the parent of a grandchild is one of the two children just loaded
+        pe.score = parent == c1 ? c.a.score : c.b.score; pe.node = parent == c1 ? c.a.node : c.b.node;
         if (MAX ? (pe.score > elt.score) : (pe.score < elt.score)) { hp_set(A, parent, elt); elt = pe; }
     }
     hp_set(A, pos, elt);
@@ -463,10 +464,14 @@ template <bool NL>
 MAPAD_HD HeapEntry mm_find_max(const ArenaT<NL>& A, uint32_t n, uint32_t& idx) {
     const HeapPair p = load_pair(A.top + 1);  // logical slots 1 and 2 (stale if n < 3, handled below)
     const HeapEntry first = A.top[0];
-    if (n >= 3) { if (p.a.score > p.b.score) { idx = 1; return p.a; } idx = 2; return p.b; }
-    if (n == 2) { idx = 1; return p.a; }
-    idx = 0;
-    return first;
+    // selects, not branches: n >= 3 -> the larger of slots 1 and 2 (slot 2 on a tie); n == 2 -> slot 1; n == 1 -> slot 0
+    const bool use_a = (n == 2) | ((n >= 3) & (p.a.score > p.b.score));
+    const bool use_b = (n >= 3) & !(p.a.score > p.b.score);
+    idx = use_a ? 1u : use_b ? 2u : 0u;
+    HeapEntry r = first;
+    r.score = use_a ? p.a.score : use_b ? p.b.score : r.score;
+    r.node = use_a ? p.a.node : use_b ? p.b.node : r.node;
+    return r;
 }
 template <bool MAX, bool NL>
 MAPAD_HD void mm_remove_at(const ArenaT<NL>& A, uint32_t& n, uint32_t idx) {
@@ -601,13 +606,12 @@ MAPAD_HD void hits_push(HP hits, uint32_t& n, const HitRec& h) {
 // ---- D array access (src/map/bi_d_array.rs:200-224) ------------------------------------------------------------------------
 template <class DPtr>
 MAPAD_HD float d_get(DPtr d, int L, int split, int backward_index, int forward_index) {
-    float d_rev = 0.0f, d_fwd = 0.0f;
-    if (backward_index >= 0 && backward_index < L) d_rev = d[backward_index];
-    const int sub = 1 + forward_index;
-    if (L >= sub) {
-        const int idx = (L - sub) + split;
-        if (idx < L) d_fwd = d[idx];
-    }
+    // both reads unconditionally from clamped indices (L >= 1: index 0 exists), the range checks as selects: no branches around two LDS reads
+    const bool rev_ok = (backward_index >= 0) & (backward_index < L);
+    const int sub = 1 + forward_index, idx = (L - sub) + split;
+    const bool fwd_ok = (L >= sub) & (idx < L) & (idx >= 0);
+    const float v_rev = d[rev_ok ? backward_index : 0], v_fwd = d[fwd_ok ? idx : 0];
+    const float d_rev = rev_ok ? v_rev : 0.0f, d_fwd = fwd_ok ? v_fwd : 0.0f;
     return d_rev + d_fwd;
 }
 
@@ -747,13 +751,9 @@ MAPAD_HD bool search_step(const DevIndex& ix, const DevParams& P, const ReadInT<
     st.c_pop += 1;
     const Frame f = unpack_frame(top_node);
     const float f_score = top.score;
-    int j, d_k, d_l;
-    bool forward;
-    if (f.start <= L - f.start - f.len) {  // :1077-1097
-        j = f.start + f.len; forward = true; d_k = f.start; d_l = f.start + f.len;
-    } else {
-        j = f.start - 1; forward = false; d_k = f.start - 1; d_l = f.start + f.len - 1;
-    }
+    const bool forward = f.start <= L - f.start - f.len;  // :1077-1097
+    const int j = forward ? f.start + f.len : f.start - 1;
+    const int d_k = forward ? f.start : f.start - 1, d_l = forward ? f.start + f.len : f.start + f.len - 1;
     const int to_class = rd.qc[2 * j];
     const Float4 row = sdm_row_at(P, rd.table, j, rd.qc[2 * j + 1], to_class);  // shared score table: hot in L1/L2; consumed after the rank queries
     const uint32_t gap_side = forward ? f.gap_f : f.gap_b;
@@ -806,8 +806,8 @@ MAPAD_HD bool search_step(const DevIndex& ix, const DevParams& P, const ReadInT<
     const int ins_dist = j < (L - j - 1) ? j : (L - j - 1);
     const int dist5 = forward ? j : j + 1, dist3 = L - dist5;
     const int del_dist = dist5 < dist3 ? dist5 : dist3;
-    const bool ins_ok = !mb_reject<CONT>(rd.thr, P.cutoff, insertion_score + lower_bound) && ins_dist >= P.gap_dist_ends;  // :1214-1216
-    const bool del_ok = !mb_reject<CONT>(rd.thr, P.cutoff, deletion_score + lower_bound) && del_dist >= P.gap_dist_ends;   // :1279-1281
+    const bool ins_ok = !mb_reject<CONT>(rd.thr, P.cutoff, insertion_score + lower_bound) & (ins_dist >= P.gap_dist_ends);  // :1214-1216
+    const bool del_ok = !mb_reject<CONT>(rd.thr, P.cutoff, deletion_score + lower_bound) & (del_dist >= P.gap_dist_ends);   // :1279-1281
     uint32_t cand = ins_ok ? 1u : 0u;
     const float optimal = sdm_optimal(row, to_class);
     float mm[4];
@@ -816,10 +816,9 @@ MAPAD_HD bool search_step(const DevIndex& ix, const DevParams& P, const ReadInT<
         const int k = 3 - i;
         const int cb = forward ? 3 - k : k;  // symbol in read orientation: backward = base k, forward = its complement
         mm[i] = f4_get(row, cb) - optimal + f_score;  // get - optimal + score, left to right (:1138-1145)
-        if ((nonempty >> k) & 1u) {
-            if (del_ok) cand |= 2u << (2 * i);
-            if (!mb_reject<CONT>(rd.thr, P.cutoff, mm[i] + lower_bound)) cand |= 4u << (2 * i);  // :1308
-        }
+        const uint32_t has = (nonempty >> k) & 1u;
+        cand |= (has & (uint32_t)del_ok) << (1 + 2 * i);
+        cand |= (has & (uint32_t)!mb_reject<CONT>(rd.thr, P.cutoff, mm[i] + lower_bound)) << (2 + 2 * i);  // :1308
     }
     const int child_start = forward ? f.start : f.start - 1;
     // tree node (= frame payload) of child t; (xl, xr, xs) = extension of the frame's interval by base k (unused for t = 0)
@@ -953,9 +952,9 @@ MAPAD_HD bool search_step(const DevIndex& ix, const DevParams& P, const ReadInT<
 #endif
     if (MAPAD_UNLIKELY(st.status != ST_OK)) return false;
     // :1348-1355
-    if (MAPAD_UNLIKELY(st.n_hits > 9 || (st.n_hits > 0 && st.best_size > 1))) return false;
+    if (MAPAD_UNLIKELY((st.n_hits > 9) | ((st.n_hits > 0) & (st.best_size > 1)))) return false;
     // :1358-1380
-    if (MAPAD_UNLIKELY(st.heap_len > P.stack_limit || st.tree_len > P.edit_tree_limit)) {
+    if (MAPAD_UNLIKELY((st.heap_len > P.stack_limit) | (st.tree_len > P.edit_tree_limit))) {
         if (P.stack_limit_abort) { st.status = ST_LIMIT_ABORT; return false; }
         const int64_t a = (int64_t)st.heap_len - (int64_t)P.stack_limit;
         const int64_t b = (int64_t)st.tree_len - (int64_t)P.edit_tree_limit;
