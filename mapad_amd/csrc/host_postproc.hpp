@@ -21,6 +21,7 @@
 #include "../../include/mapad_amd.h"
 #include "host_index.hpp"
 #include "host_models.hpp"
+#include "postproc_core.hpp"
 
 namespace mapad {
 namespace host {
@@ -338,6 +339,90 @@ inline mapad_records_t* hits_to_records(const Index& ix, const mapad_params_t& p
         }
         rec.flags = flags;
         own->recs[r] = rec;
+        }
+      } catch (...) { errors[t] = std::current_exception(); }
+    };
+    if (n_threads == 1) work(0);
+    else {
+        std::vector<std::thread> pool;
+        for (unsigned t = 0; t < n_threads; ++t) pool.emplace_back(work, t);
+        for (auto& th : pool) th.join();
+    }
+    for (auto& e : errors) if (e) std::rethrow_exception(e);
+    uint64_t total = 0;
+    for (auto& t : texts) total += t.size();
+    if (total > 0xFFFFFFFFull) throw std::runtime_error("record text of one batch exceeds 4 GiB");
+    own->text.reserve(total);
+    for (unsigned t = 0; t < n_threads; ++t) {
+        const uint32_t base = (uint32_t)own->text.size();
+        if (base) for (uint64_t r = res.n_reads * t / n_threads; r < res.n_reads * (t + 1) / n_threads; ++r) {
+            mapad_record_t& rec = own->recs[r];
+            if (rec.mapped) { rec.cigar_off += base; rec.md_off += base; rec.xa_off += base; }
+        }
+        own->text += texts[t];
+    }
+    own->pub.n = res.n_reads; own->pub.recs = own->recs.data(); own->pub.text = own->text.c_str(); own->pub.text_len = own->text.size();
+    return &own.release()->pub;
+}
+// The text half of intervals_to_bam for coordinates that were computed on the device (postproc_core.hpp: record_coords): flags, CIGAR / MD /
+// XA strings, XS / XT and the mapping quality (libm: exp2f, log10f — on the host like every other transcendental of this design).
+inline mapad_records_t* records_from_coords(const Index& ix, const mapad_params_t& prm, const mapad_batch_result_t& res, const uint16_t* in_flags, const CoordRec* coords) {
+    auto own = std::unique_ptr<RecordsOwner>(new RecordsOwner());
+    own->recs.resize(res.n_reads);
+    unsigned n_threads = 1;
+    if (const char* e = std::getenv("MAPAD_POSTPROC_THREADS")) n_threads = (unsigned)std::max(1, std::atoi(e));
+    else n_threads = std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 64u);
+    n_threads = (unsigned)std::min<uint64_t>(n_threads, std::max<uint64_t>(1, res.n_reads / 2048));
+    std::vector<std::string> texts(n_threads);
+    std::vector<std::exception_ptr> errors(n_threads);
+    auto work = [&](unsigned t) {
+      try {
+        const uint64_t r0 = res.n_reads * t / n_threads, r1 = res.n_reads * (t + 1) / n_threads;
+        std::string& text = texts[t];
+        auto put = [&](const std::string& s, uint32_t& off, uint32_t& len) { off = (uint32_t)text.size(); len = (uint32_t)s.size(); text += s; };
+        std::vector<uint32_t> order;
+        for (uint64_t r = r0; r < r1; ++r) {
+            mapad_record_t rec{};
+            const CoordRec& cr = coords[r];
+            if (cr.error) throw std::runtime_error("Could not enumerate possible reference positions");
+            uint16_t flags = in_flags ? in_flags[r] : 0;
+            flags &= (uint16_t)~(0x8 | 0x20 | 0x2 | 0x100 | 0x800);  // :750-755
+            const mapad_hit_t* hits = res.hits + res.hit_begin[r];
+            if (cr.mapped) {
+                const mapad_hit_t& best = hits[cr.best];
+                const Track bt{res.ops + best.ops_offset, best.n_ops};
+                std::string xa;
+                for (uint32_t k = 0; k < cr.n_xa; ++k) {  // :436-491
+                    const CoordOut& c = cr.xa[k];
+                    const mapad_hit_t& h = hits[c.hit];
+                    const Track tk{res.ops + h.ops_offset, h.n_ops};
+                    const BamFields bf = to_bam_fields(tk, c.backward != 0, c.abs, ix);
+                    char buf[64];
+                    std::snprintf(buf, sizeof buf, "%.2f", (double)h.alignment_score);
+                    xa += ix.contigs[(size_t)c.tid].name + "," + (c.backward ? "-" : "+") + std::to_string(c.rel + 1) + "," + bf.cigar + "," + bf.md + "," + std::to_string(bf.nm) +
+                          "," + std::to_string(h.size) + "," + buf + ";";
+                }
+                order.assign(cr.order, cr.order + cr.n_order);
+                rec.x0 = cr.x0 > 0x7FFFFFFFull ? 0x7FFFFFFF : (int32_t)cr.x0;
+                rec.x1 = cr.x1 > 0x7FFFFFFFull ? 0x7FFFFFFF : (int32_t)cr.x1;
+                rec.xs_score = order.empty() ? 0.0f : hits[order.back()].alignment_score;  // :510-513
+                rec.has_xs = rec.x1 > 0;                                                    // :895
+                rec.xt = cr.x0 == 0 ? 'N' : cr.x0 == 1 ? 'U' : 'R';
+                rec.mapq = mapping_quality(prm, best, cr.x0, bt.read_len(), hits, order);
+                const BamFields bf = to_bam_fields(bt, cr.first.backward != 0, cr.first.abs, ix);
+                put(bf.cigar, rec.cigar_off, rec.cigar_len);
+                put(bf.md, rec.md_off, rec.md_len);
+                put(xa, rec.xa_off, rec.xa_len);
+                rec.nm = bf.nm; rec.as_score = best.alignment_score;
+                rec.mapped = 1; rec.reverse = cr.first.backward != 0; rec.tid = cr.first.tid; rec.pos = (int64_t)cr.first.rel;
+                flags &= (uint16_t)~0x4;
+                if (cr.first.backward) flags |= 0x10; else flags &= (uint16_t)~0x10;
+            } else {  // :553-566, :765-776
+                flags |= 0x4; flags &= (uint16_t)~0x10; flags &= (uint16_t)~0x2;
+                rec.mapq = 0; rec.tid = -1; rec.pos = -1;
+            }
+            rec.flags = flags;
+            own->recs[r] = rec;
         }
       } catch (...) { errors[t] = std::current_exception(); }
     };

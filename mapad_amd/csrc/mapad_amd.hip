@@ -27,6 +27,7 @@
 #include "host_index_io.hpp"
 #include "host_models.hpp"
 #include "host_postproc.hpp"
+#include "postproc_core.hpp"
 #include "search_core.hpp"
 
 using namespace mapad;
@@ -248,6 +249,15 @@ __global__ void __launch_bounds__(64) locate_kernel(DevIndex ix, LocateDev Q) {
         }
     }
     if (active && w == 0) { Q.out[q] = result; if (Q.steps) atomicAdd(Q.steps, (unsigned long long)n_steps); }
+}
+
+// ---- hits -> coordinates: the index-bound half of intervals_to_bam, one thread per read (postproc_core.hpp) -----------------
+__global__ void __launch_bounds__(256) records_kernel(PostIndex Q, const uint64_t* __restrict__ hit_begin, const HitRec* __restrict__ hits, const uint32_t* __restrict__ ops,
+                                                      uint64_t n_reads, uint64_t seed, CoordRec* __restrict__ out) {
+    const uint64_t r = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= n_reads) return;
+    const uint64_t b = hit_begin[r];
+    record_coords(Q, hits + b, (uint32_t)(hit_begin[r + 1] - b), ops, seed, r, out[r]);
 }
 
 // ---- search: persistent quads -----------------------------------------------------------------------------------------
@@ -699,7 +709,10 @@ struct mapad_ctx {
     DevBuf<GrowPools> d_grow;
     GrowPools grow{};
     // SA locate
-    DevBuf<uint64_t> d_sa, d_xc, d_rows, d_pos;
+    DevBuf<uint64_t> d_sa, d_xc, d_rows, d_pos, d_contigs, d_r_begin;
+    DevBuf<HitRec> d_r_hits;
+    DevBuf<uint32_t> d_r_ops;
+    DevBuf<CoordRec> d_r_out;
     DevBuf<unsigned long long> d_steps;
     bool sa_uploaded = false;
     hipEvent_t lev[2] = {nullptr, nullptr};
@@ -718,6 +731,7 @@ struct mapad_ctx {
         for (auto& a : d_owner) a.release();
         d_grow.release();
         d_sa.release(); d_xc.release(); d_rows.release(); d_pos.release(); d_steps.release();
+        d_contigs.release(); d_r_begin.release(); d_r_hits.release(); d_r_ops.release(); d_r_out.release();
         for (auto& e : lev) if (e) (void)hipEventDestroy(e);
         if (ev_ref) (void)hipEventDestroy(ev_ref);
     }
@@ -1533,6 +1547,27 @@ int mapad_kernel_history(mapad_ctx_t* ctx, float* out, uint32_t cap, uint32_t* n
 
 // ---- SA locate on the device ---------------------------------------------------------------------------------------------
 namespace {
+int ensure_sa_uploaded(mapad_ctx* c) {
+    if (c->sa_uploaded) return MAPAD_OK;
+    const host::Index& ix = c->index->ix;
+    int rc;
+    if ((rc = c->d_sa.ensure(std::max<size_t>(ix.sa_sample.size(), 1), true))) return rc;
+    HIP_TRY(hipMemcpyAsync(c->d_sa.p, ix.sa_sample.data(), ix.sa_sample.size() * 8, hipMemcpyHostToDevice, c->stream));
+    if (!ix.x_counts.empty()) {
+        if ((rc = c->d_xc.ensure(ix.x_counts.size(), true))) return rc;
+        HIP_TRY(hipMemcpyAsync(c->d_xc.p, ix.x_counts.data(), ix.x_counts.size() * 8, hipMemcpyHostToDevice, c->stream));
+    }
+    std::vector<uint64_t> cs;  // contig starts, then ends
+    for (auto& k : ix.contigs) cs.push_back(k.start);
+    for (auto& k : ix.contigs) cs.push_back(k.end);
+    if ((rc = c->d_contigs.ensure(std::max<size_t>(cs.size(), 2), true))) return rc;
+    if (!cs.empty()) HIP_TRY(hipMemcpyAsync(c->d_contigs.p, cs.data(), cs.size() * 8, hipMemcpyHostToDevice, c->stream));
+    if ((rc = c->d_steps.ensure(1))) return rc;
+    for (auto& e : c->lev) if (!e) HIP_TRY(hipEventCreate(&e));
+    HIP_TRY(hipStreamSynchronize(c->stream));  // `cs` goes out of scope
+    c->sa_uploaded = true;
+    return MAPAD_OK;
+}
 int locate_rows(mapad_ctx* c, const uint64_t* rows, uint64_t n, uint64_t* out) {
     if (hipSetDevice(c->device) != hipSuccess) return MAPAD_ERR_NO_DEVICE;
     const host::Index& ix = c->index->ix;
@@ -1540,17 +1575,7 @@ int locate_rows(mapad_ctx* c, const uint64_t* rows, uint64_t n, uint64_t* out) {
     while ((1ull << shift) < ix.sa_rate) ++shift;
     if ((1ull << shift) != ix.sa_rate || shift < 1 || shift > 8 || ix.extra_rows.size() > 2) return MAPAD_ERR_INVALID;  // the kernel's assumptions
     int rc;
-    if (!c->sa_uploaded) {
-        if ((rc = c->d_sa.ensure(std::max<size_t>(ix.sa_sample.size(), 1), true))) return rc;
-        HIP_TRY(hipMemcpyAsync(c->d_sa.p, ix.sa_sample.data(), ix.sa_sample.size() * 8, hipMemcpyHostToDevice, c->stream));
-        if (!ix.x_counts.empty()) {
-            if ((rc = c->d_xc.ensure(ix.x_counts.size(), true))) return rc;
-            HIP_TRY(hipMemcpyAsync(c->d_xc.p, ix.x_counts.data(), ix.x_counts.size() * 8, hipMemcpyHostToDevice, c->stream));
-        }
-        if ((rc = c->d_steps.ensure(1))) return rc;
-        for (auto& e : c->lev) if (!e) HIP_TRY(hipEventCreate(&e));
-        c->sa_uploaded = true;
-    }
+    if ((rc = ensure_sa_uploaded(c))) return rc;
     c->last_locate_rows = n; c->last_locate_steps = 0;
     if (n == 0) return MAPAD_OK;
     if ((rc = c->d_rows.ensure(n))) return rc;
@@ -1588,21 +1613,41 @@ int mapad_last_locate_info(mapad_ctx_t* ctx, float* kernel_ms, uint64_t* rows, u
 int mapad_hits_to_records_gpu(mapad_ctx_t* ctx, const mapad_batch_result_t* res, const uint8_t* seqs, const uint8_t* quals, const uint64_t* offsets,
                               const uint16_t* in_flags, uint64_t seed, mapad_records_t** out) {
     if (!ctx || !res || !out || (res->n_reads && (!seqs || !quals || !offsets))) return MAPAD_ERR_INVALID;
+    if (hipSetDevice(ctx->device) != hipSuccess) return MAPAD_ERR_NO_DEVICE;
     try {
-        // rows of every small hit interval are located on the device; the (rare) larger intervals are walked on the host on demand
-        constexpr uint64_t kMaxRows = 8;
-        std::vector<uint64_t> rows;
-        for (uint64_t i = 0; i < res->n_hits; ++i)
-            if (res->hits[i].size <= kMaxRows) for (uint64_t r = 0; r < res->hits[i].size; ++r) rows.push_back(res->hits[i].lower + r);
-        std::sort(rows.begin(), rows.end());
-        rows.erase(std::unique(rows.begin(), rows.end()), rows.end());
-        std::vector<uint64_t> pos(rows.size());
-        const int rc = locate_rows(ctx, rows.data(), rows.size(), pos.data());
-        if (rc) return rc;
-        host::SaCache cache;
-        cache.v.reserve(rows.size());
-        for (size_t i = 0; i < rows.size(); ++i) if (pos[i] != ~0ull) cache.v.emplace_back(rows[i], pos[i]);
-        *out = host::hits_to_records(ctx->index->ix, ctx->params, *res, seqs, quals, offsets, in_flags, seed, &cache);
+        const host::Index& ix = ctx->index->ix;
+        uint32_t shift = 0;
+        while ((1ull << shift) < ix.sa_rate) ++shift;
+        if ((1ull << shift) != ix.sa_rate || shift < 1 || shift > 8 || ix.extra_rows.size() > 2) return MAPAD_ERR_INVALID;  // the kernels' assumptions
+        int rc;
+        if ((rc = ensure_sa_uploaded(ctx))) return rc;
+        const uint64_t n = res->n_reads;
+        std::vector<CoordRec> coords(n);
+        if (n) {
+            // the hit records go back to the GPU that produced them (page-locked results: DMA), the index-bound half of intervals_to_bam runs
+            // there — SA walks, strand and contig, X0 / X1, XA candidates — and one compact record per read comes back
+            if ((rc = ctx->d_r_begin.ensure(n + 1))) return rc;
+            if ((rc = ctx->d_r_hits.ensure(std::max<uint64_t>(res->n_hits, 1)))) return rc;
+            if ((rc = ctx->d_r_ops.ensure(std::max<uint64_t>(res->n_ops, 1)))) return rc;
+            if ((rc = ctx->d_r_out.ensure(n))) return rc;
+            HIP_TRY(hipMemcpyAsync(ctx->d_r_begin.p, res->hit_begin, (n + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+            if (res->n_hits) HIP_TRY(hipMemcpyAsync(ctx->d_r_hits.p, res->hits, res->n_hits * sizeof(HitRec), hipMemcpyHostToDevice, ctx->stream));
+            if (res->n_ops) HIP_TRY(hipMemcpyAsync(ctx->d_r_ops.p, res->ops, res->n_ops * 4, hipMemcpyHostToDevice, ctx->stream));
+            PostIndex Q{};
+            Q.ix = ctx->dix; Q.sa_sample = ctx->d_sa.p; Q.x_counts = ix.x_counts.empty() ? nullptr : ctx->d_xc.p; Q.sa_shift = shift;
+            int k = 0;
+            for (const auto& kv : ix.extra_rows) { Q.extra_row[k] = kv.first; Q.extra_val[k] = kv.second; ++k; }
+            for (; k < 2; ++k) { Q.extra_row[k] = ~0ull; Q.extra_val[k] = 0; }
+            Q.n_contigs = (uint32_t)ix.contigs.size(); Q.contig_start = ctx->d_contigs.p; Q.contig_end = ctx->d_contigs.p + ix.contigs.size();
+            HIP_TRY(hipEventRecord(ctx->lev[0], ctx->stream));
+            hipLaunchKernelGGL(records_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, ctx->stream, Q, ctx->d_r_begin.p, ctx->d_r_hits.p, ctx->d_r_ops.p, n, seed, ctx->d_r_out.p);
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipEventRecord(ctx->lev[1], ctx->stream));
+            HIP_TRY(hipMemcpyAsync(coords.data(), ctx->d_r_out.p, n * sizeof(CoordRec), hipMemcpyDeviceToHost, ctx->stream));
+            HIP_TRY(hipStreamSynchronize(ctx->stream));
+            ctx->last_locate_rows = n; ctx->last_locate_steps = 0;
+        }
+        *out = host::records_from_coords(ix, ctx->params, *res, in_flags, coords.data());
         return MAPAD_OK;
     } catch (const std::bad_alloc&) { return MAPAD_ERR_NOMEM; } catch (const std::exception& e) {
         std::fprintf(stderr, "mapad_hits_to_records_gpu: %s\n", e.what());

@@ -61,6 +61,32 @@ def test_records_from_device_located_positions_equal_host_path():
         ctx.close()
 
 
+def test_device_coordinates_on_contigs_x_runs_and_multi_row_hits():
+    """The records kernel (postproc_core.hpp: strand, contig, X0 / X1, XA candidates, PrRange order) against the host restatement on a
+    multi-contig text with X runs, repeats (hit intervals of many rows: the permutation matters) and reads that straddle contig ends."""
+    rng = np.random.default_rng(5)
+    unit = synth.genome(3_000, seed=21)
+    parts = [np.array(synth.genome(50_000, seed=20), dtype=np.uint8).copy(), np.concatenate([unit, unit, unit, unit, unit]), np.array(synth.genome(700, seed=22)),
+             np.array(synth.genome(40_000, seed=23), dtype=np.uint8).copy()]
+    parts[0][2000:2030] = ord("N"); parts[3][100] = ord("N")
+    g = np.concatenate(parts)
+    contigs = [("c0", parts[0].tobytes()), ("rep", parts[1].tobytes()), ("tiny", parts[2].tobytes()), ("c3", parts[3].tobytes())]
+    idx = mapad_amd.Index.build(contigs, seed=3, device=0)
+    seqs, quals, offsets = synth.reads(g, 4000, 50, seed=10, qual_range=(20, 40), damage=dict(f=0.5, t=0.5, d=0.02, s=1.0), len_range=(30, 70), indel_frac=0.05)
+    params = mapad_amd.make_params(resolve_params(DAMAGE))
+    ctx = mapad_amd.Context(idx, params, 0)
+    try:
+        res = ctx.map_batch(seqs, quals, offsets)
+        assert (res.hits_arr["size"] >= 5).sum() > 100  # reads from the repeat
+        for seed in (1, 99):
+            host = mapad_amd.hits_to_records(idx, params, res, seqs, quals, offsets, seed=seed)
+            dev = ctx.hits_to_records(res, seqs, quals, offsets, seed=seed)
+            assert dev == host
+        assert sum(1 for r in host if r["mapped"] and r["xa"]) > 100 and len({r["tid"] for r in host if r["mapped"]}) == 4
+    finally:
+        ctx.close()
+
+
 def test_integration_records_through_device_locate(monkeypatch):
     """tests/integration_tests.rs expectation, with the suffix-array lookups done by the kernel."""
     from test_host_logic import check_integration_records
