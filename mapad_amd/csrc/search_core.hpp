@@ -326,7 +326,10 @@ MAPAD_HD void mm_bubble_up(const ArenaT<NL>& A, uint32_t pos, const HeapEntry el
 // grandparents and the grandparents of their parents in two each.  Loading that window once — right after the pop, so that the loads are in
 // flight during the rank queries — takes the memory round trip out of every push of the commit loop (it was the largest share of a step:
 // 44 % of the wave time, profiles/r02/sections_before.txt).  Pushes update the window as they store, so a later sibling sees what an earlier
-// one moved.  Used when the parents are beyond the near part of the heap (n0 >= kTop) and for the first kWinPushes pushes of a step.
+// one moved.  Used for frames with two or more children whose parents are beyond the near part of the heap (n0 >= kTop), for the first
+// kWinPushes pushes of the step.  OFF by default (-DMAPAD_ANCESTOR_WINDOW): it lost both ways on MI355X — loaded for every pop right after the heap
+// repair 336 vs 282 ms per 1 M reads (C2), loaded only for multi-child frames 277 vs 249 ms: the loop is bound by requests and issue
+// slots, not by the latency the window hides.  Kept as a measured dead end, compiled out.
 constexpr uint32_t kWinPushes = 4;
 // Entries are kept as packed 64-bit values and every access is a chain of value selects: field-wise conditional stores let the compiler
 // merge them into one store through a computed address, which pins the whole window in scratch memory.
@@ -351,11 +354,7 @@ MAPAD_HD HeapEntry unpack_entry(uint64_t v) {
 template <bool NL>
 MAPAD_HD AncWindow win_load(const ArenaT<NL>& A, uint32_t n0) {
     AncWindow W;
-#if defined(MAPAD_ANCESTOR_WINDOW)
     W.on = n0 >= (uint32_t)kTop;
-#else
-    W.on = false;  // measured on MI355X (C2): the window's seven loads per pop cost more than the round trips they save (336 vs 282 ms per 1 M reads)
-#endif
     W.n0 = n0;
     W.pb = n0 > 0 ? (n0 - 1) >> 1 : 0; W.gb = n0 > 2 ? (n0 - 3) >> 2 : 0; W.hb = W.pb > 2 ? (W.pb - 3) >> 2 : 0;
     W.p0 = W.p1 = W.p2 = W.g0 = W.g1 = W.h0 = W.h1 = 0;
@@ -618,10 +617,22 @@ MAPAD_HD float d_get(DPtr d, int L, int split, int backward_index, int forward_i
 // Fills the quad's per-read position data; lane w of LPR lanes handles positions w, w + LPR, ...
 template <class QcPtr, class DPtr>
 MAPAD_HD void read_setup(const uint8_t* seq, const uint8_t* qual, const float* d_in, int L, QcPtr qc, DPtr d, int w, int lpr) {
-    for (int j = w; j < L; j += lpr) {
-        qc[2 * j] = (uint8_t)base_index(seq[j]);
-        qc[2 * j + 1] = qual[j];
-        d[j] = d_in[j];
+    // eight positions per lane at a time: their 24 loads are issued before the first store, so a 50 bp read costs two waits for memory, not 13
+    constexpr int kChunk = 8;
+    for (int base = w; base < L; base += lpr * kChunk) {
+        uint8_t s[kChunk], q[kChunk];
+        float dv[kChunk];
+#pragma unroll
+        for (int i = 0; i < kChunk; ++i) {
+            const int j = base + i * lpr;
+            const int jj = j < L ? j : L - 1;  // clamped: the loads stay unconditional
+            s[i] = seq[jj]; q[i] = qual[jj]; dv[i] = d_in[jj];
+        }
+#pragma unroll
+        for (int i = 0; i < kChunk; ++i) {
+            const int j = base + i * lpr;
+            if (j < L) { qc[2 * j] = (uint8_t)base_index(s[i]); qc[2 * j + 1] = q[i]; d[j] = dv[i]; }
+        }
     }
 }
 
@@ -783,7 +794,8 @@ MAPAD_HD bool search_step(const DevIndex& ix, const DevParams& P, const ReadInT<
 #if defined(MAPAD_LATE_EXT) && defined(__HIP_DEVICE_COMPILE__)
     if constexpr (kLaneKids) ext_loads = ext4_quad_issue(ix, x_lower, f.size, w);
 #endif
-    AncWindow W = win_load(A, st.heap_len);
+    AncWindow W;  // off unless the fast commit loop below turns it on
+    W.on = false; W.n0 = 0; W.pb = 0; W.gb = 0; W.hb = 0; W.p0 = W.p1 = W.p2 = W.g0 = W.g1 = W.h0 = W.h1 = 0;
     MAPAD_MARK(PROF_POP);
     Ext4 e;
     uint64_t my_lower = 0, my_lower_rev = 0, my_size = 0;  // kLaneKids: extension by base w
@@ -881,6 +893,19 @@ MAPAD_HD bool search_step(const DevIndex& ix, const DevParams& P, const ReadInT<
             for (int i = 0; i < 4; ++i) if (mm[i] < lim) cand &= ~(4u << (2 * i));
         }
         const uint32_t cand0 = cand, id0 = st.tree_next;  // == tree_entries: the slab grows at its end, child t gets key id0 + (children before t)
+#if defined(MAPAD_ANCESTOR_WINDOW)  // measured on MI355X (C2, per 1 M reads): 277 ms with this window, 249 ms without
+        // A frame with several children (13 % of the pops, but half of the wavefront steps have one among their 16 read slots) pushes to
+        // consecutive slots whose ancestors overlap: seven entries instead of three per child, loaded once, then every push of the frame works
+        // on registers and the later trips of the loop carry no memory wait.  Single children keep the three direct loads.
+        {
+#if defined(__HIP_DEVICE_COMPILE__)
+            const int n_kids = __popc(cand);
+#else
+            const int n_kids = __builtin_popcount(cand);
+#endif
+            if (n_kids >= 2 && st.heap_len >= (uint32_t)kTop) W = win_load(A, st.heap_len);
+        }
+#endif
         while (cand != 0) {
 #if defined(__HIP_DEVICE_COMPILE__)
             const int t = __ffs((int)cand) - 1;
