@@ -102,30 +102,95 @@ public:
         g_ = path == "-" ? gzdopen(0, "rb") : gzopen(path.c_str(), "rb");
         if (!g_) throw std::runtime_error("The given input file could not be found: " + path);
         gzbuffer(g_, 1 << 20);
+        buf_.resize(4u << 20);
     }
     ~GzReader() { if (g_) gzclose(g_); }
     bool read_exact(void* p, size_t n) {
         uint8_t* b = (uint8_t*)p;
         while (n) {
-            const int k = gzread(g_, b, (unsigned)std::min<size_t>(n, 1u << 30));
-            if (k <= 0) return false;
-            b += k; n -= (size_t)k;
+            if (pos_ == end_ && !fill()) return false;
+            const size_t k = std::min(n, end_ - pos_);
+            std::memcpy(b, buf_.data() + pos_, k);
+            pos_ += k; b += k; n -= k;
         }
         return true;
     }
-    bool getline(std::string& s) {
-        s.clear();
-        char buf[4096];
+    // One line without its terminator as a view into the read buffer (valid until the next call); false at end of input.
+    // The FASTQ parser works on these views: no per-line string, one memchr per line.
+    bool line_view(const char*& p, size_t& n) {
         for (;;) {
-            if (!gzgets(g_, buf, sizeof buf)) return !s.empty();
-            s += buf;
-            if (!s.empty() && s.back() == '\n') { s.pop_back(); if (!s.empty() && s.back() == '\r') s.pop_back(); return true; }
+            const void* nl = pos_ < end_ ? std::memchr(buf_.data() + pos_, '\n', end_ - pos_) : nullptr;
+            if (nl) {
+                const size_t e = (const uint8_t*)nl - buf_.data();
+                p = (const char*)buf_.data() + pos_; n = e - pos_;
+                pos_ = e + 1;
+                if (n && p[n - 1] == '\r') n -= 1;
+                return true;
+            }
+            // no terminator in the buffer: move the partial line to the front and read on
+            if (pos_ > 0) { std::memmove(buf_.data(), buf_.data() + pos_, end_ - pos_); end_ -= pos_; pos_ = 0; }
+            if (end_ == buf_.size()) buf_.resize(buf_.size() * 2);
+            const int k = eof_ ? 0 : gzread(g_, buf_.data() + end_, (unsigned)std::min<size_t>(buf_.size() - end_, 1u << 30));
+            if (k <= 0) {
+                eof_ = true;
+                if (end_ == 0) return false;
+                p = (const char*)buf_.data(); n = end_; pos_ = end_ = 0;  // last line without a newline
+                if (n && p[n - 1] == '\r') n -= 1;
+                return true;
+            }
+            end_ += (size_t)k;
         }
     }
-    int peek() { const int c = gzgetc(g_); if (c >= 0) gzungetc(c, g_); return c; }
+    // Up to `max_lines` whole lines as (offset, length) pairs into one contiguous block (valid until the next call): the text of a chunk of
+    // FASTQ records, to be parsed by several threads.  Fewer lines only at the end of the input.
+    const char* lines_block(size_t max_lines, std::vector<std::pair<uint32_t, uint32_t>>& lines) {
+        lines.clear();
+        if (pos_ > 0) { std::memmove(buf_.data(), buf_.data() + pos_, end_ - pos_); end_ -= pos_; pos_ = 0; }
+        size_t scan = 0;
+        while (lines.size() < max_lines) {
+            const void* nl = scan < end_ ? std::memchr(buf_.data() + scan, '\n', end_ - scan) : nullptr;
+            if (nl) {
+                const size_t e = (const uint8_t*)nl - buf_.data();
+                size_t n = e - scan;
+                if (n && buf_[e - 1] == '\r') n -= 1;
+                lines.emplace_back((uint32_t)scan, (uint32_t)n);
+                scan = e + 1;
+                continue;
+            }
+            if (end_ == buf_.size()) { if (buf_.size() >= (1ull << 31)) throw std::runtime_error("input chunk larger than 2 GiB of text"); buf_.resize(buf_.size() * 2); }
+            const int k = eof_ ? 0 : gzread(g_, buf_.data() + end_, (unsigned)std::min<size_t>(buf_.size() - end_, 1u << 30));
+            if (k <= 0) {
+                eof_ = true;
+                if (scan < end_) { size_t n = end_ - scan; if (buf_[end_ - 1] == '\r') n -= 1; lines.emplace_back((uint32_t)scan, (uint32_t)n); scan = end_; }
+                break;
+            }
+            end_ += (size_t)k;
+        }
+        pos_ = scan;
+        return (const char*)buf_.data();
+    }
+    void unread_from(uint32_t offset) { pos_ = offset; }  // hand the tail of the last lines_block() back (offset = start of the first unused line)
+    bool getline(std::string& s) {
+        const char* p; size_t n;
+        if (!line_view(p, n)) { s.clear(); return false; }
+        s.assign(p, n);
+        return true;
+    }
+    int peek() { if (pos_ == end_ && !fill()) return -1; return buf_[pos_]; }
 
 private:
     gzFile g_ = nullptr;
+    std::vector<uint8_t> buf_;
+    size_t pos_ = 0, end_ = 0;
+    bool eof_ = false;
+    bool fill() {
+        if (eof_) return false;
+        pos_ = end_ = 0;
+        const int k = gzread(g_, buf_.data(), (unsigned)std::min<size_t>(buf_.size(), 1u << 30));
+        if (k <= 0) { eof_ = true; return false; }
+        end_ = (size_t)k;
+        return true;
+    }
 };
 
 // ---- records ------------------------------------------------------------------------------------------------------------
@@ -181,6 +246,30 @@ public:
     bool next(InRecord& r) {
         return is_bam_ ? next_bam(r) : next_fastq(r);
     }
+    // FASTQ only: the lines of up to `max_records` records (4 lines each) for parse_fastq_record(); nullptr for BAM input
+    const char* fastq_block(size_t max_records, std::vector<std::pair<uint32_t, uint32_t>>& lines) {
+        if (is_bam_) return nullptr;
+        return in_.lines_block(4 * max_records, lines);
+    }
+    void fastq_unread_from(uint32_t offset) { in_.unread_from(offset); }
+    // one record from its four lines; false if they do not form a FASTQ record
+    static bool parse_fastq_record(const char* base, const std::pair<uint32_t, uint32_t>* ln, InRecord& r) {
+        const char* h = base + ln[0].first; const size_t hn = ln[0].second;
+        const char* sq = base + ln[1].first; const size_t sn = ln[1].second;
+        const char* pl = base + ln[2].first; const size_t pn = ln[2].second;
+        const char* q = base + ln[3].first; const size_t qn = ln[3].second;
+        if (hn == 0 || h[0] != '@' || pn == 0 || pl[0] != '+' || sn != qn) return false;
+        r = InRecord();
+        size_t e = 1;
+        while (e < hn && h[e] != ' ' && h[e] != '\t') ++e;
+        r.name.assign(h + 1, e - 1);
+        r.has_name = true; r.flags = 0;
+        r.seq.resize(sn);
+        for (size_t i = 0; i < sn; ++i) { const char ch = sq[i]; r.seq[i] = (ch >= 'a' && ch <= 'z') ? (char)(ch - 'a' + 'A') : ch; }
+        r.qual.resize(qn);
+        for (size_t i = 0; i < qn; ++i) r.qual[i] = (uint8_t)(q[i] - 33);
+        return true;
+    }
 
 private:
     GzReader in_;
@@ -188,20 +277,25 @@ private:
     std::string header_text_;
 
     bool next_fastq(InRecord& r) {  // TryFrom<fastq::Record> (record.rs:185-215)
-        std::string l1, l2, l3, l4;
+        const char* p; size_t n;
         for (;;) {
-            if (!in_.getline(l1)) return false;
-            if (l1.empty()) continue;
-            if (!in_.getline(l2) || !in_.getline(l3) || !in_.getline(l4)) return false;
-            if (l1[0] != '@' || l3.empty() || l3[0] != '+' || l2.size() != l4.size()) { std::fprintf(stderr, "Skip record due to an error: malformed FASTQ record\n"); continue; }
+            if (!in_.line_view(p, n)) return false;
+            if (n == 0) continue;
+            const bool head_ok = p[0] == '@';
             r = InRecord();
-            const size_t sp = l1.find_first_of(" \t");
-            r.name = l1.substr(1, sp == std::string::npos ? std::string::npos : sp - 1);
+            size_t e = 1;
+            while (e < n && p[e] != ' ' && p[e] != '\t') ++e;
+            if (head_ok) r.name.assign(p + 1, e - 1);
             r.has_name = true; r.flags = 0;
-            r.seq = l2;
-            for (auto& ch : r.seq) ch = (char)std::toupper((unsigned char)ch);
-            r.qual.resize(l4.size());
-            for (size_t i = 0; i < l4.size(); ++i) r.qual[i] = (uint8_t)(l4[i] - 33);
+            if (!in_.line_view(p, n)) return false;
+            r.seq.resize(n);
+            for (size_t i = 0; i < n; ++i) { const char ch = p[i]; r.seq[i] = (ch >= 'a' && ch <= 'z') ? (char)(ch - 'a' + 'A') : ch; }
+            if (!in_.line_view(p, n)) return false;
+            const bool plus_ok = n > 0 && p[0] == '+';
+            if (!in_.line_view(p, n)) return false;
+            if (!head_ok || !plus_ok || n != r.seq.size()) { std::fprintf(stderr, "Skip record due to an error: malformed FASTQ record\n"); continue; }
+            r.qual.resize(n);
+            for (size_t i = 0; i < n; ++i) r.qual[i] = (uint8_t)(p[i] - 33);
             return true;
         }
     }

@@ -159,6 +159,10 @@ struct PinnedBytes {  // page-locked byte buffer from the library (DMA at link s
         if (k) std::memcpy(p + n, src, k);
         n += k;
     }
+    void resize_uninitialized(size_t k) {  // contents are written by the caller
+        if (k > cap) { n = 0; append(nullptr, 0); const size_t want = std::max<size_t>(k * 2, 1 << 20); uint8_t* q = (uint8_t*)mapad_host_alloc(want); if (!q) die("out of page-locked host memory"); mapad_host_free(p); p = q; cap = want; }
+        n = k;
+    }
     ~PinnedBytes() { mapad_host_free(p); }
 };
 
@@ -275,20 +279,67 @@ int cmd_map(const Args& a, uint64_t seed, const std::vector<int>& devices, const
                 c->no = chunk_no;
                 c->offsets.assign(1, 0);
                 size_t bases = 0;
-                InRecord r;
-                while (c->in.size() < prm.chunk_size && (more = src.next(r))) {
+                auto admit = [&](InRecord&& r, bool copy) {
                     // Reads the device cannot take (longer than MAPAD_MAX_READ_LEN; the reference's limit is i16::MAX, src/map/record.rs:144-150) and empty
                     // reads stay in the output as unmapped records, so that input and output hold the same number of records.
                     const bool mappable = !r.seq.empty() && r.seq.size() <= MAPAD_MAX_READ_LEN;
                     if (!mappable) std::fprintf(stderr, "mapad-amd: read \"%s\" (%zu bp) is %s; written as unmapped\n", r.name.c_str(), r.seq.size(), r.seq.empty() ? "empty" : "longer than the device limit");
                     c->read_of.push_back(mappable ? (int64_t)(c->offsets.size() - 1) : -1);
                     if (mappable) {
-                        c->seqs.append(r.seq.data(), r.seq.size()); c->quals.append(r.qual.data(), r.seq.size());
+                        if (copy) { c->seqs.append(r.seq.data(), r.seq.size()); c->quals.append(r.qual.data(), r.seq.size()); }
                         bases += r.seq.size();
                         c->offsets.push_back(bases);
                         c->flags.push_back(r.flags);
                     }
                     c->in.push_back(std::move(r));
+                };
+                std::vector<std::pair<uint32_t, uint32_t>> lines;
+                const char* block = src.fastq_block(prm.chunk_size, lines);
+                bool block_done = false;
+                if (block && !lines.empty() && lines.size() % 4 == 0) {
+                    // FASTQ fast path: the chunk's lines are cut sequentially (one memchr per line), the records are parsed by several threads
+                    const size_t n_rec = lines.size() / 4;
+                    std::vector<InRecord> recs(n_rec);
+                    std::vector<char> good(n_rec, 0);
+                    parallel_for(n_rec, host_threads, [&](size_t lo, size_t hi, unsigned) {
+                        for (size_t i = lo; i < hi; ++i) good[i] = ReadSource::parse_fastq_record(block, &lines[4 * i], recs[i]);
+                    });
+                    bool all_good = true;
+                    for (char g : good) all_good &= g != 0;
+                    if (all_good) {
+                        c->in.reserve(n_rec);
+                        for (auto& r : recs) admit(std::move(r), false);
+                        // bases of the mappable reads into the page-locked buffers, in parallel (offsets are known now)
+                        c->seqs.append(nullptr, 0); c->quals.append(nullptr, 0);
+                        c->seqs.resize_uninitialized(bases); c->quals.resize_uninitialized(bases);
+                        parallel_for(c->in.size(), host_threads, [&](size_t lo, size_t hi, unsigned) {
+                            for (size_t i = lo; i < hi; ++i) {
+                                const int64_t k = c->read_of[i];
+                                if (k < 0) continue;
+                                const InRecord& r = c->in[i];
+                                std::memcpy(c->seqs.p + c->offsets[(size_t)k], r.seq.data(), r.seq.size());
+                                std::memcpy(c->quals.p + c->offsets[(size_t)k], r.qual.data(), r.seq.size());
+                            }
+                        });
+                        more = lines.size() == 4 * prm.chunk_size;
+                        block_done = true;
+                    }
+                }
+                if (block && !block_done) {
+                    // irregular text (blank lines, a malformed record, a truncated tail): the same lines through the tolerant sequential rules
+                    size_t i = 0;
+                    while (i < lines.size()) {
+                        if (lines[i].second == 0) { ++i; continue; }
+                        if (i + 4 > lines.size()) { if (lines.size() == 4 * prm.chunk_size) src.fastq_unread_from(lines[i].first); break; }  // a cut record goes back
+                        InRecord r;
+                        if (ReadSource::parse_fastq_record(block, &lines[i], r)) admit(std::move(r), true);
+                        else std::fprintf(stderr, "Skip record due to an error: malformed FASTQ record\n");
+                        i += 4;
+                    }
+                    more = lines.size() == 4 * prm.chunk_size;
+                } else if (!block) {
+                    InRecord r;
+                    while (c->in.size() < prm.chunk_size && (more = src.next(r))) admit(std::move(r), true);
                 }
                 if (c->in.empty()) break;
                 const uint64_t n_reads = c->offsets.size() - 1;
