@@ -56,11 +56,11 @@ class DevArray:
         self.__cuda_array_interface__ = {"shape": shape, "typestr": typestr, "data": (int(ptr), False), "version": 2}
 
 
-def spawn_ranks(n):
+def spawn_ranks(n, same_device=False):
     """Start n ranks as children of this (GPU-free) process and exit with their status."""
     import torch
     have = torch.cuda.device_count()  # does not initialise the GPU
-    if have < n:
+    if have < (1 if same_device else n):
         log(f"bench.py: --gpus {n} but only {have} device(s) visible")
         sys.exit(2)
     with socket.socket() as s:
@@ -102,15 +102,17 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target wall time of the CPU baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the e2e / sa_locate / post_search legs")
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="gloo: test mode for boxes with one GPU — every rank uses device 0 and the gather goes through host memory")
     ap.add_argument("--depth", type=int, default=3, help="batches in flight (1 = every step runs alone on the stream)")
     args = ap.parse_args()
     genome_bp = args.genome_bp or CONFIGS[args.config][0]
     n_reads = args.reads or CONFIGS[args.config][1]
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
-        spawn_ranks(args.gpus)  # never returns
+        spawn_ranks(args.gpus, same_device=args.dist_backend == "gloo")  # never returns
     rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    local_rank = 0 if args.dist_backend == "gloo" else int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         log(f"bench.py: --gpus {args.gpus} but WORLD_SIZE {world}")
@@ -131,8 +133,12 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
         assert dist.get_world_size() == world == args.gpus
+    xdev = dev if args.dist_backend == "nccl" else torch.device("cpu")  # where the exchanged tensors live
 
     # ---- workload --------------------------------------------------------------------------------------------------------
     t0 = time.time()
@@ -175,7 +181,10 @@ def main():
         begin = torch.as_tensor(DevArray(p_begin, (n_reads + 1,), "<i8"), device=dev).view(torch.int32)
         hits = torch.as_tensor(DevArray(p_hits, (max(n_hits, 1) * 10,), "<i4"), device=dev)[:n_hits * 10]
         ops = torch.as_tensor(DevArray(p_ops, (max(n_ops, 1),), "<i4"), device=dev)[:n_ops]
-        return gather_hit_records(begin, hits, ops, rank, world, device=dev)
+        if args.dist_backend == "gloo":
+            torch.cuda.synchronize(dev)
+            begin, hits, ops = begin.cpu(), hits.cpu(), ops.cpu()
+        return gather_hit_records(begin, hits, ops, rank, world, device=xdev)
 
     def run_steps(k):
         """k steps back to back.  With depth > 1 step i + 1 is submitted while step i's tail is still running; the gather of step i's
@@ -207,7 +216,7 @@ def main():
     torch.cuda.synchronize(dev)
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=xdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     hist = ctx.kernel_history().astype(np.float64)  # per launch: ms from the first launch's start to its four event marks
