@@ -80,6 +80,10 @@ struct ArenaPool {
     uint64_t stride;
     uint64_t off_nodes, off_hits, off_hit_ops, off_scratch, off_near;  // off_near: HBM stand-in for the LDS-resident data (long reads)
     uint32_t heap_cap, node_cap, hit_ops_cap;
+    // Base arenas are handed out in sets of one wavefront's read slots; a wavefront claims a set when it starts and gives it back when it
+    // exits, so the launches of all batches in flight share one pool no bigger than the chip's resident wavefronts (set_owner: 0 = free).
+    uint32_t* set_owner;
+    uint32_t n_sets;
 };
 
 // Size-class pools of grown arenas (heap + nodes only; hit staging stays in the slot's base arena).  A read that outgrows its
@@ -315,6 +319,33 @@ __device__ MAPAD_FINALIZE_ATTR void finalize_read(const BatchDev B, const ReadIn
 constexpr uint32_t kPartitionMin = 64;
 __device__ __forceinline__ uint32_t xcc_id() { return (uint32_t)__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u; }  // HW_REG_XCC_ID[3:0]
 
+// A wavefront's set of base arenas (ArenaPool::set_owner).  Pools of at least kPartitionMin sets are split by XCD like the size classes
+// above: a set is then only ever used through one L2.  The probe starts at a hash of the workgroup id; a full pool (more wavefronts
+// resident than sets) makes the wavefront wait for an exit — the owners never wait for a newcomer, so this cannot deadlock.
+__device__ __forceinline__ uint32_t acquire_set(const ArenaPool& ap) {
+    uint32_t set = 0;
+    const bool part = ap.n_sets >= kPartitionMin;
+    if ((threadIdx.x & 63) == 0) {
+        const uint32_t m = part ? ap.n_sets / 8 : ap.n_sets, lo = part ? xcc_id() * m : 0;
+        uint32_t i = (uint32_t)(((uint64_t)blockIdx.x * 2654435761u) % m), since = 0;
+        for (;;) {
+            if (atomicCAS(&ap.set_owner[lo + i], 0u, 1u) == 0u) break;
+            if (++i == m) i = 0;
+            if (++since == m) { since = 0; __builtin_amdgcn_s_sleep(64); }
+        }
+        set = lo + i;
+    }
+    set = (uint32_t)__builtin_amdgcn_readfirstlane((int)set);
+    if (part) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // stale lines of this CU's L1 from an earlier owner on this CU
+    else __threadfence();
+    return set;
+}
+__device__ __forceinline__ void release_set(const ArenaPool& ap, uint32_t set) {
+    if (ap.n_sets < kPartitionMin) __threadfence();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the old owner's stores have reached the L2 before the next owner starts (see release_grown)
+    if ((threadIdx.x & 63) == 0) atomicExch(&ap.set_owner[set], 0u);
+}
+
 template <int LPR>
 __device__ __forceinline__ void release_grown(const GrowPools* gp, uint32_t grown, int w) {
     const uint32_t cls = (grown >> kGrownShift) - 1;
@@ -411,7 +442,10 @@ template <int LPR, bool CONT, int PASS, bool NL>
 __global__ void __launch_bounds__(64, (LPR == 1 && NL) ? 1 : MAPAD_MIN_WAVES) search_kernel(DevIndex ix, DevParams P, BatchDev B, ArenaPool AP, const GrowPools* GP, uint32_t near_stride, uint32_t near_lmax, int stage) {
     const int lane = threadIdx.x & 63, w = lane & (LPR - 1);
     const int tier = stage;
-    const uint32_t slot = blockIdx.x * (64 / LPR) + (lane / LPR);
+    const uint32_t n_items = tier == 0 ? B.n_reads : B.cursors[CUR_OVF + 2 * (tier - 1)];
+    if (n_items == 0) return;  // retry / full-limit stages normally have nothing to do
+    const uint32_t set = acquire_set(AP);
+    const uint32_t slot = set * (64 / LPR) + (lane / LPR);
     ArenaT<NL> A = carve<NL>(AP, slot);
     // near data of this read slot: [kTop + 1 heap slots][2*lmax bytes class/quality][lmax floats D]
     extern __shared__ __attribute__((aligned(16))) uint8_t near_lds[];
@@ -422,7 +456,6 @@ __global__ void __launch_bounds__(64, (LPR == 1 && NL) ? 1 : MAPAD_MIN_WAVES) se
     A.top = (typename near_ptr<HeapEntry, NL>::type)near + 1;
     const NearBytes near_qc = near + (kTop + 1) * sizeof(HeapEntry);
     const typename near_ptr<float, NL>::type near_d = (typename near_ptr<float, NL>::type)(near_qc + ((2 * near_lmax + 15) & ~15u));
-    const uint32_t n_items = tier == 0 ? B.n_reads : B.cursors[CUR_OVF + 2 * (tier - 1)];
     uint32_t* work = &B.cursors[CUR_WORK + 2 * tier];
     const uint32_t* items = B.overflow_list + (size_t)(tier > 0 ? tier - 1 : 0) * B.n_reads;
     // reads of the first stages give up after kMaxWaits fruitless waits for an arena and are restarted by the next stage, when the
@@ -486,6 +519,7 @@ __global__ void __launch_bounds__(64, (LPR == 1 && NL) ? 1 : MAPAD_MIN_WAVES) se
             }
         }
     }
+    release_set(AP, set);
 #if defined(MAPAD_PROFILE_SECTIONS)
     __syncthreads();
     if (PASS == 0 && lane < 2 * PROF_N && B.prof) atomicAdd(&B.prof[lane], g_prof_lds[lane]);
@@ -641,7 +675,7 @@ ArenaPool make_pool_layout(uint32_t heap_cap, uint32_t node_cap, uint32_t hit_op
 // Everything one batch in flight owns: its stream, result and scratch buffers, per-read-slot base arenas.  A context keeps `depth` of
 // them so that the serial tail of batch k (its few heaviest reads) runs beside the bulk of batch k + 1; the size-class pools the read
 // slots grow into are shared (arenas are claimed through owner words, whichever launch asks).
-constexpr int kMaxDepth = 4;
+constexpr int kMaxDepth = 16;
 struct BatchSlot {
     hipStream_t stream = nullptr;
     bool own_stream = false;
@@ -653,7 +687,6 @@ struct BatchSlot {
     DevBuf<ReadCounters> d_counters;
     DevBuf<uint32_t> d_status, d_hit_count, d_hit_first, d_ops, d_cursors, d_overflow, d_sort_key, d_key_hist, d_order;
     DevBuf<HitRec> d_hits;
-    DevBuf<uint8_t> d_arena[kTiers];
     // read-ordered results (compact_* kernels)
     DevBuf<uint64_t> d_c_hit_begin, d_c_ops_begin;
     DevBuf<unsigned long long> d_c_tiles;
@@ -672,7 +705,6 @@ struct BatchSlot {
         d_seqs.release(); d_quals.release(); d_offsets.release(); d_darr.release(); d_counters.release(); d_status.release(); d_hit_count.release();
         d_hit_first.release(); d_ops.release(); d_cursors.release(); d_overflow.release(); d_sort_key.release(); d_key_hist.release(); d_order.release();
         d_hits.release();
-        for (auto& a : d_arena) a.release();
         d_c_hit_begin.release(); d_c_ops_begin.release(); d_c_tiles.release(); d_c_hits.release(); d_c_ops.release();
         for (auto& e : ev) if (e) { (void)hipEventDestroy(e); e = nullptr; }
         if (ev_in) { (void)hipEventDestroy(ev_in); ev_in = nullptr; }
@@ -702,8 +734,11 @@ struct mapad_ctx {
     std::vector<float> history;        // 4 floats per finished launch: ms from ev_ref to its ev[0..3]
     // arenas
     ArenaPool pool[kTiers] = {};
-    uint32_t slots[kTiers] = {0, 0}, arena_lmax = 0;
+    uint32_t slots[kTiers] = {0, 0}, arena_lmax = 0;  // read slots of a tier = its wave sets x reads per wavefront
+    uint32_t resident_waves = 0;                      // wavefronts of the search kernel the chip holds at once
     uint64_t arena_reads = 0;
+    DevBuf<uint8_t> d_arena[kTiers];
+    DevBuf<uint32_t> d_set_owner[kTiers];
     DevBuf<uint8_t> d_class[kClasses];
     DevBuf<uint32_t> d_owner[kClasses];
     DevBuf<GrowPools> d_grow;
@@ -729,6 +764,8 @@ struct mapad_ctx {
         d_blocks.release(); d_sdm.release(); d_thr.release(); d_base.release();
         for (auto& a : d_class) a.release();
         for (auto& a : d_owner) a.release();
+        for (auto& a : d_arena) a.release();
+        for (auto& a : d_set_owner) a.release();
         d_grow.release();
         d_sa.release(); d_xc.release(); d_rows.release(); d_pos.release(); d_steps.release();
         d_contigs.release(); d_r_begin.release(); d_r_hits.release(); d_r_ops.release(); d_r_out.release();
@@ -779,33 +816,44 @@ uint32_t env_u32(const char* name, uint32_t dflt) {
 // the reads pass 0 could not finish (a size-class pool ran dry).  Semantic limits are the same everywhere.
 int ensure_arenas(mapad_ctx* c, BatchSlot& S, uint32_t lmax, uint64_t n_reads) {
     int rc;
-    if (c->pool[0].stride && lmax <= c->arena_lmax && n_reads <= c->arena_reads) {  // layouts and pools stand: only this slot's own arenas may be missing
-        for (int t = 0; t < kTiers; ++t) if ((rc = S.d_arena[t].ensure((size_t)c->slots[t] * c->pool[t].stride, true))) return rc;
-        return MAPAD_OK;
-    }
+    if (c->pool[0].stride && lmax <= c->arena_lmax && n_reads <= c->arena_reads) return MAPAD_OK;  // layouts and pools stand
     if ((rc = sync_all_slots(c))) return rc;  // the layouts change: nothing may be in flight
-    for (auto& b : c->bs) for (auto& a : b.d_arena) a.release();
+    for (auto& a : c->d_arena) a.release();
     n_reads = std::max<uint64_t>(n_reads, c->arena_reads);  // pools never shrink; a batch cannot use more arenas than it has reads
     c->lpr = env_u32("MAPAD_LANES_PER_READ", 4) == 1 ? 1 : 4;
     const uint32_t lm = std::max<uint32_t>(std::max<uint32_t>(lmax, c->arena_lmax), 128);
     const uint64_t stack_cap = (uint64_t)c->dprm.stack_limit + 10, tree_cap = (uint64_t)c->dprm.edit_tree_limit + 10;
     const uint32_t hit_ops_cap = kMaxHits * (lm + 32);
     const uint32_t rpw = 64 / c->lpr;
-    {   // pass 0 base arenas
+    const uint64_t need_waves = (std::max<uint64_t>(n_reads, 1) + rpw - 1) / rpw;
+    uint32_t n_sets[kTiers];
+    {   // pass 0 base arenas: one set per wavefront the chip can hold (+ a third: the probe of a late wavefront stays short), for all batches in flight
         const uint32_t nodes = env_u32("MAPAD_TIER0_NODES", 8192);
         c->pool[0] = make_pool_layout((uint32_t)std::min<uint64_t>(nodes, stack_cap), (uint32_t)std::min<uint64_t>(nodes, tree_cap), hit_ops_cap, lm);
-        c->slots[0] = env_u32("MAPAD_TIER0_WAVES_PER_CU", c->lpr == 4 ? 4 * MAPAD_MIN_WAVES : 8) * (uint32_t)c->n_cu * rpw;
-        c->slots[0] = (uint32_t)std::min<uint64_t>(c->slots[0], (std::max<uint64_t>(n_reads, 1) + rpw - 1) / rpw * rpw);
+        c->resident_waves = env_u32("MAPAD_TIER0_WAVES_PER_CU", c->lpr == 4 ? 4 * MAPAD_MIN_WAVES : 8) * (uint32_t)c->n_cu;
+        const uint64_t per_xcd_full = ((uint64_t)c->resident_waves * 4 / 3 + 7) / 8;
+        const uint64_t per_xcd_need = (need_waves * (uint64_t)std::min(c->depth, 4) + 7) / 8 + 4;  // small batches (tests): no more than they can use
+        n_sets[0] = 8 * (uint32_t)std::max<uint64_t>(std::min(per_xcd_full, per_xcd_need), kPartitionMin / 8);
     }
     {   // pass 1: full limits
         c->pool[1] = make_pool_layout((uint32_t)stack_cap, (uint32_t)tree_cap, hit_ops_cap, lm);
-        c->slots[1] = std::max<uint32_t>(env_u32("MAPAD_LAST_PASS_WAVES", 1), 1) * rpw;
+        n_sets[1] = std::min<uint32_t>(std::max<uint32_t>(env_u32("MAPAD_LAST_PASS_WAVES", 1), 1), kPartitionMin - 1);  // shared by all XCDs
     }
-    for (int t = 0; t < kTiers; ++t) if ((rc = S.d_arena[t].ensure((size_t)c->slots[t] * c->pool[t].stride, true))) return rc;
-    const uint64_t other_slots_bytes = (uint64_t)(c->depth - 1) * ((uint64_t)c->slots[0] * c->pool[0].stride + (uint64_t)c->slots[1] * c->pool[1].stride);
+    for (int t = 0; t < kTiers; ++t) {
+        c->slots[t] = n_sets[t] * rpw;
+        if ((rc = c->d_arena[t].ensure((size_t)c->slots[t] * c->pool[t].stride, true))) return rc;
+        if ((rc = c->d_set_owner[t].ensure(n_sets[t]))) return rc;
+        HIP_TRY(hipMemsetAsync(c->d_set_owner[t].p, 0, (size_t)n_sets[t] * 4, S.stream));
+        c->pool[t].base = c->d_arena[t].p; c->pool[t].set_owner = c->d_set_owner[t].p; c->pool[t].n_sets = n_sets[t];
+    }
+    const uint64_t other_slots_bytes = 0;  // base arenas belong to the context, not to a batch
     // size classes: 2x steps; the last one holds the reference's full limits so that its owners never have to grow (no wait cycles)
-    uint32_t counts[kClasses] = {c->slots[0] / 2, c->slots[0] / 4, c->slots[0] / 8, c->slots[0] / 16, 1024, 256, 64, 32, 16, 16};
-    for (int k = 0; k < kClasses; ++k) counts[k] = std::max<uint32_t>(counts[k], 16);
+    const uint32_t rs = (uint32_t)std::min<uint64_t>((uint64_t)c->resident_waves * rpw, need_waves * rpw);  // read slots that can be busy at once
+    // The big classes are held for seconds by the few heaviest reads of every batch in flight (C5 read mix: 0.5 % of the reads need class 4
+    // or more; with 1024 / 256 / 64 arenas a 1 M-read launch spent a third of its time waiting for them): HBM is there to be used.
+    uint32_t counts[kClasses] = {rs / 2, rs / 4, rs / 8, rs / 16, 4096, 1024, 256, 64, 32, 16};
+    const uint32_t big_cap = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(n_reads / 64, 16), 1u << 20);  // small batches cannot use that many
+    for (int k = 0; k < kClasses; ++k) counts[k] = std::max<uint32_t>(k >= 4 ? std::min(counts[k], big_cap) : counts[k], 16);
     if (const char* e = std::getenv("MAPAD_CLASS_COUNTS")) {  // comma list, missing entries = 0
         for (int k = 0; k < kClasses; ++k) counts[k] = 0;
         int k = 0;
@@ -978,12 +1026,11 @@ int launch_batch(mapad_ctx* c, BatchSlot& S, const uint8_t* d_seqs, const uint8_
     // 16 per CU x 2 batches in flight 273 ms, 8 x 2 247 ms, 8 x 3 252 ms; C3: 8 x 2 589 ms, 8 x 3 529 ms).
     bool others_running = false;
     for (auto& o : c->bs) if (&o != &S && o.ev_valid && hipEventQuery(o.ev[3]) == hipErrorNotReady) others_running = true;
-    const uint32_t full_waves = c->slots[0] / rpw, shared_waves = std::max<uint32_t>(1, std::min<uint32_t>(full_waves, env_u32("MAPAD_SHARED_WAVES_PER_CU", 2 * MAPAD_MIN_WAVES) * (uint32_t)c->n_cu));
+    const uint32_t full_waves = c->resident_waves, shared_waves = std::max<uint32_t>(1, std::min<uint32_t>(full_waves, env_u32("MAPAD_SHARED_WAVES_PER_CU", 2 * MAPAD_MIN_WAVES) * (uint32_t)c->n_cu));
     const uint32_t grid_s = warm ? 1u : (uint32_t)std::min<uint64_t>((n_reads + rpw - 1) / rpw, others_running ? shared_waves : full_waves);
     for (int stage = 0; stage + 1 < kStages; ++stage) {  // every read, then the reads that gave up waiting (normally none: the launch exits at once)
         const uint32_t grid = grid_s;
-        ArenaPool ap = c->pool[0];
-        ap.base = S.d_arena[0].p;
+        const ArenaPool ap = c->pool[0];
         if (stage == 0) { MAPAD_LAUNCH_PASS(0) } else { MAPAD_LAUNCH_PASS(2) }  // PASS 2 = PASS 0 under its own symbol, so that profiles keep the passes apart
         HIP_TRY(hipGetLastError());
     }
@@ -991,8 +1038,7 @@ int launch_batch(mapad_ctx* c, BatchSlot& S, const uint8_t* d_seqs, const uint8_
     {   // leftovers with the reference's full limits
         const int stage = kStages - 1;
         const uint32_t grid = warm ? 1u : (uint32_t)std::min<uint64_t>((n_reads + rpw - 1) / rpw, c->slots[1] / rpw);
-        ArenaPool ap = c->pool[1];
-        ap.base = S.d_arena[1].p;
+        const ArenaPool ap = c->pool[1];
         MAPAD_LAUNCH_PASS(1)
         HIP_TRY(hipGetLastError());
     }
