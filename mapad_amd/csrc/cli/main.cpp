@@ -4,7 +4,7 @@
 //
 //   mapad-amd [--seed N] [--devices K] index -g ref.fa
 //   mapad-amd [--seed N] [--devices 0-7 | 0,1,...] map -r reads.{bam,fastq,fastq.gz} -g ref.fa -o out.bam -l single_stranded|double_stranded
-//             -p 0.03 | (-c CUTOFF [-e EXP]) -f F -t T -d D -s S [-D 0.02] -i I [-x 1.0] [--batch_size 250000] [--ignore_base_quality]
+//             -p 0.03 | (-c CUTOFF [-e EXP]) -f F -t T -d D -s S [-D 0.02] -i I [-x 1.0] [--batch_size 250000] [--in_flight 4] [--ignore_base_quality]
 //             [--gap_dist_ends 5] [--max_num_gaps_open 2] [--no_search_limit_recovery] [--force_overwrite] [-R ID]
 #include <atomic>
 #include <chrono>
@@ -224,6 +224,8 @@ int cmd_map(const Args& a, uint64_t seed, const std::vector<int>& devices, const
                                 a.f("gap_extension_penalty", 1.0f), std::atoi(a.get("gap_dist_ends", "5").c_str()), std::atoi(a.get("max_num_gaps_open", "2").c_str()),
                                 a.flag("ignore_base_quality"), a.flag("no_search_limit_recovery"), std::strtoull(a.get("chunk_size", "250000").c_str(), nullptr, 10)),
           "mapad_params_from_cli");
+    // chunks in flight per device: the serial tail of a chunk (its few heaviest reads) runs beside the bulk of the following ones
+    const int in_flight = std::max(1, std::min(std::atoi(a.get("in_flight", "4").c_str()), 16));
     const auto t_start = std::chrono::steady_clock::now();
     mapad_index_t* idx = nullptr;
     check(mapad_index_open(a.get("reference").c_str(), &idx), "mapad_index_open");
@@ -232,7 +234,7 @@ int cmd_map(const Args& a, uint64_t seed, const std::vector<int>& devices, const
     for (size_t d = 0; d < n_dev; ++d) {  // the read-only index is replicated into every GPU's HBM
         check(mapad_ctx_create(idx, &prm, devices[d], &ctxs[d]), "mapad_ctx_create");
         check(mapad_ctx_set_fetch_d_arrays(ctxs[d], 0), "mapad_ctx_set_fetch_d_arrays");
-        check(mapad_ctx_set_pipeline_depth(ctxs[d], 2), "mapad_ctx_set_pipeline_depth");
+        check(mapad_ctx_set_pipeline_depth(ctxs[d], in_flight), "mapad_ctx_set_pipeline_depth");
         const uint64_t per_dev = (prm.chunk_size + n_dev - 1) / n_dev;  // both batch slots' buffers up front (typical short reads; longer ones grow them)
         check(mapad_ctx_reserve(ctxs[d], per_dev, per_dev * 64, 128, 1), "mapad_ctx_reserve");
     }
@@ -259,7 +261,7 @@ int cmd_map(const Args& a, uint64_t seed, const std::vector<int>& devices, const
     }
     const unsigned host_threads = std::max(1u, std::min(std::thread::hardware_concurrency(), 32u));
     std::vector<std::unique_ptr<BoundedQueue<ChunkPtr>>> dev_q;
-    for (size_t d = 0; d < n_dev; ++d) dev_q.emplace_back(new BoundedQueue<ChunkPtr>(2));
+    for (size_t d = 0; d < n_dev; ++d) dev_q.emplace_back(new BoundedQueue<ChunkPtr>(2));  // read ahead; `in_flight` more are on the device
     BoundedQueue<ChunkPtr> done_q(4);
     std::atomic<bool> failed{false};
     std::atomic<uint64_t> us_reader{0}, us_device{0}, us_writer{0};  // busy time of the three stages (the slowest one sets the throughput)
@@ -393,26 +395,27 @@ int cmd_map(const Args& a, uint64_t seed, const std::vector<int>& devices, const
             check(mapad_map_batch(ctx, c->seqs.p + b0, c->quals.p + b0, sl.offsets.data(), sl.hi - sl.lo, &c->slices[d].res), "mapad_map_batch");
         };
         try {
-            ChunkPtr prev, c;
+            std::deque<ChunkPtr> flying;  // submitted, oldest first
+            // the oldest chunk's results; rare: a hit pool was too small — finish everything in flight, then repair synchronously, in order
+            auto retire_oldest = [&] {
+                if (collect(flying.front(), (int)flying.size() - 1)) { records(flying.front()); flying.pop_front(); return; }
+                std::vector<bool> ok(flying.size(), false);
+                for (size_t i = 1; i < flying.size(); ++i) ok[i] = collect(flying[i], (int)(flying.size() - 1 - i));
+                for (size_t i = 0; i < flying.size(); ++i) { if (!ok[i]) rerun(flying[i]); records(flying[i]); }
+                flying.clear();
+            };
+            ChunkPtr c;
             while (dev_q[d]->pop(c)) {
                 if (failed) continue;
                 const uint64_t t_d0 = now_us();
-                submit(c);                       // the GPU starts on chunk k + 1 ...
-                if (prev) {                      // ... while chunk k is collected and turned into records
-                    if (collect(prev, 1)) records(prev);
-                    else {                       // rare: finish the newer batch first, then repair the older one synchronously
-                        const bool ok = collect(c, 0);
-                        rerun(prev); records(prev);
-                        if (!ok) rerun(c);
-                        records(c);
-                        c.reset();
-                    }
-                }
-                prev = c;
+                submit(c);  // the GPU starts on this chunk while older ones are collected and turned into records
+                flying.push_back(c);
+                c.reset();
+                if ((int)flying.size() >= in_flight) retire_oldest();
                 if (d == 0) us_device += now_us() - t_d0;
             }
             const uint64_t t_d1 = now_us();
-            if (prev && !failed) { if (!collect(prev, 0)) rerun(prev); records(prev); }
+            while (!flying.empty() && !failed) retire_oldest();
             if (d == 0) us_device += now_us() - t_d1;
         } catch (const std::exception& e) { fail(e.what()); }
     };
@@ -521,6 +524,9 @@ int main(int argc, char** argv) {
         if (is_flag) a.flags.push_back(key);
         else { if (i + 1 >= argc) die("missing value for " + k); a.kv[key] = argv[++i]; }
     }
+    // every chunk in flight has its own HIP stream; the runtime multiplexes streams onto 4 hardware queues unless told otherwise, and a
+    // chunk's long tail would then hold back the launches queued behind it (must be set before the first HIP call)
+    if (std::atoi(a.get("in_flight", "4").c_str()) > 3) setenv("GPU_MAX_HW_QUEUES", "20", 0);
     const uint64_t seed = std::strtoull(a.get("seed", "1234").c_str(), nullptr, 10);
     const std::vector<int> devices = parse_devices(a.get("devices", a.get("device", "0")));
     try {

@@ -155,7 +155,8 @@ def test_cli_map_devices_chunks_and_unmappable_reads(tmp_path):
     base = [_cli(), "map", "-r", fq, "-g", fa, "-l", "single_stranded", "-p", "0.03", "-f", "0.5", "-t", "0.5", "-d", "0.02", "-s", "1.0", "-i", "0.001", "--seed", "7"]
     outs = {}
     for tag, extra in (("one", ["--devices", "0", "--batch_size", "250000"]), ("two", ["--devices", "0,0", "--batch_size", "250000"]),
-                       ("chunks", ["--devices", "0", "--batch_size", "301"])):
+                       ("chunks", ["--devices", "0", "--batch_size", "301"]), ("chunks_serial", ["--devices", "0", "--batch_size", "301", "--in_flight", "1"]),
+                       ("chunks_deep", ["--devices", "0,0", "--batch_size", "301", "--in_flight", "7"])):
         out = str(tmp_path / f"{tag}.bam")
         subprocess.check_call(base + ["-o", out] + extra)
         outs[tag] = _decoded(out)
@@ -170,3 +171,5 @@ def test_cli_map_devices_chunks_and_unmappable_reads(tmp_path):
     # chunk boundaries change the per-chunk seed (seed + chunk_no, like one rng per rayon chunk): positions of multi-row hits may differ, nothing else
     for a_, b_ in zip(outs["chunks"][1], one):
         assert a_[:3] == b_[:3] and a_[4:8] == b_[4:8]
+    # the number of chunks in flight (1 = strictly serial, 7 = every chunk's stream on its own hardware queue) never changes a record
+    assert outs["chunks_serial"][1] == outs["chunks"][1] and outs["chunks_deep"][1] == outs["chunks"][1]
