@@ -851,9 +851,12 @@ int ensure_arenas(mapad_ctx* c, BatchSlot& S, uint32_t lmax, uint64_t n_reads) {
     const uint32_t rs = (uint32_t)std::min<uint64_t>((uint64_t)c->resident_waves * rpw, need_waves * rpw);  // read slots that can be busy at once
     // The big classes are held for seconds by the few heaviest reads of every batch in flight (C5 read mix: 0.5 % of the reads need class 4
     // or more; with 1024 / 256 / 64 arenas a 1 M-read launch spent a third of its time waiting for them): HBM is there to be used.
-    uint32_t counts[kClasses] = {rs / 2, rs / 4, rs / 8, rs / 16, 4096, 1024, 256, 64, 32, 16};
-    const uint32_t big_cap = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(n_reads / 64, 16), 1u << 20);  // small batches cannot use that many
-    for (int k = 0; k < kClasses; ++k) counts[k] = std::max<uint32_t>(k >= 4 ? std::min(counts[k], big_cap) : counts[k], 16);
+    uint32_t counts[kClasses] = {rs / 2, rs / 4, rs / 8, rs / 16, 4096, 1024, 256, 128, 64, 64};
+    // ... in proportion to the reads in flight (1 in 64 may need class 4, ..., 1 in 16384 the full limits; a read at the reference's limits
+    // holds a 400 MB arena for a minute, and only as many of those run at once as the last class has arenas), never fewer than 16
+    const uint64_t in_flight = n_reads * (uint64_t)std::min(c->depth, 4);
+    const uint64_t one_in[kClasses] = {1, 1, 1, 1, 64, 256, 1024, 4096, 8192, 16384};
+    for (int k = 0; k < kClasses; ++k) counts[k] = std::max<uint32_t>(k >= 4 ? (uint32_t)std::min<uint64_t>(counts[k], in_flight / one_in[k]) : counts[k], 16);
     if (const char* e = std::getenv("MAPAD_CLASS_COUNTS")) {  // comma list, missing entries = 0
         for (int k = 0; k < kClasses; ++k) counts[k] = 0;
         int k = 0;
