@@ -47,10 +47,24 @@ if tr:
                 end = hi
         overlap[k] = {"launches": len(lst), "mean_duration_ms": sum(h - l for l, h in lst) / len(lst) / 1e6, "union_ms": total / 1e6,
                       "union_per_launch_ms": total / len(lst) / 1e6}
+    # the same from the --depth 1 trace: every launch alone on the chip; the plain `--stats` average of that run is diluted by the empty launches
+    # that warm the batch slot (Calls counts them), this one is not
+    solo = {}
+    tr1 = glob.glob(os.path.join(out, "stats_d1", "**", "*kernel_trace.csv"), recursive=True)
+    if tr1:
+        iv1 = collections.defaultdict(list)
+        for r in csv.DictReader(open(max(tr1, key=os.path.getmtime))):
+            k = short(r["Kernel_Name"])
+            if k:
+                iv1[k].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+        for k, lst in iv1.items():
+            real = [x for x in lst if x > 0.01 * max(lst)]
+            solo[k] = {"launches": len(real), "empty_launches_dropped": len(lst) - len(real), "mean_duration_ms": sum(real) / len(real) / 1e6}
     json.dump({"note": "kernel trace of the default bench command (batches pipelined): per kernel, mean duration of a launch, union of all launches' intervals, "
                        "and union / launches = the effective per-launch time bench.py uses for the roofline (includes the warm-up step and the final solo launch of bench.py, "
-                       "which run with nothing beside them; the empty launches that warm the batch slots are dropped)",
-               "kernels": overlap}, open(os.path.join(ROOT, "profiles", f"{tag}_kernel_overlap.json"), "w"), indent=1)
+                       "which run with nothing beside them; the empty launches that warm the batch slots are dropped).  depth1: the --depth 1 run, every launch alone on "
+                       "the chip = bench.py's roofline.solo_launch",
+               "kernels": overlap, "depth1": solo}, open(os.path.join(ROOT, "profiles", f"{tag}_kernel_overlap.json"), "w"), indent=1)
 counters = collections.defaultdict(lambda: collections.defaultdict(float))
 launches = collections.defaultdict(lambda: collections.defaultdict(set))
 for d in ("pmc_fetch", "pmc_write", "pmc_tcc"):
