@@ -3,6 +3,7 @@
 // calls a Rust caller would bind: index open/build, parameters, mapad_map_batch (GPU), mapad_hits_to_records_gpu (SA locate on the GPU), BAM output.
 //
 //   mapad-amd [--seed N] [--devices K] index -g ref.fa
+//   mapad-amd [--devices K] worker --host H [--port 3130] [--dry_run]
 //   mapad-amd [--seed N] [--devices 0-7 | 0,1,...] map -r reads.{bam,fastq,fastq.gz} -g ref.fa -o out.bam -l single_stranded|double_stranded
 //             -p 0.03 | (-c CUTOFF [-e EXP]) -f F -t T -d D -s S [-D 0.02] -i I [-x 1.0] [--batch_size 250000] [--in_flight 4] [--ignore_base_quality]
 //             [--gap_dist_ends 5] [--max_num_gaps_open 2] [--no_search_limit_recovery] [--force_overwrite] [-R ID]
@@ -25,6 +26,11 @@
 
 #include "../../../include/mapad_amd.h"
 #include "bam_io.hpp"
+#include "wire.hpp"
+
+#include <netdb.h>
+#include <sys/socket.h>
+#include <unistd.h>
 
 using namespace mapad::cli;
 
@@ -499,6 +505,91 @@ int cmd_recode(const Args& a) {
     return 0;
 }
 
+
+// ---- `worker`: the reference's `mapad worker --host H --port P` (src/distributed/worker.rs:35-236) with the search on a GPU --------------------
+// Connects to a dispatcher, and for every TaskSheet it receives maps the records (k_mismatch_search per record: here one batch on the
+// device) and answers with a ResultSheet: each record as it arrived, its hits in BinaryHeap array order, the time spent.  The first task
+// names the index and carries the alignment parameters (worker.rs:57-75).  The dispatcher hands a worker one task at a time, so there
+// is nothing to pipeline on this side.  Reads the device cannot take (empty, longer than MAPAD_MAX_READ_LEN) come back without hits.
+// --dry_run answers every task with hit-less results without touching a GPU or an index (framing / codec check).
+bool read_exact(int fd, uint8_t* p, size_t n) {  // false: the peer closed the connection before the first byte
+    size_t got = 0;
+    while (got < n) {
+        const ssize_t k = ::read(fd, p + got, n - got);
+        if (k == 0) { if (got == 0) return false; die("worker: connection closed inside a message"); }
+        if (k < 0) { if (errno == EINTR) continue; die(std::string("worker: read: ") + std::strerror(errno)); }
+        got += (size_t)k;
+    }
+    return true;
+}
+
+int cmd_worker(const Args& a, const std::vector<int>& devices) {
+    const std::string host = a.get("host"), port = a.get("port", "3130");
+    if (host.empty()) die("worker: --host is required");
+    const bool dry = a.flag("dry_run");
+    addrinfo hints{}, *ai = nullptr;
+    hints.ai_family = AF_UNSPEC; hints.ai_socktype = SOCK_STREAM;
+    if (getaddrinfo(host.c_str(), port.c_str(), &hints, &ai) != 0 || !ai) die("worker: cannot resolve " + host);
+    int fd = -1;
+    for (addrinfo* p = ai; p; p = p->ai_next) {
+        fd = ::socket(p->ai_family, p->ai_socktype, p->ai_protocol);
+        if (fd < 0) continue;
+        if (::connect(fd, p->ai_addr, p->ai_addrlen) == 0) break;
+        ::close(fd); fd = -1;
+    }
+    freeaddrinfo(ai);
+    if (fd < 0) die("worker: cannot connect to " + host + ":" + port);
+    mapad_index_t* idx = nullptr;
+    mapad_ctx_t* ctx = nullptr;
+    std::vector<uint8_t> msg;
+    uint64_t n_tasks = 0, n_reads_total = 0;
+    for (;;) {
+        msg.resize(8);
+        if (!read_exact(fd, msg.data(), 8)) break;  // the dispatcher has dropped the connection: done (worker.rs:203-206)
+        uint64_t size; std::memcpy(&size, msg.data(), 8);
+        if (size < 8 + 8 + 8 + 2 || size > (1ull << 40)) die("worker: implausible task size");
+        msg.resize(size);
+        if (!read_exact(fd, msg.data() + 8, size - 8)) die("worker: connection closed inside a message");
+        const wire::Task t = wire::decode_task(msg.data(), msg.size());
+        if (!dry && !idx) {  // worker.rs:57-65
+            if (!t.has_reference) die("worker: the first task does not name the reference");
+            check(mapad_index_open(t.reference_path.c_str(), &idx), "mapad_index_open");
+        }
+        if (!dry && !ctx) {  // worker.rs:67-75
+            if (!t.has_params) die("worker: the first task carries no alignment parameters");
+            check(mapad_ctx_create(idx, &t.params, devices[0], &ctx), "mapad_ctx_create");
+            check(mapad_ctx_set_fetch_d_arrays(ctx, 0), "mapad_ctx_set_fetch_d_arrays");
+        }
+        std::vector<int64_t> read_of(t.records.size(), -1);
+        std::vector<uint8_t> seqs, quals;
+        std::vector<uint64_t> offsets{0};
+        for (size_t i = 0; i < t.records.size(); ++i) {
+            const wire::RecordView& r = t.records[i];
+            if (r.len == 0 || r.len > MAPAD_MAX_READ_LEN || r.qual_len != r.len) continue;
+            read_of[i] = (int64_t)offsets.size() - 1;
+            seqs.insert(seqs.end(), r.seq, r.seq + r.len); quals.insert(quals.end(), r.qual, r.qual + r.len);
+            offsets.push_back(seqs.size());
+        }
+        const auto t0 = std::chrono::steady_clock::now();
+        mapad_batch_result_t* res = nullptr;
+        if (!dry) check(mapad_map_batch(ctx, seqs.data(), quals.data(), offsets.data(), offsets.size() - 1, &res), "mapad_map_batch");
+        const double per_read = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() / (double)std::max<size_t>(t.records.size(), 1);
+        const std::vector<uint8_t> out = wire::encode_result(t, res, read_of, per_read);
+        if (res) mapad_batch_result_free(res);
+        for (size_t sent = 0; sent < out.size();) {
+            const ssize_t k = ::write(fd, out.data() + sent, out.size() - sent);
+            if (k < 0) { if (errno == EINTR) continue; die(std::string("worker: write: ") + std::strerror(errno)); }
+            sent += (size_t)k;
+        }
+        n_tasks += 1; n_reads_total += t.records.size();
+    }
+    ::close(fd);
+    std::fprintf(stderr, "mapad-amd worker: %llu task(s), %llu reads; the dispatcher closed the connection\n", (unsigned long long)n_tasks, (unsigned long long)n_reads_total);
+    if (ctx) mapad_ctx_destroy(ctx);
+    if (idx) mapad_index_free(idx);
+    return 0;
+}
+
 }  // namespace
 
 int main(int argc, char** argv) {
@@ -506,13 +597,13 @@ int main(int argc, char** argv) {
         {"-g", "reference"}, {"-r", "reads"}, {"-o", "output"}, {"-p", "poisson_prob"}, {"-c", "as_cutoff"}, {"-e", "as_cutoff_exponent"}, {"-l", "library"},
         {"-f", "five_prime_overhang"}, {"-t", "three_prime_overhang"}, {"-d", "ds_deamination_rate"}, {"-s", "ss_deamination_rate"}, {"-D", "divergence"},
         {"-i", "indel_rate"}, {"-x", "gap_extension_penalty"}, {"-R", "read_group"}};
-    static const std::vector<std::string> bool_flags = {"ignore_base_quality", "no_search_limit_recovery", "force_overwrite", "host_index"};
+    static const std::vector<std::string> bool_flags = {"ignore_base_quality", "no_search_limit_recovery", "force_overwrite", "host_index", "dry_run"};
     std::string cmdline, sub;
     for (int i = 0; i < argc; ++i) cmdline += std::string(i ? " " : "") + argv[i];
     Args a;
     for (int i = 1; i < argc; ++i) {
         std::string k = argv[i];
-        if (k == "index" || k == "map" || k == "recode") { sub = k; continue; }
+        if (k == "index" || k == "map" || k == "recode" || k == "worker") { sub = k; continue; }
         if (k == "-v" || k == "-vv" || k == "-vvv") continue;
         if (k == "--batch_size") k = "--chunk_size";
         std::string key;
@@ -533,6 +624,7 @@ int main(int argc, char** argv) {
         if (sub == "index") return cmd_index(a, seed, devices[0]);
         if (sub == "map") return cmd_map(a, seed, devices, cmdline);
         if (sub == "recode") return cmd_recode(a);
-        die("usage: mapad-amd [--seed N] [--devices 0[,1,...|-7]] index|map ...");
+        if (sub == "worker") return cmd_worker(a, devices);
+        die("usage: mapad-amd [--seed N] [--devices 0[,1,...|-7]] index|map|worker ...");
     } catch (const std::exception& e) { die(e.what()); }
 }
