@@ -13,7 +13,7 @@ Workloads (synthetic genome = i.i.d. ACGT from splitmix64(1234), re
   c2  48 Mbp genome (chr21-size), 1 M x 50 bp per GPU, no-damage model, Phred 40            [default: BASELINE.json configs[1]]
   c3  the same genome, single-stranded library f = t = 0.5, d = 0.02, s = 1.0, Phred 20-40
   c4  3 Gbp genome (hg19-size, n = 6e9 rows > 2^32), 10 M x 50 bp per GPU, no-damage model, Phred 40
-  c5  the read mix of C5 (35-100 bp, 5 % of the reads with an indel, damage model) on the 48 Mbp genome
+  c5  the read mix of C5 (35-100 bp, 5 % of the reads with an indel, damage model) on the 48 Mbp genome, 1 M reads per step
 One "step" = one pass of the hot path (D-array kernel, ordering, search kernel + its retry / full-limit launches) over the batch;
 reads, index and score tables are resident in HBM before the timed region.  With N > 1 every rank holds a replica of the index, maps
 its own shard (weak scaling) and, inside every step, lays its hits out in read order on the device and sends them to rank 0 (RCCL
@@ -41,7 +41,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s
 
 CONFIGS = {  # genome bp, reads per GPU
-    "c1": (5_386, 1_000), "c2": (48_000_000, 1_000_000), "c3": (48_000_000, 1_000_000), "c4": (3_000_000_000, 10_000_000), "c5": (48_000_000, 250_000),
+    "c1": (5_386, 1_000), "c2": (48_000_000, 1_000_000), "c3": (48_000_000, 1_000_000), "c4": (3_000_000_000, 10_000_000), "c5": (48_000_000, 1_000_000),
 }
 
 

@@ -130,10 +130,11 @@ def test_arena_handoff_stress(monkeypatch):
         assert_same_as_oracle(ores, res, offsets)
 
 
-@pytest.mark.parametrize("depth,tiny", [(2, False), (3, True)])
+@pytest.mark.parametrize("depth,tiny", [(2, False), (3, True), (6, "sets")])
 def test_batches_in_flight_do_not_change_results(depth, tiny, monkeypatch):
-    """mapad_ctx_set_pipeline_depth: batch k + 1 is submitted while batch k is still running (own streams and buffers, shared size-class
-    pools); every batch must come out exactly as it does alone."""
+    """mapad_ctx_set_pipeline_depth: batch k + 1 is submitted while batch k is still running (own streams and buffers, shared base arenas and
+    size-class pools); every batch must come out exactly as it does alone.  "sets": one wavefront per CU's worth of base-arena sets, so the
+    wavefronts of six launches in flight outnumber the sets and wait for one another's exit."""
     import ctypes as C
     hip = C.CDLL("libamdhip64.so")  # the runtime the library itself uses: device-resident inputs without torch
 
@@ -144,7 +145,10 @@ def test_batches_in_flight_do_not_change_results(depth, tiny, monkeypatch):
         assert hip.hipMemcpy(p, a.ctypes.data_as(C.c_void_p), C.c_size_t(a.nbytes), 1) == 0  # hipMemcpyHostToDevice
         return p.value
 
-    if tiny:  # reads migrate constantly and the concurrent launches compete for the same few arenas
+    if tiny == "sets":
+        monkeypatch.setenv("MAPAD_TIER0_WAVES_PER_CU", "1")
+        monkeypatch.setenv("GPU_MAX_HW_QUEUES", "12")  # read at the first HIP call of the process; harmless if that is over
+    elif tiny:  # reads migrate constantly and the concurrent launches compete for the same few arenas
         monkeypatch.setenv("MAPAD_TIER0_NODES", "64")
         monkeypatch.setenv("MAPAD_CLASS_COUNTS", "256,128,64,64,64,64,64,16,16,16")
     g = synth.genome(300_000, seed=31)
