@@ -617,7 +617,7 @@ int main(int argc, char** argv) {
     }
     // every chunk in flight has its own HIP stream; the runtime multiplexes streams onto 4 hardware queues unless told otherwise, and a
     // chunk's long tail would then hold back the launches queued behind it (must be set before the first HIP call)
-    if (std::atoi(a.get("in_flight", "4").c_str()) > 3) setenv("GPU_MAX_HW_QUEUES", "20", 0);
+    setenv("GPU_MAX_HW_QUEUES", "20", 0);
     const uint64_t seed = std::strtoull(a.get("seed", "1234").c_str(), nullptr, 10);
     const std::vector<int> devices = parse_devices(a.get("devices", a.get("device", "0")));
     try {

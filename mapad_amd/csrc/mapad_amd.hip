@@ -806,6 +806,12 @@ int upload_tables(mapad_ctx* c) {
     return MAPAD_OK;
 }
 
+// Every batch in flight has its own HIP stream.  The runtime multiplexes streams onto GPU_MAX_HW_QUEUES (default 4) hardware queues; a launch
+// queued behind another batch's long-running kernel on the same hardware queue then waits for it (C2, 3 in flight: 4.97 -> 5.10 M reads/s with 12
+// queues; 4 and 6 in flight: 4.57 / 4.53 -> 4.98 / 5.04 M).  The variable is read at the first HIP call of the process, so it is set when the library is loaded, unless the
+// user has set it.
+__attribute__((constructor)) void mapad_default_hw_queues() { setenv("GPU_MAX_HW_QUEUES", "16", 0); }
+
 uint32_t env_u32(const char* name, uint32_t dflt) {
     const char* e = std::getenv(name);
     return e && e[0] ? (uint32_t)std::strtoul(e, nullptr, 10) : dflt;
@@ -1024,12 +1030,14 @@ int launch_batch(mapad_ctx* c, BatchSlot& S, const uint8_t* d_seqs, const uint8_
     else if (c->lpr == 4) { if (!cont) MAPAD_LAUNCH(4, false, P, false); else MAPAD_LAUNCH(4, true, P, false); }          \
     else if (near_stride) { if (!cont) MAPAD_LAUNCH(1, false, P, true); else MAPAD_LAUNCH(1, true, P, true); }              \
     else { if (!cont) MAPAD_LAUNCH(1, false, P, false); else MAPAD_LAUNCH(1, true, P, false); }
+    // (re-measured with the shared base arenas, C2 / C3 reads/s at 4, 6, 8, 12 wavefronts per CU for a launch that finds another one running:
+    // 4.96 / 2.00 M, 4.86 / 2.25 M, 4.89 / 2.28 M, 4.71 / 2.23 M -> 8)
     // A launch alone on the chip fills it (16 wavefronts per CU at 128 VGPRs).  While another batch is still running, a launch takes half: two
     // bulks then share the chip all the time and a launch that is down to its tail does not hold the next one back (measured, C2, per 1 M reads:
     // 16 per CU x 2 batches in flight 273 ms, 8 x 2 247 ms, 8 x 3 252 ms; C3: 8 x 2 589 ms, 8 x 3 529 ms).
     bool others_running = false;
     for (auto& o : c->bs) if (&o != &S && o.ev_valid && hipEventQuery(o.ev[3]) == hipErrorNotReady) others_running = true;
-    const uint32_t full_waves = c->resident_waves, shared_waves = std::max<uint32_t>(1, std::min<uint32_t>(full_waves, env_u32("MAPAD_SHARED_WAVES_PER_CU", 2 * MAPAD_MIN_WAVES) * (uint32_t)c->n_cu));
+    const uint32_t full_waves = c->resident_waves, shared_waves = std::max<uint32_t>(1, std::min<uint32_t>(full_waves, env_u32("MAPAD_SHARED_WAVES_PER_CU", 8) * (uint32_t)c->n_cu));
     const uint32_t grid_s = warm ? 1u : (uint32_t)std::min<uint64_t>((n_reads + rpw - 1) / rpw, others_running ? shared_waves : full_waves);
     for (int stage = 0; stage + 1 < kStages; ++stage) {  // every read, then the reads that gave up waiting (normally none: the launch exits at once)
         const uint32_t grid = grid_s;
