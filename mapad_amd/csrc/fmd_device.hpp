@@ -174,7 +174,11 @@ __device__ __forceinline__ ExtLoads ext4_quad_issue(const DevIndex& ix, uint64_t
     l.hi = quad_occ_issue(ix, r_hi, w);
     return l;
 }
-__device__ __forceinline__ void ext4_quad_lane_finish(const DevIndex& ix, const ExtLoads& l, uint64_t lower, uint64_t lower_rev, uint64_t size, int w, ExtLane& out) {
+// lane_less = ix.less[w + 1], picked once per kernel by the caller: as a select over the kernel arguments inside the step it came out as nested
+// branches, each arm re-reading the eight spilled scalar registers of `less` (45 v_readlane per step); `above` is written as masked adds for the
+// same reason.
+__device__ __forceinline__ void ext4_quad_lane_finish(const DevIndex& ix, const ExtLoads& l, uint64_t lower, uint64_t lower_rev, uint64_t size, int w, uint64_t lane_less,
+                                                      ExtLane& out) {
     const uint64_t r_lo = lower == 0 ? 0 : lower - 1, r_hi = lower + size - 1;
     const uint64_t occ_lo = quad_occ_finish(l.lo, r_lo, w);
     const uint64_t my_hi = quad_occ_finish(l.hi, r_hi, w);
@@ -183,9 +187,8 @@ __device__ __forceinline__ void ext4_quad_lane_finish(const DevIndex& ix, const 
     const uint64_t s0 = quad_bcast64<0>(my_size), s1 = quad_bcast64<1>(my_size), s2 = quad_bcast64<2>(my_size), s3 = quad_bcast64<3>(my_size);
     const uint64_t o_s = lower == 0 ? 0 : sentinel_le(ix, lower - 1);
     const uint64_t sent = sentinel_le(ix, lower + size - 1) - o_s;  // '$' rows inside the interval
-    const uint64_t above = w == 3 ? 0 : w == 2 ? s3 : w == 1 ? s3 + s2 : s3 + s2 + s1;
-    const uint64_t less = w == 0 ? ix.less[1] : w == 1 ? ix.less[2] : w == 2 ? ix.less[3] : ix.less[4];
-    out.lower = less + my_lo;
+    const uint64_t above = (w < 3 ? s3 : 0ull) + (w < 2 ? s2 : 0ull) + (w < 1 ? s1 : 0ull);  // fmd_index.rs:137-181 iterates T, G, C, A
+    out.lower = lane_less + my_lo;
     out.lower_rev = lower_rev + sent + above;
     out.size = my_size;
     out.nonempty = (s0 >= 1 ? 1u : 0u) | (s1 >= 1 ? 2u : 0u) | (s2 >= 1 ? 4u : 0u) | (s3 >= 1 ? 8u : 0u);

@@ -177,6 +177,7 @@ struct ReadInT {
     int L;
     float thr;          // DevParams::reject_thr[L]
     int32_t table;      // DevParams::table_base[L]
+    uint64_t lane_less = 0;  // device quads: Less of the base this lane extends by (DevIndex::less[w + 1]), picked once per kernel
 };
 using ReadIn = ReadInT<false>;
 
@@ -803,7 +804,7 @@ MAPAD_HD bool search_step(const DevIndex& ix, const DevParams& P, const ReadInT<
     if constexpr (kLaneKids) {
 #if defined(__HIP_DEVICE_COMPILE__)
         ExtLane x;
-        ext4_quad_lane_finish(ix, ext_loads, x_lower, x_lower_rev, f.size, w, x);
+        ext4_quad_lane_finish(ix, ext_loads, x_lower, x_lower_rev, f.size, w, rd.lane_less, x);
         my_lower = x.lower; my_lower_rev = x.lower_rev; my_size = x.size; nonempty = x.nonempty;
 #endif
     } else {
@@ -845,7 +846,7 @@ MAPAD_HD bool search_step(const DevIndex& ix, const DevParams& P, const ReadInT<
             op = pack_op(OP_INS, (uint32_t)j, 0);
         } else {
             const int cb = forward ? 3 - k : k;
-            const uint32_t c_ascii = cb == 0 ? 'A' : cb == 1 ? 'C' : cb == 2 ? 'G' : 'T';
+            const uint32_t c_ascii = (0x54474341u >> (8 * cb)) & 0xFFu;  // "ACGT"[cb] (a chain of conditionals comes out as nested branches)
             c.size = xs;
             c.lower = forward ? xr : xl;  // swapped back for forward extension (:1256)
             c.lower_rev = forward ? xl : xr;
