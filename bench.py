@@ -393,7 +393,7 @@ def main():
                    "process_wall_s": round(t_map, 2), "mapped": int(m.group(2)), "bam_bytes": os.path.getsize(bam), "index_cmd_s": round(t_idx, 2),
                    "stage_busy_s": (lambda mm: {"reader": float(mm.group(1)), "device_worker": float(mm.group(2)), "writer": float(mm.group(3))} if mm else None)(
                        re.search(r"reader ([0-9.]+) s, device worker 0 ([0-9.]+) s, writer ([0-9.]+) s", pr.stderr)),
-                   "what": "mapad-amd map: FASTQ -> BAM, --batch_size 250000 (the reference's default), chunks pipelined 2 deep on one GPU; reader, records and BGZF on host threads"}
+                   "what": "mapad-amd map: FASTQ -> BAM, --batch_size 250000 (the reference's default), up to 4 chunks in flight on one GPU; reader, records and BGZF on host threads"}
         finally:
             shutil.rmtree(tmp, ignore_errors=True)
 

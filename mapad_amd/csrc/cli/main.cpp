@@ -265,7 +265,7 @@ int cmd_map(const Args& a, uint64_t seed, const std::vector<int>& devices, const
         }
         out.write(h.data(), h.size());
     }
-    const unsigned host_threads = std::max(1u, std::min(std::thread::hardware_concurrency(), 64u));
+    const unsigned host_threads = std::max(1u, std::min(std::thread::hardware_concurrency(), 32u));
     std::vector<std::unique_ptr<BoundedQueue<ChunkPtr>>> dev_q;
     for (size_t d = 0; d < n_dev; ++d) dev_q.emplace_back(new BoundedQueue<ChunkPtr>(2));  // read ahead; `in_flight` more are on the device
     BoundedQueue<ChunkPtr> done_q(4);
