@@ -419,9 +419,43 @@ MAPAD_HD void mm_bubble_up_win(const ArenaT<NL>& A, AncWindow& W, uint32_t pos, 
 // candidates scanned in ascending index order (child1, child2, grandchildren); a later one wins only if strictly better.
 // `elt` is the element being placed, starting at the hole `pos`.  Entries at or beyond n are stale memory: they are loaded
 // (the arena has slack) but neutralised by an index test.
+// A sift that starts at slot 1 or 2 (every pop_max of a heap with more than two entries) takes its first two strides through levels 1-5, which
+// with kTop = 63 lie in the near array entirely: those strides run without the near / arena selection of the general stride.
 template <bool MAX, bool NL>
 MAPAD_HD void mm_trickle_down(const ArenaT<NL>& A, uint32_t n, uint32_t pos, HeapEntry elt) {
-    while (2 * pos + 1 < n) {
+    bool going = true;
+    // one stride: the hole moves to the best child or grandchild; false = the sift ends at `pos`
+    auto stride = [&](const HeapPair& c, const HeapPair& ga, const HeapPair& gb, uint32_t c1, uint32_t g1, auto&& set) -> bool {
+        uint32_t best = c1;
+        HeapEntry be = c.a;
+        auto consider = [&](uint32_t idx, const HeapEntry cand) {  // a later candidate wins only if strictly better; plain selects
+            const bool take = (idx < n) & (MAX ? (cand.score > be.score) : (cand.score < be.score));
+            best = take ? idx : best; be.score = take ? cand.score : be.score; be.node = take ? cand.node : be.node;
+        };
+        consider(c1 + 1, c.b); consider(g1, ga.a); consider(g1 + 1, ga.b); consider(g1 + 2, gb.a); consider(g1 + 3, gb.b);
+        if (!(MAX ? (be.score > elt.score) : (be.score < elt.score))) return false;
+        set(pos, be);
+        pos = best;
+        if (best < g1) return false;  // moved to a child: done
+        const uint32_t parent = (pos - 1) >> 1;
+        HeapEntry pe;  // the parent of a grandchild is one of the two children just loaded
+        pe.score = parent == c1 ? c.a.score : c.b.score; pe.node = parent == c1 ? c.a.node : c.b.node;
+        if (MAX ? (pe.score > elt.score) : (pe.score < elt.score)) { set(parent, elt); elt = pe; }
+        return true;
+    };
+    auto set_near = [&](uint32_t i, const HeapEntry e) { store_entry(A.top + i, e); };
+    auto set_any = [&](uint32_t i, const HeapEntry e) { hp_set(A, i, e); };
+#if !defined(MAPAD_BRANCHY_HEAP)
+    if constexpr (kTop >= 63) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const uint32_t c1 = 2 * pos + 1, g1 = 2 * c1 + 1;
+            if (!(going & (c1 < n) & (g1 + 3 < (uint32_t)kTop))) break;  // levels below 5, or a sift that started deeper: the general loop
+            going = stride(load_pair(A.top + c1), load_pair(A.top + g1), load_pair(A.top + g1 + 2), c1, g1, set_near);
+        }
+    }
+#endif
+    while (going && 2 * pos + 1 < n) {
         const uint32_t c1 = 2 * pos + 1, g1 = 2 * c1 + 1;
         HeapPair c, ga, gb;  // a level is entirely near or entirely in the arena
 #if defined(MAPAD_BRANCHY_HEAP)
@@ -439,21 +473,7 @@ MAPAD_HD void mm_trickle_down(const ArenaT<NL>& A, uint32_t n, uint32_t pos, Hea
             c = c_near ? nc : hc; ga = g_near ? nga : hga; gb = g_near ? ngb : hgb;
         }
 #endif
-        uint32_t best = c1;
-        HeapEntry be = c.a;
-        auto consider = [&](uint32_t idx, const HeapEntry cand) {  // a later candidate wins only if strictly better; plain selects
-            const bool take = (idx < n) & (MAX ? (cand.score > be.score) : (cand.score < be.score));
-            best = take ? idx : best; be.score = take ? cand.score : be.score; be.node = take ? cand.node : be.node;
-        };
-        consider(c1 + 1, c.b); consider(g1, ga.a); consider(g1 + 1, ga.b); consider(g1 + 2, gb.a); consider(g1 + 3, gb.b);
-        if (!(MAX ? (be.score > elt.score) : (be.score < elt.score))) break;
-        hp_set(A, pos, be);
-        pos = best;
-        if (best < g1) break;  // moved to a child: done
-        const uint32_t parent = (pos - 1) >> 1;
-        HeapEntry pe;  // the parent of a grandchild is one of the two children just loaded
-        pe.score = parent == c1 ? c.a.score : c.b.score; pe.node = parent == c1 ? c.a.node : c.b.node;
-        if (MAX ? (pe.score > elt.score) : (pe.score < elt.score)) { hp_set(A, parent, elt); elt = pe; }
+        going = stride(c, ga, gb, c1, g1, set_any);
     }
     hp_set(A, pos, elt);
 }
