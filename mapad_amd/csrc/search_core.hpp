@@ -256,6 +256,11 @@ MAPAD_HD bool mm_is_min_level(uint32_t pos) {
 #endif
 }
 
+// "a beats b" on a min level means a > b, on a max level a < b.  Flipping the sign bit of both operands reverses the order of two floats
+// (scores are never NaN), so one compare serves both cases: the two-sided form `(min & (a > b)) | (!min & (a < b))` came out as two compares,
+// two materialised booleans, a select and a third compare.
+MAPAD_HD float flip_sign(float x, uint32_t mask) { return __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, x) ^ mask); }
+
 // The first two compares of a bubble-up (parent, then the grandparent of wherever the element sits after the first compare) decide
 // 98 % of all pushes (measured, C2/C3); their three possible slots are known from `pos` alone, so they are loaded together and the
 // dependent chain of a push is one memory round trip instead of two.
@@ -294,15 +299,18 @@ MAPAD_HD void mm_bubble_up(const ArenaT<NL>& A, uint32_t pos, const HeapEntry el
     const HeapEntry e1 = an.e1, e2 = an.e2, e3 = an.e3;
     const bool min_level = mm_is_min_level(pos);
     // (bitwise on purpose: short-circuit forms of these predicates come out as nested branches on the device)
-    const bool moved = (pos > 0) & ((min_level & (elt.score > e1.score)) | (!min_level & (elt.score < e1.score)));
+    const uint32_t flip1 = min_level ? 0u : 0x80000000u;
+    const bool moved = (pos > 0) & (flip_sign(elt.score, flip1) > flip_sign(e1.score, flip1));
     const bool greater = min_level == moved;            // which grandparent chain to follow
+    const uint32_t flip2 = greater ? 0u : 0x80000000u;
+    const float elt_key = flip_sign(elt.score, flip2);  // along the chain: climbs while its key is greater
 #if defined(MAPAD_PROFILE_SECTIONS) && defined(__HIP_DEVICE_COMPILE__)
     if (__ballot(moved) != 0xFFFFFFFFFFFFFFFFull || e2.score != e3.score) MAPAD_MARK(PROF_C_LOAD);  // forces the wait for the three entries before the mark
 #endif
     const uint32_t pos1 = moved ? i1 : pos;
     const HeapEntry ge = moved ? e3 : e2;
     const uint32_t gp = moved ? i3 : i2;
-    const bool moved2 = (pos1 > 2) & ((greater & (elt.score > ge.score)) | (!greater & (elt.score < ge.score)));
+    const bool moved2 = (pos1 > 2) & (elt_key > flip_sign(ge.score, flip2));
     if (moved) hp_set(A, pos, e1);
     if (moved2) {
         hp_set(A, pos1, ge);
@@ -311,7 +319,7 @@ MAPAD_HD void mm_bubble_up(const ArenaT<NL>& A, uint32_t pos, const HeapEntry el
             while (pos > 2) {
                 const uint32_t g2 = (pos - 3) >> 2;
                 const HeapEntry g = hp_get(A, g2);
-                if (!(greater ? (elt.score > g.score) : (elt.score < g.score))) break;
+                if (!(elt_key > flip_sign(g.score, flip2))) break;
                 hp_set(A, pos, g);
                 pos = g2;
             }
