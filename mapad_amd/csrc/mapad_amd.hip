@@ -467,9 +467,6 @@ __global__ void __launch_bounds__(64, (LPR == 1 && NL) ? 1 : MAPAD_MIN_WAVES) se
     if (lane == 0) g_prof_lds[2 * PROF_N] = __builtin_amdgcn_s_memtime();
 #endif
     bool have = false, done = false;
-#if defined(MAPAD_ACTIVE_QUADS)
-    if ((lane / LPR) >= MAPAD_ACTIVE_QUADS) done = true;  // experiment: fewer reads per wavefront
-#endif
     ReadInT<NL> rd{near_qc, near_d, 0, 0.0f, 0};
     if constexpr (LPR == 4) rd.lane_less = w == 0 ? ix.less[1] : w == 1 ? ix.less[2] : w == 2 ? ix.less[3] : ix.less[4];
     SearchState st;

@@ -269,13 +269,6 @@ template <bool NL>
 MAPAD_HD Ancestors load_ancestors(const ArenaT<NL>& A, uint32_t pos) {
     const uint32_t i1 = pos > 0 ? (pos - 1) >> 1 : 0, i2 = pos > 2 ? (pos - 3) >> 2 : 0, i3 = i1 > 2 ? (i1 - 3) >> 2 : 0;
     Ancestors a;  // i3 <= i2 <= i1
-#if defined(MAPAD_BRANCHY_HEAP)
-    // one branch per near/arena split, so that the arena loads of a case are in flight together
-    if (i1 < (uint32_t)kTop) { a.e1 = load_entry(A.top + i1); a.e2 = load_entry(A.top + i2); a.e3 = load_entry(A.top + i3); }
-    else if (i2 < (uint32_t)kTop) { a.e1 = load_entry(A.heap + i1); a.e2 = load_entry(A.top + i2); a.e3 = load_entry(A.top + i3); }
-    else if (i3 < (uint32_t)kTop) { a.e1 = load_entry(A.heap + i1); a.e2 = load_entry(A.heap + i2); a.e3 = load_entry(A.top + i3); }
-    else { a.e1 = load_entry(A.heap + i1); a.e2 = load_entry(A.heap + i2); a.e3 = load_entry(A.heap + i3); }
-#else
     // The read slots of a wavefront are at different heap sizes: a four-way branch on where the three entries live runs its cases one after
     // the other, each with its own wait for memory.  Here every slot reads the near array (index clamped into it) and only the arena loads
     // are predicated, back to back, so that a wavefront waits for memory once.
@@ -286,7 +279,6 @@ MAPAD_HD Ancestors load_ancestors(const ArenaT<NL>& A, uint32_t pos) {
     if (i2 >= (uint32_t)kTop) g2 = load_entry(A.heap + i2);
     if (i3 >= (uint32_t)kTop) g3 = load_entry(A.heap + i3);
     a.e1 = i1 < (uint32_t)kTop ? n1 : g1; a.e2 = i2 < (uint32_t)kTop ? n2 : g2; a.e3 = i3 < (uint32_t)kTop ? n3 : g3;
-#endif
     return a;
 }
 template <bool NL>
@@ -331,96 +323,6 @@ MAPAD_HD void mm_bubble_up(const ArenaT<NL>& A, uint32_t pos, const HeapEntry el
 template <bool NL>
 MAPAD_HD void mm_bubble_up(const ArenaT<NL>& A, uint32_t pos, const HeapEntry elt) { mm_bubble_up(A, pos, elt, load_ancestors(A, pos)); }
 
-// The children of one popped frame are pushed to consecutive slots n0, n0 + 1, ...; their parents lie in three consecutive slots, their
-// grandparents and the grandparents of their parents in two each.  Loading that window once — right after the pop, so that the loads are in
-// flight during the rank queries — takes the memory round trip out of every push of the commit loop (it was the largest share of a step:
-// 44 % of the wave time, profiles/r02/sections_before.txt).  Pushes update the window as they store, so a later sibling sees what an earlier
-// one moved.  Used for frames with two or more children whose parents are beyond the near part of the heap (n0 >= kTop), for the first
-// kWinPushes pushes of the step.  OFF by default (-DMAPAD_ANCESTOR_WINDOW): it lost both ways on MI355X — loaded for every pop right after the heap
-// repair 336 vs 282 ms per 1 M reads (C2), loaded only for multi-child frames 277 vs 249 ms: the loop is bound by requests and issue
-// slots, not by the latency the window hides.  Kept as a measured dead end, compiled out.
-constexpr uint32_t kWinPushes = 4;
-// Entries are kept as packed 64-bit values and every access is a chain of value selects: field-wise conditional stores let the compiler
-// merge them into one store through a computed address, which pins the whole window in scratch memory.
-struct AncWindow {
-    uint64_t p0, p1, p2, g0, g1, h0, h1;  // slots pb .. pb + 2, gb .. gb + 1, hb .. hb + 1
-    uint32_t pb, gb, hb;
-    uint32_t n0;     // first slot the window serves
-    bool on;
-};
-MAPAD_HD uint64_t pack_entry(const HeapEntry e) {
-    uint32_t sb;
-    std::memcpy(&sb, &e.score, 4);
-    return (uint64_t)sb | ((uint64_t)e.node << 32);
-}
-MAPAD_HD HeapEntry unpack_entry(uint64_t v) {
-    HeapEntry e;
-    const uint32_t sb = (uint32_t)v;
-    std::memcpy(&e.score, &sb, 4);
-    e.node = (uint32_t)(v >> 32);
-    return e;
-}
-template <bool NL>
-MAPAD_HD AncWindow win_load(const ArenaT<NL>& A, uint32_t n0) {
-    AncWindow W;
-    W.on = n0 >= (uint32_t)kTop;
-    W.n0 = n0;
-    W.pb = n0 > 0 ? (n0 - 1) >> 1 : 0; W.gb = n0 > 2 ? (n0 - 3) >> 2 : 0; W.hb = W.pb > 2 ? (W.pb - 3) >> 2 : 0;
-    W.p0 = W.p1 = W.p2 = W.g0 = W.g1 = W.h0 = W.h1 = 0;
-    if (W.on) {  // slots past the current end of the heap are stale memory inside the arena (it has slack); they are never selected
-        W.p0 = pack_entry(hp_get(A, W.pb)); W.p1 = pack_entry(hp_get(A, W.pb + 1)); W.p2 = pack_entry(hp_get(A, W.pb + 2));
-        W.g0 = pack_entry(hp_get(A, W.gb)); W.g1 = pack_entry(hp_get(A, W.gb + 1));
-        W.h0 = pack_entry(hp_get(A, W.hb)); W.h1 = pack_entry(hp_get(A, W.hb + 1));
-    }
-    return W;
-}
-MAPAD_HD Ancestors win_ancestors(const AncWindow& W, uint32_t pos) {  // == load_ancestors(A, pos) for pos in [n0, n0 + kWinPushes)
-    const uint32_t i1 = (pos - 1) >> 1, i2 = (pos - 3) >> 2, i3 = (i1 - 3) >> 2;  // n0 >= kTop: all three exist
-    const uint32_t a = i1 - W.pb, b = i2 - W.gb, c = i3 - W.hb;
-    Ancestors r;
-    r.e1 = unpack_entry(a == 0 ? W.p0 : a == 1 ? W.p1 : W.p2);
-    r.e2 = unpack_entry(b == 0 ? W.g0 : W.g1);
-    r.e3 = unpack_entry(c == 0 ? W.h0 : W.h1);
-    return r;
-}
-// hp_set that keeps the window current
-template <bool NL>
-MAPAD_HD void hp_set_win(const ArenaT<NL>& A, AncWindow& W, uint32_t i, const HeapEntry e) {
-    hp_set(A, i, e);
-    const uint64_t v = pack_entry(e);
-    const uint32_t a = i - W.pb, b = i - W.gb, c = i - W.hb;
-    W.p0 = a == 0 ? v : W.p0; W.p1 = a == 1 ? v : W.p1; W.p2 = a == 2 ? v : W.p2;
-    W.g0 = b == 0 ? v : W.g0; W.g1 = b == 1 ? v : W.g1;
-    W.h0 = c == 0 ? v : W.h0; W.h1 = c == 1 ? v : W.h1;
-}
-// mm_bubble_up with the first two compares served by the window; every store goes through hp_set_win
-template <bool NL>
-MAPAD_HD void mm_bubble_up_win(const ArenaT<NL>& A, AncWindow& W, uint32_t pos, const HeapEntry elt) {
-    const Ancestors an = win_ancestors(W, pos);
-    const uint32_t i1 = (pos - 1) >> 1, i2 = (pos - 3) >> 2, i3 = (i1 - 3) >> 2;
-    const HeapEntry e1 = an.e1, e2 = an.e2, e3 = an.e3;
-    bool greater, moved;
-    if (mm_is_min_level(pos)) { moved = elt.score > e1.score; greater = moved; }
-    else { moved = elt.score < e1.score; greater = !moved; }
-    if (moved) { hp_set_win(A, W, pos, e1); pos = i1; }
-    {
-        const HeapEntry ge = moved ? e3 : e2;
-        const uint32_t gp = moved ? i3 : i2;
-        if (greater ? (elt.score > ge.score) : (elt.score < ge.score)) {
-            hp_set_win(A, W, pos, ge);
-            pos = gp;
-            while (pos > 2) {
-                const uint32_t g2 = (pos - 3) >> 2;
-                const HeapEntry g = hp_get(A, g2);
-                if (!(greater ? (elt.score > g.score) : (elt.score < g.score))) break;
-                hp_set_win(A, W, pos, g);
-                pos = g2;
-            }
-        }
-    }
-    hp_set_win(A, W, pos, elt);
-}
-
 // The heap array is stored shifted by one entry (logical index i lives in physical slot i + 1; `v` points at logical 0), so the
 // two children of a node (logical 2p+1, 2p+2) form one 16-byte aligned pair and its four grandchildren (4p+3 .. 4p+6) one
 // 32-byte aligned group: a trickle-down level is three 16-byte loads instead of six 8-byte ones and touches at most 2 lines.
@@ -453,7 +355,6 @@ MAPAD_HD void mm_trickle_down(const ArenaT<NL>& A, uint32_t n, uint32_t pos, Hea
     };
     auto set_near = [&](uint32_t i, const HeapEntry e) { store_entry(A.top + i, e); };
     auto set_any = [&](uint32_t i, const HeapEntry e) { hp_set(A, i, e); };
-#if !defined(MAPAD_BRANCHY_HEAP)
     if constexpr (kTop >= 63) {
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
@@ -462,15 +363,9 @@ MAPAD_HD void mm_trickle_down(const ArenaT<NL>& A, uint32_t n, uint32_t pos, Hea
             going = stride(load_pair(A.top + c1), load_pair(A.top + g1), load_pair(A.top + g1 + 2), c1, g1, set_near);
         }
     }
-#endif
     while (going && 2 * pos + 1 < n) {
         const uint32_t c1 = 2 * pos + 1, g1 = 2 * c1 + 1;
         HeapPair c, ga, gb;  // a level is entirely near or entirely in the arena
-#if defined(MAPAD_BRANCHY_HEAP)
-        if (g1 + 3 < (uint32_t)kTop) { c = load_pair(A.top + c1); ga = load_pair(A.top + g1); gb = load_pair(A.top + g1 + 2); }
-        else if (c1 < (uint32_t)kTop) { c = load_pair(A.top + c1); ga = load_pair(A.heap + g1); gb = load_pair(A.heap + g1 + 2); }
-        else { c = load_pair(A.heap + c1); ga = load_pair(A.heap + g1); gb = load_pair(A.heap + g1 + 2); }
-#else
         {   // near reads for every slot (clamped), arena loads predicated and back to back: one wait per level for the whole wavefront
             const bool c_near = c1 < (uint32_t)kTop, g_near = g1 + 3 < (uint32_t)kTop;
             const uint32_t kc = c_near ? c1 : 1u, kg = g_near ? g1 : 3u;  // clamped indices keep the 16-byte alignment of a pair (odd logical index)
@@ -480,7 +375,6 @@ MAPAD_HD void mm_trickle_down(const ArenaT<NL>& A, uint32_t n, uint32_t pos, Hea
             if (!g_near) { hga = load_pair(A.heap + g1); hgb = load_pair(A.heap + g1 + 2); }
             c = c_near ? nc : hc; ga = g_near ? nga : hga; gb = g_near ? ngb : hgb;
         }
-#endif
         going = stride(c, ga, gb, c1, g1, set_any);
     }
     hp_set(A, pos, elt);
@@ -699,7 +593,7 @@ struct NoGrow {
 // `owner` is the owning lane (the frame of a finished alignment is fetched from it).  Everything else is quad-uniform.
 template <int LPR, bool NL>
 MAPAD_HD void commit_child(const DevParams& P, const ReadInT<NL>& rd, ArenaT<NL>& A, SearchState& st, int alignment_start, float score, uint32_t ngaps, int len,
-                           const Node& nd, bool store, int owner, AncWindow& W) {
+                           const Node& nd, bool store, int owner) {
     if (st.n_hits > 0 && mb_reject_iterative(P, score, st.best_score)) return;
     if ((int)ngaps > P.max_num_gaps_open) return;
     if (MAPAD_UNLIKELY(st.tree_next == st.tree_entries && st.tree_entries >= A.node_cap)) { st.status = ST_ARENA_OVERFLOW; return; }  // cannot happen (search_step)
@@ -707,9 +601,8 @@ MAPAD_HD void commit_child(const DevParams& P, const ReadInT<NL>& rd, ArenaT<NL>
     // the loads of a push go out before the stores of its node: the wait for them then leaves the stores in flight (vmcnt counts in order)
     const bool pushes = len != rd.L;
     const uint32_t pos = st.heap_len;
-    const bool use_win = W.on && pos - W.n0 < kWinPushes;
     Ancestors an{};
-    if (pushes && !use_win) an = load_ancestors(A, pos);
+    if (pushes) an = load_ancestors(A, pos);
     if (store) A.nodes[id] = nd;
     st.c_node += 1;
     if (MAPAD_UNLIKELY(len == rd.L)) {  // rare: the state takes a round trip through memory only here, so it can live in registers otherwise
@@ -730,8 +623,7 @@ MAPAD_HD void commit_child(const DevParams& P, const ReadInT<NL>& rd, ArenaT<NL>
     if (MAPAD_UNLIKELY(st.heap_len >= A.heap_cap)) { st.status = ST_ARENA_OVERFLOW; return; }  // cannot happen (search_step)
     st.heap_len += 1;
     MAPAD_MARK(PROF_C_PRE);
-    if (use_win) mm_bubble_up_win(A, W, pos, HeapEntry{score, id});
-    else mm_bubble_up(A, pos, HeapEntry{score, id}, an);  // the ancestors were read from memory, which every earlier store of this step has reached
+    mm_bubble_up(A, pos, HeapEntry{score, id}, an);  // the ancestors were read from memory, which every earlier store of this step has reached
     st.c_push += 1;
 }
 
@@ -813,18 +705,11 @@ MAPAD_HD bool search_step(const DevIndex& ix, const DevParams& P, const ReadInT<
     const uint64_t x_lower = forward ? f.lower_rev : f.lower, x_lower_rev = forward ? f.lower : f.lower_rev;
 #if defined(__HIP_DEVICE_COMPILE__)
     ExtLoads ext_loads{};
-#if !defined(MAPAD_LATE_EXT)
     if constexpr (kLaneKids) ext_loads = ext4_quad_issue(ix, x_lower, f.size, w);  // one call site: forward and backward quads of a wavefront share the round trip
-#endif
 #endif
     // pop_max of the crate, second half: the last entry takes the place of the maximum and trickles down
     st.heap_len -= 1;
     if (top_idx < st.heap_len) mm_trickle_down<true>(A, st.heap_len, top_idx, last);
-#if defined(MAPAD_LATE_EXT) && defined(__HIP_DEVICE_COMPILE__)
-    if constexpr (kLaneKids) ext_loads = ext4_quad_issue(ix, x_lower, f.size, w);
-#endif
-    AncWindow W;  // off unless the fast commit loop below turns it on
-    W.on = false; W.n0 = 0; W.pb = 0; W.gb = 0; W.hb = 0; W.p0 = W.p1 = W.p2 = W.g0 = W.g1 = W.h0 = W.h1 = 0;
     MAPAD_MARK(PROF_POP);
     Ext4 e;
     uint64_t my_lower = 0, my_lower_rev = 0, my_size = 0;  // kLaneKids: extension by base w
@@ -911,7 +796,6 @@ MAPAD_HD bool search_step(const DevIndex& ix, const DevParams& P, const ReadInT<
     // static — so both fold into the candidate mask and the loop body is: slab key, arena loads of the push, node store, bubble-up.  (The
     // general loop below pays ~350 instructions per child for the checks, the selects around them and the hit path; children are 2.4 loop
     // trips per wavefront step and were half of a step's instructions.)
-#if !defined(MAPAD_NO_FAST_COMMIT)
     if (f.len + 1 < L && st.tree_next == st.tree_entries) {
         if ((int)num_gaps_open > P.max_num_gaps_open) cand &= 0x154u;  // Ins and Del children open or extend a gap; M/MM children keep the frame's count
         if (st.n_hits > 0 && P.bound_kind != BOUND_TEST) {             // mb_reject_iterative (commit_child)
@@ -922,19 +806,6 @@ MAPAD_HD bool search_step(const DevIndex& ix, const DevParams& P, const ReadInT<
             for (int i = 0; i < 4; ++i) if (mm[i] < lim) cand &= ~(4u << (2 * i));
         }
         const uint32_t cand0 = cand, id0 = st.tree_next;  // == tree_entries: the slab grows at its end, child t gets key id0 + (children before t)
-#if defined(MAPAD_ANCESTOR_WINDOW)  // measured on MI355X (C2, per 1 M reads): 277 ms with this window, 249 ms without
-        // A frame with several children (13 % of the pops, but half of the wavefront steps have one among their 16 read slots) pushes to
-        // consecutive slots whose ancestors overlap: seven entries instead of three per child, loaded once, then every push of the frame works
-        // on registers and the later trips of the loop carry no memory wait.  Single children keep the three direct loads.
-        {
-#if defined(__HIP_DEVICE_COMPILE__)
-            const int n_kids = __popc(cand);
-#else
-            const int n_kids = __builtin_popcount(cand);
-#endif
-            if (n_kids >= 2 && st.heap_len >= (uint32_t)kTop) W = win_load(A, st.heap_len);
-        }
-#endif
         while (cand != 0) {
 #if defined(__HIP_DEVICE_COMPILE__)
             const int t = __ffs((int)cand) - 1;
@@ -951,17 +822,14 @@ MAPAD_HD bool search_step(const DevIndex& ix, const DevParams& P, const ReadInT<
             st.tree_next = id + 1; st.tree_entries = id + 1; st.tree_len += 1;
             const uint32_t pos = st.heap_len;
             st.heap_len = pos + 1;
-            const bool use_win = W.on && pos - W.n0 < kWinPushes;
-            Ancestors an{};
-            if (!use_win) an = load_ancestors(A, pos);
+            const Ancestors an = load_ancestors(A, pos);
             if constexpr (!kLaneKids) {
                 const uint64_t xl = k == 0 ? e.lower[0] : k == 1 ? e.lower[1] : k == 2 ? e.lower[2] : e.lower[3];
                 const uint64_t xr = k == 0 ? e.lower_rev[0] : k == 1 ? e.lower_rev[1] : k == 2 ? e.lower_rev[2] : e.lower_rev[3];
                 const uint64_t xs = k == 0 ? e.size[0] : k == 1 ? e.size[1] : k == 2 ? e.size[2] : e.size[3];
                 A.nodes[id] = make_child(t, k, xl, xr, xs);
             }
-            if (use_win) mm_bubble_up_win(A, W, pos, HeapEntry{score, id});
-            else mm_bubble_up(A, pos, HeapEntry{score, id}, an);
+            mm_bubble_up(A, pos, HeapEntry{score, id}, an);
             st.c_node += 1; st.c_push += 1;
         }
         if constexpr (kLaneKids) {
@@ -976,7 +844,6 @@ MAPAD_HD bool search_step(const DevIndex& ix, const DevParams& P, const ReadInT<
             if ((cand0 & 1u) && w == 0) A.nodes[id0] = nd_ins;
         }
     }
-#endif
     while (cand != 0 && st.status == ST_OK) {
 #if defined(__HIP_DEVICE_COMPILE__)
         const int t = __ffs((int)cand) - 1;
@@ -992,12 +859,12 @@ MAPAD_HD bool search_step(const DevIndex& ix, const DevParams& P, const ReadInT<
         if constexpr (kLaneKids) {
             const Node nd = pick_node(is_ins, is_del, nd_ins, nd_del, nd_mm);
             const int owner = is_ins ? 0 : k;
-            commit_child<LPR>(P, rd, A, st, alignment_start, score, ngaps, len, nd, w == owner, owner, W);
+            commit_child<LPR>(P, rd, A, st, alignment_start, score, ngaps, len, nd, w == owner, owner);
         } else {
             const uint64_t xl = k == 0 ? e.lower[0] : k == 1 ? e.lower[1] : k == 2 ? e.lower[2] : e.lower[3];
             const uint64_t xr = k == 0 ? e.lower_rev[0] : k == 1 ? e.lower_rev[1] : k == 2 ? e.lower_rev[2] : e.lower_rev[3];
             const uint64_t xs = k == 0 ? e.size[0] : k == 1 ? e.size[1] : k == 2 ? e.size[2] : e.size[3];
-            commit_child<LPR>(P, rd, A, st, alignment_start, score, ngaps, len, make_child(t, k, xl, xr, xs), true, 0, W);
+            commit_child<LPR>(P, rd, A, st, alignment_start, score, ngaps, len, make_child(t, k, xl, xr, xs), true, 0);
         }
     }
     MAPAD_MARK(PROF_COMMIT);
