@@ -359,7 +359,7 @@ def main():
 
     # ---- the command line end to end: FASTQ in, BAM out (reader, GPU mapping, records, BAM encoding + BGZF, all overlapped) -----------------
     cli = None
-    if extras and args.config in ("c2", "c3") and n_reads <= 2_000_000:
+    if extras and args.config in ("c2", "c3") and n_reads <= 8_000_000:
         import re
         import shutil
         import tempfile

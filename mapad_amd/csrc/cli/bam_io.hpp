@@ -57,6 +57,16 @@ public:
         }
         write(b, n);
     }
+    // BGZF blocks of a whole buffer (full blocks and a last shorter one), appended to `out`: for callers that deflate on their own threads
+    static void compress_all(const uint8_t* p, size_t n, std::vector<uint8_t>& out) {
+        Deflater d;
+        for (size_t off = 0; off < n; off += kBlock) d.block(p + off, std::min(kBlock, n - off), out);
+    }
+    // blocks made by compress_all, in stream order (closes the block that write() may have left open first)
+    void write_compressed(const std::vector<uint8_t>& blocks) {
+        if (!buf_.empty()) flush_block();
+        if (std::fwrite(blocks.data(), 1, blocks.size(), f_) != blocks.size()) throw std::runtime_error("write failed");
+    }
     void close() {
         if (!f_) return;
         if (!buf_.empty()) flush_block();
@@ -70,6 +80,27 @@ private:
     static constexpr size_t kBlock = 0xff00;
     FILE* f_ = nullptr;
     std::vector<uint8_t> buf_;
+    struct Deflater {  // one zlib state for many blocks (deflateInit2 allocates a quarter of a megabyte)
+        z_stream zs{};
+        Deflater() { if (deflateInit2(&zs, 6, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) throw std::runtime_error("deflateInit2"); }
+        ~Deflater() { deflateEnd(&zs); }
+        Deflater(const Deflater&) = delete;
+        void block(const uint8_t* data, size_t len, std::vector<uint8_t>& out) {
+            const size_t base = out.size();
+            out.resize(base + kBlock + 1024);
+            deflateReset(&zs);
+            zs.next_in = const_cast<uint8_t*>(data); zs.avail_in = (uInt)len;
+            zs.next_out = out.data() + base + 18; zs.avail_out = (uInt)(kBlock + 1024 - 18 - 8);
+            if (deflate(&zs, Z_FINISH) != Z_STREAM_END) throw std::runtime_error("deflate");
+            const size_t clen = zs.total_out, bsize = clen + 18 + 8;
+            const uint8_t hdr[18] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0, (uint8_t)((bsize - 1) & 0xff), (uint8_t)((bsize - 1) >> 8)};
+            std::memcpy(out.data() + base, hdr, 18);
+            const uint32_t crc = (uint32_t)crc32(crc32(0, nullptr, 0), data, (uInt)len), isize = (uint32_t)len;
+            std::memcpy(out.data() + base + 18 + clen, &crc, 4);
+            std::memcpy(out.data() + base + 18 + clen + 4, &isize, 4);
+            out.resize(base + bsize);
+        }
+    };
     static std::vector<uint8_t> deflate_block(const uint8_t* data, size_t len) {
         std::vector<uint8_t> out(kBlock + 1024);
         z_stream zs{};

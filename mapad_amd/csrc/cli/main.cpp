@@ -270,7 +270,7 @@ int cmd_map(const Args& a, uint64_t seed, const std::vector<int>& devices, const
     for (size_t d = 0; d < n_dev; ++d) dev_q.emplace_back(new BoundedQueue<ChunkPtr>(2));  // read ahead; `in_flight` more are on the device
     BoundedQueue<ChunkPtr> done_q(4);
     std::atomic<bool> failed{false};
-    std::atomic<uint64_t> us_reader{0}, us_device{0}, us_writer{0};  // busy time of the three stages (the slowest one sets the throughput)
+    std::atomic<uint64_t> us_reader{0}, us_device{0}, us_writer{0}, us_submit{0}, us_fetch{0}, us_records{0};  // busy time of the three stages (the slowest one sets the throughput)
     auto now_us = [] { return (uint64_t)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     std::string fail_msg;
     std::mutex fail_mu;
@@ -375,14 +375,18 @@ int cmd_map(const Args& a, uint64_t seed, const std::vector<int>& devices, const
         auto submit = [&](const ChunkPtr& c) {
             const Slice& sl = c->slices[d];
             const uint64_t b0 = c->offsets[sl.lo];
+            const uint64_t t0 = now_us();
             check(mapad_submit_batch(ctx, c->seqs.p + b0, c->quals.p + b0, sl.offsets.data(), sl.hi - sl.lo), "mapad_submit_batch");
+            if (d == 0) us_submit += now_us() - t0;
         };
         auto records = [&](const ChunkPtr& c) {
             Slice& sl = c->slices[d];
             const uint64_t b0 = c->offsets[sl.lo];
+            const uint64_t t0 = now_us();
             // one seed per read of the run, whichever device maps it: the chunk's seed advanced to the slice's first read
             check(mapad_hits_to_records_gpu(ctx, sl.res, c->seqs.p + b0, c->quals.p + b0, sl.offsets.data(), c->flags.data() + sl.lo,
                                             mapad_records_seed_at(seed + c->no, sl.lo), &sl.recs), "mapad_hits_to_records_gpu");
+            if (d == 0) us_records += now_us() - t0;
             if (--c->pending == 0) {
                 c->per_read_s = std::chrono::duration<float>(std::chrono::steady_clock::now() - c->t_submit).count() / (float)std::max<size_t>(c->in.size(), 1);
                 done_q.push(c);
@@ -390,7 +394,9 @@ int cmd_map(const Args& a, uint64_t seed, const std::vector<int>& devices, const
         };
         auto collect = [&](const ChunkPtr& c, int age) -> bool {  // false: the hit pools were too small for this slice
             check(mapad_ctx_select_batch(ctx, age), "mapad_ctx_select_batch");
+            const uint64_t t0 = now_us();
             const int rc = mapad_fetch_result(ctx, &c->slices[d].res);
+            if (d == 0) us_fetch += now_us() - t0;
             if (rc == MAPAD_ERR_NOMEM) return false;
             check(rc, "mapad_fetch_result");
             return true;
@@ -437,7 +443,7 @@ int cmd_map(const Args& a, uint64_t seed, const std::vector<int>& devices, const
                 if (failed) continue;
                 const uint64_t t_w0 = now_us();
                 const size_t n = c->in.size();
-                std::vector<std::vector<uint8_t>> enc(host_threads);
+                std::vector<std::vector<uint8_t>> enc(host_threads), comp(host_threads);
                 std::vector<uint64_t> mapped(host_threads, 0);
                 parallel_for(n, host_threads, [&](size_t lo, size_t hi, unsigned t) {
                     size_t d = 0;
@@ -457,8 +463,9 @@ int cmd_map(const Args& a, uint64_t seed, const std::vector<int>& devices, const
                         f.xd = c->per_read_s;  // the reference stores the wall time of each read's search (mapping.rs:912-918); here: chunk time / reads
                         encode_bam_record(c->in[i], f, rg, enc[t]);
                     }
+                    BgzfWriter::compress_all(enc[t].data(), enc[t].size(), comp[t]);  // every thread deflates what it encoded; the blocks are written in order below
                 });
-                for (unsigned t = 0; t < host_threads; ++t) { out.write_parallel(enc[t].data(), enc[t].size(), host_threads); n_mapped += mapped[t]; }
+                for (unsigned t = 0; t < host_threads; ++t) { out.write_compressed(comp[t]); n_mapped += mapped[t]; }
                 n_total += n;
                 for (auto& sl : c->slices) { mapad_records_free(sl.recs); mapad_batch_result_free(sl.res); sl.recs = nullptr; sl.res = nullptr; }
                 us_writer += now_us() - t_w0;
@@ -476,6 +483,8 @@ int cmd_map(const Args& a, uint64_t seed, const std::vector<int>& devices, const
     std::fprintf(stderr, "mapad-amd: %llu reads, %llu mapped; %zu device(s); index + contexts %.2f s, mapping %.2f s (%.0f reads/s)\n", (unsigned long long)n_total,
                  (unsigned long long)n_mapped, n_dev, t_load, t_all - t_load, (double)n_total / std::max(t_all - t_load, 1e-9));
     std::fprintf(stderr, "mapad-amd: stage busy time: reader %.2f s, device worker 0 %.2f s, writer %.2f s\n", us_reader.load() * 1e-6, us_device.load() * 1e-6, us_writer.load() * 1e-6);
+    std::fprintf(stderr, "mapad-amd: device worker 0: submit %.2f s, fetch (incl. waiting for the GPU) %.2f s, records %.2f s\n", us_submit.load() * 1e-6, us_fetch.load() * 1e-6,
+                 us_records.load() * 1e-6);
     for (auto* c : ctxs) mapad_ctx_destroy(c);
     mapad_index_free(idx);
     return 0;

@@ -19,6 +19,7 @@
 #include <new>
 #include <set>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/mapad_amd.h"
@@ -1501,12 +1502,46 @@ int mapad_submit_batch(mapad_ctx_t* ctx, const uint8_t* seqs, const uint8_t* qua
     if ((rc = stage_host_batch(ctx, S, seqs, quals, offsets, n_reads, total, lmax))) return rc;
     return launch_batch(ctx, S, S.d_seqs.p, S.d_quals.p, S.d_offsets.p, n_reads, total, lmax);
 }
-void* mapad_host_alloc(size_t bytes) {
-    void* p = nullptr;
-    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocPortable) != hipSuccess) return nullptr;
-    return p;
-}
-void mapad_host_free(void* p) { if (p) (void)hipHostFree(p); }
+// Page-locked blocks are recycled: pinning and unpinning cost milliseconds per block, and hipHostFree waits for the device — in a chunk loop
+// that allocates its read buffers per chunk (mapad-amd map) this stalled the whole pipeline once per chunk.  Blocks come in power-of-two sizes;
+// up to 8 GB of freed blocks are kept for reuse.
+namespace {
+struct HostBlockCache {
+    std::mutex mu;
+    std::multimap<size_t, void*> free_blocks;
+    std::unordered_map<void*, size_t> size_of;
+    size_t cached = 0;
+    static size_t bucket(size_t bytes) { size_t b = 65536; while (b < bytes) b <<= 1; return b; }
+    void* alloc(size_t bytes) {
+        const size_t want = bucket(bytes);
+        {
+            std::lock_guard<std::mutex> l(mu);
+            auto it = free_blocks.find(want);
+            if (it != free_blocks.end()) { void* p = it->second; free_blocks.erase(it); cached -= want; return p; }
+        }
+        void* p = nullptr;
+        if (hipHostMalloc(&p, want, hipHostMallocPortable) != hipSuccess) return nullptr;
+        std::lock_guard<std::mutex> l(mu);
+        size_of[p] = want;
+        return p;
+    }
+    void release(void* p) {
+        size_t sz = 0;
+        {
+            std::lock_guard<std::mutex> l(mu);
+            auto it = size_of.find(p);
+            if (it == size_of.end()) return;  // not ours
+            sz = it->second;
+            if (cached + sz <= (8ull << 30)) { free_blocks.emplace(sz, p); cached += sz; return; }
+            size_of.erase(it);
+        }
+        (void)hipHostFree(p);
+    }
+};
+HostBlockCache& host_blocks() { static HostBlockCache* c = new HostBlockCache(); return *c; }  // never destroyed: the runtime may be gone at exit
+}  // namespace
+void* mapad_host_alloc(size_t bytes) { return host_blocks().alloc(bytes ? bytes : 1); }
+void mapad_host_free(void* p) { if (p) host_blocks().release(p); }
 
 int mapad_device_result_ptrs(mapad_ctx_t* ctx, void** d_hit_count, void** d_hit_first, void** d_hits, void** d_ops, void** d_cursors) {
     if (!ctx) return MAPAD_ERR_INVALID;
