@@ -140,6 +140,10 @@ def main():
             dist.init_process_group("gloo")
         assert dist.get_world_size() == world == args.gpus
     xdev = dev if args.dist_backend == "nccl" else torch.device("cpu")  # where the exchanged tensors live
+    # sizes travel over a CPU group: a GPU collective is a kernel that needs wave slots, and the persistent search wavefronts hold them (distributed.py)
+    meta_group = dist.new_group(backend="gloo") if world > 1 and args.dist_backend == "nccl" else None
+    if world > 1:  # 8 search wavefronts per CU map as fast as 12 once batches overlap, and leave registers and LDS on every CU for RCCL's kernels
+        os.environ.setdefault("MAPAD_TIER0_WAVES_PER_CU", "8")
 
     # ---- workload --------------------------------------------------------------------------------------------------------
     t0 = time.time()
@@ -185,7 +189,7 @@ def main():
         if args.dist_backend == "gloo":
             torch.cuda.synchronize(dev)
             begin, hits, ops = begin.cpu(), hits.cpu(), ops.cpu()
-        return gather_hit_records(begin, hits, ops, rank, world, device=xdev)
+        return gather_hit_records(begin, hits, ops, rank, world, device=xdev, meta_group=meta_group)
 
     def run_steps(k):
         """k steps back to back.  With depth > 1 step i + 1 is submitted while step i's tail is still running; the gather of step i's

@@ -15,12 +15,15 @@ def shard_bounds(n_reads, world, rank):
     return lo, lo + base + (1 if rank < extra else 0)
 
 
-def gather_hit_records(hit_count, hits, ops, rank, world, device=None):
+def gather_hit_records(hit_count, hits, ops, rank, world, device=None, meta_group=None):
     """Gathers (hit_begin as int32 view of uint64[n_reads_local + 1], hits int32[n_hits_local * 10], ops int32[n_ops_local]) on rank 0.
 
     Tensors may live on the GPU (nccl/RCCL) or the CPU (gloo).  Returns on rank 0 a list, indexed by source rank, of
     (hit_count, hits, ops) tensors; None elsewhere.  Sizes are exchanged first (all_gather of three int64), then every peer
     sends its three buffers straight to rank 0 — a fan-in over point-to-point links, no ring.
+    meta_group: a CPU (gloo) group for the size exchange.  On GPUs every collective is a kernel that needs free wave slots; the persistent
+    search wavefronts of the batches in flight hold them until a launch runs out of reads, and a host that waits for three integers would
+    wait that long.  The bulk transfers are not waited for by the host, so they may start late.
     """
     import torch
     import torch.distributed as dist
@@ -28,9 +31,10 @@ def gather_hit_records(hit_count, hits, ops, rank, world, device=None):
     if world == 1:
         return [(hit_count, hits, ops)]
     dev = hit_count.device if device is None else device
-    sizes = torch.tensor([hit_count.numel(), hits.numel(), ops.numel()], dtype=torch.int64, device=dev)
-    all_sizes = [torch.zeros(3, dtype=torch.int64, device=dev) for _ in range(world)]
-    dist.all_gather(all_sizes, sizes)
+    mdev = torch.device("cpu") if meta_group is not None else dev
+    sizes = torch.tensor([hit_count.numel(), hits.numel(), ops.numel()], dtype=torch.int64, device=mdev)
+    all_sizes = [torch.zeros(3, dtype=torch.int64, device=mdev) for _ in range(world)]
+    dist.all_gather(all_sizes, sizes, group=meta_group)
     all_sizes = torch.stack(all_sizes).cpu().numpy()
     if rank == 0:
         out, reqs = [(hit_count, hits, ops)], []

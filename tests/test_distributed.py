@@ -65,7 +65,8 @@ def _worker(rank, world, port, out_path):
     own_digest = hashlib.sha256(b"".join(np.ascontiguousarray(a).tobytes() for a in own)).hexdigest()
     # the rank's raw result is completion-ordered; the collect (device kernels on the GPU) lays it out in read order before the gather
     hit_begin, hits, ops = collect_in_read_order(*_as_completion_ordered_pools(*own, seed=100 + rank))
-    parts = gather_hit_records(torch.from_numpy(hit_begin.view(np.int32)), torch.from_numpy(hits.reshape(-1)), torch.from_numpy(ops), rank, world)
+    meta = dist.new_group(backend="gloo")  # the size exchange on its own CPU group, as bench.py does beside RCCL
+    parts = gather_hit_records(torch.from_numpy(hit_begin.view(np.int32)), torch.from_numpy(hits.reshape(-1)), torch.from_numpy(ops), rank, world, meta_group=meta)
     digests = [None] * world
     dist.all_gather_object(digests, own_digest)
     if rank == 0:
