@@ -112,6 +112,9 @@ def main():
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         spawn_ranks(args.gpus, same_device=args.dist_backend == "gloo")  # never returns
+    # stdout carries the one JSON line and nothing else: whatever a library prints there (gloo's connection banner, ...) goes to stderr
+    real_stdout = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = 0 if args.dist_backend == "gloo" else int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -461,7 +464,7 @@ def main():
         }
         if gather_check is not None:
             line["gather"] = gather_check
-        print(json.dumps(line), flush=True)
+        print(json.dumps(line), file=real_stdout, flush=True)
     ctx.close()
     if world > 1:
         dist.barrier()
