@@ -29,7 +29,10 @@ if len(sys.argv) > 1:  # e.g. "250000:4:MAPAD_TIER0_WAVES_PER_CU=10"
         f = a.split(":")
         cases.append((int(f[0]), int(f[1]), dict(x.split("=") for x in f[2:])))
 for bs, fl, env in cases:
-    pr = subprocess.run(base + ["--batch_size", str(bs), "--in_flight", str(fl)], stderr=subprocess.PIPE, text=True, env=dict(os.environ, **env))
+    cmd = base + ["--batch_size", str(bs), "--in_flight", str(fl)]
+    if env.pop("ROCPROF", None):  # kernel statistics of the run: the summary lands in gpurun_out/prof_cli
+        cmd = ["rocprofv3", "--kernel-trace", "--stats", "-d", os.path.join(os.getcwd(), "gpurun_out", "prof_cli"), "-o", "out", "--output-format", "csv", "--"] + cmd
+    pr = subprocess.run(cmd, stderr=subprocess.PIPE, text=True, env=dict(os.environ, **env))
     m = re.search(r"mapping ([0-9.]+) s \((\d+) reads/s\)", pr.stderr)
     b = re.search(r"reader ([0-9.]+) s, device worker 0 ([0-9.]+) s, writer ([0-9.]+) s", pr.stderr)
     w = re.search(r"submit ([0-9.]+) s, fetch \(incl. waiting for the GPU\) ([0-9.]+) s, records ([0-9.]+) s", pr.stderr)
