@@ -95,8 +95,8 @@ def make_reads(synth, genome, n_reads, seed, **kw):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
     ap.add_argument("--genome-bp", type=int, default=None)
     ap.add_argument("--reads", type=int, default=None, help="reads per GPU")
