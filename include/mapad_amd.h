@@ -167,7 +167,9 @@ void mapad_batch_result_free(mapad_batch_result_t* r);
  * context's batch slots (mapad_ctx_set_pipeline_depth) and returns.  Collect with mapad_ctx_select_batch + mapad_fetch_result; a fetch that
  * returns MAPAD_ERR_NOMEM (hit pools too small for that chunk) is repaired by running the chunk through mapad_map_batch. */
 int mapad_submit_batch(mapad_ctx_t* ctx, const uint8_t* seqs, const uint8_t* quals, const uint64_t* offsets, uint64_t n_reads);
-/* page-locked host memory: reads placed here reach the GPU by DMA at link speed (pageable memory goes through the driver's staging copies) */
+/* page-locked host memory: reads placed here reach the GPU by DMA at link speed (pageable memory goes through the driver's staging copies).
+ * Freed blocks are kept for reuse (power-of-two sizes, up to 8 GB): pinning costs milliseconds and hipHostFree waits for the device, which a
+ * chunk loop that allocates per chunk cannot afford. */
 void* mapad_host_alloc(size_t bytes);
 void mapad_host_free(void* p);
 
