@@ -143,6 +143,32 @@ def test_worker_framing_and_record_echo_without_a_gpu():
     srv.close()
 
 
+@pytest.mark.parametrize("damage", ["short_body", "bad_option_tag", "trailing_bytes", "unknown_model"])
+def test_worker_rejects_malformed_tasks(damage):
+    """a task that does not decode ends the worker with an error message and a non-zero status (the reference: InvalidData, worker.rs:229-235) —
+    it is never answered and never crashes the process"""
+    srv, port = _serve()
+    proc = subprocess.Popen([_cli(), "worker", "--host", "127.0.0.1", "--port", str(port), "--dry_run"], stderr=subprocess.PIPE)
+    conn, _ = srv.accept()
+    good = encode_task(1, [encode_record(b"ACGT", [30] * 4, b"r")], b"ref", mapad_amd.make_params(presets.resolve(presets.DAMAGE)))
+    if damage == "short_body":       # the header promises more records than the body holds
+        msg = bytearray(good); msg[16:24] = struct.pack("<Q", 5); msg = bytes(msg)
+    elif damage == "bad_option_tag":  # Option tag of the record name is neither 0 nor 1
+        rec = bytearray(encode_record(b"ACGT", [30] * 4, b"r")); rec[8 + 4 + 8 + 4] = 7
+        msg = encode_task(1, [bytes(rec)])
+    elif damage == "trailing_bytes":
+        body = good[8:] + b"xx"
+        msg = struct.pack("<Q", len(body) + 8) + body
+    else:                            # VindijaPwm (variant 1) is not available on the device
+        body = struct.pack("<QQ", 1, 0) + b"\x00" + b"\x01" + struct.pack("<I", 1) + b"\x00" * 64
+        msg = struct.pack("<Q", len(body) + 8) + body
+    conn.sendall(msg)
+    assert proc.wait(timeout=60) != 0
+    err = proc.stderr.read().decode()
+    assert any(k in err for k in ("shorter than its contents", "bad Option tag", "trailing bytes", "VindijaPwm", "bad sequence length", "bad record count"))
+    conn.close(); srv.close()
+
+
 @pytest.mark.gpu
 def test_worker_returns_the_hits_of_the_batch_api(tmp_path):
     """Two tasks (the first names the index and the parameters): hits, scores and edit tracks per record equal mapad_map_batch's,
