@@ -10,9 +10,10 @@ anything touches the GPU); under the driver's torchrun it reads RANK / LOCAL_RAN
 Workloads (SURVEY §8d; synthetic genome = i.i.d. ACGT from splitmix64(1234), reads 90 % endogenous with 2 % substitutions, 10 % exogenous;
 `-p 0.03 -D 0.02 -i 0.001 -x 1.0`, gap_dist_ends 5, max_num_gaps_open 2; the index is built on the GPU in the setup phase):
   c1  5 386 bp genome (phiX174-size), 1 k x 50 bp, no-damage model, Phred 40 — with the single-thread oracle figure
-  c2  48 Mbp genome (chr21-size), 1 M x 50 bp per GPU, no-damage model, Phred 40            [default: BASELINE.json configs[1]]
+  c2  48 Mbp genome (chr21-size), 1 M x 50 bp per GPU, no-damage model, Phred 40            [BASELINE.json configs[1]]
   c3  the same genome, single-stranded library f = t = 0.5, d = 0.02, s = 1.0, Phred 20-40
-  c4  3 Gbp genome (hg19-size, n = 6e9 rows > 2^32), 10 M x 50 bp per GPU, no-damage model, Phred 40
+  c4  3 Gbp genome (hg19-size, n = 6e9 rows > 2^32), 10 M x 50 bp per GPU, no-damage model, Phred 40   [default: BASELINE.json configs[3],
+      the largest single-GPU configuration and the north star's target]
   c5  the read mix of C5 (35-100 bp, 5 % of the reads with an indel, damage model) on the 48 Mbp genome, 1 M reads per step
 One "step" = one pass of the hot path (D-array kernel, ordering, search kernel + its retry / full-limit launches) over the batch;
 reads, index and score tables are resident in HBM before the timed region.  With N > 1 every rank holds a replica of the index, maps
@@ -97,12 +98,13 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
+    ap.add_argument("--config", default="c4", choices=sorted(CONFIGS))
     ap.add_argument("--genome-bp", type=int, default=None)
     ap.add_argument("--reads", type=int, default=None, help="reads per GPU")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target wall time of the CPU baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extras", action="store_true", help="skip the e2e / sa_locate / post_search legs")
+    ap.add_argument("--no-extras", action="store_true", help="skip the e2e / cli / sa_locate / post_search legs")
+    ap.add_argument("--no-cli", action="store_true", help="skip the command-line leg (FASTQ -> BAM; at C4 it writes and re-reads the 3 Gbp index files)")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo: test mode for boxes with one GPU — every rank uses device 0 and the gather goes through host memory")
     ap.add_argument("--depth", type=int, default=3, help="batches in flight (1 = every step runs alone on the stream)")
@@ -366,41 +368,56 @@ def main():
 
     # ---- the command line end to end: FASTQ in, BAM out (reader, GPU mapping, records, BAM encoding + BGZF, all overlapped) -----------------
     cli = None
-    if extras and args.config in ("c2", "c3") and n_reads <= 8_000_000:
+    if extras and args.config in ("c2", "c3", "c4") and not args.no_cli:
         import re
         import shutil
         import tempfile
         from mapad_amd import build as mbuild
         tmp = tempfile.mkdtemp(prefix="mapad_cli_")
         try:
+            n_cli = min(n_reads, 4_000_000)  # the first reads of the batch: enough chunks of 250 000 to fill the pipeline
             fa, fq, bam = os.path.join(tmp, "ref.fa"), os.path.join(tmp, "reads.fastq"), os.path.join(tmp, "out.bam")
-            with open(fa, "wb") as f:
-                f.write(b">chr1\n")
-                f.write(genome.tobytes())
-                f.write(b"\n")
-            rec = np.empty((n_reads, 114), np.uint8)  # "@rNNNNNNN\n" + 50 bases + "\n+\n" + 50 qualities + "\n"
+            rec = np.empty((n_cli, 114), np.uint8)  # "@rNNNNNNN\n" + 50 bases + "\n+\n" + 50 qualities + "\n"
             rec[:, 0] = ord("@"); rec[:, 1] = ord("r")
-            ids = np.arange(n_reads)
+            ids = np.arange(n_cli)
             for k in range(7):
                 rec[:, 8 - k] = 48 + (ids // 10 ** k) % 10
-            rec[:, 9] = 10; rec[:, 10:60] = seqs.reshape(n_reads, 50); rec[:, 60] = 10; rec[:, 61] = ord("+"); rec[:, 62] = 10
-            rec[:, 63:113] = quals.reshape(n_reads, 50) + 33; rec[:, 113] = 10
+            rec[:, 9] = 10; rec[:, 10:60] = seqs[:50 * n_cli].reshape(n_cli, 50); rec[:, 60] = 10; rec[:, 61] = ord("+"); rec[:, 62] = 10
+            rec[:, 63:113] = quals[:50 * n_cli].reshape(n_cli, 50) + 33; rec[:, 113] = 10
             rec.tofile(fq)
+            del rec
             exe = mbuild.build_cli()
-            t = time.perf_counter()
-            subprocess.check_call([exe, "index", "-g", fa], stderr=subprocess.DEVNULL)
-            t_idx = time.perf_counter() - t
-            model = ["-f", "0", "-t", "0", "-d", "0", "-s", "0"] if args.config == "c2" else ["-f", "0.5", "-t", "0.5", "-d", "0.02", "-s", "1.0"]
+            index_bytes = None
+            if genome_bp <= 200_000_000:  # `mapad-amd index` from the FASTA (GPU suffix sorting inside the command)
+                with open(fa, "wb") as f:
+                    f.write(b">chr1\n")
+                    f.write(genome.tobytes())
+                    f.write(b"\n")
+                t = time.perf_counter()
+                subprocess.check_call([exe, "index", "-g", fa], stderr=subprocess.DEVNULL)
+                t_idx, idx_how = time.perf_counter() - t, "mapad-amd index (FASTA -> 7 files)"
+            else:  # the index of the timed region, written through mapad_index_save (the seven files of indexing.rs:110-208) and loaded by the command
+                need = 4 * len(index) // 2 + (8 << 30)
+                if shutil.disk_usage(tmp).free < need:
+                    raise RuntimeError(f"not enough scratch space for the index files ({need >> 30} GiB)")
+                t = time.perf_counter()
+                index.save(fa)
+                t_idx, idx_how = time.perf_counter() - t, "mapad_index_save of the index built for the timed region (7 files)"
+            index_bytes = sum(os.path.getsize(fa + e) for e in (".tbw", ".tle", ".toc", ".trt", ".tsa", ".tpi", ".tos") if os.path.exists(fa + e))
+            model = ["-f", "0.5", "-t", "0.5", "-d", "0.02", "-s", "1.0"] if args.config == "c3" else ["-f", "0", "-t", "0", "-d", "0", "-s", "0"]
             t = time.perf_counter()
             pr = subprocess.run([exe, "map", "-r", fq, "-g", fa, "-o", bam, "-l", "single_stranded", "-p", "0.03", "-D", "0.02", "-i", "0.001", "-x", "1.0",
                                  "--batch_size", "250000", "--force_overwrite"] + model, stderr=subprocess.PIPE, text=True, check=True)
             t_map = time.perf_counter() - t
             m = re.search(r"(\d+) reads, (\d+) mapped; (\d+) device\(s\); index \+ contexts ([0-9.]+) s, mapping ([0-9.]+) s", pr.stderr)
-            cli = {"reads_per_s": round(n_reads / float(m.group(5)), 1), "mapping_s": float(m.group(5)), "index_load_and_contexts_s": float(m.group(4)),
-                   "process_wall_s": round(t_map, 2), "mapped": int(m.group(2)), "bam_bytes": os.path.getsize(bam), "index_cmd_s": round(t_idx, 2),
+            cli = {"reads_per_s": round(n_cli / float(m.group(5)), 1), "reads": n_cli, "mapping_s": float(m.group(5)), "index_load_and_contexts_s": float(m.group(4)),
+                   "process_wall_s": round(t_map, 2), "mapped": int(m.group(2)), "bam_bytes": os.path.getsize(bam), "index_files_s": round(t_idx, 2), "index_files": idx_how,
+                   "index_files_bytes": index_bytes,
                    "stage_busy_s": (lambda mm: {"reader": float(mm.group(1)), "device_worker": float(mm.group(2)), "writer": float(mm.group(3))} if mm else None)(
                        re.search(r"reader ([0-9.]+) s, device worker 0 ([0-9.]+) s, writer ([0-9.]+) s", pr.stderr)),
                    "what": "mapad-amd map: FASTQ -> BAM, --batch_size 250000 (the reference's default), up to 4 chunks in flight on one GPU; reader, records and BGZF on host threads"}
+        except Exception as e:  # the leg is a report, not the metric: say why it is missing
+            cli = {"skipped": f"{type(e).__name__}: {e}"}
         finally:
             shutil.rmtree(tmp, ignore_errors=True)
 

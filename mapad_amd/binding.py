@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 
 class MapadError(RuntimeError):
     CODES = {-1: "invalid argument", -2: "I/O error", -3: "index version mismatch", -4: "parse error", -5: "no gfx950 device (no CPU fallback)",
-             -6: "HIP call failed", -7: "out of memory", -8: "read too long"}
+             -6: "HIP call failed", -7: "out of memory", -8: "read too long", -9: "input beyond a documented limit of this entry point"}
 
     def __init__(self, code, what=""):
         self.code = code

@@ -108,6 +108,10 @@ int cmd_index(const Args& a, uint64_t seed, int device) {
     mapad_index_t* idx = nullptr;
     // suffix sorting on the GPU when there is one (seconds for a 3 Gbp genome); the host SA-IS path builds the same files without a GPU
     int rc = a.flag("host_index") ? MAPAD_ERR_NO_DEVICE : mapad_index_build_gpu(np.data(), sp.data(), lens.data(), (uint32_t)names.size(), seed, device, &idx);
+    if (rc == MAPAD_ERR_UNSUPPORTED || rc == MAPAD_ERR_NOMEM) {
+        std::fprintf(stderr, "index: the GPU suffix sorter cannot take this text (%s); building on the host\n", rc == MAPAD_ERR_NOMEM ? "out of device memory" : "a prefix bucket or group beyond its limits");
+        rc = MAPAD_ERR_NO_DEVICE;
+    }
     if (rc == MAPAD_ERR_NO_DEVICE) rc = mapad_index_build(np.data(), sp.data(), lens.data(), (uint32_t)names.size(), seed, &idx);
     check(rc, "mapad_index_build");
     check(mapad_index_save(idx, ref.c_str()), "mapad_index_save");  // files are named <reference>.{tbw,...} (indexing.rs:110-208)
@@ -349,7 +353,7 @@ int cmd_map(const Args& a, uint64_t seed, const std::vector<int>& devices, const
                     InRecord r;
                     while (c->in.size() < prm.chunk_size && (more = src.next(r))) admit(std::move(r), true);
                 }
-                if (c->in.empty()) break;
+                if (c->in.empty()) { if (more) continue; break; }  // a whole block of blank / malformed records: keep reading
                 const uint64_t n_reads = c->offsets.size() - 1;
                 c->slices.resize(n_dev);
                 for (size_t d = 0; d < n_dev; ++d) {  // contiguous slices: concatenation in device order = input order
@@ -556,8 +560,10 @@ int cmd_worker(const Args& a, const std::vector<int>& devices) {
         msg.resize(8);
         if (!read_exact(fd, msg.data(), 8)) break;  // the dispatcher has dropped the connection: done (worker.rs:203-206)
         uint64_t size; std::memcpy(&size, msg.data(), 8);
-        if (size < 8 + 8 + 8 + 2 || size > (1ull << 40)) die("worker: implausible task size");
-        msg.resize(size);
+        // a task is at most one chunk of records (sequence + qualities + tags) plus the parameters: anything beyond a few GiB is a corrupt header,
+        // not a task (the dispatcher sends chunk_size records, distributed/dispatcher.rs:223-247)
+        if (size < 8 + 8 + 8 + 2 || size > (4ull << 30)) die("worker: implausible task size");
+        try { msg.resize(size); } catch (const std::bad_alloc&) { die("worker: implausible task size (allocation failed)"); }
         if (!read_exact(fd, msg.data() + 8, size - 8)) die("worker: connection closed inside a message");
         const wire::Task t = wire::decode_task(msg.data(), msg.size());
         if (!dry && !idx) {  // worker.rs:57-65

@@ -118,7 +118,7 @@ inline Task decode_task(const uint8_t* msg, size_t n) {
     Task t;
     t.chunk_id = c.get<uint64_t>();
     const uint64_t n_rec = c.get<uint64_t>();
-    if (n_rec > n) throw std::runtime_error("bad record count");
+    if (n_rec > n / 24) throw std::runtime_error("bad record count");  // a Record is at least 24 bytes on the wire (three empty vectors), so the count is bounded by the message
     t.records.resize(n_rec);
     for (auto& r : t.records) {
         r.raw = c.p;

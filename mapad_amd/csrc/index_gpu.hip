@@ -345,7 +345,7 @@ struct ChunkSorter {
 // Fills bwt, sa_sample, extra_rows, blocks, x_counts, less, sentinel of `ix` (ix.n and the text `t` of n rank bytes are given).
 void suffix_products(const uint8_t* t_host, host::Index& ix, int device, bool verbose) {
     const uint64_t n = ix.n;
-    if (n < 8 || n >= (1ull << 40)) throw std::runtime_error("text length out of range for the GPU indexer");
+    if (n < 8 || n >= (1ull << 40)) throw std::length_error("text length out of range for the GPU indexer");
     GI_TRY(hipSetDevice(device));
     hipStream_t s = nullptr;
     const double t_begin = now_s();
@@ -385,7 +385,7 @@ void suffix_products(const uint8_t* t_host, host::Index& ix, int device, bool ve
     {
         uint64_t biggest = 0;
         for (int k = 0; k < kBuckets; ++k) biggest = std::max<uint64_t>(biggest, hist[k]);
-        if (biggest > kMaxSortChunk) throw std::runtime_error("a prefix bucket holds more than 2^30 suffixes (not supported)");
+        if (biggest > kMaxSortChunk) throw std::length_error("a prefix bucket holds more than 2^30 suffixes (not supported)");
         cs.reserve((size_t)std::max<uint64_t>(biggest, 1), false);
     }
     for (int k = 0; k < kBuckets; ++k) {
@@ -466,7 +466,7 @@ void suffix_products(const uint8_t* t_host, host::Index& ix, int device, bool ve
                     GI_TRY(hipStreamSynchronize(s));
                     if (z != ~0ull) hi = z;
                     else if (lim == m_unres) hi = m_unres;
-                    else throw std::runtime_error("a group of more than 2^30 equal suffixes (not supported)");
+                    else throw std::length_error("a group of more than 2^30 equal suffixes (not supported)");
                 }
             }
             const uint32_t m = (uint32_t)(hi - lo);

@@ -18,6 +18,7 @@
 #include <mutex>
 #include <new>
 #include <set>
+#include <stdexcept>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -925,12 +926,12 @@ int record_times(mapad_ctx* c, BatchSlot& S) {
 // Makes slot `k` ready for a new batch: its previous batch has finished, its stream exists and waits for the caller's stream.
 int acquire_slot(mapad_ctx* c, int k) {
     BatchSlot& S = c->bs[k];
-    if (c->depth == 1) S.stream = S.stream;  // one batch at a time: everything runs on the caller's stream
-    else if (!S.stream) { HIP_TRY(hipStreamCreateWithFlags(&S.stream, hipStreamNonBlocking)); S.own_stream = true; }
     if (S.ev_valid) { HIP_TRY(hipStreamSynchronize(S.stream)); int rc = record_times(c, S); if (rc) return rc; }
-    if (c->depth > 1) {
+    if (c->depth == 1) S.stream = c->stream;  // one batch at a time: everything runs on the caller's stream (own_stream stays false)
+    else if (!S.stream) { HIP_TRY(hipStreamCreateWithFlags(&S.stream, hipStreamNonBlocking)); S.own_stream = true; }
+    if (c->depth > 1) {  // the slot's stream is non-blocking: order it behind whatever the caller has queued on its own stream (async uploads of the inputs)
         if (!S.ev_in) HIP_TRY(hipEventCreateWithFlags(&S.ev_in, hipEventDisableTiming));
-        HIP_TRY(hipEventRecord(S.ev_in, S.stream));
+        HIP_TRY(hipEventRecord(S.ev_in, c->stream));
         HIP_TRY(hipStreamWaitEvent(S.stream, S.ev_in, 0));
     }
     c->cur = k; c->view = k;
@@ -1228,7 +1229,10 @@ int mapad_index_build_gpu(const char* const* names, const uint8_t* const* seqs, 
         gpuidx::suffix_products(t.data(), idx->ix, device_id, vb && vb[0] == '1');
         *out = idx.release();
         return MAPAD_OK;
-    } catch (const std::bad_alloc&) { return MAPAD_ERR_NOMEM; } catch (const std::exception& e) {
+    } catch (const std::bad_alloc&) { return MAPAD_ERR_NOMEM; } catch (const std::length_error& e) {  // a documented limit of the GPU sorter: mapad_index_build takes such texts
+        std::fprintf(stderr, "mapad_index_build_gpu: %s\n", e.what());
+        return MAPAD_ERR_UNSUPPORTED;
+    } catch (const std::exception& e) {
         std::fprintf(stderr, "mapad_index_build_gpu: %s\n", e.what());
         return MAPAD_ERR_PARSE;
     }
