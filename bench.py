@@ -407,8 +407,10 @@ def main():
             model = ["-f", "0.5", "-t", "0.5", "-d", "0.02", "-s", "1.0"] if args.config == "c3" else ["-f", "0", "-t", "0", "-d", "0", "-s", "0"]
             t = time.perf_counter()
             pr = subprocess.run([exe, "map", "-r", fq, "-g", fa, "-o", bam, "-l", "single_stranded", "-p", "0.03", "-D", "0.02", "-i", "0.001", "-x", "1.0",
-                                 "--batch_size", "250000", "--force_overwrite"] + model, stderr=subprocess.PIPE, text=True, check=True)
+                                 "--batch_size", "250000", "--force_overwrite"] + model, stderr=subprocess.PIPE, text=True)
             t_map = time.perf_counter() - t
+            if pr.returncode != 0:
+                raise RuntimeError(f"mapad-amd map exited with {pr.returncode}: {pr.stderr[-400:]}")
             m = re.search(r"(\d+) reads, (\d+) mapped; (\d+) device\(s\); index \+ contexts ([0-9.]+) s, mapping ([0-9.]+) s", pr.stderr)
             cli = {"reads_per_s": round(n_cli / float(m.group(5)), 1), "reads": n_cli, "mapping_s": float(m.group(5)), "index_load_and_contexts_s": float(m.group(4)),
                    "process_wall_s": round(t_map, 2), "mapped": int(m.group(2)), "bam_bytes": os.path.getsize(bam), "index_files_s": round(t_idx, 2), "index_files": idx_how,

@@ -42,17 +42,23 @@ namespace mapad { namespace gpuidx { void suffix_products(const uint8_t* t_host,
 namespace {
 
 enum : uint32_t { ST_POOL_OVERFLOW = 4, ST_NO_TABLE = 8 };
-// Launches over a batch: stage 0 maps every read from a per-slot base arena that GROWS on demand (size classes below; the grown arena
-// goes back to its pool when the read ends); stages 1-2 restart the reads that gave up waiting for an arena; the last stage re-runs,
-// with the reference's full limits, reads that no size class could hold.
+// Launches over a batch (all on the batch's stream):
+//   Q0  search_kernel, every read: one quad per read, a per-slot base arena that GROWS on demand (size classes below).  A read that has outgrown
+//       its base arena is HEAVY: its state moves into the grown arena and the read is suspended (HeavyItem) — the quad takes its next read.
+//   H0  heavy_kernel: one WAVEFRONT per suspended read continues it where the quad stopped (heap levels 0-9 in LDS, the deep levels of a sift
+//       fetched speculatively across the lanes, all children of a frame scored lane-parallel; heavy_kernel.hpp).
+//   Q1  search_kernel again over the reads that gave up waiting for an arena in Q0 (normally none: the launch exits at once), H1 its suspended reads.
+//   F   heavy_kernel from scratch, with arenas that hold the reference's full limits (STACK_LIMIT / EDIT_TREE_LIMIT, mapping.rs:52-54), for the reads
+//       that no size class could hold.
 constexpr int kTiers = 2;   // arena pools: growable base arenas, full-limit arenas
-constexpr int kStages = 4;  // launches over a batch: every read; two retries of reads that gave up waiting for an arena; full limits
-constexpr int kClasses = 10;  // grown arenas: 2x steps above the base arena (8 Ki nodes -> 16 Ki ... 4 Mi), the last one with the full limits
+constexpr int kStages = 3;  // hand-over lists: Q0 -> Q1 -> F
+constexpr int kClasses = 10;  // grown arenas: 2x steps above the base arena (16 Ki nodes -> 32 Ki ... ), the last one with the full limits
 constexpr int kKeyBins = kMaxReadLen + 2;
-// cursors (u32 words): global bump allocators and work counters; per pass t: CUR_WORK + 2t = next work item, CUR_OVF + 2t = reads pass t
+// cursors (u32 words): global bump allocators and work counters; per stage t: CUR_WORK + 2t = next work item, CUR_OVF + 2t = reads stage t
 // handed on.  The two pool cursors are 64-bit (words 0-1 and 2-3): a batch may ask for more than 2^32 op words, which must show up as a pool
 // overflow, not wrap around.
-enum { CUR_HITS = 0, CUR_OPS = 2, CUR_POOL_OVF = 4, CUR_ERR = 5, CUR_WORK = 6, CUR_OVF = 7, CUR_GROWN = 6 + 2 * kStages, CUR_COUNT = 6 + 2 * kStages + 4 };
+enum { CUR_HITS = 0, CUR_OPS = 2, CUR_POOL_OVF = 4, CUR_ERR = 5, CUR_WORK = 6, CUR_OVF = 7, CUR_GROWN = 6 + 2 * kStages, CUR_HEAVY_N = CUR_GROWN + 4 /* per quad stage */, CUR_HEAVY_WORK = CUR_GROWN + 6 /* per heavy stage */,
+       CUR_HEAVY_POPS = CUR_GROWN + 8 /* 64-bit */, CUR_COUNT = CUR_GROWN + 10 };
 inline uint64_t cur64(const uint32_t* cur, int k) { return (uint64_t)cur[k] | ((uint64_t)cur[k + 1] << 32); }
 
 struct BatchDev {
@@ -75,7 +81,16 @@ struct BatchDev {
     uint32_t order_shift;     // log2 of the chunk size: reads are ordered inside chunks of 2^order_shift consecutive reads
     uint32_t* order;          // [n_reads] read ids, most expensive class first (nullptr: in input order)
     unsigned long long* prof; // -DMAPAD_PROFILE_SECTIONS builds: section cycle sums (else nullptr)
+    struct HeavyItem* heavy;  // [2][heavy_cap] reads suspended by the two quad stages, continued by heavy_kernel (one wavefront each)
+    uint32_t heavy_cap;
 };
+
+// A read that has outgrown its base arena, as the quad stage leaves it: everything else (heap, nodes, hit staging) is in the grown arena.
+struct HeavyItem {
+    uint32_t read, grown;  // grown: (class + 1) << kGrownShift | arena index
+    SearchState st;
+};
+static_assert(sizeof(HeavyItem) == 72, "heavy item layout");
 
 struct ArenaPool {
     uint8_t* base;
@@ -95,8 +110,12 @@ struct GrowPools {
     uint8_t* base[kClasses];
     uint32_t* owner[kClasses];  // [count] 0 = free
     uint64_t stride[kClasses], off_nodes[kClasses];
+    uint64_t off_hits[kClasses], off_hit_ops[kClasses], off_scratch[kClasses];  // hit staging of a suspended (heavy) read: it leaves its slot's base arena behind
     uint32_t heap_cap[kClasses], node_cap[kClasses], count[kClasses];
+    uint32_t hit_ops_cap;
     uint32_t max_waits;  // fruitless requests (x 64 steps sat out each) after which a read of the first stages gives up and is restarted later
+    uint32_t heavy_min_class;  // a read that grows into this class or beyond is handed to heavy_kernel (kClasses: never)
+    uint32_t heavy_max_pending;  // ... unless this many reads of the launch are suspended already (each holds a grown arena)
 };
 constexpr uint32_t kGrownShift = 27;
 
@@ -274,10 +293,13 @@ __global__ void __launch_bounds__(256) records_kernel(PostIndex Q, const uint64_
 #endif
 
 template <int LPR>
-__device__ __forceinline__ uint32_t group_bcast(uint32_t v) { return LPR == 4 ? dpp_quad<0>(v) : v; }
+__device__ __forceinline__ uint32_t group_bcast(uint32_t v) {  // value of the group's first lane (64: the wavefront's first active lane)
+    if constexpr (LPR == 64) return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+    else return LPR == 4 ? dpp_quad<0>(v) : v;
+}
 
-template <int LPR, bool NL>
-__device__ MAPAD_FINALIZE_ATTR void finalize_read(const BatchDev B, const ReadInT<NL> rd, const ArenaT<NL> A, const SearchState st, uint32_t read, int w, int tier) {
+template <int LPR, bool NL, int TOP>
+__device__ MAPAD_FINALIZE_ATTR void finalize_read(const BatchDev B, const ReadInT<NL> rd, const ArenaT<NL, TOP> A, const SearchState st, uint32_t read, int w, int tier) {
     if (st.status == ST_ARENA_OVERFLOW && tier + 1 < kStages) {  // hand the read to the next stage
         if (w == 0) {
             const uint32_t k = atomicAdd(&B.cursors[CUR_OVF + 2 * tier], 1u);
@@ -348,14 +370,16 @@ __device__ __forceinline__ void release_set(const ArenaPool& ap, uint32_t set) {
     if ((threadIdx.x & 63) == 0) atomicExch(&ap.set_owner[set], 0u);
 }
 
+// `foreign`: this wavefront is not on the XCD whose part of a partitioned pool the arena belongs to (a heavy wavefront that continues a read a
+// quad on another XCD suspended): its stores sit in another L2 and must be written back like those to a shared pool's arena.
 template <int LPR>
-__device__ __forceinline__ void release_grown(const GrowPools* gp, uint32_t grown, int w) {
+__device__ __forceinline__ void release_grown(const GrowPools* gp, uint32_t grown, int w, bool foreign = false) {
     const uint32_t cls = (grown >> kGrownShift) - 1;
     // A partitioned pool's arena stays behind one L2, so no write-back is needed, but the old owner's stores must have COMPLETED (reached
     // that L2) before the owner word is cleared: a workgroup-scope fence emits nothing on gfx950, hence the explicit wait.
     // Shared pools: every access has completed and is written back before another XCD may take the arena; the explicit wait after the
     // fence keeps the compiler from dropping the one that orders the owner word behind the write-back.
-    if (gp->count[cls] < kPartitionMin) __threadfence();
+    if (foreign || gp->count[cls] < kPartitionMin) __threadfence();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (w == 0) atomicExch(&gp->owner[cls][grown & ((1u << kGrownShift) - 1)], 0u);
 }
@@ -370,14 +394,15 @@ __device__ __forceinline__ void copy_units(MAPAD_GLOBAL uint4* dst, const MAPAD_
     for (; i < end; i += LPR) dst[i] = src[i];
 }
 
-template <int LPR, bool NL>
+template <int LPR, bool NL, int TOP = kTop, bool HITS = false>
 struct DeviceGrow {
     const GrowPools* gp;
     uint32_t* grown_counter;
     uint32_t slot;
     int w;
     bool may_give_up;
-    __device__ __forceinline__ int operator()(ArenaT<NL>& A, const SearchState& st) const {
+    mutable bool foreign = false;  // HITS: the arena the read is in now was taken by a wavefront on another XCD (release_grown)
+    __device__ __forceinline__ int operator()(ArenaT<NL, TOP>& A, const SearchState& st) const {
         if (A.wait) { A.wait -= 1; return GROW_WAIT; }
         const uint32_t first = A.grown >> kGrownShift;  // first class to try (0 = from the base arena); a dry class falls through to the next
         uint32_t cls = first;
@@ -405,8 +430,9 @@ struct DeviceGrow {
         if (idx == ~0u) {
             if (!exists) return GROW_NEVER;  // no class can hold this read: it goes to the full-limit pass
             // only reads that are still small give up (cheap to restart, and it is the many mid-size reads that clog the big pools);
-            // a read that already fills a large arena keeps waiting for the few larger ones
-            if (may_give_up && first < 4 && ++A.n_waits > gp->max_waits) return GROW_NEVER;
+            // a read that already fills a large arena keeps waiting for the few larger ones.  With the heavy path every waiting read may give up:
+            // the arenas it waits for can be held by SUSPENDED reads, which only move again in the next launch (heavy_kernel.hpp).
+            if (may_give_up && (first < 4 || gp->heavy_min_class < (uint32_t)kClasses) && ++A.n_waits > gp->max_waits) return GROW_NEVER;
             A.wait = 64;                     // every suitable arena is taken: its owners finish and give it back
             if (w == 0) atomicAdd(grown_counter + 2, 1u);
             return GROW_WAIT;
@@ -416,22 +442,49 @@ struct DeviceGrow {
         uint8_t* b = gp->base[cls] + (uint64_t)idx * gp->stride[cls];
         MAPAD_GLOBAL HeapEntry* nheap = (MAPAD_GLOBAL HeapEntry*)(b) + 1;
         MAPAD_GLOBAL Node* nnodes = (MAPAD_GLOBAL Node*)(b + gp->off_nodes[cls]);
-        // migrate heap slots [kTop, heap_len) (the top of the heap lives in the near array) and nodes [0, tree_entries)
+        // migrate heap slots [TOP, heap_len) (the top of the heap lives in the near array) and nodes [0, tree_entries)
         // (16-byte units, four loads in flight per lane: the other reads of the wavefront wait for this copy)
         {
             const MAPAD_GLOBAL uint4* hs = (const MAPAD_GLOBAL uint4*)(A.heap - 1);  // physical slot 0 is 16-byte aligned
             MAPAD_GLOBAL uint4* hd = (MAPAD_GLOBAL uint4*)(nheap - 1);
-            const uint32_t h_end = (st.heap_len + 2) >> 1;  // pairs covering physical slots [kTop + 1, heap_len + 1)
-            copy_units<LPR>(hd, hs, (kTop + 1) >> 1, h_end, w);
+            const uint32_t h_end = (st.heap_len + 2) >> 1;  // pairs covering physical slots [TOP + 1, heap_len + 1)
+            copy_units<LPR>(hd, hs, (TOP + 1) >> 1, h_end, w);
             copy_units<LPR>((MAPAD_GLOBAL uint4*)nnodes, (const MAPAD_GLOBAL uint4*)A.nodes, 0, 2 * st.tree_entries, w);
         }
-        if (A.grown) release_grown<LPR>(gp, A.grown, w);
+        if constexpr (HITS) {  // the hit staging travels with the read
+            MAPAD_GLOBAL HitRec* nhits = (MAPAD_GLOBAL HitRec*)(b + gp->off_hits[cls]);
+            MAPAD_GLOBAL uint32_t* nops = (MAPAD_GLOBAL uint32_t*)(b + gp->off_hit_ops[cls]);
+            for (uint32_t i = w; i < st.n_hits * 10u; i += LPR) ((MAPAD_GLOBAL uint32_t*)nhits)[i] = ((const MAPAD_GLOBAL uint32_t*)A.hits)[i];
+            for (uint32_t i = w; i < st.hit_ops_used; i += LPR) nops[i] = A.hit_ops[i];
+            A.hits = nhits; A.hit_ops = nops; A.scratch = (MAPAD_GLOBAL uint16_t*)(b + gp->off_scratch[cls]);
+        }
+        if (A.grown) release_grown<LPR>(gp, A.grown, w, foreign);
         A.heap = nheap; A.nodes = nnodes; A.heap_cap = gp->heap_cap[cls]; A.node_cap = gp->node_cap[cls];
         A.grown = ((cls + 1) << kGrownShift) | idx;
+        foreign = false;  // taken from this XCD's part of the pool
         if (w == 0) atomicAdd(grown_counter, 1u);
         return GROW_OK;
     }
 };
+
+// A quad hands its read to heavy_kernel: heap top (near array) -> logical slots [0, kTop) of the grown arena's heap, hit staging (base arena) ->
+// the grown arena's hit area, search state -> a HeavyItem.  The item is read by a later launch on the same stream.
+template <int LPR, bool NL>
+__device__ __forceinline__ void suspend_heavy(const BatchDev& B, const GrowPools* gp, const ArenaT<NL>& A, const SearchState& st, uint32_t read, int w, int tier) {
+    const uint32_t cls = (A.grown >> kGrownShift) - 1, idx = A.grown & ((1u << kGrownShift) - 1);
+    uint8_t* b = gp->base[cls] + (uint64_t)idx * gp->stride[cls];
+    const uint32_t n_top = st.heap_len < (uint32_t)kTop ? st.heap_len : (uint32_t)kTop;
+    for (uint32_t i = w; i < n_top; i += LPR) store_entry(A.heap + i, load_entry(A.top + i));
+    MAPAD_GLOBAL uint32_t* nhits = (MAPAD_GLOBAL uint32_t*)(b + gp->off_hits[cls]);
+    MAPAD_GLOBAL uint32_t* nops = (MAPAD_GLOBAL uint32_t*)(b + gp->off_hit_ops[cls]);
+    for (uint32_t i = w; i < st.n_hits * 10u; i += LPR) nhits[i] = ((const MAPAD_GLOBAL uint32_t*)A.hits)[i];
+    for (uint32_t i = w; i < st.hit_ops_used; i += LPR) nops[i] = A.hit_ops[i];
+    if (w == 0) {
+        const uint32_t k = atomicAdd(&B.cursors[CUR_HEAVY_N + tier], 1u);
+        if (k < B.heavy_cap) { HeavyItem it; it.read = read; it.grown = A.grown; it.st = st; B.heavy[(size_t)tier * B.heavy_cap + k] = it; }
+        else atomicOr(&B.cursors[CUR_ERR], ST_ARENA_OVERFLOW);  // cannot happen: a suspended read holds a grown arena, and the list has room for all of them
+    }
+}
 
 // PASS 0: every read, growable arenas (PASS 2: the same code for the retry launches).  PASS 1: the reads that no size class could
 // hold, arenas with the reference's full limits.
@@ -462,7 +515,7 @@ __global__ void __launch_bounds__(64, (LPR == 1 && NL) ? 1 : MAPAD_MIN_WAVES) se
     const uint32_t* items = B.overflow_list + (size_t)(tier > 0 ? tier - 1 : 0) * B.n_reads;
     // reads of the first stages give up after kMaxWaits fruitless waits for an arena and are restarted by the next stage, when the
     // pools are quiet; the last growable stage waits as long as it takes
-    const DeviceGrow<LPR, NL> grow{GP, &B.cursors[CUR_GROWN], slot, w, stage + 2 < kStages};
+    const DeviceGrow<LPR, NL> grow{GP, &B.cursors[CUR_GROWN], slot, w, stage + 2 < kStages || GP->heavy_min_class < (uint32_t)kClasses};
 #if defined(MAPAD_PROFILE_SECTIONS)
     if (lane < 2 * PROF_N + 2) g_prof_lds[lane] = 0;
     g_prof_hist[lane] = 0;
@@ -507,7 +560,7 @@ __global__ void __launch_bounds__(64, (LPR == 1 && NL) ? 1 : MAPAD_MIN_WAVES) se
             else cont = search_step<LPR, CONT, NL>(ix, P, rd, A, st, w, NoGrow());
             MAPAD_MARK(PROF_TAIL);
             if (!cont) {
-                finalize_read<LPR, NL>(B, rd, A, st, read, w, tier);
+                finalize_read<LPR>(B, rd, A, st, read, w, tier);
                 if (PASS != 1 && A.grown) {  // give the grown arena back; the next read starts in the base arena again
                     release_grown<LPR>(GP, A.grown, w);
                     const ArenaT<NL> base = carve<NL>(AP, slot);
@@ -516,6 +569,17 @@ __global__ void __launch_bounds__(64, (LPR == 1 && NL) ? 1 : MAPAD_MIN_WAVES) se
                 have = false;
                 drain_memory();
                 MAPAD_MARK(PROF_FINALIZE);
+            } else if (PASS != 1 && MAPAD_UNLIKELY(A.grown != 0)) {
+                // The read has outgrown its base arena: it is heavy.  Its state goes into the grown arena (heap top from the near array, hit staging
+                // from the base arena), the read is queued for heavy_kernel — a wavefront of its own — and this quad takes its next read.
+                // (a suspended read keeps its grown arena until the heavy stage has finished it: no more of them than the pools can spare)
+                if ((A.grown >> kGrownShift) - 1 >= GP->heavy_min_class && *(volatile uint32_t*)&B.cursors[CUR_HEAVY_N + tier] < GP->heavy_max_pending) {
+                    suspend_heavy<LPR>(B, GP, A, st, read, w, tier);
+                    const ArenaT<NL> base = carve<NL>(AP, slot);
+                    A.heap = base.heap; A.nodes = base.nodes; A.heap_cap = base.heap_cap; A.node_cap = base.node_cap; A.grown = 0;
+                    have = false;
+                }
+                drain_memory();
             }
         }
     }
@@ -526,6 +590,8 @@ __global__ void __launch_bounds__(64, (LPR == 1 && NL) ? 1 : MAPAD_MIN_WAVES) se
     if (PASS == 0 && B.prof) atomicAdd(&B.prof[2 * PROF_N + lane], (unsigned long long)g_prof_hist[lane]);
 #endif
 }
+
+#include "heavy_kernel.hpp"
 
 // ---- order-preserving collect (mapping.rs:288) on the device ------------------------------------------------------------------
 // The search writes a read's hits wherever the bump cursors stood when the read finished.  These three kernels lay hits and edit
@@ -687,6 +753,7 @@ struct BatchSlot {
     DevBuf<ReadCounters> d_counters;
     DevBuf<uint32_t> d_status, d_hit_count, d_hit_first, d_ops, d_cursors, d_overflow, d_sort_key, d_key_hist, d_order;
     DevBuf<HitRec> d_hits;
+    DevBuf<HeavyItem> d_heavy;
     // read-ordered results (compact_* kernels)
     DevBuf<uint64_t> d_c_hit_begin, d_c_ops_begin;
     DevBuf<unsigned long long> d_c_tiles;
@@ -704,7 +771,7 @@ struct BatchSlot {
     void release() {
         d_seqs.release(); d_quals.release(); d_offsets.release(); d_darr.release(); d_counters.release(); d_status.release(); d_hit_count.release();
         d_hit_first.release(); d_ops.release(); d_cursors.release(); d_overflow.release(); d_sort_key.release(); d_key_hist.release(); d_order.release();
-        d_hits.release();
+        d_hits.release(); d_heavy.release();
         d_c_hit_begin.release(); d_c_ops_begin.release(); d_c_tiles.release(); d_c_hits.release(); d_c_ops.release();
         for (auto& e : ev) if (e) { (void)hipEventDestroy(e); e = nullptr; }
         if (ev_in) { (void)hipEventDestroy(ev_in); ev_in = nullptr; }
@@ -736,6 +803,7 @@ struct mapad_ctx {
     ArenaPool pool[kTiers] = {};
     uint32_t slots[kTiers] = {0, 0}, arena_lmax = 0;  // read slots of a tier = its wave sets x reads per wavefront
     uint32_t resident_waves = 0;                      // wavefronts of the search kernel the chip holds at once
+    uint32_t heavy_cap = 64;                          // suspended reads a batch can have at most (= grown arenas)
     uint64_t arena_reads = 0;
     DevBuf<uint8_t> d_arena[kTiers];
     DevBuf<uint32_t> d_set_owner[kTiers];
@@ -842,12 +910,12 @@ int ensure_arenas(mapad_ctx* c, BatchSlot& S, uint32_t lmax, uint64_t n_reads) {
         const uint64_t per_xcd_need = (need_waves * (uint64_t)std::min(c->depth, 4) + 7) / 8 + 4;  // small batches (tests): no more than they can use
         n_sets[0] = 8 * (uint32_t)std::max<uint64_t>(std::min(per_xcd_full, per_xcd_need), kPartitionMin / 8);
     }
-    {   // pass 1: full limits
+    {   // last stage: full limits, one arena per heavy wavefront (owner word per arena, shared by all XCDs)
         c->pool[1] = make_pool_layout((uint32_t)stack_cap, (uint32_t)tree_cap, hit_ops_cap, lm);
-        n_sets[1] = std::min<uint32_t>(std::max<uint32_t>(env_u32("MAPAD_LAST_PASS_WAVES", 1), 1), kPartitionMin - 1);  // shared by all XCDs
+        n_sets[1] = std::max<uint32_t>(env_u32("MAPAD_LAST_PASS_ARENAS", 16), 1);
     }
     for (int t = 0; t < kTiers; ++t) {
-        c->slots[t] = n_sets[t] * rpw;
+        c->slots[t] = t == 0 ? n_sets[t] * rpw : n_sets[t];
         if ((rc = c->d_arena[t].ensure((size_t)c->slots[t] * c->pool[t].stride, true))) return rc;
         if ((rc = c->d_set_owner[t].ensure(n_sets[t]))) return rc;
         HIP_TRY(hipMemsetAsync(c->d_set_owner[t].p, 0, (size_t)n_sets[t] * 4, S.stream));
@@ -877,7 +945,10 @@ int ensure_arenas(mapad_ctx* c, BatchSlot& S, uint32_t lmax, uint64_t n_reads) {
         g.node_cap[k] = (uint32_t)std::min<uint64_t>(nodes, tree_cap);
         auto align = [](uint64_t x) { return (x + 127) & ~127ull; };
         g.off_nodes[k] = align(((uint64_t)g.heap_cap[k] + 16) * sizeof(HeapEntry));
-        g.stride[k] = align(g.off_nodes[k] + (uint64_t)g.node_cap[k] * sizeof(Node));
+        g.off_hits[k] = align(g.off_nodes[k] + (uint64_t)g.node_cap[k] * sizeof(Node));  // hit staging of a suspended read (heavy_kernel.hpp)
+        g.off_hit_ops[k] = align(g.off_hits[k] + (uint64_t)kMaxHits * sizeof(HitRec));
+        g.off_scratch[k] = align(g.off_hit_ops[k] + (uint64_t)hit_ops_cap * 4);
+        g.stride[k] = align(g.off_scratch[k] + 2ull * (lm + 1) * 2);
         // a class that is no bigger than the previous one (tiny semantic limits) is pointless: give it no arenas
         const bool useful = g.node_cap[k] > (k ? g.node_cap[k - 1] : c->pool[0].node_cap) || g.heap_cap[k] > (k ? g.heap_cap[k - 1] : c->pool[0].heap_cap);
         g.count[k] = useful ? std::min<uint32_t>(counts[k], (1u << kGrownShift) - 1) : 0;
@@ -906,6 +977,15 @@ int ensure_arenas(mapad_ctx* c, BatchSlot& S, uint32_t lmax, uint64_t n_reads) {
         g.owner[k] = c->d_owner[k].p;
     }
     g.max_waits = env_u32("MAPAD_MAX_WAITS", 64);
+    g.hit_ops_cap = hit_ops_cap;
+    g.heavy_min_class = env_u32("MAPAD_HEAVY", 1) ? env_u32("MAPAD_HEAVY_MIN_CLASS", 0) : (uint32_t)kClasses;  // MAPAD_HEAVY=0: reads stay with their quad (the round-2 behaviour)
+    c->heavy_cap = 64;
+    for (int k = 0; k < kClasses; ++k) c->heavy_cap += g.count[k];  // a suspended read holds a grown arena
+    {   // suspended reads wait for the heavy stage with their arenas: they may take three quarters of the class most of them are in
+        uint32_t first = 0;
+        for (int k = (int)std::min<uint32_t>(g.heavy_min_class, kClasses - 1); k < kClasses; ++k) if (g.count[k]) { first = g.count[k]; break; }
+        g.heavy_max_pending = env_u32("MAPAD_HEAVY_MAX_PENDING", std::max<uint32_t>(4, first / 4 * 3 / (uint32_t)std::min(c->depth, 4)));  // the pools are shared by the batches in flight
+    }
     if ((rc = c->d_grow.ensure(1))) return rc;
     HIP_TRY(hipMemcpyAsync(c->d_grow.p, &c->grow, sizeof(GrowPools), hipMemcpyHostToDevice, S.stream));
     HIP_TRY(hipStreamSynchronize(S.stream));
@@ -964,6 +1044,7 @@ int ensure_batch_buffers(mapad_ctx* c, BatchSlot& S, uint64_t n_reads, uint64_t 
         if ((rc = S.d_key_hist.ensure((size_t)n_chunks * kKeyBins))) return rc;
     }
     if ((rc = S.d_cursors.ensure(CUR_COUNT))) return rc;
+    if ((rc = S.d_heavy.ensure(2 * (size_t)c->heavy_cap))) return rc;
     // 2 hits per read on average + slack; MAPAD_HIT_POOL (test hook) starts smaller so that the retry of mapad_map_batch is exercised
     const size_t hits_cap = std::max(S.d_hits.cap, (size_t)env_u32("MAPAD_HIT_POOL", (uint32_t)std::min<size_t>(2 * nr + 1024, 0xFFFFFFFFu)));
     const size_t ops_cap = std::max(S.d_ops.cap, hits_cap * (size_t)(std::min<uint32_t>(lmax, 256) + 8));
@@ -994,6 +1075,7 @@ int launch_batch(mapad_ctx* c, BatchSlot& S, const uint8_t* d_seqs, const uint8_
     B.cursors = S.d_cursors.p; B.overflow_list = S.d_overflow.p;
     B.sort_key = ordered ? S.d_sort_key.p : nullptr; B.key_hist = ordered ? S.d_key_hist.p : nullptr; B.order = ordered ? S.d_order.p : nullptr;
     B.order_shift = order_shift;
+    B.heavy = S.d_heavy.p; B.heavy_cap = c->heavy_cap;
 #if defined(MAPAD_PROFILE_SECTIONS)
     if ((rc = c->d_prof.ensure(2 * PROF_N + 64))) return rc;
     HIP_TRY(hipMemsetAsync(c->d_prof.p, 0, (2 * PROF_N + 64) * 8, S.stream));
@@ -1040,27 +1122,35 @@ int launch_batch(mapad_ctx* c, BatchSlot& S, const uint8_t* d_seqs, const uint8_
     for (auto& o : c->bs) if (&o != &S && o.ev_valid && hipEventQuery(o.ev[3]) == hipErrorNotReady) others_running = true;
     const uint32_t full_waves = c->resident_waves, shared_waves = std::max<uint32_t>(1, std::min<uint32_t>(full_waves, env_u32("MAPAD_SHARED_WAVES_PER_CU", 8) * (uint32_t)c->n_cu));
     const uint32_t grid_s = warm ? 1u : (uint32_t)std::min<uint64_t>((n_reads + rpw - 1) / rpw, others_running ? shared_waves : full_waves);
-    for (int stage = 0; stage + 1 < kStages; ++stage) {  // every read, then the reads that gave up waiting (normally none: the launch exits at once)
+    // heavy wavefronts: as many as the chip holds (LDS: heap levels 0-9 + the read's position data); a wavefront that finds no work exits at once
+    const uint32_t heavy_lds = heavy_lds_bytes(near_lmax);
+    const uint32_t heavy_per_cu = std::max<uint32_t>(1, std::min<uint32_t>(env_u32("MAPAD_HEAVY_WAVES_PER_CU", 8), (160u * 1024u) / heavy_lds));
+    const uint32_t grid_h = warm ? 1u : std::min<uint32_t>(c->heavy_cap, heavy_per_cu * (uint32_t)c->n_cu);
+#define MAPAD_LAUNCH_HEAVY(M, GRID, AP, TIER)                                                                                                                         \
+    if (!cont) hipLaunchKernelGGL((heavy_kernel<false, M>), dim3(GRID), dim3(64), heavy_lds, S.stream, c->dix, c->dprm, B, AP, c->d_grow.p, near_lmax, TIER);      \
+    else hipLaunchKernelGGL((heavy_kernel<true, M>), dim3(GRID), dim3(64), heavy_lds, S.stream, c->dix, c->dprm, B, AP, c->d_grow.p, near_lmax, TIER);
+    for (int stage = 0; stage + 1 < kStages; ++stage) {  // Q0 + H0: every read; Q1 + H1: the reads that gave up waiting (normally none: the launches exit at once)
         const uint32_t grid = grid_s;
         const ArenaPool ap = c->pool[0];
         if (stage == 0) { MAPAD_LAUNCH_PASS(0) } else { MAPAD_LAUNCH_PASS(2) }  // PASS 2 = PASS 0 under its own symbol, so that profiles keep the passes apart
+        MAPAD_LAUNCH_HEAVY(0, grid_h, ap, stage)
         HIP_TRY(hipGetLastError());
     }
     if (!warm) HIP_TRY(hipEventRecord(S.ev[2], S.stream));
-    {   // leftovers with the reference's full limits
-        const int stage = kStages - 1;
-        const uint32_t grid = warm ? 1u : (uint32_t)std::min<uint64_t>((n_reads + rpw - 1) / rpw, c->slots[1] / rpw);
+    {   // leftovers with the reference's full limits: heavy wavefronts from scratch
+        const uint32_t grid = warm ? 1u : (uint32_t)std::min<uint64_t>(n_reads, c->slots[1]);
         const ArenaPool ap = c->pool[1];
-        MAPAD_LAUNCH_PASS(1)
+        MAPAD_LAUNCH_HEAVY(1, grid, ap, kStages - 1)
         HIP_TRY(hipGetLastError());
     }
+#undef MAPAD_LAUNCH_HEAVY
 #undef MAPAD_LAUNCH_PASS
 #undef MAPAD_LAUNCH
     if (warm) return MAPAD_OK;
     HIP_TRY(hipEventRecord(S.ev[3], S.stream));
     S.ev_valid = true; S.timed = false;
     S.launch_info[0] = grid_d; S.launch_info[1] = 64; S.launch_info[2] = (uint32_t)lds_bytes;
-    S.launch_info[3] = grid_s; S.launch_info[4] = 64; S.launch_info[5] = c->slots[1] / rpw;
+    S.launch_info[3] = grid_s; S.launch_info[4] = 64; S.launch_info[5] = c->slots[1];
     S.launch_info[6] = c->pool[0].node_cap; S.launch_info[7] = (uint32_t)(c->pool[0].stride >> 10);
     return MAPAD_OK;
 }

@@ -154,10 +154,12 @@ enum : uint32_t { ST_OK = 0, ST_ARENA_OVERFLOW = 1, ST_LIMIT_ABORT = 2 };
 template <class T, bool NL> struct near_ptr { using type = T*; };
 template <class T> struct near_ptr<T, true> { using type = MAPAD_LDS T*; };
 
-template <bool NL>
+// TOP = logical heap slots kept in the near array (2^k - 1): 63 for a quad's read slot, 1023 for a read that has a wavefront to itself (heavy_core.hpp)
+template <bool NL, int TOP = kTop>
 struct ArenaT {
-    typename near_ptr<HeapEntry, NL>::type top;  // logical heap slots [0, kTop), shifted by one entry like `heap`
-    MAPAD_GLOBAL HeapEntry* heap;    // logical heap slots [kTop, ..) are used from here
+    static constexpr int kTopN = TOP;
+    typename near_ptr<HeapEntry, NL>::type top;  // logical heap slots [0, TOP), shifted by one entry like `heap`
+    MAPAD_GLOBAL HeapEntry* heap;    // logical heap slots [TOP, ..) are used from here
     MAPAD_GLOBAL Node* nodes;
     MAPAD_GLOBAL HitRec* hits;       // kMaxHits
     MAPAD_GLOBAL uint32_t* hit_ops;  // staging for the hits' edit tracks
@@ -214,15 +216,15 @@ __device__ __forceinline__ HeapPair load_pair(const MAPAD_LDS HeapEntry* p) {
 // the near/arena branches are merged the access would stay a flat_* instruction (vmcnt and lgkmcnt, no overlap with anything).
 template <class P> MAPAD_HD HeapEntry load_entry(P p) { HeapEntry e; e.score = p->score; e.node = p->node; return e; }
 template <class P> MAPAD_HD void store_entry(P p, const HeapEntry e) { p->score = e.score; p->node = e.node; }
-template <bool NL> MAPAD_HD HeapEntry hp_get(const ArenaT<NL>& A, uint32_t i) {
-    if (i < (uint32_t)kTop) return load_entry(A.top + i);
+template <bool NL, int TOP> MAPAD_HD HeapEntry hp_get(const ArenaT<NL, TOP>& A, uint32_t i) {
+    if (i < (uint32_t)TOP) return load_entry(A.top + i);
     return load_entry(A.heap + i);
 }
-template <bool NL> MAPAD_HD void hp_set(const ArenaT<NL>& A, uint32_t i, const HeapEntry e) {
-    if (i < (uint32_t)kTop) store_entry(A.top + i, e);
+template <bool NL, int TOP> MAPAD_HD void hp_set(const ArenaT<NL, TOP>& A, uint32_t i, const HeapEntry e) {
+    if (i < (uint32_t)TOP) store_entry(A.top + i, e);
     else store_entry(A.heap + i, e);
 }
-template <bool NL> MAPAD_HD HeapPair hp_pair(const ArenaT<NL>& A, uint32_t i) { if (i < (uint32_t)kTop) return load_pair(A.top + i); return load_pair(A.heap + i); }
+template <bool NL, int TOP> MAPAD_HD HeapPair hp_pair(const ArenaT<NL, TOP>& A, uint32_t i) { if (i < (uint32_t)TOP) return load_pair(A.top + i); return load_pair(A.heap + i); }
 
 struct SearchState {
     uint32_t c_esearch, c_push, c_pop, c_node, c_hits;  // event counters of the read (identical on the oracle: itself a parity check)
@@ -265,24 +267,24 @@ MAPAD_HD float flip_sign(float x, uint32_t mask) { return __builtin_bit_cast(flo
 // 98 % of all pushes (measured, C2/C3); their three possible slots are known from `pos` alone, so they are loaded together and the
 // dependent chain of a push is one memory round trip instead of two.
 struct Ancestors { HeapEntry e1, e2, e3; };  // parent, grandparent of pos, grandparent of the parent (slot 0 where there is none)
-template <bool NL>
-MAPAD_HD Ancestors load_ancestors(const ArenaT<NL>& A, uint32_t pos) {
+template <bool NL, int TOP>
+MAPAD_HD Ancestors load_ancestors(const ArenaT<NL, TOP>& A, uint32_t pos) {
     const uint32_t i1 = pos > 0 ? (pos - 1) >> 1 : 0, i2 = pos > 2 ? (pos - 3) >> 2 : 0, i3 = i1 > 2 ? (i1 - 3) >> 2 : 0;
     Ancestors a;  // i3 <= i2 <= i1
     // The read slots of a wavefront are at different heap sizes: a four-way branch on where the three entries live runs its cases one after
     // the other, each with its own wait for memory.  Here every slot reads the near array (index clamped into it) and only the arena loads
     // are predicated, back to back, so that a wavefront waits for memory once.
-    const uint32_t k1 = i1 < (uint32_t)kTop ? i1 : 0, k2 = i2 < (uint32_t)kTop ? i2 : 0, k3 = i3 < (uint32_t)kTop ? i3 : 0;
+    const uint32_t k1 = i1 < (uint32_t)TOP ? i1 : 0, k2 = i2 < (uint32_t)TOP ? i2 : 0, k3 = i3 < (uint32_t)TOP ? i3 : 0;
     const HeapEntry n1 = load_entry(A.top + k1), n2 = load_entry(A.top + k2), n3 = load_entry(A.top + k3);
     HeapEntry g1 = HeapEntry{0.0f, 0u}, g2 = HeapEntry{0.0f, 0u}, g3 = HeapEntry{0.0f, 0u};
-    if (i1 >= (uint32_t)kTop) g1 = load_entry(A.heap + i1);
-    if (i2 >= (uint32_t)kTop) g2 = load_entry(A.heap + i2);
-    if (i3 >= (uint32_t)kTop) g3 = load_entry(A.heap + i3);
-    a.e1 = i1 < (uint32_t)kTop ? n1 : g1; a.e2 = i2 < (uint32_t)kTop ? n2 : g2; a.e3 = i3 < (uint32_t)kTop ? n3 : g3;
+    if (i1 >= (uint32_t)TOP) g1 = load_entry(A.heap + i1);
+    if (i2 >= (uint32_t)TOP) g2 = load_entry(A.heap + i2);
+    if (i3 >= (uint32_t)TOP) g3 = load_entry(A.heap + i3);
+    a.e1 = i1 < (uint32_t)TOP ? n1 : g1; a.e2 = i2 < (uint32_t)TOP ? n2 : g2; a.e3 = i3 < (uint32_t)TOP ? n3 : g3;
     return a;
 }
-template <bool NL>
-MAPAD_HD void mm_bubble_up(const ArenaT<NL>& A, uint32_t pos, const HeapEntry elt, const Ancestors& an) {  // elt is the new element, destined for slot pos
+template <bool NL, int TOP>
+MAPAD_HD void mm_bubble_up(const ArenaT<NL, TOP>& A, uint32_t pos, const HeapEntry elt, const Ancestors& an) {  // elt is the new element, destined for slot pos
     // Both compares are evaluated unconditionally (slots that do not exist compare as "stay"): the three entries are then consumed on the main
     // path, where the compiler places the one wait for them, and the outcome is a store of elt plus at most two displaced entries.
     const uint32_t i1 = pos > 0 ? (pos - 1) >> 1 : 0;   // parent
@@ -320,8 +322,8 @@ MAPAD_HD void mm_bubble_up(const ArenaT<NL>& A, uint32_t pos, const HeapEntry el
     } else pos = pos1;
     hp_set(A, pos, elt);
 }
-template <bool NL>
-MAPAD_HD void mm_bubble_up(const ArenaT<NL>& A, uint32_t pos, const HeapEntry elt) { mm_bubble_up(A, pos, elt, load_ancestors(A, pos)); }
+template <bool NL, int TOP>
+MAPAD_HD void mm_bubble_up(const ArenaT<NL, TOP>& A, uint32_t pos, const HeapEntry elt) { mm_bubble_up(A, pos, elt, load_ancestors(A, pos)); }
 
 // The heap array is stored shifted by one entry (logical index i lives in physical slot i + 1; `v` points at logical 0), so the
 // two children of a node (logical 2p+1, 2p+2) form one 16-byte aligned pair and its four grandchildren (4p+3 .. 4p+6) one
@@ -331,8 +333,8 @@ MAPAD_HD void mm_bubble_up(const ArenaT<NL>& A, uint32_t pos, const HeapEntry el
 // (the arena has slack) but neutralised by an index test.
 // A sift that starts at slot 1 or 2 (every pop_max of a heap with more than two entries) takes its first two strides through levels 1-5, which
 // with kTop = 63 lie in the near array entirely: those strides run without the near / arena selection of the general stride.
-template <bool MAX, bool NL>
-MAPAD_HD void mm_trickle_down(const ArenaT<NL>& A, uint32_t n, uint32_t pos, HeapEntry elt) {
+template <bool MAX, bool NL, int TOP>
+MAPAD_HD void mm_trickle_down(const ArenaT<NL, TOP>& A, uint32_t n, uint32_t pos, HeapEntry elt) {
     bool going = true;
     // one stride: the hole moves to the best child or grandchild; false = the sift ends at `pos`
     auto stride = [&](const HeapPair& c, const HeapPair& ga, const HeapPair& gb, uint32_t c1, uint32_t g1, auto&& set) -> bool {
@@ -355,11 +357,12 @@ MAPAD_HD void mm_trickle_down(const ArenaT<NL>& A, uint32_t n, uint32_t pos, Hea
     };
     auto set_near = [&](uint32_t i, const HeapEntry e) { store_entry(A.top + i, e); };
     auto set_any = [&](uint32_t i, const HeapEntry e) { hp_set(A, i, e); };
-    if constexpr (kTop >= 63) {
+    if constexpr (TOP >= 63) {
+        constexpr int kNearStrides = TOP >= 1023 ? 4 : TOP >= 255 ? 3 : 2;  // strides that stay inside the near levels when the sift starts at slot 1 or 2
 #pragma unroll
-        for (int k = 0; k < 2; ++k) {
+        for (int k = 0; k < kNearStrides; ++k) {
             const uint32_t c1 = 2 * pos + 1, g1 = 2 * c1 + 1;
-            if (!(going & (c1 < n) & (g1 + 3 < (uint32_t)kTop))) break;  // levels below 5, or a sift that started deeper: the general loop
+            if (!(going & (c1 < n) & (g1 + 3 < (uint32_t)TOP))) break;  // levels below 5, or a sift that started deeper: the general loop
             going = stride(load_pair(A.top + c1), load_pair(A.top + g1), load_pair(A.top + g1 + 2), c1, g1, set_near);
         }
     }
@@ -367,7 +370,7 @@ MAPAD_HD void mm_trickle_down(const ArenaT<NL>& A, uint32_t n, uint32_t pos, Hea
         const uint32_t c1 = 2 * pos + 1, g1 = 2 * c1 + 1;
         HeapPair c, ga, gb;  // a level is entirely near or entirely in the arena
         {   // near reads for every slot (clamped), arena loads predicated and back to back: one wait per level for the whole wavefront
-            const bool c_near = c1 < (uint32_t)kTop, g_near = g1 + 3 < (uint32_t)kTop;
+            const bool c_near = c1 < (uint32_t)TOP, g_near = g1 + 3 < (uint32_t)TOP;
             const uint32_t kc = c_near ? c1 : 1u, kg = g_near ? g1 : 3u;  // clamped indices keep the 16-byte alignment of a pair (odd logical index)
             const HeapPair nc = load_pair(A.top + kc), nga = load_pair(A.top + kg), ngb = load_pair(A.top + kg + 2);
             HeapPair hc = HeapPair{}, hga = HeapPair{}, hgb = HeapPair{};
@@ -382,8 +385,8 @@ MAPAD_HD void mm_trickle_down(const ArenaT<NL>& A, uint32_t n, uint32_t pos, Hea
 
 // pop_max of the crate in two steps so that the caller can start loading the popped frame's node before the sift's stores:
 // mm_find_max() says which slot holds the maximum (slot 2 wins a tie between slots 1 and 2), mm_remove_at() removes it.
-template <bool NL>
-MAPAD_HD HeapEntry mm_find_max(const ArenaT<NL>& A, uint32_t n, uint32_t& idx) {
+template <bool NL, int TOP>
+MAPAD_HD HeapEntry mm_find_max(const ArenaT<NL, TOP>& A, uint32_t n, uint32_t& idx) {
     const HeapPair p = load_pair(A.top + 1);  // logical slots 1 and 2 (stale if n < 3, handled below)
     const HeapEntry first = A.top[0];
     // selects, not branches: n >= 3 -> the larger of slots 1 and 2 (slot 2 on a tie); n == 2 -> slot 1; n == 1 -> slot 0
@@ -395,14 +398,14 @@ MAPAD_HD HeapEntry mm_find_max(const ArenaT<NL>& A, uint32_t n, uint32_t& idx) {
     r.node = use_a ? p.a.node : use_b ? p.b.node : r.node;
     return r;
 }
-template <bool MAX, bool NL>
-MAPAD_HD void mm_remove_at(const ArenaT<NL>& A, uint32_t& n, uint32_t idx) {
+template <bool MAX, bool NL, int TOP>
+MAPAD_HD void mm_remove_at(const ArenaT<NL, TOP>& A, uint32_t& n, uint32_t idx) {
     const HeapEntry last = hp_get(A, n - 1);
     n -= 1;
     if (idx < n) mm_trickle_down<MAX>(A, n, idx, last);
 }
-template <bool NL>
-MAPAD_HD HeapEntry mm_pop_min(const ArenaT<NL>& A, uint32_t& n) {
+template <bool NL, int TOP>
+MAPAD_HD HeapEntry mm_pop_min(const ArenaT<NL, TOP>& A, uint32_t& n) {
     const HeapEntry item = A.top[0];
     mm_remove_at<false>(A, n, 0);
     return item;
@@ -562,8 +565,8 @@ MAPAD_HD void read_setup(const uint8_t* seq, const uint8_t* qual, const float* d
 MAPAD_HD int alignment_start_of(const DevParams& P, int L) { return P.start_at_end ? L : (L / 2); }  // find_alignment_start
 
 // The `len == pattern.len()` branch of check_and_push_stack_frame (mapping.rs:973-984): a finished alignment becomes a hit.
-template <bool NL>
-MAPAD_RARE void record_hit(const ReadInT<NL> rd, const ArenaT<NL> A, SearchState& st, int alignment_start, uint64_t lower, uint64_t lower_rev, uint64_t size,
+template <bool NL, int TOP>
+MAPAD_RARE void record_hit(const ReadInT<NL> rd, const ArenaT<NL, TOP> A, SearchState& st, int alignment_start, uint64_t lower, uint64_t lower_rev, uint64_t size,
                            float score, uint32_t id) {
     if (st.n_hits >= (uint32_t)kMaxHits) { st.status = ST_ARENA_OVERFLOW; return; }
     HitRec h;
@@ -591,8 +594,8 @@ struct NoGrow {
 // check_and_push_stack_frame (mapping.rs:932-987) for a child whose tree node `nd` is already packed.  On the device the quad
 // builds the <= 9 children of a frame lane-parallel (search_step); `store` says whether this lane owns the child and writes its node,
 // `owner` is the owning lane (the frame of a finished alignment is fetched from it).  Everything else is quad-uniform.
-template <int LPR, bool NL>
-MAPAD_HD void commit_child(const DevParams& P, const ReadInT<NL>& rd, ArenaT<NL>& A, SearchState& st, int alignment_start, float score, uint32_t ngaps, int len,
+template <int LPR, bool NL, int TOP>
+MAPAD_HD void commit_child(const DevParams& P, const ReadInT<NL>& rd, ArenaT<NL, TOP>& A, SearchState& st, int alignment_start, float score, uint32_t ngaps, int len,
                            const Node& nd, bool store, int owner) {
     if (st.n_hits > 0 && mb_reject_iterative(P, score, st.best_score)) return;
     if ((int)ngaps > P.max_num_gaps_open) return;
@@ -628,8 +631,8 @@ MAPAD_HD void commit_child(const DevParams& P, const ReadInT<NL>& rd, ArenaT<NL>
 }
 
 // Overflow recovery (mapping.rs:1371-1379): evict the worst frames and free their tree nodes.
-template <bool NL>
-MAPAD_RARE void evict_worst(const ArenaT<NL> A, SearchState& st, int64_t cnt) {
+template <bool NL, int TOP>
+MAPAD_RARE void evict_worst(const ArenaT<NL, TOP> A, SearchState& st, int64_t cnt) {
     for (int64_t i = 0; i < cnt; ++i) {
         if (st.heap_len == 0) break;
         const HeapEntry m = mm_pop_min(A, st.heap_len);
@@ -639,8 +642,8 @@ MAPAD_RARE void evict_worst(const ArenaT<NL> A, SearchState& st, int64_t cnt) {
 
 // k_mismatch_search (mapping.rs:1012-1383) after the D array has been computed, split into init / step so that a
 // persistent quad can fetch its next read as soon as the current one finishes.  `w` = lane index inside the quad.
-template <bool NL>
-MAPAD_RARE void search_init(uint64_t n_text, int alignment_start, const ReadInT<NL> rd, const ArenaT<NL> A, SearchState& st) {
+template <bool NL, int TOP>
+MAPAD_RARE void search_init(uint64_t n_text, int alignment_start, const ReadInT<NL> rd, const ArenaT<NL, TOP> A, SearchState& st) {
     st.c_esearch = 0; st.c_push = 0; st.c_pop = 0; st.c_node = 0; st.c_hits = 0;
     st.heap_len = 0; st.tree_entries = 0; st.tree_next = 0; st.tree_len = 0; st.n_hits = 0; st.hit_ops_used = 0; st.status = ST_OK;
     st.best_score = 0.0f; st.best_size = 0;
@@ -654,8 +657,8 @@ MAPAD_RARE void search_init(uint64_t n_text, int alignment_start, const ReadInT<
 }
 
 // One iteration of the `while let Some(stack_frame) = stack.pop_max()` loop.  Returns false when the search is over.
-template <int LPR, bool CONT, bool NL, class Grow>
-MAPAD_HD bool search_step(const DevIndex& ix, const DevParams& P, const ReadInT<NL>& rd, ArenaT<NL>& A, SearchState& st, int w, const Grow& grow) {
+template <int LPR, bool CONT, bool NL, class Grow, int TOP>
+MAPAD_HD bool search_step(const DevIndex& ix, const DevParams& P, const ReadInT<NL>& rd, ArenaT<NL, TOP>& A, SearchState& st, int w, const Grow& grow) {
     if (st.heap_len == 0 || st.status != ST_OK) return false;
     if (MAPAD_UNLIKELY(st.tree_len + kStepNodes > A.node_cap || st.heap_len + kStepNodes > A.heap_cap)) {
         MAPAD_MARK(PROF_LOOP);

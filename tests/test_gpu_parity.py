@@ -126,7 +126,7 @@ def test_arena_handoff_stress(monkeypatch):
     ores = oidx.map_batch(ob.make_params(rp), reads, qs, n_threads=8, keep_d=True)
     for _ in range(2):
         res = _gpu_map(pidx, mapad_amd.make_params(rp), seqs, quals, offsets)
-        assert res.n_second_pass > 20000  # arena migrations: more than one per read
+        assert res.n_second_pass > 5000  # arena migrations (quads that suspend their read into a grown arena, heavy wavefronts that grow further)
         assert_same_as_oracle(ores, res, offsets)
 
 
