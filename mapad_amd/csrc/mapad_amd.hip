@@ -58,7 +58,7 @@ constexpr int kKeyBins = kMaxReadLen + 2;
 // handed on.  The two pool cursors are 64-bit (words 0-1 and 2-3): a batch may ask for more than 2^32 op words, which must show up as a pool
 // overflow, not wrap around.
 enum { CUR_HITS = 0, CUR_OPS = 2, CUR_POOL_OVF = 4, CUR_ERR = 5, CUR_WORK = 6, CUR_OVF = 7, CUR_GROWN = 6 + 2 * kStages, CUR_HEAVY_N = CUR_GROWN + 4 /* per quad stage */, CUR_HEAVY_WORK = CUR_GROWN + 6 /* per heavy stage */,
-       CUR_HEAVY_POPS = CUR_GROWN + 8 /* 64-bit */, CUR_COUNT = CUR_GROWN + 10 };
+       CUR_HEAVY_POPS = CUR_GROWN + 8 /* 64-bit */, CUR_HPROF = CUR_GROWN + 10 /* 8 x 64-bit, -DMAPAD_HEAVY_PROF */, CUR_COUNT = CUR_GROWN + 26 };
 inline uint64_t cur64(const uint32_t* cur, int k) { return (uint64_t)cur[k] | ((uint64_t)cur[k + 1] << 32); }
 
 struct BatchDev {
@@ -115,6 +115,7 @@ struct GrowPools {
     uint32_t hit_ops_cap;
     uint32_t max_waits;  // fruitless requests (x 64 steps sat out each) after which a read of the first stages gives up and is restarted later
     uint32_t heavy_min_class;  // a read that grows into this class or beyond is handed to heavy_kernel (kClasses: never)
+    uint32_t heavy_fast;  // heavy_kernel: wavefront-cooperative steps (0: every step by the general single-lane code)
     uint32_t heavy_max_pending;  // ... unless this many reads of the launch are suspended already (each holds a grown arena)
 };
 constexpr uint32_t kGrownShift = 27;
@@ -978,7 +979,11 @@ int ensure_arenas(mapad_ctx* c, BatchSlot& S, uint32_t lmax, uint64_t n_reads) {
     }
     g.max_waits = env_u32("MAPAD_MAX_WAITS", 64);
     g.hit_ops_cap = hit_ops_cap;
-    g.heavy_min_class = env_u32("MAPAD_HEAVY", 1) ? env_u32("MAPAD_HEAVY_MIN_CLASS", 0) : (uint32_t)kClasses;  // MAPAD_HEAVY=0: reads stay with their quad (the round-2 behaviour)
+    g.heavy_fast = env_u32("MAPAD_HEAVY_FAST", 1);
+    // MAPAD_HEAVY=1: a quad hands a read that grows into class MAPAD_HEAVY_MIN_CLASS or beyond to heavy_kernel.  Off by default: measured on MI355X, a lone
+    // wavefront issues one instruction per 4-5 cycles whatever its type, a step is ~2 500 of them either way, and the wavefront-per-read step takes 5.7 us
+    // per pop against the quad's 5.5 (heavy reads); the full-limit stage runs on heavy_kernel in any case.
+    g.heavy_min_class = env_u32("MAPAD_HEAVY", 0) ? env_u32("MAPAD_HEAVY_MIN_CLASS", 0) : (uint32_t)kClasses;
     c->heavy_cap = 64;
     for (int k = 0; k < kClasses; ++k) c->heavy_cap += g.count[k];  // a suspended read holds a grown arena
     {   // suspended reads wait for the heavy stage with their arenas: they may take three quarters of the class most of them are in
@@ -1481,6 +1486,15 @@ int mapad_fetch_result(mapad_ctx_t* ctx, mapad_batch_result_t** out) {
     r->pub.n_second_pass = cur[CUR_GROWN];  // arena migrations in pass 0
     if (cur[CUR_GROWN + 1] && std::getenv("MAPAD_DEBUG")) std::fprintf(stderr, "mapad_amd: size-class pools that ran dry (bit per class): 0x%x, waits: %u, reads restarted: %u, re-run with full limits: %u\n", cur[CUR_GROWN + 1], cur[CUR_GROWN + 2], cur[CUR_OVF], cur[CUR_OVF + 2 * (kStages - 2)]);
     r->pub.n_third_pass = cur[CUR_OVF + 2 * (kStages - 2)];  // reads re-run by the full-limit pass
+    if (std::getenv("MAPAD_DEBUG")) {
+        std::fprintf(stderr, "mapad_amd: heavy reads %u + %u, pops by heavy wavefronts %llu\n", cur[CUR_HEAVY_N], cur[CUR_HEAVY_N + 1], (unsigned long long)cur64(cur, CUR_HEAVY_POPS));
+#if defined(MAPAD_HEAVY_PROF)
+        static const char* names[8] = {"find max, node + last loaded", "unpack, scores, D", "rank + ancestor loads issued", "sift", "ancestor table", "rank finish", "children", "pushes"};
+        double tot = 0;
+        for (int k = 0; k < 8; ++k) tot += (double)cur64(cur, CUR_HPROF + 2 * k);
+        for (int k = 0; k < 8; ++k) std::fprintf(stderr, "[heavy prof] %-30s %6.1f %%  %8.1f cycles per pop\n", names[k], 100.0 * cur64(cur, CUR_HPROF + 2 * k) / std::max(tot, 1.0), (double)cur64(cur, CUR_HPROF + 2 * k) / std::max<double>((double)cur64(cur, CUR_HEAVY_POPS), 1.0));
+#endif
+    }
 #if defined(MAPAD_PROFILE_SECTIONS)
     {
         unsigned long long pv[2 * PROF_N + 64];

@@ -101,6 +101,13 @@ def test_index_beyond_2_pow_32_rows_maps_like_the_oracle(monkeypatch):
     half = n_reads // 2
     batches = [(NO_DAMAGE, synth.reads(g, half, 50, seed=4325, qual=40)),
                (DAMAGE, synth.reads(g, n_reads - half, 50, seed=4326, qual_range=(20, 40), damage=dict(f=0.5, t=0.5, d=0.02, s=1.0)))]
+    # C5's read mix (BASELINE.json configs[4]: 35-100 bp, 5 % of the reads with a 1-2 bp indel, damage model, Phred 20-40) on the 3 Gbp index.  The
+    # reference's limits are scaled down 10x (STACK_LIMIT / EDIT_TREE_LIMIT, mapping.rs:52-54: the recovery code is the same and the heaviest
+    # reads then take seconds instead of a minute each), and the three largest size classes get no arenas, so that the reads which
+    # need them are re-run by the full-limit stage (wavefront-per-read kernel).
+    n_c5 = int(os.environ.get("MAPAD_TEST_C5_READS", 20_000))
+    c5_limits = {"stack_limit": int(os.environ.get("MAPAD_TEST_C5_STACK_LIMIT", 200_000)), "edit_tree_limit": int(os.environ.get("MAPAD_TEST_C5_TREE_LIMIT", 1_000_000))}
+    c5 = synth.reads(g, n_c5, 50, seed=4327, qual_range=(20, 40), damage=dict(f=0.5, t=0.5, d=0.02, s=1.0), len_range=(35, 100), indel_frac=0.05)
     t3 = time.time()
     oidx = ob.OracleIndex.from_bwt(pidx.bwt(), "$ACGTX", 128)
     t4 = time.time()
@@ -118,3 +125,20 @@ def test_index_beyond_2_pow_32_rows_maps_like_the_oracle(monkeypatch):
         assert_same_as_oracle(ores, res, offsets)
         if n > 2 ** 32:
             assert (res.hits_arr["lower"] >= 2 ** 32).sum() > 0.15 * res.n_hits  # the 64-bit half of the interval arithmetic is exercised
+    if n_c5:
+        seqs, quals, offsets = c5
+        rp = dict(resolve_params(DAMAGE), **c5_limits)
+        monkeypatch.setenv("MAPAD_CLASS_COUNTS", os.environ.get("MAPAD_TEST_C5_CLASS_COUNTS", "8192,4096,2048,1024,512,256,64,0,0,0"))
+        ctx = mapad_amd.Context(pidx, mapad_amd.make_params(rp), 0)
+        t5 = time.time()
+        res = ctx.map_batch(seqs, quals, offsets)
+        t6 = time.time()
+        ctx.close()
+        reads, qs = split_reads(seqs, quals, offsets)
+        ores = oidx.map_batch(ob.make_params(rp), reads, qs, n_threads=os.cpu_count() or 8, keep_d=True)
+        pops = res.counters["n_pop"].astype(np.int64)
+        print(f"C5 mix: {n_c5} reads of 35-100 bp on the GPU in {t6 - t5:.1f} s, oracle in {time.time() - t6:.1f} s; pops mean {pops.mean():.0f} max {pops.max()}, "
+              f"{res.n_second_pass} arena migrations, {res.n_third_pass} reads through the full-limit stage, {int((pops > c5_limits['edit_tree_limit']).sum())} reads past the tree limit")
+        assert_same_as_oracle(ores, res, offsets)
+        if "MAPAD_TEST_C5_CLASS_COUNTS" not in os.environ and n_c5 >= 20_000 and n > 2 ** 32:
+            assert res.n_third_pass > 0 and res.n_second_pass > 0  # the knobs above did send reads through growth and through the full-limit stage

@@ -68,9 +68,11 @@ def test_synthetic_batch_matches_oracle(name, prm, kw, lanes_per_read, monkeypat
 
 @pytest.mark.parametrize("env", [{"MAPAD_ORDER": "0"}, {"MAPAD_POOL_BUDGET_GB": "1", "MAPAD_TIER0_NODES": "256"}, {"MAPAD_NEAR_LDS": "0"},
                                  {"MAPAD_TIER0_NODES": "32", "MAPAD_CLASS_COUNTS": "4,4,4,4,4,4,4,4,4,4", "MAPAD_MAX_WAITS": "0"},
-                                 {"MAPAD_ORDER_CHUNK_LOG2": "10"}, {"MAPAD_HIT_POOL": "64"}],
+                                 {"MAPAD_ORDER_CHUNK_LOG2": "10"}, {"MAPAD_HIT_POOL": "64"},
+                                 {"MAPAD_HEAVY": "1", "MAPAD_TIER0_NODES": "256"}, {"MAPAD_HEAVY": "1", "MAPAD_POOL_BUDGET_GB": "1", "MAPAD_TIER0_NODES": "256"},
+                                 {"MAPAD_HEAVY": "1", "MAPAD_HEAVY_FAST": "0", "MAPAD_TIER0_NODES": "64"}],
                          ids=["input_order", "tiny_pool_budget", "near_data_in_hbm", "give_up_and_restart", "order_chunks_of_1024",
-                              "hit_pool_overflow_retry"])
+                              "hit_pool_overflow_retry", "heavy_wavefronts", "heavy_wavefronts_tiny_pools", "heavy_wavefronts_general_steps"])
 def test_scheduling_and_memory_variants_do_not_change_results(env, monkeypatch):
     """The cost-class order, the size of the arena pools and where the near data lives only change when and where a read is
     processed, never its result."""
@@ -87,8 +89,9 @@ def test_scheduling_and_memory_variants_do_not_change_results(env, monkeypatch):
     assert_same_as_oracle(ores, res, offsets)
 
 
+@pytest.mark.parametrize("heavy", ["0", "1"])
 @pytest.mark.parametrize("class_counts", ["512,512,512,512,512,512,512,512,512", "8,2"])
-def test_small_arena_growth_last_pass_and_limits(monkeypatch, class_counts):
+def test_small_arena_growth_last_pass_and_limits(monkeypatch, class_counts, heavy):
     """Reads that outgrow their arena migrate into the size-class pools (owner-word acquire / release); when a pool is dry the
     read is re-run by the full-limit pass.  Tiny STACK/EDIT_TREE limits exercise the overflow recovery of mapping.rs:1358-1380."""
     g = synth.genome(100_000, seed=5)
@@ -96,6 +99,7 @@ def test_small_arena_growth_last_pass_and_limits(monkeypatch, class_counts):
     reads, qs = split_reads(seqs, quals, offsets)
     pidx = mapad_amd.Index.build([("chr1", g)])
     oidx = ob.OracleIndex.from_bwt(pidx.bwt(), "$ACGTX", 128)
+    monkeypatch.setenv("MAPAD_HEAVY", heavy)  # 1: a read that outgrows its base arena is continued by a wavefront of its own (heavy_kernel.hpp)
     monkeypatch.setenv("MAPAD_TIER0_NODES", "32")  # classes: 64, 128, 256, ..., 16384 nodes, full limits
     monkeypatch.setenv("MAPAD_CLASS_COUNTS", class_counts)  # "8,2": reads wait for the few arenas; those that need > 128 nodes are re-run
     rp = resolve_params(NO_DAMAGE)
@@ -112,9 +116,11 @@ def test_small_arena_growth_last_pass_and_limits(monkeypatch, class_counts):
         assert_same_as_oracle(ores, res, offsets)
 
 
-def test_arena_handoff_stress(monkeypatch):
+@pytest.mark.parametrize("heavy", ["0", "1"])
+def test_arena_handoff_stress(monkeypatch, heavy):
     """Partitioned (per-XCD) pools with tiny base arenas and few grown arenas per XCD: arenas change owners constantly, under uneven
     load, and every word of every result is checked (a late store of an old owner landing in a new owner's arena would show here)."""
+    monkeypatch.setenv("MAPAD_HEAVY", heavy)
     monkeypatch.setenv("MAPAD_TIER0_NODES", "32")
     monkeypatch.setenv("MAPAD_CLASS_COUNTS", "128,128,128,64,64,64,64,64,64,16")  # >= 64: split per XCD, 8-16 arenas each
     g = synth.genome(400_000, seed=77)
@@ -126,7 +132,7 @@ def test_arena_handoff_stress(monkeypatch):
     ores = oidx.map_batch(ob.make_params(rp), reads, qs, n_threads=8, keep_d=True)
     for _ in range(2):
         res = _gpu_map(pidx, mapad_amd.make_params(rp), seqs, quals, offsets)
-        assert res.n_second_pass > 5000  # arena migrations (quads that suspend their read into a grown arena, heavy wavefronts that grow further)
+        assert res.n_second_pass > (20000 if heavy == "0" else 5000)  # arena migrations: more than one per read (heavy: reads that find the pools dry go to the full-limit stage instead)
         assert_same_as_oracle(ores, res, offsets)
 
 
@@ -177,6 +183,24 @@ def test_batches_in_flight_do_not_change_results(depth, tiny, monkeypatch):
     for b in on_dev:
         for p in b:
             hip.hipFree(C.c_void_p(p))
+
+
+@pytest.mark.parametrize("prm", [DAMAGE, CONTINUOUS], ids=["discrete", "continuous"])
+def test_heavy_wavefronts_on_mixed_lengths(monkeypatch, prm):
+    """Reads of 35-100 bp with indels, small base arenas, MAPAD_HEAVY=1: most reads are suspended by their quad and finished by a wavefront of their
+    own (deep sifts through the speculative block, pushes through the ancestor table, the general single-lane step at the last position)."""
+    monkeypatch.setenv("MAPAD_HEAVY", "1")
+    monkeypatch.setenv("MAPAD_TIER0_NODES", "128")
+    g = synth.genome(300_000, seed=17)
+    seqs, quals, offsets = synth.reads(g, 1500, 50, seed=23, qual_range=(20, 40), damage=dict(f=0.5, t=0.5, d=0.02, s=1.0), len_range=(35, 100), indel_frac=0.05)
+    rp = resolve_params(prm)
+    pidx = mapad_amd.Index.build([("chr1", g)])
+    oidx = ob.OracleIndex.from_bwt(pidx.bwt(), "$ACGTX", 128)
+    res = _gpu_map(pidx, mapad_amd.make_params(rp), seqs, quals, offsets)
+    assert res.n_second_pass > 100
+    reads, qs = split_reads(seqs, quals, offsets)
+    ores = oidx.map_batch(ob.make_params(rp), reads, qs, n_threads=8, keep_d=True)
+    assert_same_as_oracle(ores, res, offsets)
 
 
 def test_integration_expectation_on_gpu(monkeypatch):
