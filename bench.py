@@ -108,6 +108,10 @@ def main():
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo: test mode for boxes with one GPU — every rank uses device 0 and the gather goes through host memory")
     ap.add_argument("--depth", type=int, default=3, help="batches in flight (1 = every step runs alone on the stream)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="N > 1: weak = --reads per GPU (total work grows with N); strong = ONE chunk of --reads reads cut into N contiguous slices (SURVEY 8e)")
+    ap.add_argument("--watchdog-s", type=float, default=600.0, help="N > 1: exit 3 if no step or gather completes for this long (a starved transfer must not hang the node)")
+    ap.add_argument("--own-index", action="store_true", help="N > 1: every rank builds its own index instead of loading the files rank 0 wrote")
     args = ap.parse_args()
     genome_bp = args.genome_bp or CONFIGS[args.config][0]
     n_reads = args.reads or CONFIGS[args.config][1]
@@ -150,13 +154,68 @@ def main():
     if world > 1:  # 8 search wavefronts per CU map as fast as 12 once batches overlap, and leave registers and LDS on every CU for RCCL's kernels
         os.environ.setdefault("MAPAD_TIER0_WAVES_PER_CU", "8")
 
+    # ---- watchdog (N > 1): a rank that makes no progress for --watchdog-s seconds ends the job with a fresh exit (never an exec) ---------------
+    import threading
+    beat = {"t": time.time(), "what": "start"}
+
+    def heartbeat(what):
+        beat["t"], beat["what"] = time.time(), what
+
+    def watchdog():
+        while True:
+            time.sleep(2.0)
+            if time.time() - beat["t"] > args.watchdog_s:
+                log(f"[rank {rank}] WATCHDOG: no progress for {args.watchdog_s:.0f} s after '{beat['what']}'; giving up")
+                os._exit(3)
+
+    if world > 1:
+        threading.Thread(target=watchdog, daemon=True).start()
+
     # ---- workload --------------------------------------------------------------------------------------------------------
     t0 = time.time()
     genome = synth.genome(genome_bp, seed=1234)
     t_genome = time.time() - t0
+    heartbeat("genome")
     t0 = time.time()
-    index = mapad_amd.Index.build([("chr1", genome)], seed=1234, device=local_rank)  # suffix sorting on the GPU (csrc/index_gpu.hip)
-    t_index = time.time() - t0
+    index_how, t_index_save, t_index_load = "built on this rank's GPU", None, None
+    shared = None
+    if world > 1 and not args.own_index:
+        # one index for the node: rank 0 builds it on its GPU and writes the seven files (mapad_index_save), the other ranks load them
+        # (mapad_index_open) — the way a `mapad map` process finds its index — instead of N suffix sorts and N host text preparations on one host
+        import shutil
+        import tempfile
+        shared = os.path.join(tempfile.gettempdir(), f"mapad_bench_index_{os.environ.get('MASTER_PORT', '0')}_{genome_bp}")
+        need = 3 * genome_bp + (2 << 30)
+        ok = torch.tensor([1 if shutil.disk_usage(tempfile.gettempdir()).free > need else 0], dtype=torch.int64, device=xdev)
+        dist.broadcast(ok, 0)
+        if int(ok.item()) == 0:
+            shared = None
+            log(f"[rank {rank}] not enough scratch space for shared index files: every rank builds its own index")
+    if shared is None:
+        index = mapad_amd.Index.build([("chr1", genome)], seed=1234, device=local_rank)  # suffix sorting on the GPU (csrc/index_gpu.hip)
+        t_index = time.time() - t0
+    else:
+        if rank == 0:
+            index = mapad_amd.Index.build([("chr1", genome)], seed=1234, device=local_rank)
+            t_index = time.time() - t0
+            heartbeat("index built")
+            t1 = time.time()
+            os.makedirs(shared, exist_ok=True)
+            index.save(os.path.join(shared, "ref"))
+            t_index_save = time.time() - t1
+            heartbeat("index saved")
+        dist.barrier()
+        if rank != 0:
+            t1 = time.time()
+            index = mapad_amd.Index.open(os.path.join(shared, "ref"))
+            t_index_load = time.time() - t1
+            t_index = time.time() - t0
+            index_how = "loaded from the files rank 0 wrote"
+        heartbeat("index ready")
+        dist.barrier()
+        if rank == 0:
+            shutil.rmtree(shared, ignore_errors=True)
+    heartbeat("index")
     if args.config in ("c1", "c2", "c4"):
         prm, kw = NO_DAMAGE, dict(qual=40)
     elif args.config == "c3":
@@ -166,8 +225,19 @@ def main():
     cfg_id = int(args.config[1])
     rp = resolve_params(prm)
     params = mapad_amd.make_params(rp)
-    seqs, quals, offsets = make_reads(synth, genome, n_reads, 4321 + cfg_id + 1000 * rank, **kw)
-    log(f"[rank {rank}] genome {genome_bp} bp in {t_genome:.1f}s, index (n = {len(index)}) built in {t_index:.1f}s, {n_reads} reads")
+    n_chunk = n_reads  # --reads: per GPU (weak) or the whole chunk (strong)
+    if world > 1 and args.scaling == "strong":
+        from mapad_amd.distributed import shard_bounds
+        a_seqs, a_quals, a_offsets = make_reads(synth, genome, n_chunk, 4321 + cfg_id, **kw)  # the same chunk on every rank ...
+        lo, hi = shard_bounds(n_chunk, world, rank)                                            # ... of which this rank maps a contiguous slice
+        b0, b1 = int(a_offsets[lo]), int(a_offsets[hi])
+        seqs, quals, offsets = a_seqs[b0:b1].copy(), a_quals[b0:b1].copy(), (a_offsets[lo:hi + 1] - a_offsets[lo]).astype(np.uint64)
+        del a_seqs, a_quals, a_offsets
+        n_reads = hi - lo
+    else:
+        seqs, quals, offsets = make_reads(synth, genome, n_reads, 4321 + cfg_id + 1000 * rank, **kw)
+    heartbeat("reads")
+    log(f"[rank {rank}] genome {genome_bp} bp in {t_genome:.1f}s, index (n = {len(index)}) {index_how} in {t_index:.1f}s, {n_reads} reads")
 
     stream = torch.cuda.current_stream(dev)
     ctx = mapad_amd.Context(index, params, local_rank)
@@ -202,6 +272,7 @@ def main():
         last = None
         for i in range(k):
             ctx.map_batch_device(d_seqs.data_ptr(), d_quals.data_ptr(), d_offsets.data_ptr(), n_reads, max_len)
+            heartbeat(f"step {i} submitted")
             if world > 1 and i > 0 and args.depth > 1:
                 ctx.select_batch(1)
                 last = gather_hits()
@@ -210,6 +281,7 @@ def main():
                 last = gather_hits()
         if world > 1 and args.depth > 1:
             last = gather_hits()
+        heartbeat("steps done")
         return last
 
     run_steps(args.warmup)
@@ -225,10 +297,17 @@ def main():
         dist.barrier()
     torch.cuda.synchronize(dev)
     elapsed = time.perf_counter() - t0
+    per_rank = None
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=xdev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        mine = torch.tensor([elapsed, float(n_reads)], dtype=torch.float64, device=xdev)
+        every = [torch.zeros(2, dtype=torch.float64, device=xdev) for _ in range(world)]
+        dist.all_gather(every, mine)
+        per_rank = [{"rank": r, "reads": int(v[1].item()), "elapsed_s": round(float(v[0].item()), 4), "reads_per_s": round(float(v[1].item()) * args.steps / float(v[0].item()), 1)} for r, v in enumerate(every)]
+        elapsed = max(float(v[0].item()) for v in every)
+        total_reads_per_step = int(sum(float(v[1].item()) for v in every))
+    else:
+        total_reads_per_step = n_reads
+    heartbeat("timed region done")
     hist = ctx.kernel_history().astype(np.float64)  # per launch: ms from the first launch's start to its four event marks
     assert hist.shape[0] == args.steps
 
@@ -256,11 +335,15 @@ def main():
         own = digest(res.hit_begin, res.hits_arr, res.ops)
         all_own = [None] * world
         dist.all_gather_object(all_own, own)
+        loads = [None] * world
+        dist.all_gather_object(loads, None if t_index_load is None else round(t_index_load, 1))
         if rank == 0:
             hb, hits, ops, per_rank = merge_gathered(gathered)
             ok = [per_rank[r] == all_own[r] for r in range(world)]
             gather_check = {"world_size_seen": dist.get_world_size(), "ranks_identical_to_own_fetch": int(sum(ok)), "merged_reads": int(len(hb) - 1),
-                            "merged_hits": int(hits.shape[0]), "merged_ops": int(ops.size)}
+                            "merged_hits": int(hits.shape[0]), "merged_ops": int(ops.size), "per_rank": per_rank,
+                            "exchange": "RCCL point-to-point fan-in to rank 0 over xGMI, issued behind the next step's submission" if args.dist_backend == "nccl" else "gloo through host memory (test mode)",
+                            "index": {"built_by": "rank 0, saved, loaded by the others" if shared is not None else "every rank", "save_s": None if t_index_save is None else round(t_index_save, 1), "load_s_per_rank": loads}}
             if not all(ok):
                 log("GATHER FAILURE: a rank's gathered records differ from its own result")
 
@@ -465,14 +548,14 @@ def main():
                 "what": "mapad_hits_to_records_gpu: SA locate kernel + coordinates, MAPQ, CIGAR/MD/XA strings on host threads"}
 
     if rank == 0:
-        total_reads = n_reads * world * args.steps
+        total_reads = total_reads_per_step * args.steps
         model = "no-damage" if args.config in ("c1", "c2", "c4") else "ss 50% deamination"
         line = {
             "metric": "mapped reads/sec (50 bp, -p 0.03)", "value": round(total_reads / elapsed, 1), "unit": "reads/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64+f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": args.scaling if world > 1 else "weak", "vs_baseline": None, "dtype": "u64+f32", "data": "synthetic",
             "config": {"workload": f"{args.config.upper()}: synthetic genome ({genome_bp} bp, n = {len(index)} BWT rows), "
-                                   f"{n_reads} x {'50' if args.config != 'c5' else '35-100'} bp reads per GPU, -p 0.03, "
+                                   f"{n_chunk} x {'50' if args.config != 'c5' else '35-100'} bp reads {'per GPU' if not (world > 1 and args.scaling == 'strong') else 'in one chunk, cut into contiguous slices'}, -p 0.03, "
                                    f"{model} model{', 5 % of the reads with an indel' if args.config == 'c5' else ''}",
                        "reads_per_gpu": n_reads, "genome_bp": genome_bp, "index_bytes_hbm": int((len(index) + 255) // 256 * 128),
                        "batches_in_flight": args.depth,

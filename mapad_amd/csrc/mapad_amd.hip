@@ -494,29 +494,53 @@ __device__ __forceinline__ void suspend_heavy(const BatchDev& B, const GrowPools
 #if !defined(MAPAD_MIN_WAVES)
 #define MAPAD_MIN_WAVES 3  // 12 wavefronts per CU: 168 VGPRs (no SGPR spills into VGPR lanes) and 853 B of LDS per read slot (heap levels 0-5)
 #endif
-template <int LPR, bool CONT, int PASS, bool NL>
-__global__ void __launch_bounds__(64, (LPR == 1 && NL) ? 1 : MAPAD_MIN_WAVES) search_kernel(DevIndex ix, DevParams P, BatchDev B, ArenaPool AP, const GrowPools* GP, uint32_t near_stride, uint32_t near_lmax, int stage) {
+// The batch and arena descriptors are only needed when a read starts, ends or changes arenas, but as by-value kernel arguments they stay live
+// in scalar registers across the whole search loop (~60 of them: the loop spilled 75 scalar registers into VGPR lanes, v_writelane / v_readlane).
+// Inside the loop they are therefore re-read from the kernel-argument segment where they are used (a scalar load from constant memory; the empty
+// asm keeps the optimiser from hoisting the loads back out of the rare paths).
+#if !defined(MAPAD_KERNARG_RELOAD)
+#define MAPAD_KERNARG_RELOAD 1
+#endif
+constexpr size_t kArgAlign(size_t off, size_t a) { return (off + a - 1) / a * a; }
+constexpr size_t kArgOffP = kArgAlign(sizeof(DevIndex), alignof(DevParams));
+constexpr size_t kArgOffB = kArgAlign(kArgOffP + sizeof(DevParams), alignof(BatchDev));
+constexpr size_t kArgOffAP = kArgAlign(kArgOffB + sizeof(BatchDev), alignof(ArenaPool));
+template <class T>
+__device__ __forceinline__ T kernarg_reload(size_t off, const T& by_value) {
+#if MAPAD_KERNARG_RELOAD && defined(__HIP_DEVICE_COMPILE__)
+    const __attribute__((address_space(4))) char* p = (const __attribute__((address_space(4))) char*)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(p));
+    return *(const __attribute__((address_space(4))) T*)(p + off);
+#else
+    return by_value;
+#endif
+}
+
+// HEAVY: the kernel hands reads that outgrow their base arena to heavy_kernel (MAPAD_HEAVY=1); compiled out otherwise (the hand-over code in the
+// loop costs the common path registers and waits: C2 -15 % with it in, measured).
+template <int LPR, bool CONT, int PASS, bool NL, bool HEAVY>
+__global__ void __launch_bounds__(64, (LPR == 1 && NL) ? 1 : MAPAD_MIN_WAVES) search_kernel(DevIndex ix, DevParams P, BatchDev B0, ArenaPool AP0, const GrowPools* GP, uint32_t near_stride, uint32_t near_lmax, int stage) {
     const int lane = threadIdx.x & 63, w = lane & (LPR - 1);
     const int tier = stage;
-    const uint32_t n_items = tier == 0 ? B.n_reads : B.cursors[CUR_OVF + 2 * (tier - 1)];
+    const uint32_t n_items = tier == 0 ? B0.n_reads : B0.cursors[CUR_OVF + 2 * (tier - 1)];
     if (n_items == 0) return;  // retry / full-limit stages normally have nothing to do
-    const uint32_t set = acquire_set(AP);
+    uint32_t* const cursors = B0.cursors;
+    const uint32_t set = acquire_set(AP0);
     const uint32_t slot = set * (64 / LPR) + (lane / LPR);
-    ArenaT<NL> A = carve<NL>(AP, slot);
+    ArenaT<NL> A = carve<NL>(AP0, slot);
     // near data of this read slot: [kTop + 1 heap slots][2*lmax bytes class/quality][lmax floats D]
     extern __shared__ __attribute__((aligned(16))) uint8_t near_lds[];
     using NearBytes = typename near_ptr<uint8_t, NL>::type;
     NearBytes near;
     if constexpr (NL) near = (NearBytes)near_lds + (size_t)(lane / LPR) * near_stride;
-    else near = AP.base + (uint64_t)slot * AP.stride + AP.off_near;
+    else near = AP0.base + (uint64_t)slot * AP0.stride + AP0.off_near;
     A.top = (typename near_ptr<HeapEntry, NL>::type)near + 1;
     const NearBytes near_qc = near + (kTop + 1) * sizeof(HeapEntry);
     const typename near_ptr<float, NL>::type near_d = (typename near_ptr<float, NL>::type)(near_qc + ((2 * near_lmax + 15) & ~15u));
-    uint32_t* work = &B.cursors[CUR_WORK + 2 * tier];
-    const uint32_t* items = B.overflow_list + (size_t)(tier > 0 ? tier - 1 : 0) * B.n_reads;
+    uint32_t* work = &cursors[CUR_WORK + 2 * tier];
     // reads of the first stages give up after kMaxWaits fruitless waits for an arena and are restarted by the next stage, when the
     // pools are quiet; the last growable stage waits as long as it takes
-    const DeviceGrow<LPR, NL> grow{GP, &B.cursors[CUR_GROWN], slot, w, stage + 2 < kStages || GP->heavy_min_class < (uint32_t)kClasses};
+    const DeviceGrow<LPR, NL> grow{GP, &cursors[CUR_GROWN], slot, w, stage + 2 < kStages || HEAVY};
 #if defined(MAPAD_PROFILE_SECTIONS)
     if (lane < 2 * PROF_N + 2) g_prof_lds[lane] = 0;
     g_prof_hist[lane] = 0;
@@ -535,18 +559,21 @@ __global__ void __launch_bounds__(64, (LPR == 1 && NL) ? 1 : MAPAD_MIN_WAVES) se
             item = group_bcast<LPR>(item);
             if (item >= n_items) done = true;
             else {
+                const BatchDev B = kernarg_reload(kArgOffB, B0);
+                const uint32_t* items = B.overflow_list + (size_t)(tier > 0 ? tier - 1 : 0) * B.n_reads;
                 read = tier == 0 ? (B.order ? B.order[item] : item) : items[item] - 1u;
                 const uint64_t off = B.offsets[read];
                 rd.L = (int)(B.offsets[read + 1] - off);
-                rd.thr = P.reject_thr[rd.L];
-                rd.table = P.table_base[rd.L];
+                const DevParams Pf = kernarg_reload(kArgOffP, P);  // the two table pointers are only used here
+                rd.thr = Pf.reject_thr[rd.L];
+                rd.table = Pf.table_base[rd.L];
                 if (tier == 0 && B.status[read] == ST_NO_TABLE) {  // the D kernel already flagged it
                     if (w == 0) { B.hit_count[read] = 0; B.hit_first[read] = 0; }
                 } else {
                     read_setup(B.seqs + off, B.quals + off, B.d_arrays + off, rd.L, near_qc, near_d, w, LPR);
                     SearchState tmp;
                     A.n_waits = 0;
-                    search_init(ix.n, alignment_start_of(P, rd.L), rd, A, tmp);
+                    search_init(kernarg_reload(0, ix).n, alignment_start_of(P, rd.L), rd, A, tmp);
                     st = tmp;
                     have = true;
                     drain_memory();  // rare path of the step loop (search_core.hpp: drain_memory)
@@ -561,22 +588,22 @@ __global__ void __launch_bounds__(64, (LPR == 1 && NL) ? 1 : MAPAD_MIN_WAVES) se
             else cont = search_step<LPR, CONT, NL>(ix, P, rd, A, st, w, NoGrow());
             MAPAD_MARK(PROF_TAIL);
             if (!cont) {
-                finalize_read<LPR>(B, rd, A, st, read, w, tier);
+                finalize_read<LPR>(kernarg_reload(kArgOffB, B0), rd, A, st, read, w, tier);
                 if (PASS != 1 && A.grown) {  // give the grown arena back; the next read starts in the base arena again
                     release_grown<LPR>(GP, A.grown, w);
-                    const ArenaT<NL> base = carve<NL>(AP, slot);
+                    const ArenaT<NL> base = carve<NL>(kernarg_reload(kArgOffAP, AP0), slot);
                     A.heap = base.heap; A.nodes = base.nodes; A.heap_cap = base.heap_cap; A.node_cap = base.node_cap; A.grown = 0;
                 }
                 have = false;
                 drain_memory();
                 MAPAD_MARK(PROF_FINALIZE);
-            } else if (PASS != 1 && MAPAD_UNLIKELY(A.grown != 0)) {
+            } else if (HEAVY && MAPAD_UNLIKELY(A.grown != 0)) {
                 // The read has outgrown its base arena: it is heavy.  Its state goes into the grown arena (heap top from the near array, hit staging
                 // from the base arena), the read is queued for heavy_kernel — a wavefront of its own — and this quad takes its next read.
                 // (a suspended read keeps its grown arena until the heavy stage has finished it: no more of them than the pools can spare)
-                if ((A.grown >> kGrownShift) - 1 >= GP->heavy_min_class && *(volatile uint32_t*)&B.cursors[CUR_HEAVY_N + tier] < GP->heavy_max_pending) {
-                    suspend_heavy<LPR>(B, GP, A, st, read, w, tier);
-                    const ArenaT<NL> base = carve<NL>(AP, slot);
+                if ((A.grown >> kGrownShift) - 1 >= GP->heavy_min_class && *(volatile uint32_t*)&cursors[CUR_HEAVY_N + tier] < GP->heavy_max_pending) {
+                    suspend_heavy<LPR>(kernarg_reload(kArgOffB, B0), GP, A, st, read, w, tier);
+                    const ArenaT<NL> base = carve<NL>(kernarg_reload(kArgOffAP, AP0), slot);
                     A.heap = base.heap; A.nodes = base.nodes; A.heap_cap = base.heap_cap; A.node_cap = base.node_cap; A.grown = 0;
                     have = false;
                 }
@@ -584,9 +611,10 @@ __global__ void __launch_bounds__(64, (LPR == 1 && NL) ? 1 : MAPAD_MIN_WAVES) se
             }
         }
     }
-    release_set(AP, set);
+    release_set(kernarg_reload(kArgOffAP, AP0), set);
 #if defined(MAPAD_PROFILE_SECTIONS)
     __syncthreads();
+    const BatchDev B = kernarg_reload(kArgOffB, B0);
     if (PASS == 0 && lane < 2 * PROF_N && B.prof) atomicAdd(&B.prof[lane], g_prof_lds[lane]);
     if (PASS == 0 && B.prof) atomicAdd(&B.prof[2 * PROF_N + lane], (unsigned long long)g_prof_hist[lane]);
 #endif
@@ -1112,12 +1140,15 @@ int launch_batch(mapad_ctx* c, BatchSlot& S, const uint8_t* d_seqs, const uint8_
     const uint32_t near_stride = (near_fits && env_u32("MAPAD_NEAR_LDS", 1)) ? near_bytes(near_lmax) : 0;
     const size_t lds = (size_t)near_stride * rpw;
     const bool cont = c->dprm.bound_kind == BOUND_CONTINUOUS;
-#define MAPAD_LAUNCH(L, C, P, N) hipLaunchKernelGGL((search_kernel<L, C, P, N>), dim3(grid), dim3(64), lds, S.stream, c->dix, c->dprm, B, ap, c->d_grow.p, near_stride, near_lmax, stage)
+    const bool heavy_on = c->grow.heavy_min_class < (uint32_t)kClasses;
+#define MAPAD_LAUNCH(L, C, P, N)                                                                                                                                   \
+    if (heavy_on) hipLaunchKernelGGL((search_kernel<L, C, P, N, true>), dim3(grid), dim3(64), lds, S.stream, c->dix, c->dprm, B, ap, c->d_grow.p, near_stride, near_lmax, stage); \
+    else hipLaunchKernelGGL((search_kernel<L, C, P, N, false>), dim3(grid), dim3(64), lds, S.stream, c->dix, c->dprm, B, ap, c->d_grow.p, near_stride, near_lmax, stage)
 #define MAPAD_LAUNCH_PASS(P)                                                                                      \
-    if (c->lpr == 4 && near_stride) { if (!cont) MAPAD_LAUNCH(4, false, P, true); else MAPAD_LAUNCH(4, true, P, true); }   \
-    else if (c->lpr == 4) { if (!cont) MAPAD_LAUNCH(4, false, P, false); else MAPAD_LAUNCH(4, true, P, false); }          \
-    else if (near_stride) { if (!cont) MAPAD_LAUNCH(1, false, P, true); else MAPAD_LAUNCH(1, true, P, true); }              \
-    else { if (!cont) MAPAD_LAUNCH(1, false, P, false); else MAPAD_LAUNCH(1, true, P, false); }
+    if (c->lpr == 4 && near_stride) { if (!cont) { MAPAD_LAUNCH(4, false, P, true); } else { MAPAD_LAUNCH(4, true, P, true); } }   \
+    else if (c->lpr == 4) { if (!cont) { MAPAD_LAUNCH(4, false, P, false); } else { MAPAD_LAUNCH(4, true, P, false); } }          \
+    else if (near_stride) { if (!cont) { MAPAD_LAUNCH(1, false, P, true); } else { MAPAD_LAUNCH(1, true, P, true); } }              \
+    else { if (!cont) { MAPAD_LAUNCH(1, false, P, false); } else { MAPAD_LAUNCH(1, true, P, false); } }
     // (re-measured with the shared base arenas, C2 / C3 reads/s at 4, 6, 8, 12 wavefronts per CU for a launch that finds another one running:
     // 4.96 / 2.00 M, 4.86 / 2.25 M, 4.89 / 2.28 M, 4.71 / 2.23 M -> 8)
     // A launch alone on the chip fills it (16 wavefronts per CU at 128 VGPRs).  While another batch is still running, a launch takes half: two
@@ -1138,7 +1169,7 @@ int launch_batch(mapad_ctx* c, BatchSlot& S, const uint8_t* d_seqs, const uint8_
         const uint32_t grid = grid_s;
         const ArenaPool ap = c->pool[0];
         if (stage == 0) { MAPAD_LAUNCH_PASS(0) } else { MAPAD_LAUNCH_PASS(2) }  // PASS 2 = PASS 0 under its own symbol, so that profiles keep the passes apart
-        MAPAD_LAUNCH_HEAVY(0, grid_h, ap, stage)
+        if (heavy_on || warm) { MAPAD_LAUNCH_HEAVY(0, grid_h, ap, stage) }
         HIP_TRY(hipGetLastError());
     }
     if (!warm) HIP_TRY(hipEventRecord(S.ev[2], S.stream));

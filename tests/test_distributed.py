@@ -5,6 +5,7 @@ import socket
 import sys
 
 import numpy as np
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -94,3 +95,26 @@ def test_two_rank_sharding_and_gather_matches_single_process(tmp_path):
     assert np.array_equal(got["hit_begin"], hb)
     assert np.array_equal(got["hits"], hits) and np.array_equal(got["ops"], ops)  # incl. rebased ops offsets
     assert hb[-1] > 50
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("scaling", ["weak", "strong"])
+def test_bench_two_ranks_on_one_gpu_over_gloo(scaling):
+    """bench.py's N > 1 path end to end on a one-GPU box: two ranks share device 0, rank 0 builds and saves the index, rank 1 loads the files,
+    both map their shard with batches in flight, the read-ordered hit records are gathered on rank 0 (gloo, through host memory) and merged;
+    every rank's gathered part must equal that rank's own result."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dist-backend", "gloo", "--config", "c2", "--genome-bp", "2000000", "--reads", "60000",
+                        "--steps", "3", "--warmup", "1", "--scaling", scaling, "--no-cpu-baseline", "--no-extras", "--watchdog-s", "120"],
+                       capture_output=True, text=True, env=env, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    line = json.loads(p.stdout.strip().splitlines()[-1])
+    g = line["gather"]
+    assert line["n_gpus"] == 2 and line["scaling"] == scaling and g["world_size_seen"] == 2 and g["ranks_identical_to_own_fetch"] == 2
+    assert g["merged_reads"] == (120000 if scaling == "weak" else 60000)
+    assert g["index"]["built_by"].startswith("rank 0") and g["index"]["load_s_per_rank"][1] is not None
+    assert len(g["per_rank"]) == 2 and sum(r["reads"] for r in g["per_rank"]) == g["merged_reads"]
