@@ -107,12 +107,15 @@ def main():
     ap.add_argument("--no-cli", action="store_true", help="skip the command-line leg (FASTQ -> BAM; at C4 it writes and re-reads the 3 Gbp index files)")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo: test mode for boxes with one GPU — every rank uses device 0 and the gather goes through host memory")
-    ap.add_argument("--depth", type=int, default=3, help="batches in flight (1 = every step runs alone on the stream)")
+    ap.add_argument("--depth", type=int, default=None, help="batches in flight (1 = every step runs alone on the stream); default 3, C4: 2 (its 10 M-read launches "
+                    "run one after the other, the next batch's D arrays beside the search), C5: 6 (heavy-tailed reads: more tails to overlap)")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="N > 1: weak = --reads per GPU (total work grows with N); strong = ONE chunk of --reads reads cut into N contiguous slices (SURVEY 8e)")
     ap.add_argument("--watchdog-s", type=float, default=600.0, help="N > 1: exit 3 if no step or gather completes for this long (a starved transfer must not hang the node)")
     ap.add_argument("--own-index", action="store_true", help="N > 1: every rank builds its own index instead of loading the files rank 0 wrote")
     args = ap.parse_args()
+    if args.depth is None:
+        args.depth = {"c4": 2, "c5": 6}.get(args.config, 3)
     genome_bp = args.genome_bp or CONFIGS[args.config][0]
     n_reads = args.reads or CONFIGS[args.config][1]
 
@@ -458,15 +461,17 @@ def main():
         from mapad_amd import build as mbuild
         tmp = tempfile.mkdtemp(prefix="mapad_cli_")
         try:
-            n_cli = min(n_reads, 4_000_000)  # the first reads of the batch: enough chunks of 250 000 to fill the pipeline
+            n_src = min(n_reads, 4_000_000)
+            n_cli = n_src * max(1, 8_000_000 // n_src)  # the batch's first reads, repeated up to 8 M: 32 chunks of 250 000, so that the fill and drain of the pipeline are a small part of the run
             fa, fq, bam = os.path.join(tmp, "ref.fa"), os.path.join(tmp, "reads.fastq"), os.path.join(tmp, "out.bam")
             rec = np.empty((n_cli, 114), np.uint8)  # "@rNNNNNNN\n" + 50 bases + "\n+\n" + 50 qualities + "\n"
             rec[:, 0] = ord("@"); rec[:, 1] = ord("r")
             ids = np.arange(n_cli)
             for k in range(7):
                 rec[:, 8 - k] = 48 + (ids // 10 ** k) % 10
-            rec[:, 9] = 10; rec[:, 10:60] = seqs[:50 * n_cli].reshape(n_cli, 50); rec[:, 60] = 10; rec[:, 61] = ord("+"); rec[:, 62] = 10
-            rec[:, 63:113] = quals[:50 * n_cli].reshape(n_cli, 50) + 33; rec[:, 113] = 10
+            reps = n_cli // n_src
+            rec[:, 9] = 10; rec[:, 10:60] = np.tile(seqs[:50 * n_src].reshape(n_src, 50), (reps, 1)); rec[:, 60] = 10; rec[:, 61] = ord("+"); rec[:, 62] = 10
+            rec[:, 63:113] = np.tile(quals[:50 * n_src].reshape(n_src, 50), (reps, 1)) + 33; rec[:, 113] = 10
             rec.tofile(fq)
             del rec
             exe = mbuild.build_cli()

@@ -11,6 +11,8 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math",
          # device code at -O2: fewer branches and scalar instructions in the search kernel than -O3 (measured 1-3 % faster on MI355X)
          "-Xarch_device", "-O2",
+         # small per-thread arrays of the kernels around the search stay out of LDS (those kernels must fit beside the search wavefronts, which own it)
+         "-mllvm", "-disable-promote-alloca-to-lds",
          # keep libm out of the constant folder / pow->exp10 rewrites: the reference evaluates these at run time with glibc
          "-fno-builtin-log2f", "-fno-builtin-powf", "-fno-builtin-expf", "-fno-builtin-exp2f", "-fno-builtin-log10f",
          "-Wall", "-Wno-unused-function", "-Wno-unknown-pragmas"]

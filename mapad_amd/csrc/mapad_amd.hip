@@ -134,8 +134,9 @@ __device__ __forceinline__ ArenaT<NL> carve(const ArenaPool& ap, uint32_t slot) 
     return a;
 }
 
+#define MAPAD_SLIM_EARLY __launch_bounds__(64)  // see MAPAD_SLIM below
 // ---- D arrays: one wavefront per read, quad q = offset chain q ------------------------------------------------------------
-__global__ void __launch_bounds__(64) darray_kernel(DevIndex ix, DevParams P, BatchDev B, int lmax) {
+__global__ void MAPAD_SLIM_EARLY darray_kernel(DevIndex ix, DevParams P, BatchDev B, int lmax) {  // 56 VGPRs: fits beside 12 search wavefronts per CU
     extern __shared__ float lds[];
     float* pen = lds;            // [lmax]
     float* chains = lds + lmax;  // [15][lmax]
@@ -201,19 +202,32 @@ __global__ void order_scan_kernel(uint32_t* hist, uint32_t n_chunks) {
         for (int k = kKeyBins - 1; k >= 0; --k) { const uint32_t c = h[k]; h[k] = acc; acc += c; }
     }
 }
-__global__ void __launch_bounds__(1024) order_scatter_kernel(BatchDev B) {
-    // ranks inside the block through LDS atomics, one global atomic per (block, class that occurs in it)
-    __shared__ uint32_t cnt[kKeyBins], base[kKeyBins];
-    for (int k = threadIdx.x; k < kKeyBins; k += 1024) cnt[k] = 0;
-    __syncthreads();
-    const uint32_t i = blockIdx.x * 1024u + threadIdx.x;
-    uint32_t key = 0, r = 0;
-    if (i < B.n_reads) { key = B.sort_key[i]; r = atomicAdd(&cnt[key], 1u); }
-    __syncthreads();
-    uint32_t* hist = B.key_hist + (size_t)((blockIdx.x * 1024u) >> B.order_shift) * kKeyBins;  // a block never straddles chunks (chunk size >= 1024)
-    for (int k = threadIdx.x; k < kKeyBins; k += 1024) { const uint32_t c = cnt[k]; if (c) base[k] = atomicAdd(&hist[k], c); }
-    __syncthreads();
-    if (i < B.n_reads) B.order[base[key] + r] = i;
+// The kernels around the search (D arrays, ordering, collect, records) must find room BESIDE the persistent search wavefronts of other batches.
+// Twelve of those per CU take all of its LDS and leave 56 VGPRs per SIMD (the compiler does not go below 64), so a search launch asks for a little
+// more LDS than it needs: eleven fit per CU, which leaves 13 KB of LDS and the registers of one wavefront on one SIMD of every CU.  The kernels
+// around it are one-wavefront blocks without static LDS (wave-level ballots / shuffles instead of block-wide LDS scans); as 1024-thread blocks
+// with 8-16 KB of LDS they waited for search wavefronts to retire (round 2: 243 ms instead of 0.02 ms for this kernel, 30-45 ms instead of 0.5 ms
+// for the records kernel).
+#define MAPAD_SLIM __launch_bounds__(64)
+__global__ void MAPAD_SLIM order_scatter_kernel(BatchDev B) {
+    // ranks inside the wavefront by ballots, one global atomic per (wavefront, class that occurs in it)
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t i = blockIdx.x * 64u + lane;
+    const bool act = i < B.n_reads;
+    const uint32_t key = act ? B.sort_key[i] : 0xFFFFFFFFu;
+    uint32_t* hist = B.key_hist + (size_t)((blockIdx.x * 64u) >> B.order_shift) * kKeyBins;  // a block never straddles chunks (chunk size >= 1024)
+    uint64_t todo = __ballot(act);
+    while (todo) {
+        const int leader = __ffsll((long long)todo) - 1;
+        const uint32_t k = (uint32_t)__builtin_amdgcn_readlane((int)key, leader);
+        const bool mine = act && key == k;
+        const uint64_t m = __ballot(mine);
+        uint32_t base = 0;
+        if ((int)lane == leader) base = atomicAdd(&hist[k], (uint32_t)__popcll(m));
+        base = (uint32_t)__builtin_amdgcn_readlane((int)base, leader);
+        if (mine) B.order[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = i;
+        todo &= ~m;
+    }
 }
 
 // ---- SA locate: SampledSuffixArray::get (src/index/mod.rs:160-187) on the device, one quad per row ------------------------
@@ -278,9 +292,9 @@ __global__ void __launch_bounds__(64) locate_kernel(DevIndex ix, LocateDev Q) {
 }
 
 // ---- hits -> coordinates: the index-bound half of intervals_to_bam, one thread per read (postproc_core.hpp) -----------------
-__global__ void __launch_bounds__(256) records_kernel(PostIndex Q, const uint64_t* __restrict__ hit_begin, const HitRec* __restrict__ hits, const uint32_t* __restrict__ ops,
-                                                      uint64_t n_reads, uint64_t seed, CoordRec* __restrict__ out) {
-    const uint64_t r = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+__global__ void MAPAD_SLIM_EARLY records_kernel(PostIndex Q, const uint64_t* __restrict__ hit_begin, const HitRec* __restrict__ hits, const uint32_t* __restrict__ ops,
+                                                        uint64_t n_reads, uint64_t seed, CoordRec* __restrict__ out) {
+    const uint64_t r = (uint64_t)blockIdx.x * 64 + threadIdx.x;
     if (r >= n_reads) return;
     const uint64_t b = hit_begin[r];
     record_coords(Q, hits + b, (uint32_t)(hit_begin[r + 1] - b), ops, seed, r, out[r]);
@@ -626,7 +640,7 @@ __global__ void __launch_bounds__(64, (LPR == 1 && NL) ? 1 : MAPAD_MIN_WAVES) se
 // The search writes a read's hits wherever the bump cursors stood when the read finished.  These three kernels lay hits and edit
 // operations out in read order (hit_begin / ops_begin = exclusive prefix sums over the reads), so that results leave the GPU — to
 // the host or to rank 0 — as dense arrays that concatenate across shards.
-constexpr int kScanTile = 1024;  // reads per block, 4 per thread
+constexpr int kScanTile = 256;  // reads per block (one wavefront), 4 per lane
 struct CompactDev {
     const uint32_t* hit_count; const uint32_t* hit_first; const HitRec* pool; const uint32_t* ops_pool;
     uint64_t n_reads;
@@ -640,44 +654,40 @@ __device__ __forceinline__ uint32_t read_ops(const CompactDev& Q, uint64_t r) {
     for (uint32_t k = 0; k < c; ++k) s += Q.pool[f + k].n_ops;
     return s;
 }
-__global__ void __launch_bounds__(256) compact_sums_kernel(CompactDev Q) {
-    __shared__ unsigned long long sh[2];
-    if (threadIdx.x == 0) { sh[0] = 0; sh[1] = 0; }
-    __syncthreads();
+// inclusive scan over the wavefront's lanes (two sums at once)
+__device__ __forceinline__ void wave_scan2(unsigned long long& a, unsigned long long& b, uint32_t lane) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const unsigned long long ua = __shfl_up(a, d), ub = __shfl_up(b, d);
+        if (lane >= (uint32_t)d) { a += ua; b += ub; }
+    }
+}
+__global__ void MAPAD_SLIM compact_sums_kernel(CompactDev Q) {
     unsigned long long h = 0, o = 0;
     for (int q = 0; q < 4; ++q) {
-        const uint64_t r = (uint64_t)blockIdx.x * kScanTile + q * 256 + threadIdx.x;
+        const uint64_t r = (uint64_t)blockIdx.x * kScanTile + q * 64 + threadIdx.x;
         if (r < Q.n_reads) { h += Q.hit_count[r]; o += read_ops(Q, r); }
     }
     for (int d = 32; d; d >>= 1) { h += __shfl_xor(h, d); o += __shfl_xor(o, d); }
-    if ((threadIdx.x & 63) == 0) { atomicAdd(&sh[0], h); atomicAdd(&sh[1], o); }
-    __syncthreads();
-    if (threadIdx.x == 0) { Q.tile_hits[blockIdx.x] = sh[0]; Q.tile_ops[blockIdx.x] = sh[1]; }
+    if (threadIdx.x == 0) { Q.tile_hits[blockIdx.x] = h; Q.tile_ops[blockIdx.x] = o; }
 }
-__global__ void __launch_bounds__(1024) compact_scan_tiles_kernel(CompactDev Q, uint64_t n_tiles) {  // one block: exclusive scan of the tile sums
-    __shared__ unsigned long long sh[2][1024];
+__global__ void MAPAD_SLIM compact_scan_tiles_kernel(CompactDev Q, uint64_t n_tiles) {  // one wavefront: exclusive scan of the tile sums
+    const uint32_t lane = threadIdx.x & 63u;
     unsigned long long carry_h = 0, carry_o = 0;
-    for (uint64_t base = 0; base < n_tiles; base += 1024) {
-        const uint64_t i = base + threadIdx.x;
+    for (uint64_t base = 0; base < n_tiles; base += 64) {
+        const uint64_t i = base + lane;
         const unsigned long long vh = i < n_tiles ? Q.tile_hits[i] : 0, vo = i < n_tiles ? Q.tile_ops[i] : 0;
-        sh[0][threadIdx.x] = vh; sh[1][threadIdx.x] = vo;
-        __syncthreads();
-        for (int d = 1; d < 1024; d <<= 1) {
-            const unsigned long long ah = threadIdx.x >= (unsigned)d ? sh[0][threadIdx.x - d] : 0, ao = threadIdx.x >= (unsigned)d ? sh[1][threadIdx.x - d] : 0;
-            __syncthreads();
-            sh[0][threadIdx.x] += ah; sh[1][threadIdx.x] += ao;
-            __syncthreads();
-        }
-        if (i < n_tiles) { Q.tile_hits[i] = carry_h + sh[0][threadIdx.x] - vh; Q.tile_ops[i] = carry_o + sh[1][threadIdx.x] - vo; }
-        carry_h += sh[0][1023]; carry_o += sh[1][1023];
-        __syncthreads();
+        unsigned long long sh = vh, so = vo;
+        wave_scan2(sh, so, lane);
+        if (i < n_tiles) { Q.tile_hits[i] = carry_h + sh - vh; Q.tile_ops[i] = carry_o + so - vo; }
+        carry_h += __shfl(sh, 63); carry_o += __shfl(so, 63);
     }
-    if (threadIdx.x == 0) { Q.hit_begin[Q.n_reads] = carry_h; Q.ops_begin[Q.n_reads] = carry_o; }
+    if (lane == 0) { Q.hit_begin[Q.n_reads] = carry_h; Q.ops_begin[Q.n_reads] = carry_o; }
 }
-__global__ void __launch_bounds__(256) compact_move_kernel(CompactDev Q) {
-    __shared__ unsigned long long sh[2][256];
-    // tile-local exclusive scan: thread t owns reads 4t .. 4t+3 of the tile
-    const uint64_t r0 = (uint64_t)blockIdx.x * kScanTile + 4 * threadIdx.x;
+__global__ void MAPAD_SLIM compact_move_kernel(CompactDev Q) {
+    // tile-local exclusive scan: lane t owns reads 4t .. 4t+3 of the tile
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t r0 = (uint64_t)blockIdx.x * kScanTile + 4 * lane;
     uint32_t c[4], o[4];
     unsigned long long th = 0, to = 0;
     for (int q = 0; q < 4; ++q) {
@@ -685,15 +695,9 @@ __global__ void __launch_bounds__(256) compact_move_kernel(CompactDev Q) {
         c[q] = r < Q.n_reads ? Q.hit_count[r] : 0; o[q] = r < Q.n_reads ? read_ops(Q, r) : 0;
         th += c[q]; to += o[q];
     }
-    sh[0][threadIdx.x] = th; sh[1][threadIdx.x] = to;
-    __syncthreads();
-    for (int d = 1; d < 256; d <<= 1) {
-        const unsigned long long ah = threadIdx.x >= (unsigned)d ? sh[0][threadIdx.x - d] : 0, ao = threadIdx.x >= (unsigned)d ? sh[1][threadIdx.x - d] : 0;
-        __syncthreads();
-        sh[0][threadIdx.x] += ah; sh[1][threadIdx.x] += ao;
-        __syncthreads();
-    }
-    unsigned long long hb = Q.tile_hits[blockIdx.x] + sh[0][threadIdx.x] - th, ob = Q.tile_ops[blockIdx.x] + sh[1][threadIdx.x] - to;
+    unsigned long long sh = th, so = to;
+    wave_scan2(sh, so, lane);
+    unsigned long long hb = Q.tile_hits[blockIdx.x] + sh - th, ob = Q.tile_ops[blockIdx.x] + so - to;
     for (int q = 0; q < 4; ++q) {
         const uint64_t r = r0 + q;
         if (r >= Q.n_reads) break;
@@ -1128,7 +1132,7 @@ int launch_batch(mapad_ctx* c, BatchSlot& S, const uint8_t* d_seqs, const uint8_
     }
     if (ordered && !warm) {
         hipLaunchKernelGGL(order_scan_kernel, dim3(1), dim3(64), 0, S.stream, S.d_key_hist.p, n_chunks);
-        hipLaunchKernelGGL(order_scatter_kernel, dim3((uint32_t)((n_reads + 1023) / 1024)), dim3(1024), 0, S.stream, B);
+        hipLaunchKernelGGL(order_scatter_kernel, dim3((uint32_t)((n_reads + 63) / 64)), dim3(64), 0, S.stream, B);
         HIP_TRY(hipGetLastError());
     }
     if (!warm) HIP_TRY(hipEventRecord(S.ev[1], S.stream));
@@ -1138,7 +1142,12 @@ int launch_batch(mapad_ctx* c, BatchSlot& S, const uint8_t* d_seqs, const uint8_
     // lanes-per-read 1: 64 read slots per wavefront, near data in LDS while it fits the 64 KB a launch may ask for without an opt-in
     const bool near_fits = c->lpr == 4 ? near_lmax <= kMaxLdsReadLen : (size_t)near_bytes(near_lmax) * 64 <= 65536;
     const uint32_t near_stride = (near_fits && env_u32("MAPAD_NEAR_LDS", 1)) ? near_bytes(near_lmax) : 0;
-    const size_t lds = (size_t)near_stride * rpw;
+    // LDS per search block: the near data of its read slots — padded, when twelve blocks would fit a CU, to what only eleven fit (see order_scatter_kernel)
+    size_t lds = (size_t)near_stride * rpw;
+    {
+        const size_t cu_lds = 160 * 1024, per_cu = env_u32("MAPAD_SEARCH_BLOCKS_PER_CU", 11);
+        if (lds && per_cu && per_cu < 12 && cu_lds / lds > per_cu) lds = (cu_lds / (per_cu + 1) + 256) & ~(size_t)255;
+    }
     const bool cont = c->dprm.bound_kind == BOUND_CONTINUOUS;
     const bool heavy_on = c->grow.heavy_min_class < (uint32_t)kClasses;
 #define MAPAD_LAUNCH(L, C, P, N)                                                                                                                                   \
@@ -1156,6 +1165,14 @@ int launch_batch(mapad_ctx* c, BatchSlot& S, const uint8_t* d_seqs, const uint8_
     // 16 per CU x 2 batches in flight 273 ms, 8 x 2 247 ms, 8 x 3 252 ms; C3: 8 x 2 589 ms, 8 x 3 529 ms).
     bool others_running = false;
     for (auto& o : c->bs) if (&o != &S && o.ev_valid && hipEventQuery(o.ev[3]) == hipErrorNotReady) others_running = true;
+    // Big batches (C4: 10 M reads, a 4 s launch whose tail is 3 % of it) gain nothing from a second search beside the first — two launches that
+    // share the chip ran 6-8 % slower than one after the other — but their D arrays and ordering (4 % of a step) still run beside the previous
+    // batch's search, in the room its launch leaves on every CU: the search of such a batch waits for the searches before it.
+    const bool serialize = env_u32("MAPAD_SERIALIZE_SEARCH", n_reads >= (4u << 20) ? 1 : 0) != 0;
+    if (serialize && others_running && !warm) {
+        for (auto& o : c->bs) if (&o != &S && o.ev_valid) HIP_TRY(hipStreamWaitEvent(S.stream, o.ev[3], 0));
+        others_running = false;  // this launch will have the chip to itself
+    }
     const uint32_t full_waves = c->resident_waves, shared_waves = std::max<uint32_t>(1, std::min<uint32_t>(full_waves, env_u32("MAPAD_SHARED_WAVES_PER_CU", 8) * (uint32_t)c->n_cu));
     const uint32_t grid_s = warm ? 1u : (uint32_t)std::min<uint64_t>((n_reads + rpw - 1) / rpw, others_running ? shared_waves : full_waves);
     // heavy wavefronts: as many as the chip holds (LDS: heap levels 0-9 + the read's position data); a wavefront that finds no work exits at once
@@ -1213,9 +1230,9 @@ int compact_last(mapad_ctx* c) {
     if ((rc = S.d_c_ops.ensure(std::max<uint64_t>(S.c_n_ops, 1)))) return rc;
     if (n == 0) { HIP_TRY(hipMemsetAsync(S.d_c_hit_begin.p, 0, 8, S.stream)); HIP_TRY(hipMemsetAsync(S.d_c_ops_begin.p, 0, 8, S.stream)); S.compacted = true; return MAPAD_OK; }
     CompactDev Q{B.hit_count, B.hit_first, B.hits_pool, B.ops_pool, n, S.d_c_hit_begin.p, S.d_c_ops_begin.p, S.d_c_tiles.p, S.d_c_tiles.p + n_tiles, S.d_c_hits.p, S.d_c_ops.p};
-    hipLaunchKernelGGL(compact_sums_kernel, dim3((uint32_t)n_tiles), dim3(256), 0, S.stream, Q);
-    hipLaunchKernelGGL(compact_scan_tiles_kernel, dim3(1), dim3(1024), 0, S.stream, Q, n_tiles);
-    hipLaunchKernelGGL(compact_move_kernel, dim3((uint32_t)n_tiles), dim3(256), 0, S.stream, Q);
+    hipLaunchKernelGGL(compact_sums_kernel, dim3((uint32_t)n_tiles), dim3(64), 0, S.stream, Q);
+    hipLaunchKernelGGL(compact_scan_tiles_kernel, dim3(1), dim3(64), 0, S.stream, Q, n_tiles);
+    hipLaunchKernelGGL(compact_move_kernel, dim3((uint32_t)n_tiles), dim3(64), 0, S.stream, Q);
     HIP_TRY(hipGetLastError());
     S.compacted = true;
     return MAPAD_OK;
@@ -1870,7 +1887,7 @@ int mapad_hits_to_records_gpu(mapad_ctx_t* ctx, const mapad_batch_result_t* res,
             for (; k < 2; ++k) { Q.extra_row[k] = ~0ull; Q.extra_val[k] = 0; }
             Q.n_contigs = (uint32_t)ix.contigs.size(); Q.contig_start = ctx->d_contigs.p; Q.contig_end = ctx->d_contigs.p + ix.contigs.size();
             HIP_TRY(hipEventRecord(ctx->lev[0], ctx->stream));
-            hipLaunchKernelGGL(records_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, ctx->stream, Q, ctx->d_r_begin.p, ctx->d_r_hits.p, ctx->d_r_ops.p, n, seed, ctx->d_r_out.p);
+            hipLaunchKernelGGL(records_kernel, dim3((uint32_t)((n + 63) / 64)), dim3(64), 0, ctx->stream, Q, ctx->d_r_begin.p, ctx->d_r_hits.p, ctx->d_r_ops.p, n, seed, ctx->d_r_out.p);
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipEventRecord(ctx->lev[1], ctx->stream));
             HIP_TRY(hipMemcpyAsync(coords.data(), ctx->d_r_out.p, n * sizeof(CoordRec), hipMemcpyDeviceToHost, ctx->stream));
