@@ -452,6 +452,50 @@ def main():
         r2.close()
         ctx.set_stream(ctypes.c_void_p(stream.cuda_stream))
 
+    # ---- the next row of the path (SURVEY 8f #2), outside the timed region: SA locate of the hits' rows on the device -------------
+    locate = None
+    if extras:
+        small = res.hits_arr["size"] <= 8
+        lo, sz = res.hits_arr["lower"][small].astype(np.uint64), res.hits_arr["size"][small].astype(np.uint64)
+        rows = np.unique(np.concatenate([(lo + np.uint64(k))[sz > k] for k in range(8)]))
+        pos = ctx.sa_locate(rows)
+        pos = ctx.sa_locate(rows)  # second call: SA samples already resident
+        l_ms, l_rows, l_steps = ctx.locate_info()
+        l_bytes = 128 * l_steps + 16 * l_rows  # one index block per LF step, row in, sample + position out
+        locate = {"rows": int(l_rows), "lf_steps": int(l_steps), "kernel_ms": round(l_ms, 4), "rows_per_s": round(l_rows / (l_ms * 1e-3), 1) if l_ms else None,
+                  "algorithmic_GB/s": round(l_bytes / (l_ms * 1e-3) / 1e9, 2) if l_ms else None}
+        if not args.no_cpu_baseline:
+            n_s = int(min(rows.size, 300000))
+            t = time.perf_counter()
+            want = index.sa_get_batch(rows[:n_s])
+            dt = time.perf_counter() - t
+            locate["cpu_baseline"] = {"value": round(n_s / dt, 1), "unit": "rows/s", "cores": 1, "kind": "port",
+                                      "sample": f"first {n_s} rows, host restatement of SampledSuffixArray::get on one thread"}
+            locate["identical_positions"] = bool(np.array_equal(want, pos[:n_s]))
+
+    # ---- hits -> record fields (intervals_to_bam minus BAM encoding; rows a14-a17 of SURVEY 8a), outside the timed region ----------
+    post = None
+    if extras:
+        from mapad_amd import binding as mb
+        import ctypes as C
+
+        def records_call():
+            out = C.POINTER(mb.RecordsC)()
+            t = time.perf_counter()
+            rc = mb.lib().mapad_hits_to_records_gpu(ctx.h, res._cptr, seqs.ctypes.data_as(C.c_void_p), quals.ctypes.data_as(C.c_void_p),
+                                                    offsets.ctypes.data_as(C.c_void_p), None, 0, C.byref(out))
+            dt = time.perf_counter() - t
+            assert rc == 0
+            mb.lib().mapad_records_free(out)
+            return dt
+
+        dt_all = records_call()
+        post = {"reads_per_s": round(n_reads / dt_all, 1), "wall_s": round(dt_all, 3), "host_threads": min(os.cpu_count() or 1, 64),
+                "what": "mapad_hits_to_records_gpu: SA locate kernel + coordinates, MAPQ, CIGAR/MD/XA strings on host threads"}
+
+    ctx.close()  # the command-line leg below starts a process with a context of its own on the same GPU: this one's 180 GB of pools must be gone
+    mapped_fraction = round(float((np.diff(res.hit_begin.astype(np.int64)) > 0).mean()), 4)
+    del res
     # ---- the command line end to end: FASTQ in, BAM out (reader, GPU mapping, records, BAM encoding + BGZF, all overlapped) -----------------
     cli = None
     if extras and args.config in ("c2", "c3", "c4") and not args.no_cli:
@@ -511,47 +555,6 @@ def main():
         finally:
             shutil.rmtree(tmp, ignore_errors=True)
 
-    # ---- the next row of the path (SURVEY 8f #2), outside the timed region: SA locate of the hits' rows on the device -------------
-    locate = None
-    if extras:
-        small = res.hits_arr["size"] <= 8
-        lo, sz = res.hits_arr["lower"][small].astype(np.uint64), res.hits_arr["size"][small].astype(np.uint64)
-        rows = np.unique(np.concatenate([(lo + np.uint64(k))[sz > k] for k in range(8)]))
-        pos = ctx.sa_locate(rows)
-        pos = ctx.sa_locate(rows)  # second call: SA samples already resident
-        l_ms, l_rows, l_steps = ctx.locate_info()
-        l_bytes = 128 * l_steps + 16 * l_rows  # one index block per LF step, row in, sample + position out
-        locate = {"rows": int(l_rows), "lf_steps": int(l_steps), "kernel_ms": round(l_ms, 4), "rows_per_s": round(l_rows / (l_ms * 1e-3), 1) if l_ms else None,
-                  "algorithmic_GB/s": round(l_bytes / (l_ms * 1e-3) / 1e9, 2) if l_ms else None}
-        if not args.no_cpu_baseline:
-            n_s = int(min(rows.size, 300000))
-            t = time.perf_counter()
-            want = index.sa_get_batch(rows[:n_s])
-            dt = time.perf_counter() - t
-            locate["cpu_baseline"] = {"value": round(n_s / dt, 1), "unit": "rows/s", "cores": 1, "kind": "port",
-                                      "sample": f"first {n_s} rows, host restatement of SampledSuffixArray::get on one thread"}
-            locate["identical_positions"] = bool(np.array_equal(want, pos[:n_s]))
-
-    # ---- hits -> record fields (intervals_to_bam minus BAM encoding; rows a14-a17 of SURVEY 8a), outside the timed region ----------
-    post = None
-    if extras:
-        from mapad_amd import binding as mb
-        import ctypes as C
-
-        def records_call():
-            out = C.POINTER(mb.RecordsC)()
-            t = time.perf_counter()
-            rc = mb.lib().mapad_hits_to_records_gpu(ctx.h, res._cptr, seqs.ctypes.data_as(C.c_void_p), quals.ctypes.data_as(C.c_void_p),
-                                                    offsets.ctypes.data_as(C.c_void_p), None, 0, C.byref(out))
-            dt = time.perf_counter() - t
-            assert rc == 0
-            mb.lib().mapad_records_free(out)
-            return dt
-
-        dt_all = records_call()
-        post = {"reads_per_s": round(n_reads / dt_all, 1), "wall_s": round(dt_all, 3), "host_threads": min(os.cpu_count() or 1, 64),
-                "what": "mapad_hits_to_records_gpu: SA locate kernel + coordinates, MAPQ, CIGAR/MD/XA strings on host threads"}
-
     if rank == 0:
         total_reads = total_reads_per_step * args.steps
         model = "no-damage" if args.config in ("c1", "c2", "c4") else "ss 50% deamination"
@@ -565,14 +568,13 @@ def main():
                        "reads_per_gpu": n_reads, "genome_bp": genome_bp, "index_bytes_hbm": int((len(index) + 255) // 256 * 128),
                        "batches_in_flight": args.depth,
                        "parallelism": f"reads sharded over {world} GPUs, index replicated, read-ordered hit records gathered on rank 0 (RCCL p2p)" if world > 1 else "1 GPU",
-                       "mapped_fraction": round(float((np.diff(res.hit_begin.astype(np.int64)) > 0).mean()), 4),
+                       "mapped_fraction": mapped_fraction,
                        "index_build_s": round(t_index, 1), "index_build": "GPU suffix sorting (prefix doubling over radix sorts) + host text preparation"},
             "roofline": roofline, "cpu_baseline": cpu, "parity": parity, "e2e": e2e, "cli": cli, "sa_locate": locate, "post_search": post,
         }
         if gather_check is not None:
             line["gather"] = gather_check
         print(json.dumps(line), file=real_stdout, flush=True)
-    ctx.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -800,6 +800,7 @@ struct BatchSlot {
     uint32_t last_lmax = 0;
     uint32_t launch_info[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     bool ev_valid = false, timed = true;  // timed: its event times are already in the context's history
+    uint64_t gen = 0;                     // counts the launches of this slot: a fetched result knows whether the slot still holds it
 
     void release() {
         d_seqs.release(); d_quals.release(); d_offsets.release(); d_darr.release(); d_counters.release(); d_status.release(); d_hit_count.release();
@@ -1119,6 +1120,7 @@ int launch_batch(mapad_ctx* c, BatchSlot& S, const uint8_t* d_seqs, const uint8_
     B.prof = c->d_prof.p;
 #endif
     S.last = B; S.last_total_bases = total_bases; S.last_lmax = lmax; S.compacted = false;
+    S.gen += 1;
     if (n_reads == 0 && !warm) return MAPAD_OK;
     const uint32_t lds_lmax = std::max<uint32_t>(lmax, 1);
     const size_t lds_bytes = (size_t)16 * lds_lmax * sizeof(float);
@@ -1295,6 +1297,9 @@ struct PinnedBuf {
 
 struct HostResult {
     mapad_batch_result_t pub{};
+    const void* owner = nullptr;  // the context and batch slot whose device buffers still hold this result in read order (while `gen` matches the slot's)
+    int slot = -1;
+    uint64_t gen = 0;
     PinnedBuf<uint64_t> hit_begin;
     PinnedBuf<mapad_hit_t> hits;
     PinnedBuf<uint32_t> ops, status;
@@ -1528,6 +1533,7 @@ int mapad_fetch_result(mapad_ctx_t* ctx, mapad_batch_result_t** out) {
         sums[0] += c.e_search; sums[1] += c.e_darray; sums[2] += c.n_push; sums[3] += c.n_pop; sums[4] += c.n_node; sums[5] += c.n_hits;
     }
     std::memcpy(ctx->counter_sums, sums, sizeof sums);
+    r->owner = ctx; r->slot = ctx->view; r->gen = S.gen;
     r->pub.n_reads = n; r->pub.n_hits = r->hits.size(); r->pub.n_ops = r->ops.size();
     r->pub.hit_begin = r->hit_begin.data(); r->pub.hits = r->hits.data(); r->pub.ops = r->ops.data();
     r->pub.status = r->status.data(); r->pub.counters = r->counters.data(); r->pub.d_arrays = ctx->fetch_d ? r->d_arrays.data() : nullptr;
@@ -1873,25 +1879,37 @@ int mapad_hits_to_records_gpu(mapad_ctx_t* ctx, const mapad_batch_result_t* res,
         if (n) {
             // the hit records go back to the GPU that produced them (page-locked results: DMA), the index-bound half of intervals_to_bam runs
             // there — SA walks, strand and contig, X0 / X1, XA candidates — and one compact record per read comes back
-            if ((rc = ctx->d_r_begin.ensure(n + 1))) return rc;
-            if ((rc = ctx->d_r_hits.ensure(std::max<uint64_t>(res->n_hits, 1)))) return rc;
-            if ((rc = ctx->d_r_ops.ensure(std::max<uint64_t>(res->n_ops, 1)))) return rc;
             if ((rc = ctx->d_r_out.ensure(n))) return rc;
-            HIP_TRY(hipMemcpyAsync(ctx->d_r_begin.p, res->hit_begin, (n + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
-            if (res->n_hits) HIP_TRY(hipMemcpyAsync(ctx->d_r_hits.p, res->hits, res->n_hits * sizeof(HitRec), hipMemcpyHostToDevice, ctx->stream));
-            if (res->n_ops) HIP_TRY(hipMemcpyAsync(ctx->d_r_ops.p, res->ops, res->n_ops * 4, hipMemcpyHostToDevice, ctx->stream));
+            // The hits are normally still on the device, laid out in read order by the collect of the fetch that produced `res` (the batch slot has not
+            // been launched again since): the kernel reads them where they are.  Otherwise (an older result) they go back over PCIe first.
+            const HostResult* hr = reinterpret_cast<const HostResult*>(res);  // results are library-owned: pub is the first member
+            const uint64_t* d_begin; const HitRec* d_hits; const uint32_t* d_ops;
+            hipStream_t rstream = ctx->stream;
+            if (hr->owner == ctx && hr->slot >= 0 && hr->slot < kMaxDepth && ctx->bs[hr->slot].gen == hr->gen && ctx->bs[hr->slot].compacted && env_u32("MAPAD_RECORDS_RESIDENT", 1)) {
+                const BatchSlot& RS = ctx->bs[hr->slot];
+                d_begin = RS.d_c_hit_begin.p; d_hits = RS.d_c_hits.p; d_ops = RS.d_c_ops.p;
+                rstream = RS.stream;  // the stream that wrote them (idle since the fetch)
+            } else {
+                if ((rc = ctx->d_r_begin.ensure(n + 1))) return rc;
+                if ((rc = ctx->d_r_hits.ensure(std::max<uint64_t>(res->n_hits, 1)))) return rc;
+                if ((rc = ctx->d_r_ops.ensure(std::max<uint64_t>(res->n_ops, 1)))) return rc;
+                HIP_TRY(hipMemcpyAsync(ctx->d_r_begin.p, res->hit_begin, (n + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+                if (res->n_hits) HIP_TRY(hipMemcpyAsync(ctx->d_r_hits.p, res->hits, res->n_hits * sizeof(HitRec), hipMemcpyHostToDevice, ctx->stream));
+                if (res->n_ops) HIP_TRY(hipMemcpyAsync(ctx->d_r_ops.p, res->ops, res->n_ops * 4, hipMemcpyHostToDevice, ctx->stream));
+                d_begin = ctx->d_r_begin.p; d_hits = ctx->d_r_hits.p; d_ops = ctx->d_r_ops.p;
+            }
             PostIndex Q{};
             Q.ix = ctx->dix; Q.sa_sample = ctx->d_sa.p; Q.x_counts = ix.x_counts.empty() ? nullptr : ctx->d_xc.p; Q.sa_shift = shift;
             int k = 0;
             for (const auto& kv : ix.extra_rows) { Q.extra_row[k] = kv.first; Q.extra_val[k] = kv.second; ++k; }
             for (; k < 2; ++k) { Q.extra_row[k] = ~0ull; Q.extra_val[k] = 0; }
             Q.n_contigs = (uint32_t)ix.contigs.size(); Q.contig_start = ctx->d_contigs.p; Q.contig_end = ctx->d_contigs.p + ix.contigs.size();
-            HIP_TRY(hipEventRecord(ctx->lev[0], ctx->stream));
-            hipLaunchKernelGGL(records_kernel, dim3((uint32_t)((n + 63) / 64)), dim3(64), 0, ctx->stream, Q, ctx->d_r_begin.p, ctx->d_r_hits.p, ctx->d_r_ops.p, n, seed, ctx->d_r_out.p);
+            HIP_TRY(hipEventRecord(ctx->lev[0], rstream));
+            hipLaunchKernelGGL(records_kernel, dim3((uint32_t)((n + 63) / 64)), dim3(64), 0, rstream, Q, d_begin, d_hits, d_ops, n, seed, ctx->d_r_out.p);
             HIP_TRY(hipGetLastError());
-            HIP_TRY(hipEventRecord(ctx->lev[1], ctx->stream));
-            HIP_TRY(hipMemcpyAsync(coords.data(), ctx->d_r_out.p, n * sizeof(CoordRec), hipMemcpyDeviceToHost, ctx->stream));
-            HIP_TRY(hipStreamSynchronize(ctx->stream));
+            HIP_TRY(hipEventRecord(ctx->lev[1], rstream));
+            HIP_TRY(hipMemcpyAsync(coords.data(), ctx->d_r_out.p, n * sizeof(CoordRec), hipMemcpyDeviceToHost, rstream));
+            HIP_TRY(hipStreamSynchronize(rstream));
             ctx->last_locate_rows = n; ctx->last_locate_steps = 0;
         }
         *out = host::records_from_coords(ix, ctx->params, *res, in_flags, coords.data());
