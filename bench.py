@@ -300,12 +300,12 @@ def main():
         dist.barrier()
     torch.cuda.synchronize(dev)
     elapsed = time.perf_counter() - t0
-    per_rank = None
+    rank_rates = None
     if world > 1:
         mine = torch.tensor([elapsed, float(n_reads)], dtype=torch.float64, device=xdev)
         every = [torch.zeros(2, dtype=torch.float64, device=xdev) for _ in range(world)]
         dist.all_gather(every, mine)
-        per_rank = [{"rank": r, "reads": int(v[1].item()), "elapsed_s": round(float(v[0].item()), 4), "reads_per_s": round(float(v[1].item()) * args.steps / float(v[0].item()), 1)} for r, v in enumerate(every)]
+        rank_rates = [{"rank": r, "reads": int(v[1].item()), "elapsed_s": round(float(v[0].item()), 4), "reads_per_s": round(float(v[1].item()) * args.steps / float(v[0].item()), 1)} for r, v in enumerate(every)]
         elapsed = max(float(v[0].item()) for v in every)
         total_reads_per_step = int(sum(float(v[1].item()) for v in every))
     else:
@@ -344,7 +344,7 @@ def main():
             hb, hits, ops, per_rank = merge_gathered(gathered)
             ok = [per_rank[r] == all_own[r] for r in range(world)]
             gather_check = {"world_size_seen": dist.get_world_size(), "ranks_identical_to_own_fetch": int(sum(ok)), "merged_reads": int(len(hb) - 1),
-                            "merged_hits": int(hits.shape[0]), "merged_ops": int(ops.size), "per_rank": per_rank,
+                            "merged_hits": int(hits.shape[0]), "merged_ops": int(ops.size), "per_rank": rank_rates,
                             "exchange": "RCCL point-to-point fan-in to rank 0 over xGMI, issued behind the next step's submission" if args.dist_backend == "nccl" else "gloo through host memory (test mode)",
                             "index": {"built_by": "rank 0, saved, loaded by the others" if shared is not None else "every rank", "save_s": None if t_index_save is None else round(t_index_save, 1), "load_s_per_rank": loads}}
             if not all(ok):

@@ -82,8 +82,9 @@ float mapad_mb_remaining_frac_of_repr_mm(const mapad_params_t* p, float value, u
 typedef struct mapad_index mapad_index_t;
 
 /* `mapad index` (src/index/indexing.rs:29-212) on an in-memory FASTA-like input: n_contigs sequences (any case, IUPAC).
- * Ambiguous bases in runs shorter than 20 are replaced by a random compatible base drawn from splitmix64(seed) (the
- * reference uses rand::StdRng(seed), whose stream is not reproduced), longer runs become 'X'; originals are kept. */
+ * Ambiguous bases in runs shorter than 20 are replaced by a random compatible base drawn like the reference draws it — rand 0.9
+ * StdRng::seed_from_u64(seed) + slice.choose(): ChaCha12 keyed through PCG32, index by Canon's method, restated in host_index.hpp and
+ * checked against the one draw the reference's integration test pins —, longer runs become 'X'; originals are kept. */
 int mapad_index_build(const char* const* names, const uint8_t* const* seqs, const uint64_t* lens, uint32_t n_contigs,
                       uint64_t seed, mapad_index_t** out);
 /* The same products (src/index/indexing.rs:163-195: suffix array -> BWT, SA sample, Less, rank structure) with the suffix sorting done on

@@ -268,9 +268,54 @@ void run_apply(std::vector<uint8_t>& seq, size_t min_run_len, F non_run_fun, G r
     }
 }
 
-struct SplitMix64 {
-    uint64_t s;
-    uint64_t next() { uint64_t z = (s += 0x9E3779B97F4A7C15ull); z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; return z ^ (z >> 31); }
+// The random source of `mapad index`: rand 0.9 `StdRng::seed_from_u64(seed)` + `slice.choose(rng)` (src/index/indexing.rs:30,78-92), restated from
+// the published algorithms (the crates are not vendored): rand_core 0.9 seed_from_u64 expands the u64 into the 32-byte key with PCG32 (XSH-RR output of an
+// LCG advanced first); StdRng is ChaCha12 with a 64-bit block counter from 0 and stream 0, whose output words are consumed in order; choose() draws
+// an index by `random_range(0..len as u32)`, which in rand 0.9 is Canon's method: the high half of (next_u32 x len), corrected by one more draw when the
+// low half falls within `len` of 2^32.  Checked against the reference where it can be: the ChaCha core against the RFC 7539 key stream, and the one draw the
+// reference's integration test pins — StdRng(1234) must turn the N of Chromosome_02 into 'A' (tests/integration_tests.rs, MD 4C5N11 with MAPQ 37).
+struct StdRngCompat {
+    uint32_t key[8];
+    uint64_t counter = 0;
+    uint32_t buf[16];
+    int idx = 16;
+    explicit StdRngCompat(uint64_t seed) {
+        uint64_t state = seed;
+        for (int i = 0; i < 8; ++i) {  // rand_core::SeedableRng::seed_from_u64
+            state = state * 6364136223846793005ull + 11634580027462260723ull;
+            const uint32_t xorshifted = (uint32_t)(((state >> 18) ^ state) >> 27), rot = (uint32_t)(state >> 59);
+            key[i] = (xorshifted >> rot) | (xorshifted << ((32 - rot) & 31));
+        }
+    }
+    static uint32_t rotl(uint32_t v, int n) { return (v << n) | (v >> (32 - n)); }
+    void refill() {  // one ChaCha12 block
+        uint32_t s[16] = {0x61707865u, 0x3320646eu, 0x79622d32u, 0x6b206574u, key[0], key[1], key[2], key[3], key[4], key[5], key[6], key[7],
+                          (uint32_t)counter, (uint32_t)(counter >> 32), 0u, 0u};
+        uint32_t w[16];
+        for (int i = 0; i < 16; ++i) w[i] = s[i];
+        auto qr = [&](int a, int b, int c, int d) {
+            w[a] += w[b]; w[d] = rotl(w[d] ^ w[a], 16); w[c] += w[d]; w[b] = rotl(w[b] ^ w[c], 12);
+            w[a] += w[b]; w[d] = rotl(w[d] ^ w[a], 8);  w[c] += w[d]; w[b] = rotl(w[b] ^ w[c], 7);
+        };
+        for (int r = 0; r < 6; ++r) {
+            qr(0, 4, 8, 12); qr(1, 5, 9, 13); qr(2, 6, 10, 14); qr(3, 7, 11, 15);
+            qr(0, 5, 10, 15); qr(1, 6, 11, 12); qr(2, 7, 8, 13); qr(3, 4, 9, 14);
+        }
+        for (int i = 0; i < 16; ++i) buf[i] = w[i] + s[i];
+        counter += 1;
+        idx = 0;
+    }
+    uint32_t next_u32() { if (idx == 16) refill(); return buf[idx++]; }
+    uint32_t index_below(uint32_t n) {  // rand 0.9 UniformInt<u32>::sample_single_inclusive(0, n - 1)
+        const uint64_t m = (uint64_t)next_u32() * n;
+        uint32_t result = (uint32_t)(m >> 32);
+        const uint32_t lo = (uint32_t)m;
+        if (lo > (uint32_t)(0u - n)) {
+            const uint32_t new_hi = (uint32_t)(((uint64_t)next_u32() * n) >> 32);
+            if ((uint64_t)lo + new_hi > 0xFFFFFFFFull) result += 1;
+        }
+        return result;
+    }
 };
 
 inline bool is_iupac(uint8_t c) {
@@ -278,7 +323,8 @@ inline bool is_iupac(uint8_t c) {
 }
 
 // indexing.rs:43-160: contigs -> uppercase -> IUPAC check -> replacement of ambiguity codes -> text $ revcomp $ as ranks ($=0 A=1 C=2 G=3 T=4 X=5).
-// Fills ix.contigs, ix.original_symbols and ix.n.  `fixed_replacement` != 0 forces every short-run replacement to that base (test hook).
+// Fills ix.contigs, ix.original_symbols and ix.n.  `fixed_replacement` != 0 forces every short-run replacement to that base (a test hook for texts
+// whose tests want a known base; the reference's own stream is reproduced by StdRngCompat).
 inline std::vector<uint8_t> prepare_text(const std::vector<std::string>& names, const uint8_t* const* seqs, const uint64_t* lens, uint64_t seed, uint8_t fixed_replacement, Index& ix) {
     std::vector<uint8_t> text;
     uint64_t end = 0;
@@ -311,8 +357,8 @@ inline std::vector<uint8_t> prepare_text(const std::vector<std::string>& names, 
     bool ambiguous = false;
     for (int fl : flag) { if (fl & 2) throw std::runtime_error("Found non-IUPAC symbol in reference sequence"); ambiguous |= (fl & 1) != 0; }  // :71
     if (ambiguous) {
-        SplitMix64 rng{seed};
-        auto pick = [&](const char* set) -> uint8_t { const size_t k = std::char_traits<char>::length(set); return (uint8_t)set[rng.next() % k]; };
+        StdRngCompat rng(seed);
+        auto pick = [&](const char* set) -> uint8_t { const size_t k = std::char_traits<char>::length(set); return (uint8_t)set[rng.index_below((uint32_t)k)]; };
         auto replace = [&](uint8_t b) -> uint8_t {  // :78-92
             if (b == 'U') return 'T';
             if (fixed_replacement) return fixed_replacement;

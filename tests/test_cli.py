@@ -70,7 +70,7 @@ def test_cli_record_io_roundtrip(tmp_path):
 def test_cli_map_matches_integration_expectation(tmp_path, monkeypatch):
     """tests/integration_tests.rs:174-215 through the command line: header prefix and every decoded record field."""
     k = load("integration")
-    monkeypatch.setenv("MAPAD_INDEX_FIXED_REPLACEMENT", k["n_replacement"])
+    monkeypatch.delenv("MAPAD_INDEX_FIXED_REPLACEMENT", raising=False)  # StdRng(1234) itself must draw the base the reference's expectation implies
     fa, inp, out = str(tmp_path / "test_genome.fa"), str(tmp_path / "input_reads.bam"), str(tmp_path / "out.bam")
     _write_fasta(fa, [(c["name"], c["seq"]) for c in k["contigs"]])
     header = ("@HD\tVN:1.0\n@RG\tID:A12345\tSM:Sample1\n@SQ\tSN:chr1\tLN:600\n"

@@ -51,6 +51,41 @@ def test_gpu_index_equals_host_index(name, contigs):
     assert_same_index(host, dev)
 
 
+def test_gpu_index_equals_oracle_index_directly():
+    """The GPU-built index against the ORACLE's own construction (naive suffix sort of its own text, oracle/mapad_oracle.hpp), not via the product's
+    host SA-IS: multi-contig texts with long N runs (-> X, deterministic), lower case, and a 1 Mbp genome; BWT, sampled SA and SA values of random rows."""
+    rng = np.random.default_rng(5)
+    g = synth.genome(1_000_000, seed=11)
+    g2 = g[:200_000].copy()
+    g2[3000:3100] = ord("N"); g2[150_000:150_020] = ord("N"); g2[199_900:] = ord("N")
+    cases = [[("chr1", g.tobytes())],
+             [("a", g2[:70_000].tobytes()), ("b", g2[70_000:70_003].tobytes()), ("c", g2[70_003:].tobytes().lower())]]
+    for contigs in cases:
+        dev = mapad_amd.Index.build(contigs, seed=1234, device=0)
+        text = b"".join(s for _, s in contigs).upper().replace(b"N", b"X")
+        o = ob.OracleIndex.from_text(text, "$ACGTX", 128)
+        assert np.array_equal(dev.bwt(), o.bwt())
+        sa = o.sa()
+        rows = np.concatenate([rng.integers(0, len(sa), 5000), np.array([0, 1, len(sa) - 1])]).astype(np.uint64)
+        assert [int(x) for x in dev.sa_get_batch(rows)] == [int(sa[int(r)]) for r in rows]
+
+
+def test_c1_workload_matches_oracle():
+    """BASELINE.json configs[0] as specified: the 5 386 bp genome, 1 000 synthetic 50 bp reads, -p 0.03, no-damage model — every read against the oracle."""
+    g = synth.genome(5_386, seed=1234)
+    seqs, quals, offsets = synth.reads(g, 1000, 50, seed=4321 + 1, qual=40)
+    rp = resolve_params(NO_DAMAGE)
+    pidx = mapad_amd.Index.build([("chr1", g)], seed=1234, device=0)
+    oidx = ob.OracleIndex.from_text(g.tobytes(), "$ACGTX", 128)
+    assert np.array_equal(pidx.bwt(), oidx.bwt())
+    ctx = mapad_amd.Context(pidx, mapad_amd.make_params(rp), 0)
+    res = ctx.map_batch(seqs, quals, offsets)
+    ctx.close()
+    reads, qs = split_reads(seqs, quals, offsets)
+    ores = oidx.map_batch(ob.make_params(rp), reads, qs, n_threads=8, keep_d=True)
+    assert_same_as_oracle(ores, res, offsets)
+
+
 def test_gpu_index_equals_host_index_100mbp():
     g = synth.genome(100_000_000, seed=1234)
     t0 = time.time()

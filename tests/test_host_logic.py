@@ -296,7 +296,7 @@ def check_integration_records(k, recs):
 
 def test_postproc_integration_expectation(monkeypatch):
     k = load("integration")
-    monkeypatch.setenv("MAPAD_INDEX_FIXED_REPLACEMENT", k["n_replacement"])
+    monkeypatch.delenv("MAPAD_INDEX_FIXED_REPLACEMENT", raising=False)  # StdRng(1234) itself must draw the base the reference's expectation implies
     pidx = mapad_amd.Index.build([(c["name"], c["seq"].encode()) for c in k["contigs"]], seed=1234)
     params = mapad_amd.make_params(resolve_params(k["params"]))
     reads, quals = integration_reads(k)
@@ -361,3 +361,66 @@ def test_postproc_thread_count_does_not_change_records(monkeypatch):
     monkeypatch.setenv("MAPAD_POSTPROC_THREADS", "4")
     four = mapad_amd.hits_to_records(pidx, params, res, seqs, quals, offsets, seed=3)
     assert one == four and sum(r["mapped"] for r in one) > 7000
+
+
+def test_iupac_replacement_follows_rand_stdrng(monkeypatch):
+    """`mapad index` replaces ambiguity codes with rand 0.9 `StdRng::seed_from_u64(seed)` + `choose` (indexing.rs:30,78-92).  The restatement
+    (host_index.hpp: StdRngCompat) against an independent Python restatement of the same published algorithms — PCG32 key expansion, ChaCha12,
+    Canon's method — over a text with every ambiguity code, and against the one draw the reference pins: seed 1234 turns a lone N into 'A'."""
+    monkeypatch.delenv("MAPAD_INDEX_FIXED_REPLACEMENT", raising=False)
+    M64 = (1 << 64) - 1
+
+    def key_of(seed):
+        out, state = [], seed
+        for _ in range(8):
+            state = (state * 6364136223846793005 + 11634580027462260723) & M64
+            x, rot = (((state >> 18) ^ state) >> 27) & 0xFFFFFFFF, state >> 59
+            out.append(((x >> rot) | (x << ((32 - rot) & 31))) & 0xFFFFFFFF)
+        return out
+
+    def rotl(v, n):
+        return ((v << n) | (v >> (32 - n))) & 0xFFFFFFFF
+
+    def block(key, counter):
+        s = [0x61707865, 0x3320646e, 0x79622d32, 0x6b206574] + key + [counter & 0xFFFFFFFF, counter >> 32, 0, 0]
+        w = s[:]
+
+        def qr(a, b, c, d):
+            w[a] = (w[a] + w[b]) & 0xFFFFFFFF; w[d] = rotl(w[d] ^ w[a], 16)
+            w[c] = (w[c] + w[d]) & 0xFFFFFFFF; w[b] = rotl(w[b] ^ w[c], 12)
+            w[a] = (w[a] + w[b]) & 0xFFFFFFFF; w[d] = rotl(w[d] ^ w[a], 8)
+            w[c] = (w[c] + w[d]) & 0xFFFFFFFF; w[b] = rotl(w[b] ^ w[c], 7)
+        for _ in range(6):
+            qr(0, 4, 8, 12); qr(1, 5, 9, 13); qr(2, 6, 10, 14); qr(3, 7, 11, 15)
+            qr(0, 5, 10, 15); qr(1, 6, 11, 12); qr(2, 7, 8, 13); qr(3, 4, 9, 14)
+        return [(w[i] + s[i]) & 0xFFFFFFFF for i in range(16)]
+
+    def stream(seed):
+        key, c = key_of(seed), 0
+        while True:
+            yield from block(key, c)
+            c += 1
+
+    sets = {"R": "AG", "Y": "CT", "K": "GT", "M": "AC", "S": "CG", "W": "AT", "B": "CGT", "D": "AGT", "H": "ACT", "V": "ACG", "N": "ACGT"}
+    for seed in (1234, 0, 7):
+        codes = "NRYKMSWBDHVU" * 40
+        seq = "ACGT".join(codes)  # every code is a run of one
+        want, words = [], stream(seed)
+        for ch in seq:
+            if ch in "ACGT":
+                want.append(ch)
+            elif ch == "U":
+                want.append("T")
+            else:
+                n = len(sets[ch])
+                m = next(words) * n
+                r, lo = m >> 32, m & 0xFFFFFFFF
+                if lo > ((-n) & 0xFFFFFFFF):
+                    if lo + ((next(words) * n) >> 32) > 0xFFFFFFFF:
+                        r += 1
+                want.append(sets[ch][r])
+        p = mapad_amd.Index.build([("c", seq.encode())], seed=seed)
+        o = ob.OracleIndex.from_text("".join(want).encode(), "$ACGTX", 128)
+        assert np.array_equal(p.bwt(), o.bwt()), seed
+    p = mapad_amd.Index.build([("c", b"ACGTACGTNACGTTTGA")], seed=1234)
+    assert np.array_equal(p.bwt(), ob.OracleIndex.from_text(b"ACGTACGTAACGTTTGA", "$ACGTX", 128).bwt())
