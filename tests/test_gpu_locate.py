@@ -34,7 +34,7 @@ def test_sa_locate_matches_host_walk(with_x):
         assert np.array_equal(got, want)
         assert np.array_equal(np.sort(got), rows)  # the suffix array is a permutation of the text positions
         ms, n_rows, steps = ctx.locate_info()
-        assert n_rows == n and 0 < steps <= 31 * n
+        assert n_rows == n and 16 * n < steps < 48 * n  # rows are sampled by row number (every 32nd): a walk takes 31 LF steps on average, not at most
         # ragged / out-of-range / empty requests
         odd = np.array([0, n - 1, n, n + 5, 31, 32, 33], dtype=np.uint64)
         out = ctx.sa_locate(odd)
