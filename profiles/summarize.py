@@ -18,6 +18,8 @@ def short(name):
         return "darray_kernel"
     if "search_kernel" in name:
         return "search_kernel" if ", 0, " in name else "search_kernel_retry" if ", 2, " in name else "search_kernel_last_pass"
+    if "heavy_kernel" in name:  # the full-limit stage (and, with MAPAD_HEAVY=1, the suspended reads): one wavefront per read
+        return "search_kernel_last_pass"
     if "order_" in name:
         return "order_kernels"
     return None
