@@ -257,6 +257,16 @@ int mapad_last_locate_info(mapad_ctx_t* ctx, float* kernel_ms, uint64_t* rows, u
 int mapad_hits_to_records_gpu(mapad_ctx_t* ctx, const mapad_batch_result_t* res, const uint8_t* seqs, const uint8_t* quals, const uint64_t* offsets,
                               const uint16_t* in_flags, uint64_t seed, mapad_records_t** out);
 
+/* The same in two calls, for a chunk loop whose GPU thread should not spend its time on strings: mapad_hits_to_coords_gpu() is the device half
+ * (which hit is reported, its coordinate, the XA candidates, X0 / X1: one kernel over the hits that are still resident on the device, one small copy back);
+ * mapad_coords_to_records() is the host half (flags, CIGAR / MD / XA text, XS / XT, mapping quality) — it needs no context and may run on any thread
+ * while the GPU thread goes on submitting and fetching.  Together they return exactly what mapad_hits_to_records_gpu() returns. */
+typedef struct mapad_coords mapad_coords_t;
+int mapad_hits_to_coords_gpu(mapad_ctx_t* ctx, const mapad_batch_result_t* res, uint64_t seed, mapad_coords_t** out);
+int mapad_coords_to_records(const mapad_index_t* idx, const mapad_params_t* params, const mapad_batch_result_t* res, const uint16_t* in_flags,
+                            const mapad_coords_t* coords, mapad_records_t** out);
+void mapad_coords_free(mapad_coords_t* c);
+
 const char* mapad_version(void);
 
 #ifdef __cplusplus

@@ -129,6 +129,9 @@ SYMBOLS = {
     "mapad_sa_locate": (_i32, [_vp, _vp, _u64, _vp]),
     "mapad_last_locate_info": (_i32, [_vp, C.POINTER(C.c_float), C.POINTER(_u64), C.POINTER(_u64)]),
     "mapad_hits_to_records_gpu": (_i32, [_vp, C.POINTER(BatchResultC), _vp, _vp, _vp, _vp, _u64, C.POINTER(C.POINTER(RecordsC))]),
+    "mapad_hits_to_coords_gpu": (_i32, [_vp, C.POINTER(BatchResultC), _u64, C.POINTER(_vp)]),
+    "mapad_coords_to_records": (_i32, [_vp, _PP, C.POINTER(BatchResultC), _vp, _vp, C.POINTER(C.POINTER(RecordsC))]),
+    "mapad_coords_free": (None, [_vp]),
 }
 
 _lib = None

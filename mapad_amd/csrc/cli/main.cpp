@@ -180,6 +180,7 @@ struct Slice {
     uint64_t lo = 0, hi = 0;  // reads [lo, hi) of the chunk's mappable reads
     std::vector<uint64_t> offsets;  // rebased to the slice
     mapad_batch_result_t* res = nullptr;
+    mapad_coords_t* coords = nullptr;  // device half of the records (mapad_hits_to_coords_gpu), consumed by the records thread
     mapad_records_t* recs = nullptr;
 };
 struct Chunk {
@@ -272,9 +273,9 @@ int cmd_map(const Args& a, uint64_t seed, const std::vector<int>& devices, const
     const unsigned host_threads = std::max(1u, std::min(std::thread::hardware_concurrency(), 32u));
     std::vector<std::unique_ptr<BoundedQueue<ChunkPtr>>> dev_q;
     for (size_t d = 0; d < n_dev; ++d) dev_q.emplace_back(new BoundedQueue<ChunkPtr>(2));  // read ahead; `in_flight` more are on the device
-    BoundedQueue<ChunkPtr> done_q(4);
+    BoundedQueue<ChunkPtr> rec_q(4), done_q(4);
     std::atomic<bool> failed{false};
-    std::atomic<uint64_t> us_reader{0}, us_device{0}, us_writer{0}, us_submit{0}, us_fetch{0}, us_records{0};  // busy time of the three stages (the slowest one sets the throughput)
+    std::atomic<uint64_t> us_reader{0}, us_device{0}, us_writer{0}, us_submit{0}, us_fetch{0}, us_records{0}, us_text{0};  // busy time of the three stages (the slowest one sets the throughput)
     auto now_us = [] { return (uint64_t)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     std::string fail_msg;
     std::mutex fail_mu;
@@ -385,15 +386,15 @@ int cmd_map(const Args& a, uint64_t seed, const std::vector<int>& devices, const
         };
         auto records = [&](const ChunkPtr& c) {
             Slice& sl = c->slices[d];
-            const uint64_t b0 = c->offsets[sl.lo];
             const uint64_t t0 = now_us();
-            // one seed per read of the run, whichever device maps it: the chunk's seed advanced to the slice's first read
-            check(mapad_hits_to_records_gpu(ctx, sl.res, c->seqs.p + b0, c->quals.p + b0, sl.offsets.data(), c->flags.data() + sl.lo,
-                                            mapad_records_seed_at(seed + c->no, sl.lo), &sl.recs), "mapad_hits_to_records_gpu");
+            // The device half of intervals_to_bam (reported hit, coordinates, XA candidates, X0 / X1) from the hits still resident on this GPU; the
+            // strings and mapping qualities are the records thread's work, so that this thread goes straight back to submitting and fetching.
+            // One seed per read of the run, whichever device maps it: the chunk's seed advanced to the slice's first read.
+            check(mapad_hits_to_coords_gpu(ctx, sl.res, mapad_records_seed_at(seed + c->no, sl.lo), &sl.coords), "mapad_hits_to_coords_gpu");
             if (d == 0) us_records += now_us() - t0;
             if (--c->pending == 0) {
                 c->per_read_s = std::chrono::duration<float>(std::chrono::steady_clock::now() - c->t_submit).count() / (float)std::max<size_t>(c->in.size(), 1);
-                done_q.push(c);
+                rec_q.push(c);
             }
         };
         auto collect = [&](const ChunkPtr& c, int age) -> bool {  // false: the hit pools were too small for this slice
@@ -438,6 +439,24 @@ int cmd_map(const Args& a, uint64_t seed, const std::vector<int>& devices, const
     std::vector<std::thread> workers;
     for (size_t d = 0; d < n_dev; ++d) workers.emplace_back(worker, d);
 
+    // ---- records: the text half of intervals_to_bam (CIGAR / MD / XA strings, flags, mapping quality) on host threads, chunk by chunk in order ----
+    std::thread recorder([&] {
+        try {
+            ChunkPtr c;
+            while (rec_q.pop(c)) {
+                if (failed) continue;
+                const uint64_t t0 = now_us();
+                for (auto& sl : c->slices) {
+                    check(mapad_coords_to_records(idx, &prm, sl.res, c->flags.data() + sl.lo, sl.coords, &sl.recs), "mapad_coords_to_records");
+                    mapad_coords_free(sl.coords); sl.coords = nullptr;
+                }
+                us_text += now_us() - t0;
+                done_q.push(c);
+            }
+        } catch (const std::exception& e) { fail(e.what()); }
+        done_q.close();
+    });
+
     // ---- writer ----
     uint64_t n_total = 0, n_mapped = 0;
     std::thread writer([&] {
@@ -479,7 +498,8 @@ int cmd_map(const Args& a, uint64_t seed, const std::vector<int>& devices, const
 
     reader.join();
     for (auto& w : workers) w.join();
-    done_q.close();
+    rec_q.close();
+    recorder.join();
     writer.join();
     if (failed) die(fail_msg);
     out.close();
@@ -487,8 +507,8 @@ int cmd_map(const Args& a, uint64_t seed, const std::vector<int>& devices, const
     std::fprintf(stderr, "mapad-amd: %llu reads, %llu mapped; %zu device(s); index + contexts %.2f s, mapping %.2f s (%.0f reads/s)\n", (unsigned long long)n_total,
                  (unsigned long long)n_mapped, n_dev, t_load, t_all - t_load, (double)n_total / std::max(t_all - t_load, 1e-9));
     std::fprintf(stderr, "mapad-amd: stage busy time: reader %.2f s, device worker 0 %.2f s, writer %.2f s\n", us_reader.load() * 1e-6, us_device.load() * 1e-6, us_writer.load() * 1e-6);
-    std::fprintf(stderr, "mapad-amd: device worker 0: submit %.2f s, fetch (incl. waiting for the GPU) %.2f s, records %.2f s\n", us_submit.load() * 1e-6, us_fetch.load() * 1e-6,
-                 us_records.load() * 1e-6);
+    std::fprintf(stderr, "mapad-amd: device worker 0: submit %.2f s, fetch (incl. waiting for the GPU) %.2f s, coordinates %.2f s; records thread (strings, MAPQ) %.2f s\n",
+                 us_submit.load() * 1e-6, us_fetch.load() * 1e-6, us_records.load() * 1e-6, us_text.load() * 1e-6);
     for (auto* c : ctxs) mapad_ctx_destroy(c);
     mapad_index_free(idx);
     return 0;

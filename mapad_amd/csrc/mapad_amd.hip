@@ -1863,62 +1863,94 @@ int mapad_last_locate_info(mapad_ctx_t* ctx, float* kernel_ms, uint64_t* rows, u
     if (ctx->last_locate_rows && ctx->lev[0]) HIP_TRY(hipEventElapsedTime(kernel_ms, ctx->lev[0], ctx->lev[1]));
     return MAPAD_OK;
 }
+// the device half of intervals_to_bam for one batch result: one CoordRec per read (records_kernel), in host memory
+static int record_coords_gpu(mapad_ctx_t* ctx, const mapad_batch_result_t* res, uint64_t seed, std::vector<CoordRec>& coords) {
+    const host::Index& ix = ctx->index->ix;
+    uint32_t shift = 0;
+    while ((1ull << shift) < ix.sa_rate) ++shift;
+    if ((1ull << shift) != ix.sa_rate || shift < 1 || shift > 8 || ix.extra_rows.size() > 2) return MAPAD_ERR_INVALID;  // the kernels' assumptions
+    int rc;
+    if ((rc = ensure_sa_uploaded(ctx))) return rc;
+    const uint64_t n = res->n_reads;
+    coords.resize(n);
+    if (!n) return MAPAD_OK;
+    if ((rc = ctx->d_r_out.ensure(n))) return rc;
+    // The hits are normally still on the device, laid out in read order by the collect of the fetch that produced `res` (the batch slot has not
+    // been launched again since): the kernel reads them where they are.  Otherwise (an older result) they go back over PCIe first.
+    const HostResult* hr = reinterpret_cast<const HostResult*>(res);  // results are library-owned: pub is the first member
+    const uint64_t* d_begin; const HitRec* d_hits; const uint32_t* d_ops;
+    hipStream_t rstream = ctx->stream;
+    if (hr->owner == ctx && hr->slot >= 0 && hr->slot < kMaxDepth && ctx->bs[hr->slot].gen == hr->gen && ctx->bs[hr->slot].compacted && env_u32("MAPAD_RECORDS_RESIDENT", 1)) {
+        const BatchSlot& RS = ctx->bs[hr->slot];
+        d_begin = RS.d_c_hit_begin.p; d_hits = RS.d_c_hits.p; d_ops = RS.d_c_ops.p;
+        rstream = RS.stream;  // the stream that wrote them (idle since the fetch)
+    } else {
+        if ((rc = ctx->d_r_begin.ensure(n + 1))) return rc;
+        if ((rc = ctx->d_r_hits.ensure(std::max<uint64_t>(res->n_hits, 1)))) return rc;
+        if ((rc = ctx->d_r_ops.ensure(std::max<uint64_t>(res->n_ops, 1)))) return rc;
+        HIP_TRY(hipMemcpyAsync(ctx->d_r_begin.p, res->hit_begin, (n + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+        if (res->n_hits) HIP_TRY(hipMemcpyAsync(ctx->d_r_hits.p, res->hits, res->n_hits * sizeof(HitRec), hipMemcpyHostToDevice, ctx->stream));
+        if (res->n_ops) HIP_TRY(hipMemcpyAsync(ctx->d_r_ops.p, res->ops, res->n_ops * 4, hipMemcpyHostToDevice, ctx->stream));
+        d_begin = ctx->d_r_begin.p; d_hits = ctx->d_r_hits.p; d_ops = ctx->d_r_ops.p;
+    }
+    PostIndex Q{};
+    Q.ix = ctx->dix; Q.sa_sample = ctx->d_sa.p; Q.x_counts = ix.x_counts.empty() ? nullptr : ctx->d_xc.p; Q.sa_shift = shift;
+    int k = 0;
+    for (const auto& kv : ix.extra_rows) { Q.extra_row[k] = kv.first; Q.extra_val[k] = kv.second; ++k; }
+    for (; k < 2; ++k) { Q.extra_row[k] = ~0ull; Q.extra_val[k] = 0; }
+    Q.n_contigs = (uint32_t)ix.contigs.size(); Q.contig_start = ctx->d_contigs.p; Q.contig_end = ctx->d_contigs.p + ix.contigs.size();
+    HIP_TRY(hipEventRecord(ctx->lev[0], rstream));
+    hipLaunchKernelGGL(records_kernel, dim3((uint32_t)((n + 63) / 64)), dim3(64), 0, rstream, Q, d_begin, d_hits, d_ops, n, seed, ctx->d_r_out.p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(ctx->lev[1], rstream));
+    HIP_TRY(hipMemcpyAsync(coords.data(), ctx->d_r_out.p, n * sizeof(CoordRec), hipMemcpyDeviceToHost, rstream));
+    HIP_TRY(hipStreamSynchronize(rstream));
+    ctx->last_locate_rows = n; ctx->last_locate_steps = 0;
+    return MAPAD_OK;
+}
+struct mapad_coords { std::vector<CoordRec> v; };
+
 int mapad_hits_to_records_gpu(mapad_ctx_t* ctx, const mapad_batch_result_t* res, const uint8_t* seqs, const uint8_t* quals, const uint64_t* offsets,
                               const uint16_t* in_flags, uint64_t seed, mapad_records_t** out) {
     if (!ctx || !res || !out || (res->n_reads && (!seqs || !quals || !offsets))) return MAPAD_ERR_INVALID;
     if (hipSetDevice(ctx->device) != hipSuccess) return MAPAD_ERR_NO_DEVICE;
     try {
-        const host::Index& ix = ctx->index->ix;
-        uint32_t shift = 0;
-        while ((1ull << shift) < ix.sa_rate) ++shift;
-        if ((1ull << shift) != ix.sa_rate || shift < 1 || shift > 8 || ix.extra_rows.size() > 2) return MAPAD_ERR_INVALID;  // the kernels' assumptions
-        int rc;
-        if ((rc = ensure_sa_uploaded(ctx))) return rc;
-        const uint64_t n = res->n_reads;
-        std::vector<CoordRec> coords(n);
-        if (n) {
-            // the hit records go back to the GPU that produced them (page-locked results: DMA), the index-bound half of intervals_to_bam runs
-            // there — SA walks, strand and contig, X0 / X1, XA candidates — and one compact record per read comes back
-            if ((rc = ctx->d_r_out.ensure(n))) return rc;
-            // The hits are normally still on the device, laid out in read order by the collect of the fetch that produced `res` (the batch slot has not
-            // been launched again since): the kernel reads them where they are.  Otherwise (an older result) they go back over PCIe first.
-            const HostResult* hr = reinterpret_cast<const HostResult*>(res);  // results are library-owned: pub is the first member
-            const uint64_t* d_begin; const HitRec* d_hits; const uint32_t* d_ops;
-            hipStream_t rstream = ctx->stream;
-            if (hr->owner == ctx && hr->slot >= 0 && hr->slot < kMaxDepth && ctx->bs[hr->slot].gen == hr->gen && ctx->bs[hr->slot].compacted && env_u32("MAPAD_RECORDS_RESIDENT", 1)) {
-                const BatchSlot& RS = ctx->bs[hr->slot];
-                d_begin = RS.d_c_hit_begin.p; d_hits = RS.d_c_hits.p; d_ops = RS.d_c_ops.p;
-                rstream = RS.stream;  // the stream that wrote them (idle since the fetch)
-            } else {
-                if ((rc = ctx->d_r_begin.ensure(n + 1))) return rc;
-                if ((rc = ctx->d_r_hits.ensure(std::max<uint64_t>(res->n_hits, 1)))) return rc;
-                if ((rc = ctx->d_r_ops.ensure(std::max<uint64_t>(res->n_ops, 1)))) return rc;
-                HIP_TRY(hipMemcpyAsync(ctx->d_r_begin.p, res->hit_begin, (n + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
-                if (res->n_hits) HIP_TRY(hipMemcpyAsync(ctx->d_r_hits.p, res->hits, res->n_hits * sizeof(HitRec), hipMemcpyHostToDevice, ctx->stream));
-                if (res->n_ops) HIP_TRY(hipMemcpyAsync(ctx->d_r_ops.p, res->ops, res->n_ops * 4, hipMemcpyHostToDevice, ctx->stream));
-                d_begin = ctx->d_r_begin.p; d_hits = ctx->d_r_hits.p; d_ops = ctx->d_r_ops.p;
-            }
-            PostIndex Q{};
-            Q.ix = ctx->dix; Q.sa_sample = ctx->d_sa.p; Q.x_counts = ix.x_counts.empty() ? nullptr : ctx->d_xc.p; Q.sa_shift = shift;
-            int k = 0;
-            for (const auto& kv : ix.extra_rows) { Q.extra_row[k] = kv.first; Q.extra_val[k] = kv.second; ++k; }
-            for (; k < 2; ++k) { Q.extra_row[k] = ~0ull; Q.extra_val[k] = 0; }
-            Q.n_contigs = (uint32_t)ix.contigs.size(); Q.contig_start = ctx->d_contigs.p; Q.contig_end = ctx->d_contigs.p + ix.contigs.size();
-            HIP_TRY(hipEventRecord(ctx->lev[0], rstream));
-            hipLaunchKernelGGL(records_kernel, dim3((uint32_t)((n + 63) / 64)), dim3(64), 0, rstream, Q, d_begin, d_hits, d_ops, n, seed, ctx->d_r_out.p);
-            HIP_TRY(hipGetLastError());
-            HIP_TRY(hipEventRecord(ctx->lev[1], rstream));
-            HIP_TRY(hipMemcpyAsync(coords.data(), ctx->d_r_out.p, n * sizeof(CoordRec), hipMemcpyDeviceToHost, rstream));
-            HIP_TRY(hipStreamSynchronize(rstream));
-            ctx->last_locate_rows = n; ctx->last_locate_steps = 0;
-        }
-        *out = host::records_from_coords(ix, ctx->params, *res, in_flags, coords.data());
+        std::vector<CoordRec> coords;
+        const int rc = record_coords_gpu(ctx, res, seed, coords);
+        if (rc) return rc;
+        *out = host::records_from_coords(ctx->index->ix, ctx->params, *res, in_flags, coords.data());
         return MAPAD_OK;
     } catch (const std::bad_alloc&) { return MAPAD_ERR_NOMEM; } catch (const std::exception& e) {
         std::fprintf(stderr, "mapad_hits_to_records_gpu: %s\n", e.what());
         return MAPAD_ERR_INVALID;
     }
 }
+int mapad_hits_to_coords_gpu(mapad_ctx_t* ctx, const mapad_batch_result_t* res, uint64_t seed, mapad_coords_t** out) {
+    if (!ctx || !res || !out) return MAPAD_ERR_INVALID;
+    if (hipSetDevice(ctx->device) != hipSuccess) return MAPAD_ERR_NO_DEVICE;
+    try {
+        auto c = std::make_unique<mapad_coords>();
+        const int rc = record_coords_gpu(ctx, res, seed, c->v);
+        if (rc) return rc;
+        *out = c.release();
+        return MAPAD_OK;
+    } catch (const std::bad_alloc&) { return MAPAD_ERR_NOMEM; } catch (const std::exception& e) {
+        std::fprintf(stderr, "mapad_hits_to_coords_gpu: %s\n", e.what());
+        return MAPAD_ERR_INVALID;
+    }
+}
+int mapad_coords_to_records(const mapad_index_t* idx, const mapad_params_t* params, const mapad_batch_result_t* res, const uint16_t* in_flags, const mapad_coords_t* coords,
+                            mapad_records_t** out) {
+    if (!idx || !params || !res || !coords || !out || coords->v.size() != res->n_reads) return MAPAD_ERR_INVALID;
+    try {
+        *out = host::records_from_coords(idx->ix, *params, *res, in_flags, coords->v.data());
+        return MAPAD_OK;
+    } catch (const std::bad_alloc&) { return MAPAD_ERR_NOMEM; } catch (const std::exception& e) {
+        std::fprintf(stderr, "mapad_coords_to_records: %s\n", e.what());
+        return MAPAD_ERR_INVALID;
+    }
+}
+void mapad_coords_free(mapad_coords_t* c) { delete c; }
 }  // extern "C"
 
 extern "C" {
