@@ -22,6 +22,7 @@
 #include "host_index.hpp"
 #include "host_models.hpp"
 #include "postproc_core.hpp"
+#include "text_core.hpp"
 
 namespace mapad {
 namespace host {
@@ -446,6 +447,69 @@ inline mapad_records_t* records_from_coords(const Index& ix, const mapad_params_
         own->text += texts[t];
     }
     own->pub.n = res.n_reads; own->pub.recs = own->recs.data(); own->pub.text = own->text.c_str(); own->pub.text_len = own->text.size();
+    return &own.release()->pub;
+}
+// What is left for the host when the text was built on the device (text_core.hpp: DevRecord, text pool, pair pool): flags (:750-776) and the
+// mapping quality (estimate_mapping_quality, :658-718) from the pairs (score, (float)size) of the hits that count — libm, like every transcendental
+// of this design.
+inline uint8_t mapping_quality_from_pairs(const mapad_params_t& prm, float best_score, float best_size_f, uint64_t best_read_len, const float* pairs, uint32_t n_pairs) {
+    float p;
+    const float prob_best = std::exp2(best_score);
+    if (best_size_f > 1.0f) p = 1.0f / best_size_f;
+    else {
+        float acc = 0.0f;
+        for (uint32_t i = 0; i < n_pairs; ++i) acc = std::fmaf(std::exp2(pairs[2 * i]), pairs[2 * i + 1], acc);
+        p = prob_best / (prob_best + acc);
+    }
+    if (p < 0.0f) p = 0.0f;
+    if (p > 1.0f) p = 1.0f;
+    const float phred = -10.0f * std::log10(1.0f - p);
+    const uint8_t mq = f32_to_u8(std::round(phred < 37.0f ? phred : 37.0f));
+    if (mq == 37) {
+        float frac = mb_remaining_frac(prm, best_score, best_read_len);
+        if (!(frac < 1.0f)) frac = 1.0f;
+        return f32_to_u8(std::round(std::fmaf(17.0f, frac, 20.0f)));
+    }
+    return mq;
+}
+inline mapad_records_t* records_from_device_text(const mapad_params_t& prm, uint64_t n_reads, const uint16_t* in_flags, const DevRecord* dev, const char* text, size_t text_len,
+                                                 const float* pairs) {
+    auto own = std::unique_ptr<RecordsOwner>(new RecordsOwner());
+    own->recs.resize(n_reads);
+    own->text.assign(text, text_len);
+    unsigned n_threads = (unsigned)std::min<uint64_t>(std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 16u), std::max<uint64_t>(1, n_reads / 16384));
+    std::vector<int> bad(n_threads, 0);
+    auto work = [&](unsigned t) {
+        for (uint64_t r = n_reads * t / n_threads; r < n_reads * (t + 1) / n_threads; ++r) {
+            const DevRecord& d = dev[r];
+            if (d.error) { bad[t] = (int)d.error; continue; }
+            mapad_record_t rec{};
+            uint16_t flags = in_flags ? in_flags[r] : 0;
+            flags &= (uint16_t)~(0x8 | 0x20 | 0x2 | 0x100 | 0x800);  // :750-755
+            if (d.mapped) {
+                rec.mapped = 1; rec.reverse = (uint8_t)d.reverse; rec.tid = d.tid; rec.pos = d.pos;
+                rec.as_score = d.as_score; rec.xs_score = d.xs_score; rec.nm = d.nm; rec.x0 = d.x0; rec.x1 = d.x1; rec.has_xs = (uint8_t)d.has_xs; rec.xt = (char)d.xt;
+                rec.cigar_off = d.text_off; rec.cigar_len = d.cigar_len; rec.md_off = d.text_off + d.cigar_len; rec.md_len = d.md_len;
+                rec.xa_off = d.text_off + d.cigar_len + d.md_len; rec.xa_len = d.xa_len;
+                rec.mapq = mapping_quality_from_pairs(prm, d.as_score, d.best_size_f, d.read_len, pairs + 2 * (size_t)d.mq_off, d.mq_n);
+                flags &= (uint16_t)~0x4;
+                if (d.reverse) flags |= 0x10; else flags &= (uint16_t)~0x10;
+            } else {  // :553-566, :765-776
+                flags |= 0x4; flags &= (uint16_t)~0x10; flags &= (uint16_t)~0x2;
+                rec.mapq = 0; rec.tid = -1; rec.pos = -1;
+            }
+            rec.flags = flags;
+            own->recs[r] = rec;
+        }
+    };
+    if (n_threads == 1) work(0);
+    else {
+        std::vector<std::thread> pool;
+        for (unsigned t = 0; t < n_threads; ++t) pool.emplace_back(work, t);
+        for (auto& th : pool) th.join();
+    }
+    for (int b : bad) if (b) throw std::runtime_error(b == 1 ? "Could not enumerate possible reference positions" : "record text pools too small");
+    own->pub.n = n_reads; own->pub.recs = own->recs.data(); own->pub.text = own->text.c_str(); own->pub.text_len = own->text.size();
     return &own.release()->pub;
 }
 inline void free_records(mapad_records_t* r) { if (r) delete reinterpret_cast<RecordsOwner*>(r); }

@@ -30,6 +30,7 @@
 #include "host_models.hpp"
 #include "host_postproc.hpp"
 #include "postproc_core.hpp"
+#include "text_core.hpp"
 #include "search_core.hpp"
 
 using namespace mapad;
@@ -298,6 +299,44 @@ __global__ void MAPAD_SLIM_EARLY records_kernel(PostIndex Q, const uint64_t* __r
     if (r >= n_reads) return;
     const uint64_t b = hit_begin[r];
     record_coords(Q, hits + b, (uint32_t)(hit_begin[r + 1] - b), ops, seed, r, out[r]);
+}
+
+// ---- hits -> record text: the text half of intervals_to_bam, one thread per read (text_core.hpp) -----------------------------------------------
+// CIGAR / MD / XA bytes go into one pool per batch, the (score, size) pairs of the mapping quality into another; a wavefront claims the space of its
+// 64 reads with one atomic add per pool (sizes first, then the bytes).
+struct TextDev {
+    TextIndex T;
+    const uint64_t* hit_begin; const HitRec* hits; const uint32_t* ops; const CoordRec* coords;
+    uint64_t n_reads;
+    char* text; float* pairs;
+    unsigned long long* cursors;  // [0] text bytes, [1] pairs claimed so far (beyond the capacities: the host grows the pools and runs the kernel again)
+    uint64_t text_cap, pair_cap;
+    DevRecord* out;
+};
+__global__ void __launch_bounds__(64) text_kernel(TextDev Q) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t r = (uint64_t)blockIdx.x * 64 + lane;
+    const bool act = r < Q.n_reads;
+    DevRecord rec{};
+    uint32_t bytes = 0, n_pairs = 0;
+    const HitRec* hits = act ? Q.hits + Q.hit_begin[r] : Q.hits;
+    if (act) record_text_sizes(Q.T, hits, Q.ops, Q.coords[r], rec, bytes, n_pairs);
+    unsigned long long sb = bytes, sp = n_pairs;  // inclusive scans over the wavefront
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const unsigned long long ub = __shfl_up(sb, d), up = __shfl_up(sp, d);
+        if (lane >= (uint32_t)d) { sb += ub; sp += up; }
+    }
+    const unsigned long long tot_b = __shfl(sb, 63), tot_p = __shfl(sp, 63);
+    unsigned long long base_b = 0, base_p = 0;
+    if (lane == 0) { base_b = tot_b ? atomicAdd(&Q.cursors[0], tot_b) : 0; base_p = tot_p ? atomicAdd(&Q.cursors[1], tot_p) : 0; }
+    base_b = __shfl(base_b, 0); base_p = __shfl(base_p, 0);
+    const bool fits = base_b + tot_b <= Q.text_cap && base_p + tot_p <= Q.pair_cap && base_b + tot_b <= 0xFFFFFFFFull && base_p + tot_p <= 0xFFFFFFFFull;
+    if (!act) return;
+    if (!fits) { if (rec.mapped) rec.error = 2; Q.out[r] = rec; return; }
+    rec.text_off = (uint32_t)(base_b + sb - bytes); rec.mq_off = (uint32_t)(base_p + sp - n_pairs);
+    record_text_write(Q.T, hits, Q.ops, Q.coords[r], Q.text, Q.pairs, rec);
+    Q.out[r] = rec;
 }
 
 // ---- search: persistent quads -----------------------------------------------------------------------------------------
@@ -850,6 +889,15 @@ struct mapad_ctx {
     DevBuf<HitRec> d_r_hits;
     DevBuf<uint32_t> d_r_ops;
     DevBuf<CoordRec> d_r_out;
+    // record text on the device (text_kernel)
+    DevBuf<uint64_t> d_os_pos;
+    DevBuf<uint8_t> d_os_sym, d_names;
+    DevBuf<uint32_t> d_name_off;
+    DevBuf<DevRecord> d_t_out;
+    DevBuf<char> d_t_text;
+    DevBuf<float> d_t_pairs;
+    DevBuf<unsigned long long> d_t_cur;
+    uint64_t n_os = 0;
     DevBuf<unsigned long long> d_steps;
     bool sa_uploaded = false;
     hipEvent_t lev[2] = {nullptr, nullptr};
@@ -871,6 +919,7 @@ struct mapad_ctx {
         d_grow.release();
         d_sa.release(); d_xc.release(); d_rows.release(); d_pos.release(); d_steps.release();
         d_contigs.release(); d_r_begin.release(); d_r_hits.release(); d_r_ops.release(); d_r_out.release();
+        d_os_pos.release(); d_os_sym.release(); d_names.release(); d_name_off.release(); d_t_out.release(); d_t_text.release(); d_t_pairs.release(); d_t_cur.release();
         for (auto& e : lev) if (e) (void)hipEventDestroy(e);
         if (ev_ref) (void)hipEventDestroy(ev_ref);
     }
@@ -1816,8 +1865,27 @@ int ensure_sa_uploaded(mapad_ctx* c) {
     if ((rc = c->d_contigs.ensure(std::max<size_t>(cs.size(), 2), true))) return rc;
     if (!cs.empty()) HIP_TRY(hipMemcpyAsync(c->d_contigs.p, cs.data(), cs.size() * 8, hipMemcpyHostToDevice, c->stream));
     if ((rc = c->d_steps.ensure(1))) return rc;
+    // what the text kernel needs of the index: original symbols (ascending positions) and contig names
+    std::vector<uint64_t> os_pos;
+    std::vector<uint8_t> os_sym;
+    for (const auto& kv : ix.original_symbols) { os_pos.push_back(kv.first); os_sym.push_back(kv.second); }
+    c->n_os = os_pos.size();
+    if ((rc = c->d_os_pos.ensure(std::max<size_t>(os_pos.size(), 1), true))) return rc;
+    if ((rc = c->d_os_sym.ensure(std::max<size_t>(os_sym.size(), 1), true))) return rc;
+    if (!os_pos.empty()) {
+        HIP_TRY(hipMemcpyAsync(c->d_os_pos.p, os_pos.data(), os_pos.size() * 8, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(c->d_os_sym.p, os_sym.data(), os_sym.size(), hipMemcpyHostToDevice, c->stream));
+    }
+    std::vector<uint32_t> name_off{0};
+    std::string names;
+    for (const auto& k : ix.contigs) { names += k.name; name_off.push_back((uint32_t)names.size()); }
+    if ((rc = c->d_names.ensure(std::max<size_t>(names.size(), 1), true))) return rc;
+    if ((rc = c->d_name_off.ensure(name_off.size(), true))) return rc;
+    if (!names.empty()) HIP_TRY(hipMemcpyAsync(c->d_names.p, names.data(), names.size(), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->d_name_off.p, name_off.data(), name_off.size() * 4, hipMemcpyHostToDevice, c->stream));
+    if ((rc = c->d_t_cur.ensure(2))) return rc;
     for (auto& e : c->lev) if (!e) HIP_TRY(hipEventCreate(&e));
-    HIP_TRY(hipStreamSynchronize(c->stream));  // `cs` goes out of scope
+    HIP_TRY(hipStreamSynchronize(c->stream));  // the host vectors go out of scope
     c->sa_uploaded = true;
     return MAPAD_OK;
 }
@@ -1864,7 +1932,19 @@ int mapad_last_locate_info(mapad_ctx_t* ctx, float* kernel_ms, uint64_t* rows, u
     return MAPAD_OK;
 }
 // the device half of intervals_to_bam for one batch result: one CoordRec per read (records_kernel), in host memory
-static int record_coords_gpu(mapad_ctx_t* ctx, const mapad_batch_result_t* res, uint64_t seed, std::vector<CoordRec>& coords) {
+struct mapad_coords {
+    std::vector<CoordRec> v;     // MAPAD_RECORDS_TEXT=host: the coordinates; strings and MAPQ from host::records_from_coords
+    bool device_text = false;    // default: the text kernel's products; flags and MAPQ from host::records_from_device_text
+    std::vector<DevRecord> recs;
+    std::vector<char> text;
+    std::vector<float> pairs;
+    uint64_t n = 0;
+};
+static int record_coords_gpu(mapad_ctx_t* ctx, const mapad_batch_result_t* res, uint64_t seed, mapad_coords& co) {
+    std::vector<CoordRec>& coords = co.v;
+    co.n = res->n_reads;
+    const char* tm = std::getenv("MAPAD_RECORDS_TEXT");
+    co.device_text = !(tm && std::strcmp(tm, "host") == 0);
     const host::Index& ix = ctx->index->ix;
     uint32_t shift = 0;
     while ((1ull << shift) < ix.sa_rate) ++shift;
@@ -1872,7 +1952,7 @@ static int record_coords_gpu(mapad_ctx_t* ctx, const mapad_batch_result_t* res, 
     int rc;
     if ((rc = ensure_sa_uploaded(ctx))) return rc;
     const uint64_t n = res->n_reads;
-    coords.resize(n);
+    if (!co.device_text) coords.resize(n);
     if (!n) return MAPAD_OK;
     if ((rc = ctx->d_r_out.ensure(n))) return rc;
     // The hits are normally still on the device, laid out in read order by the collect of the fetch that produced `res` (the batch slot has not
@@ -1902,23 +1982,57 @@ static int record_coords_gpu(mapad_ctx_t* ctx, const mapad_batch_result_t* res, 
     HIP_TRY(hipEventRecord(ctx->lev[0], rstream));
     hipLaunchKernelGGL(records_kernel, dim3((uint32_t)((n + 63) / 64)), dim3(64), 0, rstream, Q, d_begin, d_hits, d_ops, n, seed, ctx->d_r_out.p);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipEventRecord(ctx->lev[1], rstream));
-    HIP_TRY(hipMemcpyAsync(coords.data(), ctx->d_r_out.p, n * sizeof(CoordRec), hipMemcpyDeviceToHost, rstream));
-    HIP_TRY(hipStreamSynchronize(rstream));
     ctx->last_locate_rows = n; ctx->last_locate_steps = 0;
+    if (!co.device_text) {
+        HIP_TRY(hipEventRecord(ctx->lev[1], rstream));
+        HIP_TRY(hipMemcpyAsync(coords.data(), ctx->d_r_out.p, n * sizeof(CoordRec), hipMemcpyDeviceToHost, rstream));
+        HIP_TRY(hipStreamSynchronize(rstream));
+        return MAPAD_OK;
+    }
+    // the text half on the device: CIGAR / MD / XA bytes and the pairs of the mapping quality into two pools; what crosses PCIe is one 88-byte record
+    // per read plus the text (typically "50M" + "50": a dozen bytes per read)
+    if ((rc = ctx->d_t_out.ensure(n))) return rc;
+    if ((rc = ctx->d_t_text.ensure(std::max<size_t>(ctx->d_t_text.cap, (size_t)n * 24 + (1u << 16))))) return rc;
+    if ((rc = ctx->d_t_pairs.ensure(std::max<size_t>(ctx->d_t_pairs.cap, (size_t)n * 2 + 4096)))) return rc;
+    unsigned long long used[2] = {0, 0};
+    for (int attempt = 0; attempt < 8; ++attempt) {
+        HIP_TRY(hipMemsetAsync(ctx->d_t_cur.p, 0, 16, rstream));
+        TextDev TQ{};
+        TQ.T.os_pos = ctx->d_os_pos.p; TQ.T.os_sym = ctx->d_os_sym.p; TQ.T.n_os = ctx->n_os; TQ.T.name_off = ctx->d_name_off.p; TQ.T.names = (const char*)ctx->d_names.p;
+        TQ.hit_begin = d_begin; TQ.hits = d_hits; TQ.ops = d_ops; TQ.coords = ctx->d_r_out.p; TQ.n_reads = n;
+        TQ.text = ctx->d_t_text.p; TQ.pairs = ctx->d_t_pairs.p; TQ.cursors = ctx->d_t_cur.p; TQ.text_cap = ctx->d_t_text.cap; TQ.pair_cap = ctx->d_t_pairs.cap / 2; TQ.out = ctx->d_t_out.p;
+        hipLaunchKernelGGL(text_kernel, dim3((uint32_t)((n + 63) / 64)), dim3(64), 0, rstream, TQ);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(used, ctx->d_t_cur.p, 16, hipMemcpyDeviceToHost, rstream));
+        HIP_TRY(hipStreamSynchronize(rstream));
+        if (used[0] <= TQ.text_cap && used[1] <= TQ.pair_cap) break;
+        if (used[0] > 0xFFFFFFFFull || used[1] > 0xFFFFFFFFull) return MAPAD_ERR_INVALID;  // more than 4 GiB of record text in one batch
+        if (attempt == 7) return MAPAD_ERR_NOMEM;
+        if (used[0] > TQ.text_cap && (rc = ctx->d_t_text.ensure((size_t)used[0] + (1u << 16)))) return rc;
+        if (used[1] > TQ.pair_cap && (rc = ctx->d_t_pairs.ensure((size_t)used[1] * 2 + 4096))) return rc;
+    }
+    HIP_TRY(hipEventRecord(ctx->lev[1], rstream));
+    co.recs.resize(n); co.text.resize(used[0]); co.pairs.resize(2 * used[1]);
+    HIP_TRY(hipMemcpyAsync(co.recs.data(), ctx->d_t_out.p, n * sizeof(DevRecord), hipMemcpyDeviceToHost, rstream));
+    if (used[0]) HIP_TRY(hipMemcpyAsync(co.text.data(), ctx->d_t_text.p, used[0], hipMemcpyDeviceToHost, rstream));
+    if (used[1]) HIP_TRY(hipMemcpyAsync(co.pairs.data(), ctx->d_t_pairs.p, 2 * used[1] * sizeof(float), hipMemcpyDeviceToHost, rstream));
+    HIP_TRY(hipStreamSynchronize(rstream));
     return MAPAD_OK;
 }
-struct mapad_coords { std::vector<CoordRec> v; };
+static mapad_records_t* records_from(const host::Index& ix, const mapad_params_t& prm, const mapad_batch_result_t& res, const uint16_t* in_flags, const mapad_coords& co) {
+    if (co.device_text) return host::records_from_device_text(prm, res.n_reads, in_flags, co.recs.data(), co.text.data(), co.text.size(), co.pairs.data());
+    return host::records_from_coords(ix, prm, res, in_flags, co.v.data());
+}
 
 int mapad_hits_to_records_gpu(mapad_ctx_t* ctx, const mapad_batch_result_t* res, const uint8_t* seqs, const uint8_t* quals, const uint64_t* offsets,
                               const uint16_t* in_flags, uint64_t seed, mapad_records_t** out) {
     if (!ctx || !res || !out || (res->n_reads && (!seqs || !quals || !offsets))) return MAPAD_ERR_INVALID;
     if (hipSetDevice(ctx->device) != hipSuccess) return MAPAD_ERR_NO_DEVICE;
     try {
-        std::vector<CoordRec> coords;
-        const int rc = record_coords_gpu(ctx, res, seed, coords);
+        mapad_coords co;
+        const int rc = record_coords_gpu(ctx, res, seed, co);
         if (rc) return rc;
-        *out = host::records_from_coords(ctx->index->ix, ctx->params, *res, in_flags, coords.data());
+        *out = records_from(ctx->index->ix, ctx->params, *res, in_flags, co);
         return MAPAD_OK;
     } catch (const std::bad_alloc&) { return MAPAD_ERR_NOMEM; } catch (const std::exception& e) {
         std::fprintf(stderr, "mapad_hits_to_records_gpu: %s\n", e.what());
@@ -1930,7 +2044,7 @@ int mapad_hits_to_coords_gpu(mapad_ctx_t* ctx, const mapad_batch_result_t* res, 
     if (hipSetDevice(ctx->device) != hipSuccess) return MAPAD_ERR_NO_DEVICE;
     try {
         auto c = std::make_unique<mapad_coords>();
-        const int rc = record_coords_gpu(ctx, res, seed, c->v);
+        const int rc = record_coords_gpu(ctx, res, seed, *c);
         if (rc) return rc;
         *out = c.release();
         return MAPAD_OK;
@@ -1941,9 +2055,9 @@ int mapad_hits_to_coords_gpu(mapad_ctx_t* ctx, const mapad_batch_result_t* res, 
 }
 int mapad_coords_to_records(const mapad_index_t* idx, const mapad_params_t* params, const mapad_batch_result_t* res, const uint16_t* in_flags, const mapad_coords_t* coords,
                             mapad_records_t** out) {
-    if (!idx || !params || !res || !coords || !out || coords->v.size() != res->n_reads) return MAPAD_ERR_INVALID;
+    if (!idx || !params || !res || !coords || !out || coords->n != res->n_reads) return MAPAD_ERR_INVALID;
     try {
-        *out = host::records_from_coords(idx->ix, *params, *res, in_flags, coords->v.data());
+        *out = records_from(idx->ix, *params, *res, in_flags, *coords);
         return MAPAD_OK;
     } catch (const std::bad_alloc&) { return MAPAD_ERR_NOMEM; } catch (const std::exception& e) {
         std::fprintf(stderr, "mapad_coords_to_records: %s\n", e.what());

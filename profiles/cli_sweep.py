@@ -1,13 +1,12 @@
-"""mapad-amd map on a 4 M-read FASTQ (C2 workload) for several --batch_size / --in_flight settings: reads/s and stage busy times."""
+"""mapad-amd map on an 8 M-read FASTQ (C2 workload) for several --batch_size / --in_flight settings: reads/s and stage busy times."""
 import os, re, subprocess, sys, tempfile, time
 sys.path.insert(0, ".")
 import numpy as np
 from mapad_amd import build as mbuild, synth
-n = 4_000_000
+n = 8_000_000
 g = synth.genome(48_000_000, seed=1234)
-seqs, quals, offsets = synth.reads(g, 2_000_000, 50, seed=4323, qual=40)
-s2, q2, _ = synth.reads(g, 2_000_000, 50, seed=5323, qual=40)
-seqs = np.concatenate([seqs, s2]); quals = np.concatenate([quals, q2])
+parts = [synth.reads(g, 2_000_000, 50, seed=4323 + 1000 * k, qual=40) for k in range(4)]
+seqs = np.concatenate([p[0] for p in parts]); quals = np.concatenate([p[1] for p in parts])
 tmp = tempfile.mkdtemp(prefix="mapad_cli_")
 fa, fq, bam = os.path.join(tmp, "ref.fa"), os.path.join(tmp, "reads.fastq"), os.path.join(tmp, "out.bam")
 open(fa, "wb").write(b">chr1\n" + g.tobytes() + b"\n")
@@ -22,7 +21,7 @@ rec.tofile(fq)
 exe = mbuild.build_cli()
 subprocess.check_call([exe, "index", "-g", fa], stderr=subprocess.DEVNULL)
 base = [exe, "map", "-r", fq, "-g", fa, "-o", bam, "-l", "single_stranded", "-p", "0.03", "-D", "0.02", "-i", "0.001", "-x", "1.0", "--force_overwrite", "-f", "0", "-t", "0", "-d", "0", "-s", "0"]
-cases = [(250000, 2, {}), (250000, 4, {}), (250000, 8, {}), (500000, 4, {}), (1000000, 3, {}), (1000000, 4, {})]
+cases = [(250000, 4, {}), (250000, 8, {}), (250000, 12, {}), (500000, 4, {}), (500000, 8, {}), (1000000, 4, {})]
 if len(sys.argv) > 1:  # e.g. "250000:4:MAPAD_TIER0_WAVES_PER_CU=10"
     cases = []
     for a in sys.argv[1:]:
@@ -35,6 +34,6 @@ for bs, fl, env in cases:
     pr = subprocess.run(cmd, stderr=subprocess.PIPE, text=True, env=dict(os.environ, **env))
     m = re.search(r"mapping ([0-9.]+) s \((\d+) reads/s\)", pr.stderr)
     b = re.search(r"reader ([0-9.]+) s, device worker 0 ([0-9.]+) s, writer ([0-9.]+) s", pr.stderr)
-    w = re.search(r"submit ([0-9.]+) s, fetch \(incl. waiting for the GPU\) ([0-9.]+) s, records ([0-9.]+) s", pr.stderr)
+    w = re.search(r"submit ([0-9.]+) s, fetch \(incl. waiting for the GPU\) ([0-9.]+) s, coordinates ([0-9.]+) s; records thread \(strings, MAPQ\) ([0-9.]+) s", pr.stderr)
     print("   worker:", w.groups() if w else None)
     print(bs, fl, env, m.group(1) if m else pr.stderr[-300:], m.group(2) if m else "", b.groups() if b else "", flush=True)

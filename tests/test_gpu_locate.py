@@ -61,9 +61,11 @@ def test_records_from_device_located_positions_equal_host_path():
         ctx.close()
 
 
-def test_device_coordinates_on_contigs_x_runs_and_multi_row_hits():
+@pytest.mark.parametrize("text", ["device", "host"])
+def test_device_coordinates_on_contigs_x_runs_and_multi_row_hits(text, monkeypatch):
     """The records kernel (postproc_core.hpp: strand, contig, X0 / X1, XA candidates, PrRange order) against the host restatement on a
     multi-contig text with X runs, repeats (hit intervals of many rows: the permutation matters) and reads that straddle contig ends."""
+    monkeypatch.setenv("MAPAD_RECORDS_TEXT", text)  # device: CIGAR / MD / XA text by text_kernel (text_core.hpp), MAPQ from its pairs; host: strings on host threads
     rng = np.random.default_rng(5)
     unit = synth.genome(3_000, seed=21)
     parts = [np.array(synth.genome(50_000, seed=20), dtype=np.uint8).copy(), np.concatenate([unit, unit, unit, unit, unit]), np.array(synth.genome(700, seed=22)),
@@ -87,8 +89,10 @@ def test_device_coordinates_on_contigs_x_runs_and_multi_row_hits():
         ctx.close()
 
 
-def test_integration_records_through_device_locate(monkeypatch):
-    """tests/integration_tests.rs expectation, with the suffix-array lookups done by the kernel."""
+@pytest.mark.parametrize("text", ["device", "host"])
+def test_integration_records_through_device_locate(monkeypatch, text):
+    """tests/integration_tests.rs expectation, with the suffix-array lookups (and, text = device, the CIGAR / MD / XA strings) done by kernels."""
+    monkeypatch.setenv("MAPAD_RECORDS_TEXT", text)
     from test_host_logic import check_integration_records
     k = load("integration")
     monkeypatch.delenv("MAPAD_INDEX_FIXED_REPLACEMENT", raising=False)  # StdRng(1234) itself must draw the base the reference's expectation implies
