@@ -491,7 +491,7 @@ def main():
 
         dt_all = records_call()
         post = {"reads_per_s": round(n_reads / dt_all, 1), "wall_s": round(dt_all, 3), "host_threads": min(os.cpu_count() or 1, 64),
-                "what": "mapad_hits_to_records_gpu: SA locate kernel + coordinates, MAPQ, CIGAR/MD/XA strings on host threads"}
+                "what": "mapad_hits_to_records_gpu: coordinates (SA walks, contigs, X0/X1, XA candidates) and CIGAR/MD/XA text by kernels over the device-resident hits; flags and MAPQ (exp2f/log10f) on host threads"}
 
     ctx.close()  # the command-line leg below starts a process with a context of its own on the same GPU: this one's 180 GB of pools must be gone
     mapped_fraction = round(float((np.diff(res.hit_begin.astype(np.int64)) > 0).mean()), 4)
@@ -549,7 +549,7 @@ def main():
                    "index_files_bytes": index_bytes,
                    "stage_busy_s": (lambda mm: {"reader": float(mm.group(1)), "device_worker": float(mm.group(2)), "writer": float(mm.group(3))} if mm else None)(
                        re.search(r"reader ([0-9.]+) s, device worker 0 ([0-9.]+) s, writer ([0-9.]+) s", pr.stderr)),
-                   "what": "mapad-amd map: FASTQ -> BAM, --batch_size 250000 (the reference's default), up to 4 chunks in flight on one GPU; reader, records and BGZF on host threads"}
+                   "what": "mapad-amd map: FASTQ -> BAM, --batch_size 250000 (the reference's default), up to 4 chunks in flight on one GPU; reader, MAPQ and BGZF on host threads, coordinates and record text on the GPU"}
         except Exception as e:  # the leg is a report, not the metric: say why it is missing
             cli = {"skipped": f"{type(e).__name__}: {e}"}
         finally:

@@ -142,12 +142,19 @@ def test_batches_in_flight_do_not_change_results(depth, tiny, monkeypatch):
     size-class pools); every batch must come out exactly as it does alone.  "sets": one wavefront per CU's worth of base-arena sets, so the
     wavefronts of six launches in flight outnumber the sets and wait for one another's exit."""
     import ctypes as C
-    hip = C.CDLL("libamdhip64.so")  # the runtime the library itself uses: device-resident inputs without torch
+    mapad_amd.lib()
+    # the HIP runtime the library itself has loaded (the very file: a second copy of the runtime would not see the device), for device-resident inputs without torch
+    paths = sorted({ln.split()[-1] for ln in open("/proc/self/maps") if "libamdhip64" in ln})
+    hip = C.CDLL(paths[0] if paths else "libamdhip64.so")
 
     def to_device(a):
         a = np.ascontiguousarray(a)
         p = C.c_void_p()
-        assert hip.hipMalloc(C.byref(p), C.c_size_t(max(a.nbytes, 8))) == 0
+        rc = hip.hipMalloc(C.byref(p), C.c_size_t(max(a.nbytes, 8)))
+        if rc != 0:
+            free_b, total_b = C.c_size_t(), C.c_size_t()
+            hip.hipMemGetInfo(C.byref(free_b), C.byref(total_b))
+            raise AssertionError(f"hipMalloc of {a.nbytes} bytes failed with {rc}; free {free_b.value >> 20} MiB of {total_b.value >> 20} MiB")
         assert hip.hipMemcpy(p, a.ctypes.data_as(C.c_void_p), C.c_size_t(a.nbytes), 1) == 0  # hipMemcpyHostToDevice
         return p.value
 
