@@ -33,7 +33,7 @@ typedef enum mapad_status {
     MAPAD_ERR_UNSUPPORTED = -9   /* input beyond a documented limit of this entry point; another entry point takes it */
 } mapad_status_t;
 
-#define MAPAD_MAX_READ_LEN 1024
+#define MAPAD_MAX_READ_LEN 32767
 
 /* ---- parameters: AlignmentParameters + the two plugin enums (src/map/mod.rs:21-31,
  *      sequence_difference_models.rs:67-72, mismatch_bounds.rs:26-30) ------------------------------------------------ */

@@ -47,7 +47,7 @@ struct DevIndex {
 // All transcendental math (log2, powi, exp, powf) is done on the host with glibc exactly like the reference;
 // the GPU only adds, compares and takes min/max of these f32 values, in the reference's association order.
 enum : int32_t { BOUND_DISCRETE = 0, BOUND_CONTINUOUS = 1, BOUND_TEST = 2 };
-constexpr int kMaxReadLen = 1024;  // device limit (reference: i16::MAX, src/map/record.rs:144-150)
+constexpr int kMaxReadLen = 32767;  // the reference's limit: i16::MAX (src/map/record.rs:144-150)
 
 struct DevParams {
     const float* sdm_table;      // float4 entries [A,C,G,T as `from`]: index table_base[L] + ((i*nq + q)*5 + to_class)

@@ -22,7 +22,11 @@ using HeavyRead = ReadInT<true>;
 
 // LDS of a heavy wavefront: [kHeavyTop + 1 heap slots][2 bytes per read position: class, quality][D array][scratch]
 constexpr uint32_t kHeavyScratchBytes = 8192;
-inline __host__ __device__ uint32_t heavy_lds_bytes(uint32_t lmax) { return (kHeavyTop + 1) * 8 + ((2 * lmax + 15) & ~15u) + ((4 * lmax + 15) & ~15u) + kHeavyScratchBytes; }
+constexpr uint32_t kHeavyMaxLdsReadLen = 1024;  // longer reads keep their position data (class / quality, D array) in the arena's near area in HBM
+inline __host__ __device__ uint32_t heavy_lds_bytes(uint32_t lmax) {
+    const uint32_t l = lmax <= kHeavyMaxLdsReadLen ? lmax : 0;
+    return (kHeavyTop + 1) * 8 + ((2 * l + 15) & ~15u) + ((4 * l + 15) & ~15u) + kHeavyScratchBytes;
+}
 
 // ---- the wavefront-cooperative step ---------------------------------------------------------------------------------------------------------
 // LDS scratch of a heavy wavefront (kHeavyScratchBytes): the speculative block of a deep sift and the ancestors of the step's pushes.
@@ -154,8 +158,8 @@ struct HeavyProf { unsigned long long t, acc[8]; };
 // nothing touched, and the caller runs the general step (search_core.hpp's search_step, one lane).
 // Every lane holds the same state; lanes differ only in: the sub-block of a rank query (lane & 3), the child they build (lanes 0-8), the heap
 // entries they fetch for the block of a deep sift and for the ancestors of the pushes.
-template <bool CONT>
-__device__ __forceinline__ int heavy_step(const DevIndex& ix, const DevParams& P, const HeavyRead& rd, const HeavyArena& A, SearchState& st, const int lane, const HeavyScratch& S HPROF_ARG) {
+template <bool CONT, class RD>
+__device__ __forceinline__ int heavy_step(const DevIndex& ix, const DevParams& P, const RD& rd, const HeavyArena& A, SearchState& st, const int lane, const HeavyScratch& S HPROF_ARG) {
     const uint32_t n = st.heap_len;
     const int L = rd.L;
     uint32_t top_idx;
@@ -344,8 +348,10 @@ __device__ __forceinline__ void release_slot(const ArenaPool& ap, uint32_t slot)
 
 // MODE 0: continue the reads the quad stages suspended (growable through the size classes, never gives up).
 // MODE 1: the reads no size class could hold, from scratch, in arenas with the reference's full limits.
-template <bool CONT, int MODE>
+// RDL: the read's position data in LDS; false (full-limit stage of batches with reads beyond 1 024 bp): in the near area of the wavefront's arena.
+template <bool CONT, int MODE, bool RDL>
 __global__ void __launch_bounds__(64) heavy_kernel(DevIndex ix, DevParams P, BatchDev B, ArenaPool AP, const GrowPools* GP, uint32_t lmax, int tier) {
+    static_assert(RDL || MODE == 1, "suspended reads are continued with their position data in LDS");
     const int lane = threadIdx.x & 63;
     // MODE 0: `tier` = the quad stage whose suspended reads this launch continues (its own list and work counter)
     const uint32_t n_items = MODE == 0 ? min(B.cursors[CUR_HEAVY_N + tier], B.heavy_cap) : B.cursors[CUR_OVF + 2 * (tier - 1)];
@@ -354,10 +360,11 @@ __global__ void __launch_bounds__(64) heavy_kernel(DevIndex ix, DevParams P, Bat
     extern __shared__ __attribute__((aligned(16))) uint8_t heavy_lds[];
     MAPAD_LDS uint8_t* lds = (MAPAD_LDS uint8_t*)heavy_lds;
     MAPAD_LDS HeapEntry* top = (MAPAD_LDS HeapEntry*)lds + 1;
-    MAPAD_LDS uint8_t* near_qc = lds + (kHeavyTop + 1) * sizeof(HeapEntry);
-    MAPAD_LDS float* near_d = (MAPAD_LDS float*)(near_qc + ((2 * lmax + 15) & ~15u));
+    const uint32_t lds_l = RDL ? lmax : 0;
+    MAPAD_LDS uint8_t* lds_qc = lds + (kHeavyTop + 1) * sizeof(HeapEntry);
+    MAPAD_LDS float* lds_d = (MAPAD_LDS float*)(lds_qc + ((2 * lds_l + 15) & ~15u));
     HeavyScratch S;
-    S.spec = (MAPAD_LDS HeapEntry*)((MAPAD_LDS uint8_t*)near_d + ((4 * lmax + 15) & ~15u)) + 1;
+    S.spec = (MAPAD_LDS HeapEntry*)((MAPAD_LDS uint8_t*)lds_d + ((4 * lds_l + 15) & ~15u)) + 1;
     S.anc = S.spec - 1 + kSpecEntries;
     const bool use_fast = GP->heavy_fast != 0;  // MAPAD_HEAVY_FAST=0: every step by the general single-lane code (a debugging aid)
     uint32_t slot = 0;
@@ -394,7 +401,16 @@ __global__ void __launch_bounds__(64) heavy_kernel(DevIndex ix, DevParams P, Bat
         }
         A.top = top;
         const uint64_t off = B.offsets[read];
-        HeavyRead rd{near_qc, near_d, 0, 0.0f, 0};
+        using NearBytes = typename near_ptr<uint8_t, RDL>::type;
+        using NearFloats = typename near_ptr<float, RDL>::type;
+        NearBytes near_qc;
+        NearFloats near_d;
+        if constexpr (RDL) { near_qc = lds_qc; near_d = lds_d; }
+        else {  // the arena's near area: [kTop + 1 heap slots (unused here)][2 bytes per position][D array], as search_kernel lays it out
+            uint8_t* nb = AP.base + (uint64_t)slot * AP.stride + AP.off_near + (kTop + 1) * sizeof(HeapEntry);
+            near_qc = nb; near_d = (float*)(nb + ((2 * lmax + 15) & ~15u));
+        }
+        ReadInT<RDL> rd{near_qc, near_d, 0, 0.0f, 0};
         rd.lane_less = (lane & 3) == 0 ? ix.less[1] : (lane & 3) == 1 ? ix.less[2] : (lane & 3) == 2 ? ix.less[3] : ix.less[4];
         rd.L = (int)(B.offsets[read + 1] - off);
         rd.thr = P.reject_thr[rd.L];

@@ -137,10 +137,11 @@ __device__ __forceinline__ ArenaT<NL> carve(const ArenaPool& ap, uint32_t slot) 
 
 #define MAPAD_SLIM_EARLY __launch_bounds__(64)  // see MAPAD_SLIM below
 // ---- D arrays: one wavefront per read, quad q = offset chain q ------------------------------------------------------------
-__global__ void MAPAD_SLIM_EARLY darray_kernel(DevIndex ix, DevParams P, BatchDev B, int lmax) {  // 56 VGPRs: fits beside 12 search wavefronts per CU
+__global__ void MAPAD_SLIM_EARLY darray_kernel(DevIndex ix, DevParams P, BatchDev B, int lmax, float* long_scratch) {
     extern __shared__ float lds[];
-    float* pen = lds;            // [lmax]
-    float* chains = lds + lmax;  // [15][lmax]
+    // penalties and the 15 chains of a read: in LDS, or — batches with reads beyond ~750 bp, whose 16 x lmax floats do not fit — in the block's piece of a global buffer
+    float* pen = long_scratch ? long_scratch + (size_t)blockIdx.x * 16 * lmax : lds;  // [lmax]
+    float* chains = pen + lmax;                                                            // [15][lmax]
     __shared__ uint32_t n_ext_total;
     const int lane = threadIdx.x & 63, quad = lane >> 2, w = lane & 3;
     for (uint32_t read = blockIdx.x; read < B.n_reads; read += gridDim.x) {
@@ -195,12 +196,12 @@ __global__ void MAPAD_SLIM_EARLY darray_kernel(DevIndex ix, DevParams P, BatchDe
 // hist[chunk][k] -> first position of class k of that chunk: chunks in input order, classes descending inside a chunk.  A chunk
 // (2^20 reads by default, the scale of the reference's --batch_size) bounds how many of the expensive reads start together: sorting
 // a 10 M-read batch as a whole put 150 000 arena-hungry reads in front of everything else and the size-class pools ran dry.
-__global__ void order_scan_kernel(uint32_t* hist, uint32_t n_chunks) {
+__global__ void order_scan_kernel(uint32_t* hist, uint32_t n_chunks, uint32_t n_bins) {  // n_bins: the classes that can occur (zero positions <= the batch's longest read)
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     uint32_t acc = 0;
     for (uint32_t ch = 0; ch < n_chunks; ++ch) {
         uint32_t* h = hist + (size_t)ch * kKeyBins;
-        for (int k = kKeyBins - 1; k >= 0; --k) { const uint32_t c = h[k]; h[k] = acc; acc += c; }
+        for (int k = (int)n_bins - 1; k >= 0; --k) { const uint32_t c = h[k]; h[k] = acc; acc += c; }
     }
 }
 // The kernels around the search (D arrays, ordering, collect, records) must find room BESIDE the persistent search wavefronts of other batches.
@@ -352,8 +353,8 @@ __device__ __forceinline__ uint32_t group_bcast(uint32_t v) {  // value of the g
     else return LPR == 4 ? dpp_quad<0>(v) : v;
 }
 
-template <int LPR, bool NL, int TOP>
-__device__ MAPAD_FINALIZE_ATTR void finalize_read(const BatchDev B, const ReadInT<NL> rd, const ArenaT<NL, TOP> A, const SearchState st, uint32_t read, int w, int tier) {
+template <int LPR, bool NLR, bool NL, int TOP>
+__device__ MAPAD_FINALIZE_ATTR void finalize_read(const BatchDev B, const ReadInT<NLR> rd, const ArenaT<NL, TOP> A, const SearchState st, uint32_t read, int w, int tier) {
     if (st.status == ST_ARENA_OVERFLOW && tier + 1 < kStages) {  // hand the read to the next stage
         if (w == 0) {
             const uint32_t k = atomicAdd(&B.cursors[CUR_OVF + 2 * tier], 1u);
@@ -821,7 +822,7 @@ struct BatchSlot {
     hipEvent_t ev_in = nullptr;                                // the caller's stream at submission: inputs are ready behind it
     DevBuf<uint8_t> d_seqs, d_quals;
     DevBuf<uint64_t> d_offsets;
-    DevBuf<float> d_darr;
+    DevBuf<float> d_darr, d_dscratch;
     DevBuf<ReadCounters> d_counters;
     DevBuf<uint32_t> d_status, d_hit_count, d_hit_first, d_ops, d_cursors, d_overflow, d_sort_key, d_key_hist, d_order;
     DevBuf<HitRec> d_hits;
@@ -842,7 +843,7 @@ struct BatchSlot {
     uint64_t gen = 0;                     // counts the launches of this slot: a fetched result knows whether the slot still holds it
 
     void release() {
-        d_seqs.release(); d_quals.release(); d_offsets.release(); d_darr.release(); d_counters.release(); d_status.release(); d_hit_count.release();
+        d_seqs.release(); d_quals.release(); d_offsets.release(); d_darr.release(); d_dscratch.release(); d_counters.release(); d_status.release(); d_hit_count.release();
         d_hit_first.release(); d_ops.release(); d_cursors.release(); d_overflow.release(); d_sort_key.release(); d_key_hist.release(); d_order.release();
         d_hits.release(); d_heavy.release();
         d_c_hit_begin.release(); d_c_ops_begin.release(); d_c_tiles.release(); d_c_hits.release(); d_c_ops.release();
@@ -992,6 +993,10 @@ int ensure_arenas(mapad_ctx* c, BatchSlot& S, uint32_t lmax, uint64_t n_reads) {
         const uint64_t per_xcd_full = ((uint64_t)c->resident_waves * 4 / 3 + 7) / 8;
         const uint64_t per_xcd_need = (need_waves * (uint64_t)std::min(c->depth, 4) + 7) / 8 + 4;  // small batches (tests): no more than they can use
         n_sets[0] = 8 * (uint32_t)std::max<uint64_t>(std::min(per_xcd_full, per_xcd_need), kPartitionMin / 8);
+        // long reads (up to i16::MAX): hit staging, the bucket-sort scratch and the near data of a slot grow with the read length — ~90 bytes per base and slot;
+        // such batches get as many wavefront sets as 64 GB hold (the wavefronts of a launch wait for a free set: acquire_set)
+        const uint64_t set_bytes = (uint64_t)rpw * c->pool[0].stride, budget = 64ull << 30;
+        if ((uint64_t)n_sets[0] * set_bytes > budget && lm > 1024) n_sets[0] = 8 * (uint32_t)std::max<uint64_t>(budget / set_bytes / 8, kPartitionMin / 8);
     }
     {   // last stage: full limits, one arena per heavy wavefront (owner word per arena, shared by all XCDs)
         c->pool[1] = make_pool_layout((uint32_t)stack_cap, (uint32_t)tree_cap, hit_ops_cap, lm);
@@ -1020,6 +1025,8 @@ int ensure_arenas(mapad_ctx* c, BatchSlot& S, uint32_t lmax, uint64_t n_reads) {
         int k = 0;
         for (const char* q = e; *q && k < kClasses; ++k) { counts[k] = (uint32_t)std::strtoul(q, const_cast<char**>(&q), 10); if (*q == ',') ++q; }
     }
+    // reads are handed to heavy wavefronts only on request (MAPAD_HEAVY=1) and only in batches of reads up to 1 024 bp (a heavy wavefront keeps the read's position data in LDS)
+    const bool heavy_possible = env_u32("MAPAD_HEAVY", 0) != 0 && lm <= 1024;
     uint64_t nodes = std::min<uint64_t>(c->pool[0].node_cap, env_u32("MAPAD_CLASS_ANCHOR_NODES", 8192));  // the ladder 16 K, 32 K, ... does not move with the base arena; classes the base arena already covers get no arenas
     GrowPools& g = c->grow;
     for (int k = 0; k < kClasses; ++k) {
@@ -1028,10 +1035,10 @@ int ensure_arenas(mapad_ctx* c, BatchSlot& S, uint32_t lmax, uint64_t n_reads) {
         g.node_cap[k] = (uint32_t)std::min<uint64_t>(nodes, tree_cap);
         auto align = [](uint64_t x) { return (x + 127) & ~127ull; };
         g.off_nodes[k] = align(((uint64_t)g.heap_cap[k] + 16) * sizeof(HeapEntry));
-        g.off_hits[k] = align(g.off_nodes[k] + (uint64_t)g.node_cap[k] * sizeof(Node));  // hit staging of a suspended read (heavy_kernel.hpp)
-        g.off_hit_ops[k] = align(g.off_hits[k] + (uint64_t)kMaxHits * sizeof(HitRec));
-        g.off_scratch[k] = align(g.off_hit_ops[k] + (uint64_t)hit_ops_cap * 4);
-        g.stride[k] = align(g.off_scratch[k] + 2ull * (lm + 1) * 2);
+        g.off_hits[k] = align(g.off_nodes[k] + (uint64_t)g.node_cap[k] * sizeof(Node));  // hit staging of a suspended read (heavy_kernel.hpp): only if reads can be suspended
+        g.off_hit_ops[k] = heavy_possible ? align(g.off_hits[k] + (uint64_t)kMaxHits * sizeof(HitRec)) : g.off_hits[k];
+        g.off_scratch[k] = heavy_possible ? align(g.off_hit_ops[k] + (uint64_t)hit_ops_cap * 4) : g.off_hits[k];
+        g.stride[k] = heavy_possible ? align(g.off_scratch[k] + 2ull * (lm + 1) * 2) : g.off_hits[k];
         // a class that is no bigger than the previous one (tiny semantic limits) is pointless: give it no arenas
         const bool useful = g.node_cap[k] > (k ? g.node_cap[k - 1] : c->pool[0].node_cap) || g.heap_cap[k] > (k ? g.heap_cap[k - 1] : c->pool[0].heap_cap);
         g.count[k] = useful ? std::min<uint32_t>(counts[k], (1u << kGrownShift) - 1) : 0;
@@ -1065,7 +1072,7 @@ int ensure_arenas(mapad_ctx* c, BatchSlot& S, uint32_t lmax, uint64_t n_reads) {
     // MAPAD_HEAVY=1: a quad hands a read that grows into class MAPAD_HEAVY_MIN_CLASS or beyond to heavy_kernel.  Off by default: measured on MI355X, a lone
     // wavefront issues one instruction per 4-5 cycles whatever its type, a step is ~2 500 of them either way, and the wavefront-per-read step takes 5.7 us
     // per pop against the quad's 5.5 (heavy reads); the full-limit stage runs on heavy_kernel in any case.
-    g.heavy_min_class = env_u32("MAPAD_HEAVY", 0) ? env_u32("MAPAD_HEAVY_MIN_CLASS", 0) : (uint32_t)kClasses;
+    g.heavy_min_class = heavy_possible ? env_u32("MAPAD_HEAVY_MIN_CLASS", 0) : (uint32_t)kClasses;
     c->heavy_cap = 64;
     for (int k = 0; k < kClasses; ++k) c->heavy_cap += g.count[k];  // a suspended read holds a grown arena
     {   // suspended reads wait for the heavy stage with their arenas: they may take three quarters of the class most of them are in
@@ -1172,17 +1179,24 @@ int launch_batch(mapad_ctx* c, BatchSlot& S, const uint8_t* d_seqs, const uint8_
     S.gen += 1;
     if (n_reads == 0 && !warm) return MAPAD_OK;
     const uint32_t lds_lmax = std::max<uint32_t>(lmax, 1);
-    const size_t lds_bytes = (size_t)16 * lds_lmax * sizeof(float);
-    const uint32_t grid_d = (uint32_t)std::min<uint64_t>(n_reads, (uint64_t)c->n_cu * 32);
+    size_t lds_bytes = (size_t)16 * lds_lmax * sizeof(float);
+    uint32_t grid_d = (uint32_t)std::min<uint64_t>(n_reads, (uint64_t)c->n_cu * 32);
+    float* long_scratch = nullptr;
+    if (lds_bytes > 48 * 1024) {  // long reads: the chains live in HBM (a quarter of the usual grid: such batches are rare and the buffer is 16 x lmax floats per block)
+        grid_d = std::max<uint32_t>(1, std::min<uint32_t>(grid_d, (uint32_t)c->n_cu * 8));
+        if ((rc = S.d_dscratch.ensure((size_t)grid_d * 16 * lds_lmax))) return rc;
+        long_scratch = S.d_dscratch.p;
+        lds_bytes = 0;
+    }
     for (auto& e : S.ev) if (!e) HIP_TRY(hipEventCreate(&e));
     if (!warm) {
         if (!c->ev_ref) { HIP_TRY(hipEventCreate(&c->ev_ref)); HIP_TRY(hipEventRecord(c->ev_ref, S.stream)); c->history.clear(); }
         HIP_TRY(hipEventRecord(S.ev[0], S.stream));
-        hipLaunchKernelGGL(darray_kernel, dim3(grid_d), dim3(64), lds_bytes, S.stream, c->dix, c->dprm, B, (int)lds_lmax);
+        hipLaunchKernelGGL(darray_kernel, dim3(grid_d), dim3(64), lds_bytes, S.stream, c->dix, c->dprm, B, (int)lds_lmax, long_scratch);
         HIP_TRY(hipGetLastError());
     }
     if (ordered && !warm) {
-        hipLaunchKernelGGL(order_scan_kernel, dim3(1), dim3(64), 0, S.stream, S.d_key_hist.p, n_chunks);
+        hipLaunchKernelGGL(order_scan_kernel, dim3(1), dim3(64), 0, S.stream, S.d_key_hist.p, n_chunks, std::min<uint32_t>(lmax + 2, kKeyBins));
         hipLaunchKernelGGL(order_scatter_kernel, dim3((uint32_t)((n_reads + 63) / 64)), dim3(64), 0, S.stream, B);
         HIP_TRY(hipGetLastError());
     }
@@ -1230,21 +1244,21 @@ int launch_batch(mapad_ctx* c, BatchSlot& S, const uint8_t* d_seqs, const uint8_
     const uint32_t heavy_lds = heavy_lds_bytes(near_lmax);
     const uint32_t heavy_per_cu = std::max<uint32_t>(1, std::min<uint32_t>(env_u32("MAPAD_HEAVY_WAVES_PER_CU", 8), (160u * 1024u) / heavy_lds));
     const uint32_t grid_h = warm ? 1u : std::min<uint32_t>(c->heavy_cap, heavy_per_cu * (uint32_t)c->n_cu);
-#define MAPAD_LAUNCH_HEAVY(M, GRID, AP, TIER)                                                                                                                         \
-    if (!cont) hipLaunchKernelGGL((heavy_kernel<false, M>), dim3(GRID), dim3(64), heavy_lds, S.stream, c->dix, c->dprm, B, AP, c->d_grow.p, near_lmax, TIER);      \
-    else hipLaunchKernelGGL((heavy_kernel<true, M>), dim3(GRID), dim3(64), heavy_lds, S.stream, c->dix, c->dprm, B, AP, c->d_grow.p, near_lmax, TIER);
+#define MAPAD_LAUNCH_HEAVY(M, R, GRID, AP, TIER)                                                                                                                      \
+    if (!cont) hipLaunchKernelGGL((heavy_kernel<false, M, R>), dim3(GRID), dim3(64), heavy_lds, S.stream, c->dix, c->dprm, B, AP, c->d_grow.p, near_lmax, TIER);   \
+    else hipLaunchKernelGGL((heavy_kernel<true, M, R>), dim3(GRID), dim3(64), heavy_lds, S.stream, c->dix, c->dprm, B, AP, c->d_grow.p, near_lmax, TIER);
     for (int stage = 0; stage + 1 < kStages; ++stage) {  // Q0 + H0: every read; Q1 + H1: the reads that gave up waiting (normally none: the launches exit at once)
         const uint32_t grid = grid_s;
         const ArenaPool ap = c->pool[0];
         if (stage == 0) { MAPAD_LAUNCH_PASS(0) } else { MAPAD_LAUNCH_PASS(2) }  // PASS 2 = PASS 0 under its own symbol, so that profiles keep the passes apart
-        if (heavy_on || warm) { MAPAD_LAUNCH_HEAVY(0, grid_h, ap, stage) }
+        if ((heavy_on || warm) && near_lmax <= kHeavyMaxLdsReadLen) { MAPAD_LAUNCH_HEAVY(0, true, grid_h, ap, stage) }
         HIP_TRY(hipGetLastError());
     }
     if (!warm) HIP_TRY(hipEventRecord(S.ev[2], S.stream));
     {   // leftovers with the reference's full limits: heavy wavefronts from scratch
         const uint32_t grid = warm ? 1u : (uint32_t)std::min<uint64_t>(n_reads, c->slots[1]);
         const ArenaPool ap = c->pool[1];
-        MAPAD_LAUNCH_HEAVY(1, grid, ap, kStages - 1)
+        if (near_lmax <= kHeavyMaxLdsReadLen) { MAPAD_LAUNCH_HEAVY(1, true, grid, ap, kStages - 1) } else { MAPAD_LAUNCH_HEAVY(1, false, grid, ap, kStages - 1) }
         HIP_TRY(hipGetLastError());
     }
 #undef MAPAD_LAUNCH_HEAVY

@@ -76,9 +76,9 @@ struct HeapEntry {
 
 // 32-byte tree node + frame payload (MismatchSearchStackFrame, src/map/mod.rs:105-137, minus the score that lives in the heap)
 //   w0 = op | parent << 32          (vacant slot: parent = next free key)
-//   w1 = lower (40 bit) | start << 40 (12 bit) | len << 52 (12 bit)
+//   w1 = lower (40 bit) | start << 40 (15 bit: reads up to i16::MAX, record.rs:144-150)
 //   w2 = lower_rev (40 bit) | gap_f << 40 | gap_b << 42 | ngaps << 44 (8 bit) | occupied << 52
-//   w3 = size
+//   w3 = size (40 bit) | len << 40 (15 bit)
 struct alignas(16) Node {
     uint64_t w0, w1, w2, w3;
 };
@@ -93,16 +93,16 @@ struct Frame {
 MAPAD_HD Node pack_node(uint32_t op, uint32_t parent, const Frame& f) {
     Node n;
     n.w0 = (uint64_t)op | ((uint64_t)parent << 32);
-    n.w1 = f.lower | ((uint64_t)(uint32_t)f.start << 40) | ((uint64_t)(uint32_t)f.len << 52);
+    n.w1 = f.lower | ((uint64_t)(uint32_t)f.start << 40);
     n.w2 = f.lower_rev | ((uint64_t)f.gap_f << 40) | ((uint64_t)f.gap_b << 42) | ((uint64_t)f.ngaps << 44) | (1ull << 52);
-    n.w3 = f.size;
+    n.w3 = f.size | ((uint64_t)(uint32_t)f.len << 40);
     return n;
 }
 MAPAD_HD Frame unpack_frame(const Node& n) {
     Frame f;
-    f.lower = n.w1 & kMask40; f.start = (int32_t)((n.w1 >> 40) & 0xFFF); f.len = (int32_t)(n.w1 >> 52);
+    f.lower = n.w1 & kMask40; f.start = (int32_t)(n.w1 >> 40);
     f.lower_rev = n.w2 & kMask40; f.gap_f = (uint32_t)(n.w2 >> 40) & 3; f.gap_b = (uint32_t)(n.w2 >> 42) & 3; f.ngaps = (uint32_t)(n.w2 >> 44) & 0xFF;
-    f.size = n.w3;
+    f.size = n.w3 & kMask40; f.len = (int32_t)(n.w3 >> 40);
     return f;
 }
 // word-wise selects: a conditional expression on whole structs selects an ADDRESS and copies from it, which pins all three nodes in scratch memory
@@ -565,8 +565,8 @@ MAPAD_HD void read_setup(const uint8_t* seq, const uint8_t* qual, const float* d
 MAPAD_HD int alignment_start_of(const DevParams& P, int L) { return P.start_at_end ? L : (L / 2); }  // find_alignment_start
 
 // The `len == pattern.len()` branch of check_and_push_stack_frame (mapping.rs:973-984): a finished alignment becomes a hit.
-template <bool NL, int TOP>
-MAPAD_RARE void record_hit(const ReadInT<NL> rd, const ArenaT<NL, TOP> A, SearchState& st, int alignment_start, uint64_t lower, uint64_t lower_rev, uint64_t size,
+template <bool NLR, bool NL, int TOP>
+MAPAD_RARE void record_hit(const ReadInT<NLR> rd, const ArenaT<NL, TOP> A, SearchState& st, int alignment_start, uint64_t lower, uint64_t lower_rev, uint64_t size,
                            float score, uint32_t id) {
     if (st.n_hits >= (uint32_t)kMaxHits) { st.status = ST_ARENA_OVERFLOW; return; }
     HitRec h;
@@ -594,8 +594,8 @@ struct NoGrow {
 // check_and_push_stack_frame (mapping.rs:932-987) for a child whose tree node `nd` is already packed.  On the device the quad
 // builds the <= 9 children of a frame lane-parallel (search_step); `store` says whether this lane owns the child and writes its node,
 // `owner` is the owning lane (the frame of a finished alignment is fetched from it).  Everything else is quad-uniform.
-template <int LPR, bool NL, int TOP>
-MAPAD_HD void commit_child(const DevParams& P, const ReadInT<NL>& rd, ArenaT<NL, TOP>& A, SearchState& st, int alignment_start, float score, uint32_t ngaps, int len,
+template <int LPR, bool NLR, bool NL, int TOP>
+MAPAD_HD void commit_child(const DevParams& P, const ReadInT<NLR>& rd, ArenaT<NL, TOP>& A, SearchState& st, int alignment_start, float score, uint32_t ngaps, int len,
                            const Node& nd, bool store, int owner) {
     if (st.n_hits > 0 && mb_reject_iterative(P, score, st.best_score)) return;
     if ((int)ngaps > P.max_num_gaps_open) return;
@@ -642,8 +642,8 @@ MAPAD_RARE void evict_worst(const ArenaT<NL, TOP> A, SearchState& st, int64_t cn
 
 // k_mismatch_search (mapping.rs:1012-1383) after the D array has been computed, split into init / step so that a
 // persistent quad can fetch its next read as soon as the current one finishes.  `w` = lane index inside the quad.
-template <bool NL, int TOP>
-MAPAD_RARE void search_init(uint64_t n_text, int alignment_start, const ReadInT<NL> rd, const ArenaT<NL, TOP> A, SearchState& st) {
+template <bool NLR, bool NL, int TOP>
+MAPAD_RARE void search_init(uint64_t n_text, int alignment_start, const ReadInT<NLR> rd, const ArenaT<NL, TOP> A, SearchState& st) {
     st.c_esearch = 0; st.c_push = 0; st.c_pop = 0; st.c_node = 0; st.c_hits = 0;
     st.heap_len = 0; st.tree_entries = 0; st.tree_next = 0; st.tree_len = 0; st.n_hits = 0; st.hit_ops_used = 0; st.status = ST_OK;
     st.best_score = 0.0f; st.best_size = 0;
@@ -657,8 +657,8 @@ MAPAD_RARE void search_init(uint64_t n_text, int alignment_start, const ReadInT<
 }
 
 // One iteration of the `while let Some(stack_frame) = stack.pop_max()` loop.  Returns false when the search is over.
-template <int LPR, bool CONT, bool NL, class Grow, int TOP>
-MAPAD_HD bool search_step(const DevIndex& ix, const DevParams& P, const ReadInT<NL>& rd, ArenaT<NL, TOP>& A, SearchState& st, int w, const Grow& grow) {
+template <int LPR, bool CONT, bool NL, class Grow, int TOP, bool NLR>
+MAPAD_HD bool search_step(const DevIndex& ix, const DevParams& P, const ReadInT<NLR>& rd, ArenaT<NL, TOP>& A, SearchState& st, int w, const Grow& grow) {
     if (st.heap_len == 0 || st.status != ST_OK) return false;
     if (MAPAD_UNLIKELY(st.tree_len + kStepNodes > A.node_cap || st.heap_len + kStepNodes > A.heap_cap)) {
         MAPAD_MARK(PROF_LOOP);

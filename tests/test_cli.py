@@ -137,18 +137,21 @@ def _decoded(path):
 @pytest.mark.gpu
 def test_cli_map_devices_chunks_and_unmappable_reads(tmp_path):
     """`--devices 0,0` (two contexts and worker threads, contiguous slices of every chunk) and small chunks (a pipeline of many batches)
-    must write the same records as one device and one chunk; empty and over-length reads come out unmapped, in place."""
+    must write the same records as one device and one chunk; empty reads and reads beyond i16::MAX come out unmapped, in place; a 1 500 bp read maps."""
     g = synth.genome(120_000, seed=17)
     fa, fq = str(tmp_path / "ref.fa"), str(tmp_path / "reads.fastq")
     _write_fasta(fa, [("chr1", g[:70_000].tobytes().decode()), ("chr2", g[70_000:].tobytes().decode())])
     seqs, quals, offsets = synth.reads(g, 4000, 50, seed=23, qual_range=(20, 40), damage=dict(f=0.5, t=0.5, d=0.02, s=1.0), len_range=(30, 80))
-    long_read = g[1000:2500].tobytes().decode()  # 1500 bp > MAPAD_MAX_READ_LEN
+    long_read = g[1000:2500].tobytes().decode()  # 1 500 bp: mapped (position data of such a chunk lives in HBM instead of LDS)
+    too_long = (g.tobytes() * 1)[:33_000].decode()  # > i16::MAX (MAPAD_MAX_READ_LEN, record.rs:144-150): written as an unmapped record
     with open(fq, "w") as f:
         for i in range(4000):
             s, e = int(offsets[i]), int(offsets[i + 1])
             f.write(f"@r{i}\n{seqs[s:e].tobytes().decode()}\n+\n{''.join(chr(33 + q) for q in quals[s:e])}\n")
             if i == 777:
-                f.write(f"@too_long\n{long_read}\n+\n{'I' * len(long_read)}\n")
+                f.write(f"@too_long\n{too_long}\n+\n{'I' * len(too_long)}\n")
+            if i == 1200:
+                f.write(f"@long\n{long_read}\n+\n{'I' * len(long_read)}\n")
             if i == 2500:
                 f.write("@empty\n\n+\n\n")
     subprocess.check_call([_cli(), "index", "-g", fa])
@@ -162,10 +165,12 @@ def test_cli_map_devices_chunks_and_unmappable_reads(tmp_path):
         outs[tag] = _decoded(out)
     refs, one = outs["one"]
     assert refs == [("chr1", 70_000), ("chr2", 50_000)]
-    assert len(one) == 4002 and [r[0] for r in one][778] == "too_long" and [r[0] for r in one][2502] == "empty"
+    assert len(one) == 4003 and [r[0] for r in one][778] == "too_long" and [r[0] for r in one][1202] == "long" and [r[0] for r in one][2503] == "empty"
     for name in ("too_long", "empty"):
         r = next(x for x in one if x[0] == name)
         assert r[1] & 0x4 and r[2] == -1 and r[3] == -1 and r[5] == ""
+    lr = next(x for x in one if x[0] == "long")
+    assert not (lr[1] & 0x4) and lr[2] == 0 and lr[3] == 1000 and lr[5] == "1500M"
     assert sum(1 for r in one if not (r[1] & 0x4)) > 3000
     assert outs["two"][1] == one  # identical BAM records whichever device mapped a read
     # chunk boundaries change the per-chunk seed (seed + chunk_no, like one rng per rayon chunk): positions of multi-row hits may differ, nothing else

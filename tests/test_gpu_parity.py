@@ -251,3 +251,31 @@ def test_empty_and_edge_batches():
     ores = oidx.map_batch(ob.make_params(resolve_params(NO_DAMAGE)), reads, [quals[int(offsets[i]):int(offsets[i + 1])] for i in range(len(reads))], keep_d=True)
     assert_same_as_oracle(ores, res, offsets)
     ctx.close()
+
+
+def test_long_reads_up_to_the_reference_limit():
+    """Reads of 2 kb and 10 kb (the reference maps up to i16::MAX bases, record.rs:144-150) beside short ones: D-array chains and the read's position
+    data in HBM instead of LDS, 15-bit start / length fields in the frame, score tables per length — against the oracle, bit for bit."""
+    g = synth.genome(400_000, seed=41)
+    rng = np.random.default_rng(4)
+
+    def mutate(a, n_sub, indel=False):
+        a = a.copy()
+        for p in rng.choice(len(a) - 200, n_sub, replace=False) + 100:
+            a[p] = ord("ACGT"[("ACGT".index(chr(a[p])) + 1) % 4])
+        if indel:
+            a = np.concatenate([a[:len(a) // 2], a[len(a) // 2 + 1:]])  # one base deleted from the read
+        return a
+    reads = [g[50_000:52_000].tobytes(), mutate(g[100_000:102_000], 3).tobytes(), synth.revcomp(mutate(g[150_000:152_000], 2)).tobytes(),
+             mutate(g[200_000:210_000], 4).tobytes(), mutate(g[300_000:302_001], 1, indel=True).tobytes(), g[7_000:7_050].tobytes(), g[9_000:9_300].tobytes()]
+    offsets = np.zeros(len(reads) + 1, dtype=np.uint64)
+    offsets[1:] = np.cumsum([len(r) for r in reads])
+    seqs = np.frombuffer(b"".join(reads), dtype=np.uint8)
+    quals = np.full(len(seqs), 40, np.uint8)
+    rp = resolve_params(NO_DAMAGE)
+    pidx = mapad_amd.Index.build([("chr1", g)])
+    res = _gpu_map(pidx, mapad_amd.make_params(rp), seqs, quals, offsets)
+    oidx = ob.OracleIndex.from_bwt(pidx.bwt(), "$ACGTX", 128)
+    ores = oidx.map_batch(ob.make_params(rp), reads, [quals[int(offsets[i]):int(offsets[i + 1])] for i in range(len(reads))], keep_d=True)
+    assert_same_as_oracle(ores, res, offsets)
+    assert (np.diff(res.hit_begin.astype(np.int64)) >= 1).sum() >= 5  # the long reads map

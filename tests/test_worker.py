@@ -192,7 +192,7 @@ def test_worker_returns_the_hits_of_the_batch_api(tmp_path):
     srv, port = _serve()
     proc = subprocess.Popen([_cli(), "worker", "--host", "127.0.0.1", "--port", str(port)], stderr=subprocess.PIPE)
     conn, _ = srv.accept()
-    long_read = g[2000:2000 + 1100].tobytes()
+    long_read = g[:33_000].tobytes()  # beyond i16::MAX (record.rs:144-150)
     n_hits = 0
     for chunk, (lo, hi) in enumerate([(0, 900), (900, 1500)]):
         recs = [rec(i) for i in range(lo, hi)] + [encode_record(b"", [], b"empty"), encode_record(long_read, [30] * len(long_read), b"too_long")]
