@@ -29,7 +29,7 @@ typedef enum mapad_status {
     MAPAD_ERR_NO_DEVICE = -5,    /* no gfx950 GPU / HIP runtime failure (there is no CPU path)                     */
     MAPAD_ERR_DEVICE = -6,       /* a HIP call failed                                                              */
     MAPAD_ERR_NOMEM = -7,
-    MAPAD_ERR_READ_TOO_LONG = -8,/* read longer than MAPAD_MAX_READ_LEN           (record.rs:144-150: i16::MAX)     */
+    MAPAD_ERR_READ_TOO_LONG = -8,/* read longer than MAPAD_MAX_READ_LEN = i16::MAX   (record.rs:144-150)             */
     MAPAD_ERR_UNSUPPORTED = -9   /* input beyond a documented limit of this entry point; another entry point takes it */
 } mapad_status_t;
 
