@@ -213,6 +213,83 @@ __device__ __forceinline__ void ext4_quad_lane(const DevIndex& ix, uint64_t lowe
     out.nonempty = (s0 >= 1 ? 1u : 0u) | (s1 >= 1 ? 2u : 0u) | (s2 >= 1 ? 4u : 0u) | (s3 >= 1 ? 8u : 0u);
 }
 
+// ---- pair-cooperative versions: two adjacent lanes per read (lanes-per-read 2) ----------------------------------------------------------------
+// Lane h (= lane & 1) loads sub-blocks 2h and 2h + 1 of a block — 64 contiguous bytes, the pair reads the 128-byte line — and ends up with
+// occ(r, base 2h) and occ(r, base 2h + 1): the count words of its two sub-blocks are the running counts of exactly these two bases.  Twice the
+// loads and popcounts of a quad lane per instruction stream, but a wavefront then serves 32 reads instead of 16.
+struct OccLoads2 { ulonglong2 a0, a1, b0, b1; };
+__device__ __forceinline__ OccLoads2 pair_occ_issue(const DevIndex& ix, uint64_t r, int h) {
+    const uint64_t* sb = ix.blocks + (r >> 8) * 16 + 8 * h;
+    OccLoads2 l;
+    l.a0 = *reinterpret_cast<const ulonglong2*>(sb);      l.a1 = *reinterpret_cast<const ulonglong2*>(sb + 2);
+    l.b0 = *reinterpret_cast<const ulonglong2*>(sb + 4);  l.b1 = *reinterpret_cast<const ulonglong2*>(sb + 6);
+    return l;
+}
+__device__ __forceinline__ void pair_occ_finish(const OccLoads2& l, uint64_t r, int h, uint64_t& o0, uint64_t& o1) {
+    const int r_in = (int)(r & 255);
+    uint32_t ac = 0, gt = 0;
+    {
+        const uint64_t p0 = l.a0.y, p1 = l.a1.x, p2 = l.a1.y & row_mask(2 * h, r_in);
+        const uint64_t hi1 = p2 & p1, lo1 = p2 & ~p1;
+        ac += (uint32_t)popc64(lo1 & ~p0) | ((uint32_t)popc64(lo1 & p0) << 16);
+        gt += (uint32_t)popc64(hi1 & ~p0) | ((uint32_t)popc64(hi1 & p0) << 16);
+    }
+    {
+        const uint64_t p0 = l.b0.y, p1 = l.b1.x, p2 = l.b1.y & row_mask(2 * h + 1, r_in);
+        const uint64_t hi1 = p2 & p1, lo1 = p2 & ~p1;
+        ac += (uint32_t)popc64(lo1 & ~p0) | ((uint32_t)popc64(lo1 & p0) << 16);
+        gt += (uint32_t)popc64(hi1 & ~p0) | ((uint32_t)popc64(hi1 & p0) << 16);
+    }
+    ac += dpp_quad<0xB1>(ac);  // the other lane of the pair
+    gt += dpp_quad<0xB1>(gt);
+    const uint32_t pr = h ? gt : ac;
+    o0 = l.a0.x + (pr & 0xFFFFu);
+    o1 = l.b0.x + (pr >> 16);
+}
+__device__ __forceinline__ uint64_t pair_other64(uint64_t v) {  // the value the other lane of the pair holds
+    const uint32_t lo = dpp_quad<0xB1>((uint32_t)v), hi = dpp_quad<0xB1>((uint32_t)(v >> 32));
+    return ((uint64_t)hi << 32) | lo;
+}
+__device__ __forceinline__ uint64_t pair_pick64(uint64_t v, int k) {  // value of pair lane k (k pair-uniform, dynamic)
+    const uint32_t lo0 = dpp_quad<0xA0>((uint32_t)v), hi0 = dpp_quad<0xA0>((uint32_t)(v >> 32));  // quad_perm [0,0,2,2]
+    const uint32_t lo1 = dpp_quad<0xF5>((uint32_t)v), hi1 = dpp_quad<0xF5>((uint32_t)(v >> 32));  // quad_perm [1,1,3,3]
+    return k == 0 ? (((uint64_t)hi0 << 32) | lo0) : (((uint64_t)hi1 << 32) | lo1);
+}
+struct ExtLoads2 { OccLoads2 lo, hi; };
+__device__ __forceinline__ ExtLoads2 ext4_pair_issue(const DevIndex& ix, uint64_t lower, uint64_t size, int h) {
+    const uint64_t r_lo = lower == 0 ? 0 : lower - 1, r_hi = lower + size - 1;
+    ExtLoads2 l;
+    l.lo = pair_occ_issue(ix, r_lo, h);
+    l.hi = pair_occ_issue(ix, r_hi, h);
+    return l;
+}
+// Lane h of the pair returns the extensions by bases 2h and 2h + 1 (plus the pair-uniform mask of non-empty extensions).
+struct ExtLane2 {
+    uint64_t lower[2], lower_rev[2], size[2];
+    uint32_t nonempty;
+};
+__device__ __forceinline__ void ext4_pair_lane_finish(const DevIndex& ix, const ExtLoads2& l, uint64_t lower, uint64_t lower_rev, uint64_t size, int h, uint64_t less0, uint64_t less1,
+                                                      ExtLane2& out) {
+    const uint64_t r_lo = lower == 0 ? 0 : lower - 1, r_hi = lower + size - 1;
+    uint64_t lo0, lo1, hi0, hi1;
+    pair_occ_finish(l.lo, r_lo, h, lo0, lo1);
+    pair_occ_finish(l.hi, r_hi, h, hi0, hi1);
+    if (lower == 0) { lo0 = 0; lo1 = 0; }
+    const uint64_t m0 = hi0 - lo0, m1 = hi1 - lo1;             // sizes of this lane's two bases
+    const uint64_t o0 = pair_other64(m0), o1 = pair_other64(m1);  // ... and of the other lane's
+    const uint64_t s0 = h ? o0 : m0, s1 = h ? o1 : m1, s2 = h ? m0 : o0, s3 = h ? m1 : o1;
+    const uint64_t o_s = lower == 0 ? 0 : sentinel_le(ix, lower - 1);
+    const uint64_t sent = sentinel_le(ix, lower + size - 1) - o_s;  // '$' rows inside the interval
+    // fmd_index.rs:137-181 iterates T, G, C, A: lower_rev of base k = lower_rev + '$' rows + sizes of the bases above k
+    const uint64_t above_hi = h ? 0ull : s3 + s2;          // above base 2h + 1: (h = 0: bases 2, 3; h = 1: none)
+    const uint64_t above1 = above_hi;                       // base 2h + 1
+    const uint64_t above0 = above_hi + m1;                  // base 2h: additionally this lane's upper base
+    out.lower[0] = less0 + lo0; out.lower[1] = less1 + lo1;
+    out.lower_rev[0] = lower_rev + sent + above0; out.lower_rev[1] = lower_rev + sent + above1;
+    out.size[0] = m0; out.size[1] = m1;
+    out.nonempty = (s0 >= 1 ? 1u : 0u) | (s1 >= 1 ? 2u : 0u) | (s2 >= 1 ? 4u : 0u) | (s3 >= 1 ? 8u : 0u);
+}
+
 // Single-base step for the D-array chains: new (lower, size) of the quad-uniform interval extended by base k (0..3, quad-uniform).
 // Lane w counts base k in its own sub-block only (one popcount instead of four) and every lane reads the block's count word of base k.
 __device__ __forceinline__ void ext1_quad(const DevIndex& ix, uint64_t lower, uint64_t size, int k, int w, uint64_t& new_lower, uint64_t& new_size) {

@@ -121,10 +121,10 @@ struct GrowPools {
 };
 constexpr uint32_t kGrownShift = 27;
 
-template <bool NL>
-__device__ __forceinline__ ArenaT<NL> carve(const ArenaPool& ap, uint32_t slot) {
+template <bool NL, int TOP = kTop>
+__device__ __forceinline__ ArenaT<NL, TOP> carve(const ArenaPool& ap, uint32_t slot) {
     uint8_t* b = ap.base + (uint64_t)slot * ap.stride;
-    ArenaT<NL> a;
+    ArenaT<NL, TOP> a;
     a.heap = (MAPAD_GLOBAL HeapEntry*)(b) + 1;  // logical slot 0 = physical slot 1 (aligned child pairs, search_core.hpp)
     a.nodes = (MAPAD_GLOBAL Node*)(b + ap.off_nodes);
     a.hits = (MAPAD_GLOBAL HitRec*)(b + ap.off_hits);
@@ -350,6 +350,7 @@ __global__ void __launch_bounds__(64) text_kernel(TextDev Q) {
 template <int LPR>
 __device__ __forceinline__ uint32_t group_bcast(uint32_t v) {  // value of the group's first lane (64: the wavefront's first active lane)
     if constexpr (LPR == 64) return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+    else if constexpr (LPR == 2) return dpp_quad<0xA0>(v);  // quad_perm [0,0,2,2]: the pair's first lane
     else return LPR == 4 ? dpp_quad<0>(v) : v;
 }
 
@@ -572,8 +573,15 @@ __device__ __forceinline__ T kernarg_reload(size_t off, const T& by_value) {
 
 // HEAVY: the kernel hands reads that outgrow their base arena to heavy_kernel (MAPAD_HEAVY=1); compiled out otherwise (the hand-over code in the
 // loop costs the common path registers and waits: C2 -15 % with it in, measured).
+// Lanes per read 2 (MAPAD_LANES_PER_READ=2): a pair of lanes per read, 32 reads per wavefront — the quad-uniform part of a step (heap, gates, commit loop: 80 % of
+// its instructions) then serves twice the reads per instruction issued, each lane answers the rank queries for two bases and packs their children.  Its read slots
+// keep heap levels 0-4 near (MAPAD_KTOP2 = 31: 576 B per slot at 50 bp), so that eight such blocks fit a CU's LDS.
+#if !defined(MAPAD_KTOP2)
+#define MAPAD_KTOP2 31
+#endif
+template <int LPR> struct top_of { static constexpr int value = LPR == 2 ? MAPAD_KTOP2 : kTop; };
 template <int LPR, bool CONT, int PASS, bool NL, bool HEAVY>
-__global__ void __launch_bounds__(64, (LPR == 1 && NL) ? 1 : MAPAD_MIN_WAVES) search_kernel(DevIndex ix, DevParams P, BatchDev B0, ArenaPool AP0, const GrowPools* GP, uint32_t near_stride, uint32_t near_lmax, int stage) {
+__global__ void __launch_bounds__(64, (LPR == 1 && NL) ? 1 : LPR == 2 ? 2 : MAPAD_MIN_WAVES) search_kernel(DevIndex ix, DevParams P, BatchDev B0, ArenaPool AP0, const GrowPools* GP, uint32_t near_stride, uint32_t near_lmax, int stage) {
     const int lane = threadIdx.x & 63, w = lane & (LPR - 1);
     const int tier = stage;
     const uint32_t n_items = tier == 0 ? B0.n_reads : B0.cursors[CUR_OVF + 2 * (tier - 1)];
@@ -581,7 +589,9 @@ __global__ void __launch_bounds__(64, (LPR == 1 && NL) ? 1 : MAPAD_MIN_WAVES) se
     uint32_t* const cursors = B0.cursors;
     const uint32_t set = acquire_set(AP0);
     const uint32_t slot = set * (64 / LPR) + (lane / LPR);
-    ArenaT<NL> A = carve<NL>(AP0, slot);
+    constexpr int TOPK = top_of<LPR>::value;
+    static_assert(!HEAVY || LPR == 4, "reads are handed to heavy wavefronts by quads only");
+    ArenaT<NL, TOPK> A = carve<NL, TOPK>(AP0, slot);
     // near data of this read slot: [kTop + 1 heap slots][2*lmax bytes class/quality][lmax floats D]
     extern __shared__ __attribute__((aligned(16))) uint8_t near_lds[];
     using NearBytes = typename near_ptr<uint8_t, NL>::type;
@@ -589,12 +599,12 @@ __global__ void __launch_bounds__(64, (LPR == 1 && NL) ? 1 : MAPAD_MIN_WAVES) se
     if constexpr (NL) near = (NearBytes)near_lds + (size_t)(lane / LPR) * near_stride;
     else near = AP0.base + (uint64_t)slot * AP0.stride + AP0.off_near;
     A.top = (typename near_ptr<HeapEntry, NL>::type)near + 1;
-    const NearBytes near_qc = near + (kTop + 1) * sizeof(HeapEntry);
+    const NearBytes near_qc = near + (TOPK + 1) * sizeof(HeapEntry);
     const typename near_ptr<float, NL>::type near_d = (typename near_ptr<float, NL>::type)(near_qc + ((2 * near_lmax + 15) & ~15u));
     uint32_t* work = &cursors[CUR_WORK + 2 * tier];
     // reads of the first stages give up after kMaxWaits fruitless waits for an arena and are restarted by the next stage, when the
     // pools are quiet; the last growable stage waits as long as it takes
-    const DeviceGrow<LPR, NL> grow{GP, &cursors[CUR_GROWN], slot, w, stage + 2 < kStages || HEAVY};
+    const DeviceGrow<LPR, NL, TOPK> grow{GP, &cursors[CUR_GROWN], slot, w, stage + 2 < kStages || HEAVY};
 #if defined(MAPAD_PROFILE_SECTIONS)
     if (lane < 2 * PROF_N + 2) g_prof_lds[lane] = 0;
     g_prof_hist[lane] = 0;
@@ -603,6 +613,7 @@ __global__ void __launch_bounds__(64, (LPR == 1 && NL) ? 1 : MAPAD_MIN_WAVES) se
     bool have = false, done = false;
     ReadInT<NL> rd{near_qc, near_d, 0, 0.0f, 0};
     if constexpr (LPR == 4) rd.lane_less = w == 0 ? ix.less[1] : w == 1 ? ix.less[2] : w == 2 ? ix.less[3] : ix.less[4];
+    if constexpr (LPR == 2) { rd.lane_less = w == 0 ? ix.less[1] : ix.less[3]; rd.lane_less1 = w == 0 ? ix.less[2] : ix.less[4]; }
     SearchState st;
     uint32_t read = 0;
     for (;;) {
@@ -645,13 +656,13 @@ __global__ void __launch_bounds__(64, (LPR == 1 && NL) ? 1 : MAPAD_MIN_WAVES) se
                 finalize_read<LPR>(kernarg_reload(kArgOffB, B0), rd, A, st, read, w, tier);
                 if (PASS != 1 && A.grown) {  // give the grown arena back; the next read starts in the base arena again
                     release_grown<LPR>(GP, A.grown, w);
-                    const ArenaT<NL> base = carve<NL>(kernarg_reload(kArgOffAP, AP0), slot);
+                    const ArenaT<NL, TOPK> base = carve<NL, TOPK>(kernarg_reload(kArgOffAP, AP0), slot);
                     A.heap = base.heap; A.nodes = base.nodes; A.heap_cap = base.heap_cap; A.node_cap = base.node_cap; A.grown = 0;
                 }
                 have = false;
                 drain_memory();
                 MAPAD_MARK(PROF_FINALIZE);
-            } else if (HEAVY && MAPAD_UNLIKELY(A.grown != 0)) {
+            } else if constexpr (HEAVY) { if (MAPAD_UNLIKELY(A.grown != 0)) {
                 // The read has outgrown its base arena: it is heavy.  Its state goes into the grown arena (heap top from the near array, hit staging
                 // from the base arena), the read is queued for heavy_kernel — a wavefront of its own — and this quad takes its next read.
                 // (a suspended read keeps its grown arena until the heavy stage has finished it: no more of them than the pools can spare)
@@ -662,7 +673,7 @@ __global__ void __launch_bounds__(64, (LPR == 1 && NL) ? 1 : MAPAD_MIN_WAVES) se
                     have = false;
                 }
                 drain_memory();
-            }
+            } }
         }
     }
     release_set(kernarg_reload(kArgOffAP, AP0), set);
@@ -792,7 +803,7 @@ struct DevBuf {
 };
 
 // bytes of "near" data per read slot: heap top (32 physical slots), 2 bytes + 4 bytes per read position
-uint32_t near_bytes(uint32_t lmax) { return (kTop + 1) * 8 + ((2 * lmax + 15) & ~15u) + ((4 * lmax + 15) & ~15u); }
+uint32_t near_bytes(uint32_t lmax, uint32_t top = kTop) { return (top + 1) * 8 + ((2 * lmax + 15) & ~15u) + ((4 * lmax + 15) & ~15u); }
 constexpr uint32_t kMaxLdsReadLen = 256;  // longer reads keep their near data in the HBM arena instead of LDS
 
 ArenaPool make_pool_layout(uint32_t heap_cap, uint32_t node_cap, uint32_t hit_ops_cap, uint32_t lmax) {
@@ -978,7 +989,7 @@ int ensure_arenas(mapad_ctx* c, BatchSlot& S, uint32_t lmax, uint64_t n_reads) {
     if ((rc = sync_all_slots(c))) return rc;  // the layouts change: nothing may be in flight
     for (auto& a : c->d_arena) a.release();
     n_reads = std::max<uint64_t>(n_reads, c->arena_reads);  // pools never shrink; a batch cannot use more arenas than it has reads
-    c->lpr = env_u32("MAPAD_LANES_PER_READ", 4) == 1 ? 1 : 4;
+    { const uint32_t l = env_u32("MAPAD_LANES_PER_READ", 4); c->lpr = l == 1 ? 1 : l == 2 ? 2 : 4; }
     const uint32_t lm = std::max<uint32_t>(std::max<uint32_t>(lmax, c->arena_lmax), 128);
     const uint64_t stack_cap = (uint64_t)c->dprm.stack_limit + 10, tree_cap = (uint64_t)c->dprm.edit_tree_limit + 10;
     const uint32_t hit_ops_cap = kMaxHits * (lm + 32);
@@ -989,7 +1000,7 @@ int ensure_arenas(mapad_ctx* c, BatchSlot& S, uint32_t lmax, uint64_t n_reads) {
         // 16 384 nodes: 7 K instead of 17 K arena migrations per million C2 reads, +2-3 % reads/s over 8192 (C2, C3), +6 % on the C5 read mix
         const uint32_t nodes = env_u32("MAPAD_TIER0_NODES", 16384);
         c->pool[0] = make_pool_layout((uint32_t)std::min<uint64_t>(nodes, stack_cap), (uint32_t)std::min<uint64_t>(nodes, tree_cap), hit_ops_cap, lm);
-        c->resident_waves = env_u32("MAPAD_TIER0_WAVES_PER_CU", c->lpr == 4 ? 4 * MAPAD_MIN_WAVES : 8) * (uint32_t)c->n_cu;
+        c->resident_waves = env_u32("MAPAD_TIER0_WAVES_PER_CU", c->lpr == 4 ? 4 * MAPAD_MIN_WAVES : 8) * (uint32_t)c->n_cu;  // lanes-per-read 2: eight blocks of 32 read slots per CU
         const uint64_t per_xcd_full = ((uint64_t)c->resident_waves * 4 / 3 + 7) / 8;
         const uint64_t per_xcd_need = (need_waves * (uint64_t)std::min(c->depth, 4) + 7) / 8 + 4;  // small batches (tests): no more than they can use
         n_sets[0] = 8 * (uint32_t)std::max<uint64_t>(std::min(per_xcd_full, per_xcd_need), kPartitionMin / 8);
@@ -1205,21 +1216,30 @@ int launch_batch(mapad_ctx* c, BatchSlot& S, const uint8_t* d_seqs, const uint8_
     // near data in LDS (16 read slots per wavefront) unless the batch has very long reads or every lane owns a read
     const uint32_t near_lmax = std::max<uint32_t>(lmax, 1);
     // lanes-per-read 1: 64 read slots per wavefront, near data in LDS while it fits the 64 KB a launch may ask for without an opt-in
-    const bool near_fits = c->lpr == 4 ? near_lmax <= kMaxLdsReadLen : (size_t)near_bytes(near_lmax) * 64 <= 65536;
-    const uint32_t near_stride = (near_fits && env_u32("MAPAD_NEAR_LDS", 1)) ? near_bytes(near_lmax) : 0;
+    const uint32_t near_top = c->lpr == 2 ? MAPAD_KTOP2 : kTop;
+    const bool near_fits = c->lpr == 4 ? near_lmax <= kMaxLdsReadLen : c->lpr == 2 ? (size_t)near_bytes(near_lmax, near_top) * 32 <= 65536 : (size_t)near_bytes(near_lmax) * 64 <= 65536;
+    const uint32_t near_stride = (near_fits && env_u32("MAPAD_NEAR_LDS", 1)) ? near_bytes(near_lmax, near_top) : 0;
     // LDS per search block: the near data of its read slots — padded, when twelve blocks would fit a CU, to what only eleven fit (see order_scatter_kernel)
     size_t lds = (size_t)near_stride * rpw;
     {
-        const size_t cu_lds = 160 * 1024, per_cu = env_u32("MAPAD_SEARCH_BLOCKS_PER_CU", 11);
-        if (lds && per_cu && per_cu < 12 && cu_lds / lds > per_cu) lds = (cu_lds / (per_cu + 1) + 256) & ~(size_t)255;
+        const size_t cu_lds = 160 * 1024;
+        if (lds) {
+            const size_t fit = cu_lds / lds;
+            // at least 12 KB of a CU's LDS stay free: one block fewer than fit if the blocks would leave less (quads: 12 x 13.3 KB -> 11; pairs at 50 bp: 8 x 18.4 KB leave 12.8 KB)
+            size_t per_cu = cu_lds - fit * lds < 12 * 1024 ? fit - 1 : fit;
+            per_cu = std::min<size_t>(per_cu, env_u32("MAPAD_SEARCH_BLOCKS_PER_CU", 32));
+            if (per_cu >= 1 && per_cu < fit) lds = (cu_lds / (per_cu + 1) + 256) & ~(size_t)255;
+        }
     }
     const bool cont = c->dprm.bound_kind == BOUND_CONTINUOUS;
     const bool heavy_on = c->grow.heavy_min_class < (uint32_t)kClasses;
 #define MAPAD_LAUNCH(L, C, P, N)                                                                                                                                   \
-    if (heavy_on) hipLaunchKernelGGL((search_kernel<L, C, P, N, true>), dim3(grid), dim3(64), lds, S.stream, c->dix, c->dprm, B, ap, c->d_grow.p, near_stride, near_lmax, stage); \
+    if (heavy_on && L == 4) hipLaunchKernelGGL((search_kernel<L, C, P, N, (L == 4)>), dim3(grid), dim3(64), lds, S.stream, c->dix, c->dprm, B, ap, c->d_grow.p, near_stride, near_lmax, stage); \
     else hipLaunchKernelGGL((search_kernel<L, C, P, N, false>), dim3(grid), dim3(64), lds, S.stream, c->dix, c->dprm, B, ap, c->d_grow.p, near_stride, near_lmax, stage)
 #define MAPAD_LAUNCH_PASS(P)                                                                                      \
-    if (c->lpr == 4 && near_stride) { if (!cont) { MAPAD_LAUNCH(4, false, P, true); } else { MAPAD_LAUNCH(4, true, P, true); } }   \
+    if (c->lpr == 2 && near_stride) { if (!cont) { MAPAD_LAUNCH(2, false, P, true); } else { MAPAD_LAUNCH(2, true, P, true); } }   \
+    else if (c->lpr == 2) { if (!cont) { MAPAD_LAUNCH(2, false, P, false); } else { MAPAD_LAUNCH(2, true, P, false); } }          \
+    else if (c->lpr == 4 && near_stride) { if (!cont) { MAPAD_LAUNCH(4, false, P, true); } else { MAPAD_LAUNCH(4, true, P, true); } }   \
     else if (c->lpr == 4) { if (!cont) { MAPAD_LAUNCH(4, false, P, false); } else { MAPAD_LAUNCH(4, true, P, false); } }          \
     else if (near_stride) { if (!cont) { MAPAD_LAUNCH(1, false, P, true); } else { MAPAD_LAUNCH(1, true, P, true); } }              \
     else { if (!cont) { MAPAD_LAUNCH(1, false, P, false); } else { MAPAD_LAUNCH(1, true, P, false); } }

@@ -179,7 +179,8 @@ struct ReadInT {
     int L;
     float thr;          // DevParams::reject_thr[L]
     int32_t table;      // DevParams::table_base[L]
-    uint64_t lane_less = 0;  // device quads: Less of the base this lane extends by (DevIndex::less[w + 1]), picked once per kernel
+    uint64_t lane_less = 0;  // device quads: Less of the base this lane extends by (DevIndex::less[w + 1]), picked once per kernel; pairs: of base 2w
+    uint64_t lane_less1 = 0; // device pairs (lanes-per-read 2): Less of this lane's second base, 2w + 1
 };
 using ReadIn = ReadInT<false>;
 
@@ -612,6 +613,7 @@ MAPAD_HD void commit_child(const DevParams& P, const ReadInT<NLR>& rd, ArenaT<NL
         Node u = nd;
 #if defined(__HIP_DEVICE_COMPILE__)
         if (LPR == 4) { u.w1 = quad_pick64(nd.w1, owner); u.w2 = quad_pick64(nd.w2, owner); u.w3 = quad_pick64(nd.w3, owner); }
+        if (LPR == 2) { u.w1 = pair_pick64(nd.w1, owner); u.w2 = pair_pick64(nd.w2, owner); u.w3 = pair_pick64(nd.w3, owner); }
 #endif
         (void)owner;
         const Frame c = unpack_frame(u);
@@ -701,27 +703,39 @@ MAPAD_HD bool search_step(const DevIndex& ix, const DevParams& P, const ReadInT<
 
     // Extension (:1245); forward extension works on the swapped interval.  Device quads: lane w keeps the extension by base w only.
 #if defined(__HIP_DEVICE_COMPILE__)
-    constexpr bool kLaneKids = LPR == 4;
+    constexpr bool kLaneKids = LPR == 4 || LPR == 2;  // the lanes of a read's group each build the children of their own base(s)
+    constexpr int kBases = LPR == 2 ? 2 : 1;           // bases per lane: lane w owns bases kBases * w .. kBases * w + kBases - 1
 #else
     constexpr bool kLaneKids = false;
+    constexpr int kBases = 1;
 #endif
     const uint64_t x_lower = forward ? f.lower_rev : f.lower, x_lower_rev = forward ? f.lower : f.lower_rev;
 #if defined(__HIP_DEVICE_COMPILE__)
     ExtLoads ext_loads{};
-    if constexpr (kLaneKids) ext_loads = ext4_quad_issue(ix, x_lower, f.size, w);  // one call site: forward and backward quads of a wavefront share the round trip
+    ExtLoads2 ext_loads2{};
+    if constexpr (LPR == 4) ext_loads = ext4_quad_issue(ix, x_lower, f.size, w);  // one call site: forward and backward quads of a wavefront share the round trip
+    if constexpr (LPR == 2) ext_loads2 = ext4_pair_issue(ix, x_lower, f.size, w);
 #endif
     // pop_max of the crate, second half: the last entry takes the place of the maximum and trickles down
     st.heap_len -= 1;
     if (top_idx < st.heap_len) mm_trickle_down<true>(A, st.heap_len, top_idx, last);
     MAPAD_MARK(PROF_POP);
     Ext4 e;
-    uint64_t my_lower = 0, my_lower_rev = 0, my_size = 0;  // kLaneKids: extension by base w
+    uint64_t my_lower[kBases] = {}, my_lower_rev[kBases] = {}, my_size[kBases] = {};  // kLaneKids: extension by this lane's base(s)
     uint32_t nonempty;
     if constexpr (kLaneKids) {
 #if defined(__HIP_DEVICE_COMPILE__)
-        ExtLane x;
-        ext4_quad_lane_finish(ix, ext_loads, x_lower, x_lower_rev, f.size, w, rd.lane_less, x);
-        my_lower = x.lower; my_lower_rev = x.lower_rev; my_size = x.size; nonempty = x.nonempty;
+        if constexpr (LPR == 4) {
+            ExtLane x;
+            ext4_quad_lane_finish(ix, ext_loads, x_lower, x_lower_rev, f.size, w, rd.lane_less, x);
+            my_lower[0] = x.lower; my_lower_rev[0] = x.lower_rev; my_size[0] = x.size; nonempty = x.nonempty;
+        } else {
+            ExtLane2 x;
+            ext4_pair_lane_finish(ix, ext_loads2, x_lower, x_lower_rev, f.size, w, rd.lane_less, rd.lane_less1, x);
+#pragma unroll
+            for (int b = 0; b < kBases; ++b) { my_lower[b] = x.lower[b]; my_lower_rev[b] = x.lower_rev[b]; my_size[b] = x.size[b]; }
+            nonempty = x.nonempty;
+        }
 #endif
     } else {
         ext4_any<LPR>(ix, x_lower, x_lower_rev, f.size, w, e);
@@ -780,11 +794,15 @@ MAPAD_HD bool search_step(const DevIndex& ix, const DevParams& P, const ReadInT<
         }
         return pack_node(op, top.node, c);
     };
-    Node nd_ins{}, nd_del{}, nd_mm{};
-    if constexpr (kLaneKids) {  // lane w packs the two children of base w once; the commit loop below only selects and stores
+    Node nd_ins{}, nd_del[kBases] = {}, nd_mm[kBases] = {};
+    if constexpr (kLaneKids) {  // every lane packs the two children of its base(s) once; the commit loop below only selects and stores
         nd_ins = make_child(0, 0, 0, 0, 0);
-        nd_del = make_child(1 + 2 * (3 - w), w, my_lower, my_lower_rev, my_size);
-        nd_mm = make_child(2 + 2 * (3 - w), w, my_lower, my_lower_rev, my_size);
+#pragma unroll
+        for (int b = 0; b < kBases; ++b) {
+            const int k = kBases * w + b;
+            nd_del[b] = make_child(1 + 2 * (3 - k), k, my_lower[b], my_lower_rev[b], my_size[b]);
+            nd_mm[b] = make_child(2 + 2 * (3 - k), k, my_lower[b], my_lower_rev[b], my_size[b]);
+        }
     }
     MAPAD_MARK(PROF_GATES);
 #if defined(MAPAD_PROFILE_SECTIONS) && defined(__HIP_DEVICE_COMPILE__)
@@ -839,10 +857,13 @@ MAPAD_HD bool search_step(const DevIndex& ix, const DevParams& P, const ReadInT<
             // The nodes of all children in three store groups behind the pushes (a node is only read when its frame is popped, at the earliest
             // in the next step): lane w stores the match/mismatch and the deletion child of base w, lane 0 the insertion child.  Inside the loop
             // the stores sat between a push's loads and its wait, which then had to cover them as well.
-            const uint32_t t_mm = 2u + 2u * (3u - (uint32_t)w), t_del = t_mm - 1u;
 #if defined(__HIP_DEVICE_COMPILE__)
-            if ((cand0 >> t_mm) & 1u) A.nodes[id0 + (uint32_t)__popc(cand0 & ((1u << t_mm) - 1u))] = nd_mm;
-            if ((cand0 >> t_del) & 1u) A.nodes[id0 + (uint32_t)__popc(cand0 & ((1u << t_del) - 1u))] = nd_del;
+#pragma unroll
+            for (int b = 0; b < kBases; ++b) {
+                const uint32_t t_mm = 2u + 2u * (3u - (uint32_t)(kBases * w + b)), t_del = t_mm - 1u;
+                if ((cand0 >> t_mm) & 1u) A.nodes[id0 + (uint32_t)__popc(cand0 & ((1u << t_mm) - 1u))] = nd_mm[b];
+                if ((cand0 >> t_del) & 1u) A.nodes[id0 + (uint32_t)__popc(cand0 & ((1u << t_del) - 1u))] = nd_del[b];
+            }
 #endif
             if ((cand0 & 1u) && w == 0) A.nodes[id0] = nd_ins;
         }
@@ -860,8 +881,15 @@ MAPAD_HD bool search_step(const DevIndex& ix, const DevParams& P, const ReadInT<
         const uint32_t ngaps = (is_ins || is_del) ? num_gaps_open : f.ngaps;
         const int len = is_del ? f.len : f.len + 1;
         if constexpr (kLaneKids) {
-            const Node nd = pick_node(is_ins, is_del, nd_ins, nd_del, nd_mm);
-            const int owner = is_ins ? 0 : k;
+            const int b = k & (kBases - 1);  // which of the owner's bases
+            Node sel_del = nd_del[0], sel_mm = nd_mm[0];
+            if constexpr (kBases == 2) {  // word-wise selects (pick_node: a conditional on whole structs would pin them in scratch memory)
+                const bool second = b != 0;
+                sel_del = pick_node(second, false, nd_del[kBases - 1], nd_del[0], nd_del[0]);
+                sel_mm = pick_node(second, false, nd_mm[kBases - 1], nd_mm[0], nd_mm[0]);
+            }
+            const Node nd = pick_node(is_ins, is_del, nd_ins, sel_del, sel_mm);
+            const int owner = is_ins ? 0 : k / kBases;
             commit_child<LPR>(P, rd, A, st, alignment_start, score, ngaps, len, nd, w == owner, owner);
         } else {
             const uint64_t xl = k == 0 ? e.lower[0] : k == 1 ? e.lower[1] : k == 2 ? e.lower[2] : e.lower[3];

@@ -51,7 +51,7 @@ def test_search_kat_on_gpu(case):
     ("double_stranded", DOUBLE_STRANDED, dict(qual_range=(20, 40), damage=dict(f=0.5, t=0.5, d=0.02, s=1.0))),
     ("ignore_base_quality", IGNORE_BQ, dict(qual_range=(2, 40), damage=dict(f=0.5, t=0.5, d=0.02, s=1.0))),
 ])
-@pytest.mark.parametrize("lanes_per_read", ["4", "1"])
+@pytest.mark.parametrize("lanes_per_read", ["4", "2", "1"])
 def test_synthetic_batch_matches_oracle(name, prm, kw, lanes_per_read, monkeypatch):
     monkeypatch.setenv("MAPAD_LANES_PER_READ", lanes_per_read)
     g = synth.genome(300_000, seed=99)
