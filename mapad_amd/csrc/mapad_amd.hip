@@ -116,6 +116,7 @@ struct GrowPools {
     uint32_t hit_ops_cap;
     uint32_t max_waits;  // fruitless requests (x 64 steps sat out each) after which a read of the first stages gives up and is restarted later
     uint32_t heavy_min_class;  // a read that grows into this class or beyond is handed to heavy_kernel (kClasses: never)
+    uint32_t wide_copy_nodes;  // a quad's arena migration is copied by the whole wavefront from this many nodes on (DeviceGrow::wide)
     uint32_t heavy_fast;  // heavy_kernel: wavefront-cooperative steps (0: every step by the general single-lane code)
     uint32_t heavy_max_pending;  // ... unless this many reads of the launch are suspended already (each holds a grown arena)
 };
@@ -458,11 +459,12 @@ struct DeviceGrow {
     int w;
     bool may_give_up;
     mutable bool foreign = false;  // HITS: the arena the read is in now was taken by a wavefront on another XCD (release_grown)
-    __device__ __forceinline__ int operator()(ArenaT<NL, TOP>& A, const SearchState& st) const {
+    // takes an arena of a size class that holds the read: GROW_OK (cls, idx), GROW_WAIT (all suitable arenas are busy: sit out), GROW_NEVER (no class can hold it)
+    __device__ __forceinline__ int acquire(ArenaT<NL, TOP>& A, const SearchState& st, uint32_t& cls, uint32_t& idx) const {
         if (A.wait) { A.wait -= 1; return GROW_WAIT; }
         const uint32_t first = A.grown >> kGrownShift;  // first class to try (0 = from the base arena); a dry class falls through to the next
-        uint32_t cls = first;
-        uint32_t idx = ~0u;
+        cls = first;
+        idx = ~0u;
         bool exists = false;
         for (; cls < (uint32_t)kClasses; ++cls) {
             const uint32_t n = gp->count[cls];
@@ -493,6 +495,22 @@ struct DeviceGrow {
             if (w == 0) atomicAdd(grown_counter + 2, 1u);
             return GROW_WAIT;
         }
+        return GROW_OK;
+    }
+    // the read's arena is arena idx of class cls from now on (its contents have been copied)
+    __device__ __forceinline__ void adopt(ArenaT<NL, TOP>& A, uint32_t cls, uint32_t idx) const {
+        uint8_t* b = gp->base[cls] + (uint64_t)idx * gp->stride[cls];
+        if (A.grown) release_grown<LPR>(gp, A.grown, w, foreign);
+        A.heap = (MAPAD_GLOBAL HeapEntry*)(b) + 1; A.nodes = (MAPAD_GLOBAL Node*)(b + gp->off_nodes[cls]);
+        A.heap_cap = gp->heap_cap[cls]; A.node_cap = gp->node_cap[cls];
+        A.grown = ((cls + 1) << kGrownShift) | idx;
+        foreign = false;  // taken from this XCD's part of the pool
+        if (w == 0) atomicAdd(grown_counter, 1u);
+    }
+    __device__ __forceinline__ int operator()(ArenaT<NL, TOP>& A, const SearchState& st) const {
+        uint32_t cls, idx;
+        const int rc = acquire(A, st, cls, idx);
+        if (rc != GROW_OK) return rc;
         if (gp->count[cls] >= kPartitionMin) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // drop stale lines of this CU's L1
         else __threadfence();
         uint8_t* b = gp->base[cls] + (uint64_t)idx * gp->stride[cls];
@@ -514,12 +532,40 @@ struct DeviceGrow {
             for (uint32_t i = w; i < st.hit_ops_used; i += LPR) nops[i] = A.hit_ops[i];
             A.hits = nhits; A.hit_ops = nops; A.scratch = (MAPAD_GLOBAL uint16_t*)(b + gp->off_scratch[cls]);
         }
-        if (A.grown) release_grown<LPR>(gp, A.grown, w, foreign);
-        A.heap = nheap; A.nodes = nnodes; A.heap_cap = gp->heap_cap[cls]; A.node_cap = gp->node_cap[cls];
-        A.grown = ((cls + 1) << kGrownShift) | idx;
-        foreign = false;  // taken from this XCD's part of the pool
-        if (w == 0) atomicAdd(grown_counter, 1u);
+        adopt(A, cls, idx);
         return GROW_OK;
+    }
+    // The same at a wavefront-uniform point of the kernel, for migrations worth it (`need`: this quad's arena is full and holds >= GrowPools::wide_copy_nodes nodes): the quads
+    // that need an arena are served one after the other — the quad takes it, ALL 64 lanes copy (4 KB per round trip instead of the quad's 256 bytes: a 0.64 MB base
+    // arena moves in ~0.3 ms instead of ~5 ms, during which the other 15 reads of the wavefront wait either way).  A quad whose request fails (pools busy) is left to
+    // the step's own call of operator(), which sits out.  Quads only (LPR == 4, no hit staging).
+    __device__ __forceinline__ void wide(ArenaT<NL, TOP>& A, const SearchState& st, int lane, bool need) const {
+        static_assert(!HITS, "wide migrations are for the quad kernel");
+        unsigned long long todo = __ballot(need && w == 0);
+        while (todo) {
+            const int leader = __ffsll((long long)todo) - 1;
+            todo &= todo - 1;
+            const bool mine = (lane >> 2) == (leader >> 2);
+            uint32_t cls = ~0u, idx = ~0u;
+            int rc = GROW_WAIT;
+            if (mine) rc = acquire(A, st, cls, idx);
+            rc = __builtin_amdgcn_readlane(rc, leader);
+            if (rc != GROW_OK) continue;
+            cls = (uint32_t)__builtin_amdgcn_readlane((int)cls, leader); idx = (uint32_t)__builtin_amdgcn_readlane((int)idx, leader);
+            if (gp->count[cls] >= kPartitionMin) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            else __threadfence();
+            auto bcast64 = [&](uint64_t v) -> uint64_t {
+                return ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), leader) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, leader);
+            };
+            const MAPAD_GLOBAL uint4* hs = (const MAPAD_GLOBAL uint4*)bcast64((uint64_t)(A.heap - 1));
+            const MAPAD_GLOBAL uint4* ns = (const MAPAD_GLOBAL uint4*)bcast64((uint64_t)A.nodes);
+            const uint32_t heap_len = (uint32_t)__builtin_amdgcn_readlane((int)st.heap_len, leader), entries = (uint32_t)__builtin_amdgcn_readlane((int)st.tree_entries, leader);
+            uint8_t* b = gp->base[cls] + (uint64_t)idx * gp->stride[cls];
+            copy_units<64>((MAPAD_GLOBAL uint4*)b, hs, (TOP + 1) >> 1, (heap_len + 2) >> 1, lane);
+            copy_units<64>((MAPAD_GLOBAL uint4*)(b + gp->off_nodes[cls]), ns, 0, 2 * entries, lane);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the copy has landed before the quad works in the new arena (and before its old one changes owners)
+            if (mine) adopt(A, cls, idx);
+        }
     }
 };
 
@@ -605,6 +651,7 @@ __global__ void __launch_bounds__(64, (LPR == 1 && NL) ? 1 : LPR == 2 ? 2 : MAPA
     // reads of the first stages give up after kMaxWaits fruitless waits for an arena and are restarted by the next stage, when the
     // pools are quiet; the last growable stage waits as long as it takes
     const DeviceGrow<LPR, NL, TOPK> grow{GP, &cursors[CUR_GROWN], slot, w, stage + 2 < kStages || HEAVY};
+    const uint32_t wide_copy_nodes = GP->wide_copy_nodes;
 #if defined(MAPAD_PROFILE_SECTIONS)
     if (lane < 2 * PROF_N + 2) g_prof_lds[lane] = 0;
     g_prof_hist[lane] = 0;
@@ -647,6 +694,11 @@ __global__ void __launch_bounds__(64, (LPR == 1 && NL) ? 1 : LPR == 2 ? 2 : MAPA
         }
         MAPAD_MARK(PROF_SETUP);
         if (__all(done)) break;
+        if constexpr (PASS != 1 && LPR == 4) {  // big arena migrations here, where every lane of the wavefront is active: all 64 of them copy (DeviceGrow::wide)
+            const bool need = have && (st.heap_len != 0) & (st.status == ST_OK) & ((st.tree_len + kStepNodes > A.node_cap) | (st.heap_len + kStepNodes > A.heap_cap)) &
+                              (st.tree_entries >= wide_copy_nodes);
+            if (MAPAD_UNLIKELY(__any(need))) { grow.wide(A, st, lane, need); drain_memory(); }
+        }
         if (have) {
             bool cont;
             if constexpr (PASS != 1) cont = search_step<LPR, CONT, NL>(ix, P, rd, A, st, w, grow);
@@ -997,8 +1049,15 @@ int ensure_arenas(mapad_ctx* c, BatchSlot& S, uint32_t lmax, uint64_t n_reads) {
     const uint64_t need_waves = (std::max<uint64_t>(n_reads, 1) + rpw - 1) / rpw;
     uint32_t n_sets[kTiers];
     {   // pass 0 base arenas: one set per wavefront the chip can hold (+ a third: the probe of a late wavefront stays short), for all batches in flight
-        // 16 384 nodes: 7 K instead of 17 K arena migrations per million C2 reads, +2-3 % reads/s over 8192 (C2, C3), +6 % on the C5 read mix
-        const uint32_t nodes = env_u32("MAPAD_TIER0_NODES", 16384);
+        // 16 384 nodes: 7 K instead of 17 K arena migrations per million C2 reads, +2-3 % reads/s over 8192 (C2, C3), +6 % on the C5 read mix.
+        // Large genomes (3 Gbp: spurious matches survive longer, 2.8 % of the 50 bp reads outgrow 16 Ki nodes against 0.75 % at 48 Mbp): 65 536 nodes —
+        // 280 K -> 30 K migrations per 10 M C4 reads, +9 % reads/s (24 / 32 / 48 Ki: +1 / +5 / +5.5 %; C2 +1 %, C3 +0 %) for 172 GB of HBM, if that much is free.
+        uint32_t nodes = env_u32("MAPAD_TIER0_NODES", c->dix.n >= (1ull << 31) ? 65536 : 16384);
+        {
+            size_t free_b = 0, total_b = 0;
+            if (hipMemGetInfo(&free_b, &total_b) == hipSuccess)
+                while (nodes > 16384 && (uint64_t)c->n_cu * 16 * 64 / c->lpr * ((uint64_t)nodes * 40 + 16384) > free_b / 4 * 3) nodes /= 2;  // base arenas take at most three quarters of what is free
+        }
         c->pool[0] = make_pool_layout((uint32_t)std::min<uint64_t>(nodes, stack_cap), (uint32_t)std::min<uint64_t>(nodes, tree_cap), hit_ops_cap, lm);
         c->resident_waves = env_u32("MAPAD_TIER0_WAVES_PER_CU", c->lpr == 4 ? 4 * MAPAD_MIN_WAVES : 8) * (uint32_t)c->n_cu;  // lanes-per-read 2: eight blocks of 32 read slots per CU
         const uint64_t per_xcd_full = ((uint64_t)c->resident_waves * 4 / 3 + 7) / 8;
@@ -1080,6 +1139,7 @@ int ensure_arenas(mapad_ctx* c, BatchSlot& S, uint32_t lmax, uint64_t n_reads) {
     g.max_waits = env_u32("MAPAD_MAX_WAITS", 64);
     g.hit_ops_cap = hit_ops_cap;
     g.heavy_fast = env_u32("MAPAD_HEAVY_FAST", 1);
+    g.wide_copy_nodes = env_u32("MAPAD_WIDE_COPY_NODES", 2048);
     // MAPAD_HEAVY=1: a quad hands a read that grows into class MAPAD_HEAVY_MIN_CLASS or beyond to heavy_kernel.  Off by default: measured on MI355X, a lone
     // wavefront issues one instruction per 4-5 cycles whatever its type, a step is ~2 500 of them either way, and the wavefront-per-read step takes 5.7 us
     // per pop against the quad's 5.5 (heavy reads); the full-limit stage runs on heavy_kernel in any case.

@@ -138,7 +138,7 @@ def test_index_beyond_2_pow_32_rows_maps_like_the_oracle(monkeypatch):
                (DAMAGE, synth.reads(g, n_reads - half, 50, seed=4326, qual_range=(20, 40), damage=dict(f=0.5, t=0.5, d=0.02, s=1.0)))]
     # C5's read mix (BASELINE.json configs[4]: 35-100 bp, 5 % of the reads with a 1-2 bp indel, damage model, Phred 20-40) on the 3 Gbp index.  The
     # reference's limits are scaled down 10x (STACK_LIMIT / EDIT_TREE_LIMIT, mapping.rs:52-54: the recovery code is the same and the heaviest
-    # reads then take seconds instead of a minute each), and the size classes beyond 128 Ki nodes get no arenas, so that the reads which
+    # reads then take seconds instead of a minute each), and the size classes beyond 128 Ki nodes get no arenas (the base arenas of a 3 Gbp index hold 64 Ki), so that the reads which
     # need them are re-run by the full-limit stage (wavefront-per-read kernel).
     n_c5 = int(os.environ.get("MAPAD_TEST_C5_READS", 20_000))
     c5_limits = {"stack_limit": int(os.environ.get("MAPAD_TEST_C5_STACK_LIMIT", 200_000)), "edit_tree_limit": int(os.environ.get("MAPAD_TEST_C5_TREE_LIMIT", 1_000_000))}
@@ -163,7 +163,7 @@ def test_index_beyond_2_pow_32_rows_maps_like_the_oracle(monkeypatch):
     if n_c5:
         seqs, quals, offsets = c5
         rp = dict(resolve_params(DAMAGE), **c5_limits)
-        monkeypatch.setenv("MAPAD_CLASS_COUNTS", os.environ.get("MAPAD_TEST_C5_CLASS_COUNTS", "8192,4096,2048,0,0,0,0,0,0,0"))
+        monkeypatch.setenv("MAPAD_CLASS_COUNTS", os.environ.get("MAPAD_TEST_C5_CLASS_COUNTS", "8192,4096,2048,1024,0,0,0,0,0,0"))
         ctx = mapad_amd.Context(pidx, mapad_amd.make_params(rp), 0)
         t5 = time.time()
         res = ctx.map_batch(seqs, quals, offsets)

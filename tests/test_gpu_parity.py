@@ -70,9 +70,11 @@ def test_synthetic_batch_matches_oracle(name, prm, kw, lanes_per_read, monkeypat
                                  {"MAPAD_TIER0_NODES": "32", "MAPAD_CLASS_COUNTS": "4,4,4,4,4,4,4,4,4,4", "MAPAD_MAX_WAITS": "0"},
                                  {"MAPAD_ORDER_CHUNK_LOG2": "10"}, {"MAPAD_HIT_POOL": "64"},
                                  {"MAPAD_HEAVY": "1", "MAPAD_TIER0_NODES": "256"}, {"MAPAD_HEAVY": "1", "MAPAD_POOL_BUDGET_GB": "1", "MAPAD_TIER0_NODES": "256"},
-                                 {"MAPAD_HEAVY": "1", "MAPAD_HEAVY_FAST": "0", "MAPAD_TIER0_NODES": "64"}],
+                                 {"MAPAD_HEAVY": "1", "MAPAD_HEAVY_FAST": "0", "MAPAD_TIER0_NODES": "64"},
+                                 {"MAPAD_TIER0_NODES": "64", "MAPAD_WIDE_COPY_NODES": "16"}, {"MAPAD_TIER0_NODES": "32", "MAPAD_WIDE_COPY_NODES": "1", "MAPAD_CLASS_COUNTS": "64,16,8,8,8,8,8,8,8,8"}],
                          ids=["input_order", "tiny_pool_budget", "near_data_in_hbm", "give_up_and_restart", "order_chunks_of_1024",
-                              "hit_pool_overflow_retry", "heavy_wavefronts", "heavy_wavefronts_tiny_pools", "heavy_wavefronts_general_steps"])
+                              "hit_pool_overflow_retry", "heavy_wavefronts", "heavy_wavefronts_tiny_pools", "heavy_wavefronts_general_steps",
+                              "wavefront_wide_migrations", "wavefront_wide_migrations_busy_pools"])
 def test_scheduling_and_memory_variants_do_not_change_results(env, monkeypatch):
     """The cost-class order, the size of the arena pools and where the near data lives only change when and where a read is
     processed, never its result."""
