@@ -1183,6 +1183,13 @@ int acquire_slot(mapad_ctx* c, int k) {
     return MAPAD_OK;
 }
 
+// log2 of the chunk inside which the reads of a batch are ordered by cost class (order_scan_kernel): 2^20, the scale of the reference's --batch_size; batches of
+// several million reads (C4: 10 M) in chunks of 2^21 — measured at C4: 2^18 / 2^20 / 2^21 / 2^22 -> 2.31 / 2.43 / 2.56 / 2.24 M reads/s (bigger chunks keep the reads
+// of a wavefront more alike, until so many expensive reads start together that the size-class pools run dry).
+uint32_t order_shift_for(uint64_t n_reads) {
+    return std::min<uint32_t>(std::max<uint32_t>(env_u32("MAPAD_ORDER_CHUNK_LOG2", n_reads >= (4u << 20) ? 21 : 20), 10), 31);
+}
+
 // Device buffers of a batch of n_reads reads / total_bases bases / reads up to lmax long in slot S (allocation only; hipMalloc may wait
 // for running kernels, so a pipelined caller reserves every slot up front: mapad_ctx_reserve).
 int ensure_batch_buffers(mapad_ctx* c, BatchSlot& S, uint64_t n_reads, uint64_t total_bases, uint32_t lmax, bool host_inputs) {
@@ -1201,7 +1208,7 @@ int ensure_batch_buffers(mapad_ctx* c, BatchSlot& S, uint64_t n_reads, uint64_t 
     if ((rc = S.d_hit_count.ensure(nr))) return rc;
     if ((rc = S.d_hit_first.ensure(nr))) return rc;
     if ((rc = S.d_overflow.ensure(nr * kStages))) return rc;
-    const uint32_t order_shift = std::min<uint32_t>(std::max<uint32_t>(env_u32("MAPAD_ORDER_CHUNK_LOG2", 20), 10), 31);
+    const uint32_t order_shift = order_shift_for(nr);
     const uint32_t n_chunks = (uint32_t)((nr + (1ull << order_shift) - 1) >> order_shift);
     if (env_u32("MAPAD_ORDER", 1) != 0) {
         if ((rc = S.d_sort_key.ensure(nr))) return rc;
@@ -1226,7 +1233,7 @@ int launch_batch(mapad_ctx* c, BatchSlot& S, const uint8_t* d_seqs, const uint8_
     if ((rc = ensure_batch_buffers(c, S, n_reads, total_bases, lmax, false))) return rc;
     const size_t nr = std::max<uint64_t>(n_reads, 1);
     const bool ordered = env_u32("MAPAD_ORDER", 1) != 0;
-    const uint32_t order_shift = std::min<uint32_t>(std::max<uint32_t>(env_u32("MAPAD_ORDER_CHUNK_LOG2", 20), 10), 31);
+    const uint32_t order_shift = order_shift_for(nr);
     const uint32_t n_chunks = (uint32_t)((nr + (1ull << order_shift) - 1) >> order_shift);
     if (ordered) HIP_TRY(hipMemsetAsync(S.d_key_hist.p, 0, (size_t)n_chunks * kKeyBins * 4, S.stream));
     HIP_TRY(hipMemsetAsync(S.d_cursors.p, 0, CUR_COUNT * 4, S.stream));
