@@ -1,15 +1,15 @@
-"""mapad-amd map on an 8 M-read FASTQ (C2 workload) for several --batch_size / --in_flight settings: reads/s and stage busy times."""
+"""mapad-amd map on an 8 M-read FASTQ (C2 workload; CLI_GENOME_BP=3000000000 for C4's) for several --batch_size / --in_flight settings: reads/s and stage busy times."""
 import os, re, subprocess, sys, tempfile, time
 sys.path.insert(0, ".")
 import numpy as np
 from mapad_amd import build as mbuild, synth
 n = 8_000_000
-g = synth.genome(48_000_000, seed=1234)
+genome_bp = int(float(os.environ.get("CLI_GENOME_BP", "48000000")))
+g = synth.genome(genome_bp, seed=1234)
 parts = [synth.reads(g, 2_000_000, 50, seed=4323 + 1000 * k, qual=40) for k in range(4)]
 seqs = np.concatenate([p[0] for p in parts]); quals = np.concatenate([p[1] for p in parts])
 tmp = tempfile.mkdtemp(prefix="mapad_cli_")
 fa, fq, bam = os.path.join(tmp, "ref.fa"), os.path.join(tmp, "reads.fastq"), os.path.join(tmp, "out.bam")
-open(fa, "wb").write(b">chr1\n" + g.tobytes() + b"\n")
 rec = np.empty((n, 114), np.uint8)
 rec[:, 0] = ord("@"); rec[:, 1] = ord("r")
 ids = np.arange(n)
@@ -19,7 +19,15 @@ rec[:, 9] = 10; rec[:, 10:60] = seqs.reshape(n, 50); rec[:, 60] = 10; rec[:, 61]
 rec[:, 63:113] = quals.reshape(n, 50) + 33; rec[:, 113] = 10
 rec.tofile(fq)
 exe = mbuild.build_cli()
-subprocess.check_call([exe, "index", "-g", fa], stderr=subprocess.DEVNULL)
+if genome_bp <= 200_000_000:
+    open(fa, "wb").write(b">chr1\n" + g.tobytes() + b"\n")
+    subprocess.check_call([exe, "index", "-g", fa], stderr=subprocess.DEVNULL)
+else:  # as bench.py does at C4: built in this process on the GPU, written as the seven index files
+    import mapad_amd
+    idx = mapad_amd.Index.build([("chr1", g)], device=0)
+    idx.save(fa)
+    del idx
+del g
 base = [exe, "map", "-r", fq, "-g", fa, "-o", bam, "-l", "single_stranded", "-p", "0.03", "-D", "0.02", "-i", "0.001", "-x", "1.0", "--force_overwrite", "-f", "0", "-t", "0", "-d", "0", "-s", "0"]
 cases = [(250000, 4, {}), (250000, 8, {}), (250000, 12, {}), (500000, 4, {}), (500000, 8, {}), (1000000, 4, {})]
 if len(sys.argv) > 1:  # e.g. "250000:4:MAPAD_TIER0_WAVES_PER_CU=10"
