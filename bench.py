@@ -549,7 +549,7 @@ def main():
                    "index_files_bytes": index_bytes,
                    "stage_busy_s": (lambda mm: {"reader": float(mm.group(1)), "device_worker": float(mm.group(2)), "writer": float(mm.group(3))} if mm else None)(
                        re.search(r"reader ([0-9.]+) s, device worker 0 ([0-9.]+) s, writer ([0-9.]+) s", pr.stderr)),
-                   "what": "mapad-amd map: FASTQ -> BAM, --batch_size 250000 (the reference's default), up to 4 chunks in flight on one GPU; reader, MAPQ and BGZF on host threads, coordinates and record text on the GPU"}
+                   "what": "mapad-amd map: FASTQ -> BAM, --batch_size 250000 (the reference's default), up to 4 chunks (8 on a 3 Gbp index) in flight on one GPU; reader, MAPQ and BGZF on host threads, coordinates and record text on the GPU"}
         except Exception as e:  # the leg is a report, not the metric: say why it is missing
             cli = {"skipped": f"{type(e).__name__}: {e}"}
         finally:
