@@ -253,7 +253,8 @@ int mapad_sa_locate(mapad_ctx_t* ctx, const uint64_t* rows, uint64_t n, uint64_t
 int mapad_last_locate_info(mapad_ctx_t* ctx, float* kernel_ms, uint64_t* rows, uint64_t* lf_steps);
 /* mapad_hits_to_records() with the suffix-array lookups of all hit intervals of <= 8 rows done by mapad_sa_locate's kernel first
  * (interval2coordinate, mapping.rs:590-649, is the second random-access loop of the reference); same records, uses the context's
- * index and parameters. */
+ * index and parameters.  `res` may be a result of this context that has not been freed (its hits are then read where the collect left them
+ * on the device), a result of another context, or a struct the caller has filled in itself (hit_begin, hits, ops: they are uploaded first). */
 int mapad_hits_to_records_gpu(mapad_ctx_t* ctx, const mapad_batch_result_t* res, const uint8_t* seqs, const uint8_t* quals, const uint64_t* offsets,
                               const uint16_t* in_flags, uint64_t seed, mapad_records_t** out);
 

@@ -1,7 +1,7 @@
 // bam_io.hpp — minimal BGZF / BAM / FASTQ plumbing for the `mapad-amd` command line (host I/O, not on the accelerated path).
 //
 // Stands in for the parts of noodles that `mapad map` uses (src/map/input_chunk_reader.rs:42-172, src/map/record.rs:138-215,
-// src/map/mapping.rs:92-110,292): BAM/FASTQ(.gz) records in, BAM records out.  CRAM input is not supported.
+// src/map/mapping.rs:92-110,292): BAM / CRAM 3.0 (cram_io.hpp) / FASTQ(.gz) records in, BAM records out.
 #pragma once
 #include <zlib.h>
 
@@ -11,10 +11,13 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <memory>
 #include <stdexcept>
 #include <string>
 #include <thread>
 #include <vector>
+
+#include "cram_io.hpp"
 
 namespace mapad {
 namespace cli {
@@ -247,9 +250,15 @@ inline std::string revcomp(const std::string& s) { std::string r(s.rbegin(), s.r
 class ReadSource {
 public:
     explicit ReadSource(const std::string& path) : in_(path) {
-        // format sniffing (input_chunk_reader.rs:42-135): BAM magic after gunzip, else FASTQ
+        // format sniffing (input_chunk_reader.rs:42-135): CRAM magic, BAM magic after gunzip, else FASTQ
         const int c = in_.peek();
-        if (c == 'B') {
+        if (c == 'C') {
+            char magic[4];
+            if (!in_.read_exact(magic, 4) || std::memcmp(magic, "CRAM", 4) != 0) throw std::runtime_error("unrecognised input format");
+            cram_.reset(new cram::Reader([this](uint8_t* p, size_t n) { return in_.read_exact(p, n); }, true));
+            header_text_ = cram_->header_text();
+            is_bam_ = true;  // records with flags and tags, not FASTQ text
+        } else if (c == 'B') {
             char magic[4];
             if (!in_.read_exact(magic, 4) || std::memcmp(magic, "BAM\1", 4) != 0) throw std::runtime_error("unrecognised input format");
             is_bam_ = true;
@@ -275,7 +284,7 @@ public:
 
     // next record; false at end of input.  Malformed records are reported and skipped (input_chunk_reader.rs:200-214).
     bool next(InRecord& r) {
-        return is_bam_ ? next_bam(r) : next_fastq(r);
+        return cram_ ? next_cram(r) : is_bam_ ? next_bam(r) : next_fastq(r);
     }
     // FASTQ only: the lines of up to `max_records` records (4 lines each) for parse_fastq_record(); nullptr for BAM input
     const char* fastq_block(size_t max_records, std::vector<std::pair<uint32_t, uint32_t>>& lines) {
@@ -305,7 +314,22 @@ public:
 private:
     GzReader in_;
     bool is_bam_ = false;
+    std::unique_ptr<cram::Reader> cram_;
     std::string header_text_;
+
+    bool next_cram(InRecord& r) {  // the same conversion as for a BAM record (record.rs:138-183)
+        cram::Rec c;
+        for (;;) {
+            if (!cram_->next(c)) return false;
+            if (!c.error.empty()) { std::fprintf(stderr, "Skip record due to an error: CRAM record \"%s\": %s\n", c.name.c_str(), c.error.c_str()); continue; }
+            r = InRecord();
+            r.name = std::move(c.name); r.has_name = c.has_name; r.flags = c.flags;
+            r.seq = std::move(c.seq); r.qual = std::move(c.qual); r.aux = std::move(c.aux);
+            for (auto& ch : r.seq) if (ch >= 'a' && ch <= 'z') ch = (char)(ch - 'a' + 'A');
+            if (r.flags & 0x10) { r.seq = revcomp(r.seq); std::reverse(r.qual.begin(), r.qual.end()); }
+            return true;
+        }
+    }
 
     bool next_fastq(InRecord& r) {  // TryFrom<fastq::Record> (record.rs:185-215)
         const char* p; size_t n;

@@ -4,7 +4,7 @@
 //
 //   mapad-amd [--seed N] [--devices K] index -g ref.fa
 //   mapad-amd [--devices K] worker --host H [--port 3130] [--dry_run]
-//   mapad-amd [--seed N] [--devices 0-7 | 0,1,...] map -r reads.{bam,fastq,fastq.gz} -g ref.fa -o out.bam -l single_stranded|double_stranded
+//   mapad-amd [--seed N] [--devices 0-7 | 0,1,...] map -r reads.{bam,cram,fastq,fastq.gz} -g ref.fa -o out.bam -l single_stranded|double_stranded
 //             -p 0.03 | (-c CUTOFF [-e EXP]) -f F -t T -d D -s S [-D 0.02] -i I [-x 1.0] [--batch_size 250000] [--in_flight 4 (8 on a text of >= 2^31 rows)] [--ignore_base_quality]
 //             [--gap_dist_ends 5] [--max_num_gaps_open 2] [--no_search_limit_recovery] [--force_overwrite] [-R ID]
 #include <atomic>

@@ -1458,6 +1458,16 @@ struct HostResult {
 };
 static_assert(sizeof(mapad_hit_t) == sizeof(HitRec), "public hit record == device hit record");
 static_assert(sizeof(mapad_read_counters_t) == sizeof(ReadCounters), "counter layout");
+// The results this library has handed out and not yet seen freed.  A caller may also pass a mapad_batch_result_t it has filled in itself (shards merged on
+// another rank, a result read back from disk) to the post-search calls: only a result found here is a HostResult whose private half may be looked at.
+struct LiveResults {
+    std::mutex m;
+    std::set<const mapad_batch_result_t*> s;
+    static LiveResults& get() { static LiveResults r; return r; }
+    void add(const mapad_batch_result_t* p) { std::lock_guard<std::mutex> g(m); s.insert(p); }
+    bool remove(const mapad_batch_result_t* p) { std::lock_guard<std::mutex> g(m); return s.erase(p) != 0; }
+    bool has(const mapad_batch_result_t* p) { std::lock_guard<std::mutex> g(m); return s.count(p) != 0; }
+};
 
 }  // namespace
 
@@ -1720,6 +1730,7 @@ int mapad_fetch_result(mapad_ctx_t* ctx, mapad_batch_result_t** out) {
                          (double)pv[PROF_N + k] / std::max<double>((double)pv[k], 1.0));
     }
 #endif
+    LiveResults::get().add(&r->pub);
     *out = &r.release()->pub;
     return MAPAD_OK;
 }
@@ -1742,7 +1753,7 @@ int mapad_compact_result_device(mapad_ctx_t* ctx, void** d_hit_begin, void** d_h
     return MAPAD_OK;
 }
 void mapad_batch_result_free(mapad_batch_result_t* r) {
-    if (r) delete reinterpret_cast<HostResult*>(r);  // pub is the first member
+    if (r && LiveResults::get().remove(r)) delete reinterpret_cast<HostResult*>(r);  // pub is the first member; a pointer this library did not hand out (or a second free) is left alone
 }
 
 namespace {
@@ -2058,10 +2069,10 @@ static int record_coords_gpu(mapad_ctx_t* ctx, const mapad_batch_result_t* res, 
     if ((rc = ctx->d_r_out.ensure(n))) return rc;
     // The hits are normally still on the device, laid out in read order by the collect of the fetch that produced `res` (the batch slot has not
     // been launched again since): the kernel reads them where they are.  Otherwise (an older result) they go back over PCIe first.
-    const HostResult* hr = reinterpret_cast<const HostResult*>(res);  // results are library-owned: pub is the first member
+    const HostResult* hr = LiveResults::get().has(res) ? reinterpret_cast<const HostResult*>(res) : nullptr;  // a result of this library: pub is the first member
     const uint64_t* d_begin; const HitRec* d_hits; const uint32_t* d_ops;
     hipStream_t rstream = ctx->stream;
-    if (hr->owner == ctx && hr->slot >= 0 && hr->slot < kMaxDepth && ctx->bs[hr->slot].gen == hr->gen && ctx->bs[hr->slot].compacted && env_u32("MAPAD_RECORDS_RESIDENT", 1)) {
+    if (hr && hr->owner == ctx && hr->slot >= 0 && hr->slot < kMaxDepth && ctx->bs[hr->slot].gen == hr->gen && ctx->bs[hr->slot].compacted && env_u32("MAPAD_RECORDS_RESIDENT", 1)) {
         const BatchSlot& RS = ctx->bs[hr->slot];
         d_begin = RS.d_c_hit_begin.p; d_hits = RS.d_c_hits.p; d_ops = RS.d_c_ops.p;
         rstream = RS.stream;  // the stream that wrote them (idle since the fetch)

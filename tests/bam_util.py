@@ -90,6 +90,10 @@ def read_bam(path):
                 val = struct.unpack_from("<i" if ty == "i" else "<I", b, p)[0]; p += 4
             elif ty == "f":
                 val = struct.unpack_from("<f", b, p)[0]; p += 4
+            elif ty == "B":
+                sub, n = chr(b[p]), struct.unpack_from("<I", b, p + 1)[0]
+                fmt = {"c": "b", "C": "B", "s": "h", "S": "H", "i": "i", "I": "I", "f": "f"}[sub]
+                val = (sub, list(struct.unpack_from(f"<{n}{fmt}", b, p + 5))); p += 5 + n * struct.calcsize(fmt)
             else:
                 raise ValueError(ty)
             tags[tag] = (ty, val)

@@ -1,0 +1,264 @@
+"""CRAM 3.0 input of the `mapad-amd` command line (input_chunk_reader.rs:86-95,160-168): files written by tests/cram_util.py
+from the format specification, read by csrc/cli/cram_io.hpp through `mapad-amd recode` (every input record back out as an unmapped BAM record).
+Parity unpinned: no CRAM file of the reference's or of samtools' exists in this image."""
+import random
+import struct
+import subprocess
+
+import pytest
+
+import mapad_amd
+from mapad_amd import build as mbuild
+
+import cram_util as cu
+from bam_util import read_bam
+
+COMP = str.maketrans("ACGTN", "TGCAN")
+
+
+def _cli():
+    mapad_amd.lib()
+    return mbuild.build_cli()
+
+
+def _recode(tmp_path, data, name="in.cram", expect_fail=False):
+    inp, out = str(tmp_path / name), str(tmp_path / "out.bam")
+    with open(inp, "wb") as f:
+        f.write(data)
+    pr = subprocess.run([_cli(), "recode", "-r", inp, "-o", out], stderr=subprocess.PIPE, text=True)
+    if expect_fail:
+        assert pr.returncode != 0
+        return None, pr.stderr
+    assert pr.returncode == 0, pr.stderr
+    return read_bam(out)[2], pr.stderr
+
+
+HEADER = "@HD\tVN:1.6\tSO:unsorted\n@RG\tID:libA\tSM:s1\n@RG\tID:libB\tSM:s1\n@SQ\tSN:chr1\tLN:1000\n"
+
+
+def _unmapped_series():
+    return {
+        "BF": cu.External(1), "CF": cu.Huffman({3: 0}), "RL": cu.External(2), "AP": cu.Huffman({0: 0}), "RG": cu.Beta(1, 2),
+        "RN": cu.ByteArrayStop(0, 3), "MF": cu.Huffman({0: 1, 1: 2, 2: 2}), "NS": cu.Subexp(1, 2), "NP": cu.External(4), "TS": cu.Gamma(1),
+        "TL": cu.External(5), "BA": cu.External(6, as_bytes=True), "QS": cu.External(7, as_bytes=True),
+    }
+
+
+TAG_LINES = [[], [(b"XI", "Z"), (b"FF", "i")], [(b"FF", "i")], [(b"ZC", "C"), (b"XI", "Z")]]
+TAG_ENCS = {(b"XI", "Z"): cu.ByteArrayStop(ord("\t"), 8), (b"FF", "i"): cu.ByteArrayLen(cu.Huffman({4: 0}), cu.External(9)),
+            (b"ZC", "C"): cu.ByteArrayLen(cu.External(10), cu.Huffman({7: 1, 200: 1}))}
+
+
+def _make_reads(n, seed, lens=(20, 75)):
+    rng = random.Random(seed)
+    reads = []
+    for i in range(n):
+        L = rng.randint(*lens)
+        tl = rng.randrange(len(TAG_LINES))
+        tags = []
+        for t, ty in TAG_LINES[tl]:
+            tags.append((t.decode(), ty, {"Z": "".join(rng.choice("ACGT") for _ in range(rng.randint(0, 9))), "i": rng.randint(-5, 1 << 20), "C": rng.choice([7, 200])}[ty]))
+        reads.append(dict(name=f"read_{seed}_{i}", flags=rng.choice([4, 4 | 0x10, 4 | 0x40 | 0x1, 4 | 0x200]), seq="".join(rng.choice("ACGTN" if i % 7 == 0 else "ACGT") for _ in range(L)),
+                          qual=[rng.randint(2, 41) for _ in range(L)], rg=rng.choice([-1, 0, 1]), mf=rng.choice([0, 1, 2]), tl=tl, tags=tags))
+    return reads
+
+
+def _write_unmapped_slice(series, reads):
+    st = cu.SliceStreams()
+    for r in reads:
+        series["BF"].put(st, r["flags"]); series["CF"].put(st, 3); series["RL"].put(st, len(r["seq"])); series["AP"].put(st, 0); series["RG"].put(st, r["rg"])
+        series["RN"].put(st, r["name"].encode())
+        series["MF"].put(st, r["mf"]); series["NS"].put(st, -1); series["NP"].put(st, 0); series["TS"].put(st, 0)  # detached (CF & 2)
+        series["TL"].put(st, r["tl"])
+        for t, ty, v in r["tags"]:
+            TAG_ENCS[(t.encode(), ty)].put(st, cu.aux_value(ty, v))
+        for b in r["seq"]:
+            series["BA"].put(st, ord(b))
+        for q in r["qual"]:
+            series["QS"].put(st, q)
+    return st
+
+
+def _expected(r):
+    seq, qual = (r["seq"].translate(COMP)[::-1], r["qual"][::-1]) if r["flags"] & 0x10 else (r["seq"], r["qual"])
+    tags = [t for t, _, _ in r["tags"]] + (["RG"] if r["rg"] >= 0 else [])
+    return r["name"], seq, "".join(chr(q + 33) for q in qual), tags
+
+
+def test_unmapped_reads_through_every_encoding_and_block_compression(tmp_path):
+    series = _unmapped_series()
+    ch = cu.compression_header(series, TAG_ENCS, TAG_LINES)
+    methods_a = {1: cu.RAW, 2: cu.GZIP, 3: cu.RANS1, 4: cu.RANS0, 5: cu.RAW, 6: cu.RANS1, 7: cu.RANS0, 8: cu.GZIP, 9: cu.RANS0, 10: cu.RAW, "core": cu.RAW}
+    methods_b = {k: cu.GZIP for k in methods_a}
+    methods_b.update({6: cu.RANS0, 7: cu.RANS1, "core": cu.GZIP})
+    a, b, c = _make_reads(57, 1), _make_reads(30, 2), _make_reads(3, 3, lens=(1, 2))  # 57 and 3: block sizes that are not multiples of four
+    data = cu.file_start(HEADER)
+    blocks = [cu.block(cu.RAW, cu.COMPRESSION_HEADER, 0, ch)] + cu.slice_blocks(-1, 0, 0, len(a), 0, _write_unmapped_slice(series, a), methods_a)
+    data += cu.container(-1, 0, 0, len(a), 0, sum(len(r["seq"]) for r in a), blocks, [0])
+    blocks = [cu.block(cu.GZIP, cu.COMPRESSION_HEADER, 0, ch)] + cu.slice_blocks(-1, 0, 0, len(b), len(a), _write_unmapped_slice(series, b), methods_b) \
+        + cu.slice_blocks(-1, 0, 0, len(c), len(a) + len(b), _write_unmapped_slice(series, c), methods_a)
+    data += cu.container(-1, 0, 0, len(b) + len(c), len(a), 0, blocks, [0, 1])
+    data += cu.eof_container()
+    got, _ = _recode(tmp_path, data)
+    want = [_expected(r) for r in a + b + c]
+    assert len(got) == len(want)
+    for g, w, r in zip(got, want, a + b + c):
+        assert (g["name"], g["seq"], g["qual"]) == w[:3]
+        assert g["tag_order"] == w[3] + ["XD"]
+        for t, ty, v in r["tags"]:
+            assert g["tags"][t] == (ty, v)
+        if r["rg"] >= 0:
+            assert g["tags"]["RG"] == ("Z", ["libA", "libB"][r["rg"]])
+
+
+def test_rans_blocks_of_awkward_shapes(tmp_path):
+    """one symbol only, every byte value, runs of consecutive symbols, sizes 1-9 and beyond 4 096: through both rANS orders, as the bytes of a B:C array tag"""
+    rng = random.Random(9)
+    payloads = [bytes([65] * 40), bytes(range(0, 256)) * 3, bytes(rng.choice(b"ACGT") for _ in range(1001)), bytes(rng.choice(b"ABCDEFGxyz\0\1\2") for _ in range(4098)),
+                bytes(rng.choice([0, 255]) for _ in range(333)), bytes(min(255, int(rng.expovariate(0.05))) for _ in range(20_000))]
+    payloads += [bytes(rng.choice(b"ACGT") for _ in range(k)) for k in range(1, 10)]
+    tag_lines = [[(b"ZB", "B")]]
+    for order in (cu.RANS0, cu.RANS1):
+        series = _unmapped_series()
+        tag_encs = {(b"ZB", "B"): cu.ByteArrayLen(cu.External(11), cu.External(3))}
+        st = cu.SliceStreams()
+        for k, p in enumerate(payloads):
+            series["BF"].put(st, 4); series["CF"].put(st, 3); series["RL"].put(st, 4); series["AP"].put(st, 0); series["RG"].put(st, -1)
+            series["RN"].put(st, f"p{k}".encode())
+            series["MF"].put(st, 0); series["NS"].put(st, -1); series["NP"].put(st, 0); series["TS"].put(st, 0); series["TL"].put(st, 0)
+            tag_encs[(b"ZB", "B")].put(st, b"C" + struct.pack("<I", len(p)) + p)
+            for b in "ACGT":
+                series["BA"].put(st, ord(b))
+            for q in [30] * 4:
+                series["QS"].put(st, q)
+        ch = cu.compression_header(series, tag_encs, tag_lines)
+        # every payload in one block, and each payload's own block shape through a slice of its own
+        blocks = [cu.block(cu.RAW, cu.COMPRESSION_HEADER, 0, ch)] + cu.slice_blocks(-1, 0, 0, len(payloads), 0, st, {3: order, 11: order})
+        data = cu.file_start(HEADER) + cu.container(-1, 0, 0, len(payloads), 0, 0, blocks, [0])
+        for k, p in enumerate(payloads):
+            st1 = cu.SliceStreams()
+            series["BF"].put(st1, 4); series["CF"].put(st1, 3); series["RL"].put(st1, 0); series["AP"].put(st1, 0); series["RG"].put(st1, -1)
+            series["RN"].put(st1, f"q{k}".encode())
+            series["MF"].put(st1, 0); series["NS"].put(st1, -1); series["NP"].put(st1, 0); series["TS"].put(st1, 0); series["TL"].put(st1, 0)
+            cu.ByteArrayLen(cu.External(11), cu.External(3)).put(st1, b"C" + struct.pack("<I", len(p)) + p)
+            blocks = [cu.block(cu.RAW, cu.COMPRESSION_HEADER, 0, ch)] + cu.slice_blocks(-1, 0, 0, 1, 0, st1, {3: order})
+            data += cu.container(-1, 0, 0, 1, 0, 0, blocks, [0])
+        got, _ = _recode(tmp_path, data + cu.eof_container())
+        assert [g["name"] for g in got] == [f"p{k}" for k in range(len(payloads))] + [f"q{k}" for k in range(len(payloads))]
+        for g, p in zip(got, payloads + payloads):
+            assert g["tags"]["ZB"] == ("B", ("C", list(p)))
+
+
+REF = "ACGTTGCAAGGCTTAACCGGTTACGATCGATTGCACGTACGTTAGCATGCAAGTCGATCGGATCCATGCAAGCTTGGCATCGATGCATGCCGTA"
+
+
+def _mapped_series():
+    s = _unmapped_series()
+    s.update({"CF": cu.External(12), "AP": cu.External(13), "FN": cu.External(14), "FC": cu.External(15, as_bytes=True), "FP": cu.External(16), "BS": cu.External(17, as_bytes=True),
+              "IN": cu.ByteArrayStop(0, 18), "SC": cu.ByteArrayLen(cu.External(19), cu.External(20)), "DL": cu.External(21), "MQ": cu.Huffman({37: 0}),
+              "BB": cu.ByteArrayLen(cu.External(22), cu.External(23)), "QQ": cu.ByteArrayLen(cu.External(22), cu.External(24)), "RS": cu.External(21), "HC": cu.External(21), "PD": cu.External(21)})
+    return s
+
+
+def _write_mapped(series, st, name, flags, ap_delta, rl, features, quals=None, cf_extra=0):
+    cf = (1 if quals is not None else 0) | cf_extra
+    series["BF"].put(st, flags); series["CF"].put(st, cf); series["RL"].put(st, rl); series["AP"].put(st, ap_delta); series["RG"].put(st, -1)
+    series["RN"].put(st, name.encode()); series["TL"].put(st, 0)
+    series["FN"].put(st, len(features))
+    prev = 0
+    for code, pos, val in features:
+        series["FC"].put(st, ord(code)); series["FP"].put(st, pos - prev)
+        prev = pos
+        if code == "X":
+            series["BS"].put(st, val)
+        elif code == "I":
+            series["IN"].put(st, val.encode())
+        elif code == "S":
+            series["SC"].put(st, val.encode())
+        elif code == "D":
+            series["DL"].put(st, val)
+        elif code == "N":
+            series["RS"].put(st, val)
+        elif code == "H":
+            series["HC"].put(st, val)
+        elif code == "P":
+            series["PD"].put(st, val)
+        elif code == "i":
+            series["BA"].put(st, ord(val))
+        elif code == "B":
+            series["BA"].put(st, ord(val[0])); series["QS"].put(st, val[1])
+        elif code == "Q":
+            series["QS"].put(st, val)
+        elif code == "b":
+            series["BB"].put(st, val.encode())
+        elif code == "q":
+            series["QQ"].put(st, bytes(val))
+    series["MQ"].put(st, 37)
+    if quals is not None:
+        for q in quals:
+            series["QS"].put(st, q)
+
+
+def test_mapped_reads_from_an_embedded_reference_and_without_one(tmp_path):
+    series = _mapped_series()
+    # substitution matrix: for reference A the codes of C, G, T, N are 0, 1, 2, 3; for C: A=3, G=0, T=1, N=2; the others in plain order
+    sm = [0b00011011, 0b11000110, 0b00011011, 0b00011011, 0b00011011]
+    ch = cu.compression_header(series, TAG_ENCS, TAG_LINES, sub_matrix=sm, ref_required=True)
+    start = 11  # the slice covers reference positions 11 .. (1-based)
+    emb = REF[start - 1:start - 1 + 70].encode()
+    st = cu.SliceStreams()
+    # r1: 20 bases at 11, plain match, qualities as an array
+    _write_mapped(series, st, "r1", 0, 0, 20, [], quals=list(range(10, 30)))
+    # r2 at 15 (delta 4): substitution at read position 3 (reference base at 17 = REF[16]), a 2-base insertion at 6, a 3-base deletion before read position 10, no qualities
+    _write_mapped(series, st, "r2", 0, 4, 14, [("X", 3, 1), ("I", 6, "GG"), ("D", 10, 3)])
+    # r3 at 15 (delta 0), reverse strand, soft clip of 3 at the start, one base + quality at 5, a quality alone at 7, reference skip of 5 before 9, hard clip and padding records
+    _write_mapped(series, st, "r3", 0x10, 0, 12, [("H", 1, 4), ("S", 1, "TTT"), ("B", 5, ("N", 9)), ("Q", 7, 33), ("N", 9, 5), ("P", 9, 2), ("i", 11, "C")])
+    # r4 at 20: every base spelled out by a 'b' stretch, qualities by a 'q' stretch
+    _write_mapped(series, st, "r4", 0, 5, 6, [("b", 1, "ACGTAC"), ("q", 2, [20, 21, 22])])
+    blocks = [cu.block(cu.RAW, cu.COMPRESSION_HEADER, 0, ch)] + cu.slice_blocks(0, start, 70, 4, 0, st, {}, embedded_ref=emb)
+    data = cu.file_start(HEADER) + cu.container(0, start, 70, 4, 0, 52, blocks, [0])
+    # the same first two records in a slice without the embedded reference: r1 cannot be decoded, a read spelled out by 'b' can
+    st2 = cu.SliceStreams()
+    _write_mapped(series, st2, "r5", 0, 0, 20, [], quals=list(range(10, 30)))
+    _write_mapped(series, st2, "r6", 0, 9, 6, [("b", 1, "TTGACA")], quals=[30] * 6)
+    blocks = [cu.block(cu.RAW, cu.COMPRESSION_HEADER, 0, ch)] + cu.slice_blocks(0, start, 70, 2, 4, st2, {})
+    data += cu.container(0, start, 70, 2, 4, 26, blocks, [0]) + cu.eof_container()
+    got, err = _recode(tmp_path, data)
+    assert [g["name"] for g in got] == ["r1", "r2", "r3", "r4", "r6"]
+    assert "Skip record due to an error" in err and "r5" in err
+    ref = lambda p1, n: REF[p1 - 1:p1 - 1 + n]  # noqa: E731
+    assert got[0]["seq"] == ref(11, 20) and got[0]["qual"] == "".join(chr(q + 33) for q in range(10, 30))
+    # r2: positions 1-2 match 15-16; 3 = substitution of REF[16] with code 1; 4-5 match 18-19; 6-7 inserted GG; 8-9 match 20-21; deletion of 22-24; 10-14 match 25-29
+    base17 = REF[16]
+    subs = {"A": "CGTN", "C": "GTNA", "G": "ACTN", "T": "ACGN"}[base17]
+    want2 = ref(15, 2) + subs[1] + ref(18, 2) + "GG" + ref(20, 2) + ref(25, 5)
+    assert got[1]["seq"] == want2 and [ord(c) - 33 for c in got[1]["qual"]] == [0xFF] * 14  # no qualities stored: BAM's "missing"
+    # r3 (stored in reference orientation, flag 0x10: un-reversed for mapping): TTT soft clip, position 4 matches 15, 5 = N with quality 9, 6-8 match 17-19, skip 20-24, 9-10 match 25-26, 11 inserted C, 12 matches 27
+    stored = "TTT" + ref(15, 1) + "N" + ref(17, 3) + ref(25, 2) + "C" + ref(27, 1)
+    assert got[2]["seq"] == stored.translate(COMP)[::-1]
+    q3 = [0xFF] * 12
+    q3[4], q3[6] = 9, 33
+    assert [ord(c) - 33 for c in got[2]["qual"]] == q3[::-1]
+    assert got[3]["seq"] == "ACGTAC" and [ord(c) - 33 for c in got[3]["qual"]] == [0xFF, 20, 21, 22, 0xFF, 0xFF]
+    assert got[4]["seq"] == "TTGACA" and got[4]["qual"] == "?" * 6
+
+
+def test_refusals_name_what_is_unsupported(tmp_path):
+    series = _unmapped_series()
+    ch = cu.compression_header(series, TAG_ENCS, TAG_LINES)
+    reads = _make_reads(3, 5)
+    st = _write_unmapped_slice(series, reads)
+    for method, word in ((2, "bzip2"), (3, "lzma"), (6, "3.1")):
+        blocks = [cu.block(cu.RAW, cu.COMPRESSION_HEADER, 0, ch)] + cu.slice_blocks(-1, 0, 0, 3, 0, st, {7: method})
+        data = cu.file_start(HEADER) + cu.container(-1, 0, 0, 3, 0, 0, blocks, [0]) + cu.eof_container()
+        _, err = _recode(tmp_path, data, expect_fail=True)
+        assert word in err
+    v2 = bytearray(cu.file_start(HEADER))
+    v2[4] = 2
+    _, err = _recode(tmp_path, bytes(v2), expect_fail=True)
+    assert "version" in err
+    # a file cut in the middle of a container is an error, not a silent end of input
+    blocks = [cu.block(cu.RAW, cu.COMPRESSION_HEADER, 0, ch)] + cu.slice_blocks(-1, 0, 0, 3, 0, st, {})
+    data = cu.file_start(HEADER) + cu.container(-1, 0, 0, 3, 0, 0, blocks, [0])
+    _, err = _recode(tmp_path, data[:-20], expect_fail=True)
+    assert "truncated" in err

@@ -61,6 +61,35 @@ def test_records_from_device_located_positions_equal_host_path():
         ctx.close()
 
 
+def test_caller_built_result_goes_through_the_device_post_search():
+    """mapad_hits_to_records_gpu takes any mapad_batch_result_t, not only one this library handed out (shards merged on another rank, a result kept
+    on disk): such a struct has no private half, its hits go to the device first, and the records are the same."""
+    import ctypes as C
+    from mapad_amd import binding
+    g = synth.genome(200_000, seed=31)
+    seqs, quals, offsets = synth.reads(g, 1500, 50, seed=12, qual_range=(20, 40), damage=dict(f=0.5, t=0.5, d=0.02, s=1.0))
+    idx = mapad_amd.Index.build([("chr1", g)])
+    params = mapad_amd.make_params(resolve_params(DAMAGE))
+    ctx = mapad_amd.Context(idx, params, 0)
+    try:
+        res = ctx.map_batch(seqs, quals, offsets)
+        want = ctx.hits_to_records(res, seqs, quals, offsets, seed=5)
+        hb, hits, ops = res.hit_begin.copy(), res.hits_arr.copy(), res.ops.copy()
+        status, counters = res.status.copy(), res.counters.copy()
+        own = binding.BatchResultC(n_reads=res.n_reads, n_hits=res.n_hits, n_ops=res.n_ops, hit_begin=hb.ctypes.data, hits=hits.ctypes.data if hits.size else None,
+                                   ops=ops.ctypes.data if ops.size else None, status=status.ctypes.data, counters=counters.ctypes.data, d_arrays=None,
+                                   n_second_pass=0, n_third_pass=0)
+
+        class Mine:
+            _cptr = C.pointer(own)
+        assert ctx.hits_to_records(Mine, seqs, quals, offsets, seed=5) == want
+        binding.lib().mapad_batch_result_free(Mine._cptr)  # not the library's to free: left alone
+        assert int(own.n_reads) == res.n_reads and ctx.hits_to_records(Mine, seqs, quals, offsets, seed=5) == want
+        assert sum(r["mapped"] for r in want) > 1000
+    finally:
+        ctx.close()
+
+
 @pytest.mark.parametrize("text", ["device", "host"])
 def test_device_coordinates_on_contigs_x_runs_and_multi_row_hits(text, monkeypatch):
     """The records kernel (postproc_core.hpp: strand, contig, X0 / X1, XA candidates, PrRange order) against the host restatement on a
