@@ -124,6 +124,49 @@ def test_cli_map_matches_integration_expectation(tmp_path, monkeypatch):
     assert n_mapped >= 14
 
 
+@pytest.mark.gpu
+def test_cli_map_reads_cram_like_bam(tmp_path):
+    """The integration reads as a CRAM 3.0 file (tests/cram_util.py) map to the records the same reads give as BAM input (header chain included)."""
+    import cram_util as cu
+    from test_cram import _unmapped_series
+    k = load("integration")
+    fa, bam_in, cram_in = str(tmp_path / "g.fa"), str(tmp_path / "in.bam"), str(tmp_path / "in.cram")
+    _write_fasta(fa, [(c["name"], c["seq"]) for c in k["contigs"]])
+    header = "@HD\tVN:1.0\n@RG\tID:A12345\tSM:Sample1\n@SQ\tSN:chr1\tLN:600\n@PG\tID:samtools\tPN:samtools\tVN:1.13\tCL:samtools view\n"
+    tags = [("XI", "Z", "ACGACGT"), ("FF", "i", 3), ("RG", "Z", "A12345")]
+    recs = [dict(r, tags=tags if i < 7 else [], flags=r["flags"] | 0x4) for i, r in enumerate(k["reads"])]  # unmapped input: a CRAM record's bases are then its own BA series
+    write_bam(bam_in, header, [("chr1", 600)], recs)
+    series = _unmapped_series()
+    tag_lines = [[], [(b"XI", "Z"), (b"FF", "i")]]
+    tag_encs = {(b"XI", "Z"): cu.ByteArrayStop(ord("\t"), 8), (b"FF", "i"): cu.ByteArrayLen(cu.Huffman({4: 0}), cu.External(9))}
+    st = cu.SliceStreams()
+    for i, r in enumerate(recs):
+        series["BF"].put(st, r["flags"]); series["CF"].put(st, 3); series["RL"].put(st, len(r["seq"])); series["AP"].put(st, 0)
+        series["RG"].put(st, 0 if i < 7 else -1)  # the read group travels as an index into the header's @RG lines
+        series["RN"].put(st, r["name"].encode())
+        series["MF"].put(st, 0); series["NS"].put(st, -1); series["NP"].put(st, 0); series["TS"].put(st, 0)
+        series["TL"].put(st, 1 if i < 7 else 0)
+        if i < 7:
+            tag_encs[(b"XI", "Z")].put(st, cu.aux_value("Z", "ACGACGT")); tag_encs[(b"FF", "i")].put(st, cu.aux_value("i", 3))
+        for b in r["seq"]:
+            series["BA"].put(st, ord(b))
+        for q in r["qual"]:
+            series["QS"].put(st, ord(q) - 33)
+    ch = cu.compression_header(series, tag_encs, tag_lines)
+    blocks = [cu.block(cu.GZIP, cu.COMPRESSION_HEADER, 0, ch)] + cu.slice_blocks(-1, 0, 0, len(recs), 0, st, {6: cu.RANS1, 7: cu.RANS0})
+    with open(cram_in, "wb") as f:
+        f.write(cu.file_start(header) + cu.container(-1, 0, 0, len(recs), 0, 0, blocks, [0]) + cu.eof_container())
+    subprocess.check_call([_cli(), "--seed", "1234", "index", "-g", fa])
+    outs = []
+    for inp in (bam_in, cram_in):
+        out = str(tmp_path / (os.path.basename(inp) + ".out.bam"))
+        subprocess.check_call([_cli(), "--seed", "7", "map", "-r", inp, "-g", fa, "-o", out, "-l", "single_stranded", "-p", "0.03", "-f", "0.6", "-t", "0.55", "-d", "0.01", "-s", "1.0",
+                               "-D", "0.02", "-i", "0.001", "-x", "0.5"])
+        outs.append((read_bam(out)[0].split("\n")[:-2], _decoded(out)))
+    assert outs[0][0][:9] == outs[1][0][:9]  # header: everything but the @PG line of this run (its CL names the input file)
+    assert outs[0][1] == outs[1][1] and sum(1 for r in outs[0][1][1] if r[2] >= 0) >= 14
+
+
 def _decoded(path):
     """decoded records without the wall-time tag XD (SURVEY §8c parity definition: compare decoded records, ignore XD and @PG CL)"""
     text, refs, recs = read_bam(path)
