@@ -645,7 +645,6 @@ __global__ void __launch_bounds__(64, (LPR == 1 && NL) ? 1 : LPR == 2 ? 2 : MAPA
     if constexpr (NL) near = (NearBytes)near_lds + (size_t)(lane / LPR) * near_stride;
     else near = AP0.base + (uint64_t)slot * AP0.stride + AP0.off_near;
     A.top = (typename near_ptr<HeapEntry, NL>::type)near + 1;
-    if constexpr (NL && LPR == 4 && MAPAD_ANC_WINDOW != 0) A.win = (typename near_ptr<HeapEntry, NL>::type)(near + near_stride - kWinEntries * sizeof(HeapEntry));  // the last 64 bytes of the slot
     const NearBytes near_qc = near + (TOPK + 1) * sizeof(HeapEntry);
     const typename near_ptr<float, NL>::type near_d = (typename near_ptr<float, NL>::type)(near_qc + ((2 * near_lmax + 15) & ~15u));
     uint32_t* work = &cursors[CUR_WORK + 2 * tier];
@@ -1286,7 +1285,7 @@ int launch_batch(mapad_ctx* c, BatchSlot& S, const uint8_t* d_seqs, const uint8_
     // lanes-per-read 1: 64 read slots per wavefront, near data in LDS while it fits the 64 KB a launch may ask for without an opt-in
     const uint32_t near_top = c->lpr == 2 ? MAPAD_KTOP2 : kTop;
     const bool near_fits = c->lpr == 4 ? near_lmax <= kMaxLdsReadLen : c->lpr == 2 ? (size_t)near_bytes(near_lmax, near_top) * 32 <= 65536 : (size_t)near_bytes(near_lmax) * 64 <= 65536;
-    const uint32_t near_stride = (near_fits && env_u32("MAPAD_NEAR_LDS", 1)) ? near_bytes(near_lmax, near_top) + (c->lpr == 4 && MAPAD_ANC_WINDOW != 0 ? kWinEntries * (uint32_t)sizeof(HeapEntry) : 0u) : 0;
+    const uint32_t near_stride = (near_fits && env_u32("MAPAD_NEAR_LDS", 1)) ? near_bytes(near_lmax, near_top) : 0;
     // LDS per search block: the near data of its read slots — padded, when twelve blocks would fit a CU, to what only eleven fit (see order_scatter_kernel)
     size_t lds = (size_t)near_stride * rpw;
     {
@@ -1294,7 +1293,7 @@ int launch_batch(mapad_ctx* c, BatchSlot& S, const uint8_t* d_seqs, const uint8_
         if (lds) {
             const size_t fit = cu_lds / lds;
             // at least 12 KB of a CU's LDS stay free: one block fewer than fit if the blocks would leave less (quads: 12 x 13.3 KB -> 11; pairs at 50 bp: 8 x 18.4 KB leave 12.8 KB)
-            size_t per_cu = cu_lds - fit * lds < (size_t)env_u32("MAPAD_LDS_HOLE_KB", MAPAD_ANC_WINDOW != 0 ? 5 : 12) * 1024 ? fit - 1 : fit;
+            size_t per_cu = cu_lds - fit * lds < 12 * 1024 ? fit - 1 : fit;
             per_cu = std::min<size_t>(per_cu, env_u32("MAPAD_SEARCH_BLOCKS_PER_CU", 32));
             if (per_cu >= 1 && per_cu < fit) lds = (cu_lds / (per_cu + 1) + 256) & ~(size_t)255;
         }

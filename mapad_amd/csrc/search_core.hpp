@@ -159,7 +159,6 @@ template <bool NL, int TOP = kTop>
 struct ArenaT {
     static constexpr int kTopN = TOP;
     typename near_ptr<HeapEntry, NL>::type top;  // logical heap slots [0, TOP), shifted by one entry like `heap`
-    typename near_ptr<HeapEntry, NL>::type win = nullptr;  // device quads: kWinEntries entries of LDS for the ancestors of a step's pushes (ancestor window, below)
     MAPAD_GLOBAL HeapEntry* heap;    // logical heap slots [TOP, ..) are used from here
     MAPAD_GLOBAL Node* nodes;
     MAPAD_GLOBAL HitRec* hits;       // kMaxHits
@@ -326,86 +325,6 @@ MAPAD_HD void mm_bubble_up(const ArenaT<NL, TOP>& A, uint32_t pos, const HeapEnt
 }
 template <bool NL, int TOP>
 MAPAD_HD void mm_bubble_up(const ArenaT<NL, TOP>& A, uint32_t pos, const HeapEntry elt) { mm_bubble_up(A, pos, elt, load_ancestors(A, pos)); }
-
-// ---- ancestor window (device quads) ------------------------------------------------------------------------------------------------
-// The pushes of a step go to consecutive slots p0, p0 + 1, ...; each needs its parent, its grandparent and the grandparent of its parent, and
-// left to themselves they take one memory round trip each, one after the other (2.4 trips per wavefront step: 40 % of the wave time).  The
-// ancestors of the first kWinPushes pushes are 4 + 2 + 2 consecutive entries: lane w of the quad loads entry w of the parents and one of the
-// other four right behind the heap repair of the pop, the eight entries go into the slot's window in LDS, and the pushes read — and, where they
-// displace an ancestor, write — them there (write-through to the arena).  Entries that live in the near levels are used where they are.
-#if !defined(MAPAD_ANC_WINDOW)
-#define MAPAD_ANC_WINDOW 1
-#endif
-constexpr int kWinEntries = 8, kWinPushes = 5;
-#if defined(__HIP_DEVICE_COMPILE__)
-struct WinBase { uint32_t i1p, i2p, i3p; };
-__device__ __forceinline__ WinBase win_base(uint32_t p0) {
-    const uint32_t i1 = p0 > 0 ? (p0 - 1) >> 1 : 0, i2 = p0 > 2 ? (p0 - 3) >> 2 : 0, i3 = i1 > 2 ? (i1 - 3) >> 2 : 0;
-    return WinBase{i1, i2, i3};
-}
-struct WinLoads { HeapEntry a, b; };
-template <int TOP>
-__device__ __forceinline__ WinLoads win_issue(const ArenaT<true, TOP>& A, uint32_t p0, int w) {
-    const WinBase wb = win_base(p0);
-    const uint32_t ia = wb.i1p + (uint32_t)w, ib = (w < 2 ? wb.i2p : wb.i3p) + (uint32_t)(w & 1);
-    WinLoads r;
-    r.a = HeapEntry{0.0f, 0u}; r.b = HeapEntry{0.0f, 0u};
-    if (ia >= (uint32_t)TOP) r.a = load_entry(A.heap + ia);  // (slots at or beyond the heap's end are slack memory and never read back)
-    if (ib >= (uint32_t)TOP) r.b = load_entry(A.heap + ib);
-    return r;
-}
-template <int TOP>
-__device__ __forceinline__ void win_store(const ArenaT<true, TOP>& A, const WinLoads& l, int w) { store_entry(A.win + w, l.a); store_entry(A.win + 4 + w, l.b); }
-// a store to heap slot i >= TOP behind the window's back (the rare climb beyond the grandparent): the arena, and the window if it holds the slot
-template <int TOP>
-__device__ __forceinline__ void hp_set_win(const ArenaT<true, TOP>& A, const WinBase& wb, uint32_t i, const HeapEntry e) {
-    hp_set(A, i, e);
-    if (i >= (uint32_t)TOP) {
-        const uint32_t o1 = i - wb.i1p, o2 = i - wb.i2p, o3 = i - wb.i3p;
-        if (o1 < 4u) store_entry(A.win + o1, e);
-        if (o2 < 2u) store_entry(A.win + 4 + o2, e);
-        if (o3 < 2u) store_entry(A.win + 6 + o3, e);
-    }
-}
-// mm_bubble_up for push number < kWinPushes of a step whose window stands at wb: same compares, same stores, no arena load on the common path
-template <int TOP>
-__device__ __forceinline__ void mm_bubble_up_win(const ArenaT<true, TOP>& A, const WinBase& wb, uint32_t pos, const HeapEntry elt) {
-    using LP = MAPAD_LDS HeapEntry*;
-    const uint32_t i1 = pos > 0 ? (pos - 1) >> 1 : 0, i2 = pos > 2 ? (pos - 3) >> 2 : 0, i3 = i1 > 2 ? (i1 - 3) >> 2 : 0;
-    const LP a1 = i1 < (uint32_t)TOP ? A.top + i1 : A.win + (i1 - wb.i1p);
-    const LP a2 = i2 < (uint32_t)TOP ? A.top + i2 : A.win + 4 + (i2 - wb.i2p);
-    const LP a3 = i3 < (uint32_t)TOP ? A.top + i3 : A.win + 6 + (i3 - wb.i3p);
-    const HeapEntry e1 = load_entry(a1), e2 = load_entry(a2), e3 = load_entry(a3);
-    const bool min_level = mm_is_min_level(pos);
-    const uint32_t flip1 = min_level ? 0u : 0x80000000u;
-    const bool moved = (pos > 0) & (flip_sign(elt.score, flip1) > flip_sign(e1.score, flip1));
-    const bool greater = min_level == moved;
-    const uint32_t flip2 = greater ? 0u : 0x80000000u;
-    const float elt_key = flip_sign(elt.score, flip2);
-    const uint32_t pos1 = moved ? i1 : pos;
-    const HeapEntry ge = moved ? e3 : e2;
-    const uint32_t gp = moved ? i3 : i2;
-    const bool moved2 = (pos1 > 2) & (elt_key > flip_sign(ge.score, flip2));
-    // an ancestor slot: its copy next to the quad (near level or window) and, below the near levels, the arena
-    auto store_slot = [&](uint32_t i, LP a, const HeapEntry e) { store_entry(a, e); if (i >= (uint32_t)TOP) store_entry(A.heap + i, e); };
-    if (moved) hp_set(A, pos, e1);  // the new slot is nobody's ancestor in this step
-    if (MAPAD_UNLIKELY(moved2)) {
-        if (moved) store_slot(i1, a1, ge); else hp_set(A, pos, ge);
-        uint32_t q = gp;
-        while (q > 2) {
-            const uint32_t g2 = (q - 3) >> 2;
-            const HeapEntry g = hp_get(A, g2);
-            if (!(elt_key > flip_sign(g.score, flip2))) break;
-            hp_set_win(A, wb, q, g);
-            q = g2;
-        }
-        hp_set_win(A, wb, q, elt);
-        drain_memory();
-    } else {
-        if (moved) store_slot(i1, a1, elt); else hp_set(A, pos, elt);
-    }
-}
-#endif
 
 // The heap array is stored shifted by one entry (logical index i lives in physical slot i + 1; `v` points at logical 0), so the
 // two children of a node (logical 2p+1, 2p+2) form one 16-byte aligned pair and its four grandchildren (4p+3 .. 4p+6) one
@@ -800,13 +719,6 @@ MAPAD_HD bool search_step(const DevIndex& ix, const DevParams& P, const ReadInT<
     // pop_max of the crate, second half: the last entry takes the place of the maximum and trickles down
     st.heap_len -= 1;
     if (top_idx < st.heap_len) mm_trickle_down<true>(A, st.heap_len, top_idx, last);
-#if defined(__HIP_DEVICE_COMPILE__)
-    constexpr bool kWin = MAPAD_ANC_WINDOW != 0 && NL && LPR == 4;  // ancestor window: device quads with their near data in LDS
-    WinLoads win_loads{};
-    if constexpr (kWin && MAPAD_ANC_WINDOW == 1) win_loads = win_issue(A, st.heap_len, w);  // behind the repair's stores; consumed in front of the commit loop
-#else
-    constexpr bool kWin = false;
-#endif
     MAPAD_MARK(PROF_POP);
     Ext4 e;
     uint64_t my_lower[kBases] = {}, my_lower_rev[kBases] = {}, my_size[kBases] = {};  // kLaneKids: extension by this lane's base(s)
@@ -915,15 +827,6 @@ MAPAD_HD bool search_step(const DevIndex& ix, const DevParams& P, const ReadInT<
             for (int i = 0; i < 4; ++i) if (mm[i] < lim) cand &= ~(4u << (2 * i));
         }
         const uint32_t cand0 = cand, id0 = st.tree_next;  // == tree_entries: the slab grows at its end, child t gets key id0 + (children before t)
-#if defined(__HIP_DEVICE_COMPILE__)
-        WinBase wb{};
-        uint32_t win_left = kWinPushes;
-        if constexpr (kWin) {
-            if (MAPAD_ANC_WINDOW == 2 && cand != 0) win_loads = win_issue(A, st.heap_len, w);  // variant: only for frames with children, in front of the loop
-            if (MAPAD_ANC_WINDOW == 1 || cand != 0) win_store(A, win_loads, w);
-            wb = win_base(st.heap_len);
-        }
-#endif
         while (cand != 0) {
 #if defined(__HIP_DEVICE_COMPILE__)
             const int t = __ffs((int)cand) - 1;
@@ -940,27 +843,14 @@ MAPAD_HD bool search_step(const DevIndex& ix, const DevParams& P, const ReadInT<
             st.tree_next = id + 1; st.tree_entries = id + 1; st.tree_len += 1;
             const uint32_t pos = st.heap_len;
             st.heap_len = pos + 1;
-            if constexpr (kWin) {
-#if defined(__HIP_DEVICE_COMPILE__)
-                if (MAPAD_UNLIKELY(win_left == 0)) {  // a sixth child: the window moves on (one more round trip)
-                    win_store(A, win_issue(A, pos, w), w);
-                    wb = win_base(pos);
-                    win_left = kWinPushes;
-                    drain_memory();
-                }
-                win_left -= 1;
-                mm_bubble_up_win(A, wb, pos, HeapEntry{score, id});
-#endif
-            } else {
-                const Ancestors an = load_ancestors(A, pos);
-                if constexpr (!kLaneKids) {
-                    const uint64_t xl = k == 0 ? e.lower[0] : k == 1 ? e.lower[1] : k == 2 ? e.lower[2] : e.lower[3];
-                    const uint64_t xr = k == 0 ? e.lower_rev[0] : k == 1 ? e.lower_rev[1] : k == 2 ? e.lower_rev[2] : e.lower_rev[3];
-                    const uint64_t xs = k == 0 ? e.size[0] : k == 1 ? e.size[1] : k == 2 ? e.size[2] : e.size[3];
-                    A.nodes[id] = make_child(t, k, xl, xr, xs);
-                }
-                mm_bubble_up(A, pos, HeapEntry{score, id}, an);
+            const Ancestors an = load_ancestors(A, pos);
+            if constexpr (!kLaneKids) {
+                const uint64_t xl = k == 0 ? e.lower[0] : k == 1 ? e.lower[1] : k == 2 ? e.lower[2] : e.lower[3];
+                const uint64_t xr = k == 0 ? e.lower_rev[0] : k == 1 ? e.lower_rev[1] : k == 2 ? e.lower_rev[2] : e.lower_rev[3];
+                const uint64_t xs = k == 0 ? e.size[0] : k == 1 ? e.size[1] : k == 2 ? e.size[2] : e.size[3];
+                A.nodes[id] = make_child(t, k, xl, xr, xs);
             }
+            mm_bubble_up(A, pos, HeapEntry{score, id}, an);
             st.c_node += 1; st.c_push += 1;
         }
         if constexpr (kLaneKids) {
