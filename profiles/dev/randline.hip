@@ -51,13 +51,14 @@ void run(const uint4* buf, uint4* wbuf, uint64_t bytes, uint32_t* sink, int cus)
 }
 
 int main(int argc, char** argv) {
-    const uint64_t gb = argc > 1 ? std::strtoull(argv[1], nullptr, 10) : 64;
-    const uint64_t bytes = gb << 30;
+    char* suffix = nullptr;
+    const uint64_t gb = argc > 1 ? std::strtoull(argv[1], &suffix, 10) : 64;
+    const uint64_t bytes = (suffix && *suffix == 'M') ? gb << 20 : gb << 30;  // "64" = 64 GiB (beyond every cache), "128M" = 128 MiB (Infinity-Cache resident)
     hipDeviceProp_t p; CK(hipGetDeviceProperties(&p, 0));
     uint4 *buf, *wbuf; uint32_t* sink;
     CK(hipMalloc(&buf, bytes)); CK(hipMalloc(&wbuf, bytes)); CK(hipMalloc(&sink, 4));
     CK(hipMemset(buf, 1, bytes)); CK(hipMemset(wbuf, 0, bytes));
-    std::printf("%s, %d CUs, buffers 2 x %llu GiB\n", p.name, p.multiProcessorCount, (unsigned long long)gb);
+    std::printf("%s, %d CUs, buffers 2 x %llu MiB\n", p.name, p.multiProcessorCount, (unsigned long long)(bytes >> 20));
     run<1, 4, false>(buf, wbuf, bytes, sink, p.multiProcessorCount);
     run<2, 4, false>(buf, wbuf, bytes, sink, p.multiProcessorCount);
     run<4, 4, false>(buf, wbuf, bytes, sink, p.multiProcessorCount);
