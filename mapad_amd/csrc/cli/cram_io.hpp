@@ -30,6 +30,8 @@ namespace cli {
 namespace cram {
 
 struct Error : std::runtime_error { using std::runtime_error::runtime_error; };
+// sizes a file may state before anything has been checked against them: beyond these it is taken for corrupt rather than allocated
+constexpr int64_t kMaxBlockBytes = 1ll << 30, kMaxSliceRecords = 1 << 24, kMaxReadLen = 1 << 26;
 
 // ---- byte cursor with the format's integer codes -------------------------------------------------------------------------------------------
 struct Cursor {
@@ -96,11 +98,12 @@ inline void rans_read_table(Cursor& c, RansTable& t) {
         else j = c.u8();
     } while (j != 0);
 }
-inline std::vector<uint8_t> rans4x8_decode(const uint8_t* src, size_t n) {
+inline std::vector<uint8_t> rans4x8_decode(const uint8_t* src, size_t n, size_t expect_raw) {
     Cursor c(src, n);
     const uint8_t order = c.u8();
     const uint32_t comp = (uint32_t)c.i32le(), raw = (uint32_t)c.i32le();
     if ((size_t)comp + 9 > n) throw Error("CRAM: truncated rANS block");
+    if (raw != expect_raw) throw Error("CRAM: rANS stream and block header disagree about the uncompressed size");
     std::vector<uint8_t> out(raw);
     if (raw == 0) return out;
     auto renorm = [&](uint32_t& r) { while (r < (1u << 23)) r = (r << 8) | c.u8(); };
@@ -164,15 +167,18 @@ struct Block {
 };
 inline Block read_block(Cursor& c) {
     Block b;
+    const size_t begin = c.at;
     b.method = c.u8(); b.content_type = c.u8(); b.content_id = c.itf8();
     const int32_t comp = c.itf8(), raw = c.itf8();
     if (comp < 0 || raw < 0) throw Error("CRAM: negative block size");
+    if (raw > kMaxBlockBytes) throw Error("CRAM: block larger than 1 GiB");
     const uint8_t* d = c.bytes((size_t)comp);
-    c.bytes(4);  // CRC32 of the block (version 3)
+    const uint32_t crc = (uint32_t)crc32(crc32(0, nullptr, 0), c.p + begin, (uInt)(c.at - begin));
+    if ((uint32_t)c.i32le() != crc) throw Error("CRAM: block checksum mismatch");  // CRC32 over the block, header included (version 3)
     switch (b.method) {
         case 0: b.data.assign(d, d + comp); break;
         case 1: b.data = gunzip(d, (size_t)comp, (size_t)raw); break;
-        case 4: b.data = rans4x8_decode(d, (size_t)comp); break;
+        case 4: b.data = rans4x8_decode(d, (size_t)comp, (size_t)raw); break;
         case 2: throw Error("CRAM: bzip2-compressed block (not supported by this build)");
         case 3: throw Error("CRAM: lzma-compressed block (not supported by this build)");
         case 5: case 6: case 7: case 8: throw Error("CRAM: block uses a CRAM 3.1 codec (rANS Nx16 / arithmetic / fqzcomp / name tokeniser): write the file as CRAM 3.0");
@@ -288,7 +294,7 @@ struct Encoding {
         out.clear();
         if (kind == 4) {
             const int32_t n = a->get_int(s);
-            if (n < 0) throw Error("CRAM: negative byte-array length");
+            if (n < 0 || n > kMaxReadLen) throw Error("CRAM: byte-array length out of range");
             if (b->kind == 1) { const uint8_t* d = s.external(b->id).bytes((size_t)n); out.assign(d, d + n); }
             else for (int32_t i = 0; i < n; ++i) out.push_back(b->get_byte(s));
         } else if (kind == 5) {
@@ -428,9 +434,10 @@ private:
         uint8_t l4[4];
         if (!read_(l4, 4)) return false;
         h.length = (int32_t)((uint32_t)l4[0] | (uint32_t)l4[1] << 8 | (uint32_t)l4[2] << 16 | (uint32_t)l4[3] << 24);
-        if (h.length < 0) throw Error("CRAM: negative container length");
+        if (h.length < 0 || h.length > kMaxBlockBytes) throw Error("CRAM: container length out of range");
         // the rest of the header is a sequence of variable-length integers: read them byte by byte
-        auto byte = [&]() -> uint8_t { uint8_t b; if (!read_(&b, 1)) throw Error("CRAM: truncated container header"); return b; };
+        std::vector<uint8_t> hdr(l4, l4 + 4);  // the header's bytes, for its checksum
+        auto byte = [&]() -> uint8_t { uint8_t b; if (!read_(&b, 1)) throw Error("CRAM: truncated container header"); hdr.push_back(b); return b; };
         auto itf8 = [&]() -> int32_t {
             uint8_t buf[5]; buf[0] = byte();
             const int extra = buf[0] < 0x80 ? 0 : buf[0] < 0xC0 ? 1 : buf[0] < 0xE0 ? 2 : buf[0] < 0xF0 ? 3 : 4;
@@ -451,6 +458,8 @@ private:
         for (int32_t i = 0; i < n_land; ++i) (void)itf8();
         uint8_t crc[4];
         if (!read_(crc, 4)) throw Error("CRAM: truncated container header");
+        const uint32_t want = (uint32_t)crc[0] | (uint32_t)crc[1] << 8 | (uint32_t)crc[2] << 16 | (uint32_t)crc[3] << 24;
+        if (want != (uint32_t)crc32(crc32(0, nullptr, 0), hdr.data(), (uInt)hdr.size())) throw Error("CRAM: container header checksum mismatch");
         body.resize((size_t)h.length);
         if (h.length && !read_(body.data(), body.size())) throw Error("CRAM: truncated container");
         return true;
@@ -486,6 +495,7 @@ private:
         for (int32_t i = 0; i < n_ids; ++i) (void)s.itf8();
         const int32_t embedded = s.itf8();
         // (reference MD5 and optional tags follow)
+        if (n_records < 0 || n_records > kMaxSliceRecords || n_blocks < 0) throw Error("CRAM: slice header out of range");
         std::vector<Block> blocks;
         for (int32_t i = 0; i < n_blocks; ++i) blocks.push_back(read_block(c));
         Streams st;
@@ -513,7 +523,7 @@ private:
             r.flags = (uint16_t)bf;
             if (ref_id == -2) (void)H.need("RI").get_int(st);
             const int32_t rl = H.need("RL").get_int(st);
-            if (rl < 0) throw Error("CRAM: negative read length");
+            if (rl < 0 || rl > kMaxReadLen) throw Error("CRAM: read length out of range");
             int32_t ap = H.need("AP").get_int(st);
             if (H.ap_delta) { ap += prev_pos; prev_pos = ap; }
             const int32_t rg = H.need("RG").get_int(st);

@@ -149,6 +149,9 @@ RAW, GZIP, RANS0, RANS1 = "raw", "gzip", "rans0", "rans1"
 FILE_HEADER, COMPRESSION_HEADER, SLICE_HEADER, EXTERNAL_DATA, CORE_DATA = 0, 1, 2, 4, 5
 
 
+MANGLE = None  # tests of damaged files: a function applied to a block's compressed bytes before the checksum is taken
+
+
 def block(method, content_type, content_id, data):
     data = bytes(data)
     if method == RAW:
@@ -159,6 +162,8 @@ def block(method, content_type, content_id, data):
         m, comp = 4, rans_encode(data, 0 if method == RANS0 else 1)
     else:  # a method id the reader must refuse (bzip2 = 2, lzma = 3, the CRAM 3.1 codecs 5-8)
         m, comp = int(method), data
+    if MANGLE is not None and content_type == EXTERNAL_DATA:
+        comp = MANGLE(m, comp)
     b = bytes([m, content_type]) + itf8(content_id) + itf8(len(comp)) + itf8(len(data)) + comp
     return b + struct.pack("<I", zlib.crc32(b))
 

@@ -262,3 +262,70 @@ def test_refusals_name_what_is_unsupported(tmp_path):
     data = cu.file_start(HEADER) + cu.container(-1, 0, 0, 3, 0, 0, blocks, [0])
     _, err = _recode(tmp_path, data[:-20], expect_fail=True)
     assert "truncated" in err
+
+
+def test_damaged_files_end_in_an_error_message_not_a_crash(tmp_path):
+    """bytes flipped anywhere behind the file definition: the command reports an error — the CRC32 of every block and container header is checked — or, with the
+    checksums recomputed over the damage, reads what still parses; it never dies of a signal or hangs"""
+    series = _unmapped_series()
+    ch = cu.compression_header(series, TAG_ENCS, TAG_LINES)
+    reads = _make_reads(40, 11)
+    blocks = [cu.block(cu.RAW, cu.COMPRESSION_HEADER, 0, ch)] + cu.slice_blocks(-1, 0, 0, len(reads), 0, _write_unmapped_slice(series, reads), {6: cu.RANS1, 7: cu.RANS0, 3: cu.GZIP, 2: cu.RAW})
+    good = cu.file_start(HEADER) + cu.container(-1, 0, 0, len(reads), 0, 0, blocks, [0]) + cu.eof_container()
+    rng = random.Random(77)
+    inp, out = tmp_path / "d.cram", tmp_path / "d.bam"
+    codes = set()
+    for trial in range(120):
+        bad = bytearray(good)
+        for _ in range(rng.choice([1, 1, 2, 8])):
+            at = rng.randrange(26, len(bad))
+            bad[at] = rng.randrange(256) if rng.random() < 0.5 else bad[at] ^ (1 << rng.randrange(8))
+        if trial % 10 == 0:
+            bad = bad[:rng.randrange(27, len(bad))]
+        inp.write_bytes(bytes(bad))
+        pr = subprocess.run([_cli(), "recode", "-r", str(inp), "-o", str(out)], stderr=subprocess.PIPE, text=True, timeout=60)
+        assert pr.returncode in (0, 1), (trial, pr.returncode, pr.stderr[-300:])
+        codes.add(pr.returncode)
+    assert codes == {0, 1}
+    # the same with valid checksums around the damage: compression header, slice header and data streams altered before the blocks are built
+    for trial in range(150):
+        st = _write_unmapped_slice(series, reads)
+        hdr = bytearray(ch)
+        victim = rng.choice(["header", "stream", "core", "count"])
+        n_rec = len(reads)
+        if victim == "header":
+            for _ in range(rng.choice([1, 2, 5])):
+                hdr[rng.randrange(len(hdr))] = rng.randrange(256)
+        elif victim == "stream":
+            cid = rng.choice(sorted(st.ext))
+            buf = st.ext[cid]
+            for _ in range(rng.choice([1, 3, 10])):
+                if len(buf):
+                    buf[rng.randrange(len(buf))] = rng.randrange(256)
+            if rng.random() < 0.3:
+                del buf[rng.randrange(len(buf) + 1):]
+        elif victim == "core":
+            st.core.bits = [rng.randrange(2) for _ in st.core.bits][:rng.randrange(len(st.core.bits) + 1)]
+        else:
+            n_rec = rng.choice([0, 1, len(reads) + 1, 1 << 20, (1 << 31) - 1, -1])
+        blocks = [cu.block(cu.RAW, cu.COMPRESSION_HEADER, 0, bytes(hdr))] + cu.slice_blocks(-1, 0, 0, n_rec, 0, st, {6: cu.RANS1, 7: cu.RANS0})
+        inp.write_bytes(cu.file_start(HEADER) + cu.container(-1, 0, 0, max(n_rec, 1), 0, 0, blocks, [0]) + cu.eof_container())
+        pr = subprocess.run([_cli(), "recode", "-r", str(inp), "-o", str(out)], stderr=subprocess.PIPE, text=True, timeout=60)
+        assert pr.returncode in (0, 1), (trial, victim, pr.returncode, pr.stderr[-300:])
+    # damage inside the compressed payloads (rANS tables and states, deflate streams), checksums valid
+    def mangle(method, comp):
+        comp = bytearray(comp)
+        if method in (1, 4) and len(comp) > 12 and rng.random() < 0.5:
+            for _ in range(rng.choice([1, 2, 6])):
+                comp[rng.randrange(len(comp))] = rng.randrange(256)
+        return bytes(comp)
+    cu.MANGLE = mangle
+    try:
+        for trial in range(120):
+            st = _write_unmapped_slice(series, reads)
+            blocks = [cu.block(cu.RAW, cu.COMPRESSION_HEADER, 0, ch)] + cu.slice_blocks(-1, 0, 0, len(reads), 0, st, {6: cu.RANS1, 7: cu.RANS0, 3: cu.RANS1, 2: cu.RANS0, 8: cu.GZIP})
+            inp.write_bytes(cu.file_start(HEADER) + cu.container(-1, 0, 0, len(reads), 0, 0, blocks, [0]) + cu.eof_container())
+            pr = subprocess.run([_cli(), "recode", "-r", str(inp), "-o", str(out)], stderr=subprocess.PIPE, text=True, timeout=60)
+            assert pr.returncode in (0, 1), (trial, pr.returncode, pr.stderr[-300:])
+    finally:
+        cu.MANGLE = None
