@@ -1463,7 +1463,7 @@ static_assert(sizeof(mapad_read_counters_t) == sizeof(ReadCounters), "counter la
 struct LiveResults {
     std::mutex m;
     std::set<const mapad_batch_result_t*> s;
-    static LiveResults& get() { static LiveResults r; return r; }
+    static LiveResults& get() { static LiveResults* r = new LiveResults(); return *r; }  // never destroyed: results may be freed while the process exits
     void add(const mapad_batch_result_t* p) { std::lock_guard<std::mutex> g(m); s.insert(p); }
     bool remove(const mapad_batch_result_t* p) { std::lock_guard<std::mutex> g(m); return s.erase(p) != 0; }
     bool has(const mapad_batch_result_t* p) { std::lock_guard<std::mutex> g(m); return s.count(p) != 0; }
