@@ -269,32 +269,47 @@ def main():
             begin, hits, ops = begin.cpu(), hits.cpu(), ops.cpu()
         return gather_hit_records(begin, hits, ops, rank, world, device=xdev, meta_group=meta_group)
 
+    tail_steps = []  # per collected step: the host tail's figures (csrc/host_tail.hpp)
+
+    def collect_step():
+        """The selected batch's order-preserving collect on the device — which first waits for the host threads that finish the reads the GPU handed
+        over (none for the 50 bp workloads) — and, N > 1, the gather of its records."""
+        if world == 1:
+            ctx.compact_device()
+            g = None
+        else:
+            g = gather_hits()
+        tail_steps.append(ctx.tail_info())
+        return g
+
     def run_steps(k):
-        """k steps back to back.  With depth > 1 step i + 1 is submitted while step i's tail is still running; the gather of step i's
-        records (N > 1) is issued behind the submission of step i + 1."""
+        """k steps back to back.  With depth > 1 step i + 1 is submitted while step i's tail is still running; the collect of step i (and, N > 1,
+        the gather of its records) is issued behind the submission of step i + 1."""
         last = None
         for i in range(k):
             ctx.map_batch_device(d_seqs.data_ptr(), d_quals.data_ptr(), d_offsets.data_ptr(), n_reads, max_len)
             heartbeat(f"step {i} submitted")
-            if world > 1 and i > 0 and args.depth > 1:
+            if i > 0 and args.depth > 1:
                 ctx.select_batch(1)
-                last = gather_hits()
+                last = collect_step()
                 ctx.select_batch(0)
-            elif world > 1 and args.depth == 1:
-                last = gather_hits()
-        if world > 1 and args.depth > 1:
-            last = gather_hits()
+            elif args.depth == 1:
+                last = collect_step()
+        if args.depth > 1:
+            last = collect_step()
         heartbeat("steps done")
         return last
 
     run_steps(args.warmup)
     torch.cuda.synchronize(dev)
     ctx.kernel_history()  # drop the warm-up launches' time stamps
+    tail_steps.clear()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
     gathered = run_steps(args.steps)
+    tail_timed = list(tail_steps)
     torch.cuda.synchronize(dev)
     if world > 1:
         dist.barrier()
@@ -352,6 +367,11 @@ def main():
 
     # ---- roofline of the dominant kernel (rank 0) -------------------------------------------------------------------------
     e_search, e_darray, n_push, n_pop, n_node, n_hit_events = [int(x) for x in counters]
+    # the reads the host threads finished: their events are in the per-read counters (that is what makes the counters a parity check), but the kernel did not
+    # execute them — they do not count towards the kernel's algorithmic bytes (nor does what the GPU spent on those reads before it gave them up)
+    tail_last = ctx.tail_info()
+    e_search -= tail_last["host_e_search"]; n_push -= tail_last["host_n_push"]; n_node -= tail_last["host_n_node"]
+    n_pop_all, n_pop = n_pop, n_pop - tail_last["host_pops"]
     total_bases = int(offsets[-1])
     bytes_darray = 256 * e_darray + 6 * total_bases                      # 2 x 128-B index blocks per extension + read/qual in, D out
     bytes_search = 256 * e_search + 40 * (n_push + n_pop) + 8 * n_node    # + 40-B frames through the heap, 8-B tree nodes
@@ -363,15 +383,20 @@ def main():
     dominant = "search_kernel" if ms_search >= ms_darray else "darray_kernel"
     dom_bytes, dom_ms = (bytes_search, ms_search) if dominant == "search_kernel" else (bytes_darray, ms_darray)
     achieved = dom_bytes / (dom_ms * 1e-3) / 1e9
-    traffic = None
+    # HBM traffic of the PMC passes (profiles/collect.sh) — reported only while the library is built from the sources those passes ran with
+    traffic, traffic_stale = None, None
     tp = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tp):
         try:
-            traffic = json.load(open(tp)).get(f"{args.config}:{genome_bp}:{n_reads}", {}).get(dominant)
+            from mapad_amd import build as mbuild_
+            entry = json.load(open(tp)).get(f"{args.config}:{genome_bp}:{n_reads}", {})
+            if entry.get(dominant) is not None:
+                traffic_stale = entry.get("kernel_source_sha16") != mbuild_.source_hash()
+                traffic = None if traffic_stale else entry.get(dominant)
         except Exception:
             traffic = None
     roofline = {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic,
+                "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic, "traffic_stale": traffic_stale,
                 "algorithmic_bytes_per_launch": dom_bytes, "kernel_ms": round(float(dom_ms), 4),
                 "kernel_ms_is": "union of the K launches' HIP-event intervals / K" + (f" ({args.depth} batches in flight: launch k+1 runs beside the tail of launch k)" if args.depth > 1 else ""),
                 "search_kernel_ms_per_launch_overlapped": round(per_launch_search, 4),
@@ -570,7 +595,13 @@ def main():
                        "parallelism": f"reads sharded over {world} GPUs, index replicated, read-ordered hit records gathered on rank 0 (RCCL p2p)" if world > 1 else "1 GPU",
                        "mapped_fraction": mapped_fraction,
                        "index_build_s": round(t_index, 1), "index_build": "GPU suffix sorting (prefix doubling over radix sorts) + host text preparation"},
-            "roofline": roofline, "cpu_baseline": cpu, "parity": parity, "e2e": e2e, "cli": cli, "sa_locate": locate, "post_search": post,
+            "roofline": roofline, "cpu_baseline": cpu, "parity": parity,
+            # the heavy tail (csrc/host_tail.hpp): reads past the pop budget on the GPU, finished by host threads with the kernel's own search step; inside the timed region
+            "tail": {"reads": int(sum(t["reads"] for t in tail_timed)), "reads_per_step": round(sum(t["reads"] for t in tail_timed) / max(len(tail_timed), 1), 1),
+                     "pops_share": round(tail_last["host_pops"] / max(n_pop_all, 1), 5), "gpu_pops_before_hand_over": tail_last["gpu_pops"],
+                     "host_s_per_step": round(sum(t["host_us"] for t in tail_timed) / max(len(tail_timed), 1) / 1e6, 3), "budget_pops": tail_last["budget"],
+                     "where": f"{tail_last['threads']} host threads, search_core.hpp compiled for the host (the kernel's source; from scratch), overlapped with the GPU's bulk" if tail_last["budget"] else "off"},
+            "e2e": e2e, "cli": cli, "sa_locate": locate, "post_search": post,
         }
         if gather_check is not None:
             line["gather"] = gather_check

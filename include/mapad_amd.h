@@ -122,6 +122,15 @@ void mapad_ctx_destroy(mapad_ctx_t* ctx);
 /* run every launch on this HIP stream (a hipStream_t; NULL = the default stream) */
 int mapad_ctx_set_stream(mapad_ctx_t* ctx, void* hip_stream);
 
+/* The heavy tail.  The reference absorbs the reads that run into STACK_LIMIT / EDIT_TREE_LIMIT (src/map/mapping.rs:52-54,1358-1380) on its rayon threads; here a
+ * read that has made `pops` pops on the GPU (default 2^19, MAPAD_TAIL_POPS; 0 = never) is handed — by the kernel, while it runs — to the library's host
+ * threads, which map it from scratch with the kernel's own search step compiled for the host (csrc/host_tail.hpp; MAPAD_TAIL_THREADS threads, default
+ * all).  Their results join the batch before its order-preserving collect: nothing a caller sees depends on where a read was finished. */
+int mapad_ctx_set_tail_pops(mapad_ctx_t* ctx, uint32_t pops);
+/* the batch selected by mapad_ctx_select_batch, after its collect / fetch: {reads finished on the host, pops the GPU had spent on them, pops on the host,
+ * host wall-clock microseconds from the first hand-over to the last result, host threads, pop budget, and the host reads' E_search, N_push, N_node sums
+ * (SURVEY 8d events the kernel did not execute), 0} */
+int mapad_last_tail_info(mapad_ctx_t* ctx, uint64_t out[10]);
 /* whether mapad_fetch_result()/mapad_map_batch() also copy the D arrays back (default on; bench.py turns it off) */
 int mapad_ctx_set_fetch_d_arrays(mapad_ctx_t* ctx, int on);
 /* Score tables are built lazily per read length.  mapad_map_batch() does this itself; before mapad_map_batch_device()

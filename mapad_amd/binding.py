@@ -123,6 +123,8 @@ SYMBOLS = {
     "mapad_last_batch_counters": (_i32, [_vp, _vp]),
     "mapad_last_kernel_ms": (_i32, [_vp, _vp]),
     "mapad_last_launch_info": (_i32, [_vp, _vp]),
+    "mapad_ctx_set_tail_pops": (_i32, [_vp, C.c_uint32]),
+    "mapad_last_tail_info": (_i32, [_vp, _vp]),
     "mapad_hits_to_records": (_i32, [_vp, _PP, C.POINTER(BatchResultC), _vp, _vp, _vp, _vp, _u64, C.POINTER(C.POINTER(RecordsC))]),
     "mapad_records_free": (None, [C.POINTER(RecordsC)]),
     "mapad_records_seed_at": (_u64, [_u64, _u64]),
@@ -409,6 +411,16 @@ class Context:
         out = np.zeros(3, np.float32)
         _check(lib().mapad_last_kernel_ms(self.h, _ptr(out)), "mapad_last_kernel_ms")
         return out
+
+    def set_tail_pops(self, pops):
+        """Pop budget of a read on the GPU before the library's host threads take it over (0 = never; csrc/host_tail.hpp)."""
+        _check(lib().mapad_ctx_set_tail_pops(self.h, int(pops)), "mapad_ctx_set_tail_pops")
+
+    def tail_info(self):
+        """{reads, gpu_pops, host_pops, host_us, threads, budget} of the selected batch's host tail (after its collect / fetch)."""
+        out = np.zeros(10, np.uint64)
+        _check(lib().mapad_last_tail_info(self.h, _ptr(out)), "mapad_last_tail_info")
+        return dict(zip(("reads", "gpu_pops", "host_pops", "host_us", "threads", "budget", "host_e_search", "host_n_push", "host_n_node"), (int(x) for x in out)))
 
     def launch_info(self):
         out = np.zeros(8, np.uint32)

@@ -24,7 +24,8 @@ CLI_SRC = os.path.join(CSRC, "cli", "main.cpp")
 
 def build_cli(force=False, verbose=False):
     """`mapad-amd` command line (index / map) on top of the C ABI; plain host C++ linked against the library."""
-    deps = [CLI_SRC, os.path.join(CSRC, "cli", "bam_io.hpp"), os.path.join(os.path.dirname(HERE), "include", "mapad_amd.h"), LIB]
+    cli_dir = os.path.join(CSRC, "cli")
+    deps = [os.path.join(cli_dir, f) for f in os.listdir(cli_dir)] + [os.path.join(os.path.dirname(HERE), "include", "mapad_amd.h"), LIB]
     if not force and os.path.exists(CLI) and all(os.path.getmtime(d) <= os.path.getmtime(CLI) for d in deps):
         return CLI
     cmd = [HIPCC, "-O2", "-std=c++17", "-x", "c++", CLI_SRC, "-o", CLI, "-L" + HERE, "-lmapad_amd", "-lz", "-Wl,-rpath,$ORIGIN"]
@@ -38,6 +39,18 @@ def _deps():
     out = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if os.path.isfile(os.path.join(CSRC, f))]
     out.append(os.path.join(os.path.dirname(HERE), "include", "mapad_amd.h"))
     return out
+
+
+def source_hash():
+    """sha256 (16 hex digits) over the sources the library is built from: ties measurements that are not taken live (the PMC traffic of
+    profiles/traffic.json) to the kernels they were taken with."""
+    import hashlib
+    h = hashlib.sha256()
+    for path in sorted(p for p in _deps() if p.endswith((".hip", ".hpp", ".h"))):
+        h.update(os.path.basename(path).encode())
+        with open(path, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
 
 
 def needs_build():

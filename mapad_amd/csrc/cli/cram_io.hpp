@@ -1,6 +1,6 @@
 // cram_io.hpp — CRAM 3.0 records in, for the `mapad-amd` command line (host I/O, not on the accelerated path).
 //
-// The reference reads CRAM through noodles-cram 0.83 (`cram::io::Reader::new(file)` WITHOUT a reference-sequence repository,
+// The reference reads CRAM through noodles 0.98 (Cargo.toml:28; its noodles-cram component; `cram::io::Reader::new(file)` WITHOUT a reference-sequence repository,
 // src/map/input_chunk_reader.rs:27,86-95,160-168) and turns every alignment record into its `Record` (name, flags, bases, qualities, tags:
 // src/map/record.rs:138-183).  noodles is a dependency that is not part of /root/reference; this file restates the published format (CRAM format
 // specification 3.0, samtools/hts-specs) for what that call can deliver: the file definition, containers, blocks (raw, gzip, rANS 4x8 orders 0 and 1),
@@ -517,6 +517,9 @@ private:
             return (*emb)[(size_t)o];
         };
         std::vector<uint8_t> tmp;
+        // A data series with a zero-bit HUFFMAN encoding consumes no input, so the sizes a slice states do not bound what its records decode to: the
+        // total of decoded bases per slice is capped (a real slice holds ~10 K records; 2^28 bases is three orders of magnitude above that).
+        int64_t slice_bases = 0;
         for (int32_t i = 0; i < n_records; ++i) {
             Rec r;
             const int32_t bf = H.need("BF").get_int(st), cf = H.need("CF").get_int(st);
@@ -524,6 +527,7 @@ private:
             if (ref_id == -2) (void)H.need("RI").get_int(st);
             const int32_t rl = H.need("RL").get_int(st);
             if (rl < 0 || rl > kMaxReadLen) throw Error("CRAM: read length out of range");
+            if ((slice_bases += rl) > (int64_t)1 << 28) throw Error("CRAM: a slice decodes to more than 2^28 bases");
             int32_t ap = H.need("AP").get_int(st);
             if (H.ap_delta) { ap += prev_pos; prev_pos = ap; }
             const int32_t rg = H.need("RG").get_int(st);
@@ -554,6 +558,7 @@ private:
             r.qual.assign((size_t)rl, 0xFF);
             if (!(bf & 0x4)) {  // mapped: the bases are the reference plus the read's features
                 const int32_t fn = H.need("FN").get_int(st);
+                if (fn < 0 || fn > 4 * rl + 16) throw Error("CRAM: more read features than the read can hold");
                 std::vector<uint8_t> known((size_t)rl, 0);
                 int64_t ref_pos = ap;
                 int32_t read_pos = 1, prev = 0;
@@ -567,7 +572,10 @@ private:
                 };
                 for (int32_t k = 0; k < fn; ++k) {
                     const uint8_t code = H.need("FC").get_byte(st);
-                    const int32_t pos = prev + H.need("FP").get_int(st);
+                    const int32_t fp = H.need("FP").get_int(st);
+                    if (fp < 0 || fp > rl + 1 || prev > rl + 1) throw Error("CRAM: read feature position outside the read");
+                    const int32_t pos = prev + fp;
+                    if (pos < 1 || pos > rl + 1) throw Error("CRAM: read feature position outside the read");
                     prev = pos;
                     fill_to(pos);
                     switch (code) {

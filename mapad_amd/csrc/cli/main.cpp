@@ -437,6 +437,7 @@ int cmd_map(const Args& a, uint64_t seed, const std::vector<int>& devices, const
             while (!flying.empty() && !failed) retire_oldest();
             if (d == 0) us_device += now_us() - t_d1;
         } catch (const std::exception& e) { fail(e.what()); }
+        { ChunkPtr c; while (dev_q[d]->pop(c)) {} }  // after a failure: keep taking chunks so that the stage in front never blocks on a full queue (the process then exits non-zero)
     };
     std::vector<std::thread> workers;
     for (size_t d = 0; d < n_dev; ++d) workers.emplace_back(worker, d);
@@ -456,6 +457,7 @@ int cmd_map(const Args& a, uint64_t seed, const std::vector<int>& devices, const
                 done_q.push(c);
             }
         } catch (const std::exception& e) { fail(e.what()); }
+        { ChunkPtr c; while (rec_q.pop(c)) {} }  // see the device workers: a failed stage keeps draining its input
         done_q.close();
     });
 
@@ -496,6 +498,7 @@ int cmd_map(const Args& a, uint64_t seed, const std::vector<int>& devices, const
                 us_writer += now_us() - t_w0;
             }
         } catch (const std::exception& e) { fail(e.what()); }
+        { ChunkPtr c; while (done_q.pop(c)) {} }
     });
 
     reader.join();

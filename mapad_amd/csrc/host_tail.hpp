@@ -1,0 +1,237 @@
+// host_tail.hpp — the host half of the heavy tail: reads that pass a pop budget on the GPU are finished by host threads.
+//
+// The reference absorbs its heaviest reads — those that reach STACK_LIMIT / EDIT_TREE_LIMIT and go on searching under pop_min eviction for
+// millions of steps (src/map/mapping.rs:52-54,1358-1380) — on CPU threads at a fraction of a microsecond per pop.  On the GPU one read is a serial
+// chain at ~5.5 us per pop whatever the shape (quad or wavefront: DESIGN.md section 4), so a few hundred such reads held a launch for minutes after the
+// other million were done.  A read that has made `tail_pops` pops (default 2^19: none of the 50 bp workloads gets there) is therefore given up by its
+// quad — the read's position data and D array go into a record in page-locked host memory, written by the kernel while it runs — and a host thread
+// maps it FROM SCRATCH with the product's own search step (search_core.hpp compiled for the host: the same source as the kernel, scalar rank queries
+// on the same 128-byte blocks; never the test oracle), beside the GPU's bulk of this and the next batches.  Results go back into the batch's device
+// pools before the order-preserving collect, so everything downstream (collect, gather, post-search) is unchanged; hits, edit tracks and event counters
+// are bit-identical to what the GPU stages produce for the same read (tests/test_gpu_tail.py runs both ways against the oracle).
+// This is a stage of the GPU path, not a fallback: without a gfx950 device there is no context and nothing runs (mapad_ctx_create).
+#pragma once
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <cstdlib>
+#include <deque>
+#include <functional>
+#include <memory>
+#include <mutex>
+#include <thread>
+#include <vector>
+
+#include "host_models.hpp"
+#include "search_core.hpp"
+
+namespace mapad {
+namespace host {
+
+// Header of a hand-over record (page-locked host memory, written by the quad that gives the read up; mapad_amd.hip: hand_to_host).  It is followed by
+// qc[2 * L] (base class, quality per position: ReadIn::qc) at byte 16 and d[L] (the read's D array) at byte 16 + ((2 * lmax + 15) & ~15).
+struct TailRecord {
+    uint32_t ready;  // 1 once the rest of the record is visible (system-scope release store)
+    uint32_t read;   // read number inside the batch
+    uint32_t L;
+    uint32_t pops;   // pops the GPU had made when it gave the read up
+};
+inline uint32_t tail_record_stride(uint32_t lmax) { return (16u + ((2u * lmax + 15u) & ~15u) + 4u * lmax + 63u) & ~63u; }
+
+struct TailResult {
+    uint32_t read = 0, status = 0;
+    uint32_t e_search = 0, n_push = 0, n_pop = 0, n_node = 0, n_hits = 0;
+    std::vector<HitRec> hits;   // BinaryHeap array order; ops_off relative to `ops`
+    std::vector<uint32_t> ops;
+};
+
+// Worker threads shared by every context of the process (a read at the reference's limits keeps a thread busy for seconds and its arena is 336 MB, so
+// there is one pool, as wide as the machine: MAPAD_TAIL_THREADS overrides).  Started with the first task.
+class TailWorkers {
+public:
+    static TailWorkers& instance() { static TailWorkers* w = new TailWorkers(); return *w; }  // never destroyed: workers may outlive static destructors
+    void submit(std::function<void()> f) {
+        {
+            std::lock_guard<std::mutex> g(mu_);
+            if (threads_.empty()) start();
+            q_.push_back(std::move(f));
+        }
+        cv_.notify_one();
+    }
+    unsigned size() {
+        std::lock_guard<std::mutex> g(mu_);
+        return threads_.empty() ? wanted() : (unsigned)threads_.size();
+    }
+private:
+    static unsigned wanted() {
+        const char* e = std::getenv("MAPAD_TAIL_THREADS");
+        unsigned n = e && e[0] ? (unsigned)std::strtoul(e, nullptr, 10) : std::thread::hardware_concurrency();
+        return n ? n : 8;
+    }
+    void start() {
+        const unsigned n = wanted();
+        for (unsigned i = 0; i < n; ++i) {
+            threads_.emplace_back([this] {
+                for (;;) {
+                    std::function<void()> f;
+                    {
+                        std::unique_lock<std::mutex> l(mu_);
+                        cv_.wait(l, [&] { return !q_.empty(); });
+                        f = std::move(q_.front());
+                        q_.pop_front();
+                    }
+                    f();
+                }
+            });
+            threads_.back().detach();
+        }
+    }
+    std::mutex mu_;
+    std::condition_variable cv_;
+    std::deque<std::function<void()>> q_;
+    std::vector<std::thread> threads_;
+};
+
+// A worker thread's arena with the reference's full limits.  malloc'ed, never cleared: the search writes before it reads, and untouched pages cost nothing.
+struct TailScratch {
+    HeapEntry* heap = nullptr;
+    Node* nodes = nullptr;
+    uint32_t heap_cap = 0, node_cap = 0, lmax = 0;
+    std::vector<HeapEntry> top;
+    std::vector<HitRec> hits;
+    std::vector<uint32_t> hit_ops;
+    std::vector<uint16_t> scratch;
+    uint64_t pc[8];
+    bool ensure(uint32_t hc, uint32_t nc, uint32_t lm) {
+        if (hc > heap_cap) { std::free(heap); heap = (HeapEntry*)std::malloc(((size_t)hc + 32) * sizeof(HeapEntry)); heap_cap = heap ? hc : 0; }
+        if (nc > node_cap) { std::free(nodes); nodes = (Node*)std::aligned_alloc(64, (((size_t)nc + 1) * sizeof(Node) + 63) & ~(size_t)63); node_cap = nodes ? nc : 0; }
+        if (!heap || !nodes) return false;
+        if (lm > lmax || top.empty()) {
+            lmax = std::max(lm, lmax);
+            top.assign(kTop + 1 + 8, HeapEntry{});
+            hits.assign(kMaxHits, HitRec{});
+            hit_ops.assign((size_t)kMaxHits * (lmax + 32), 0);
+            scratch.assign(2 * ((size_t)lmax + 2), 0);
+        }
+        return true;
+    }
+    ~TailScratch() { std::free(heap); std::free(nodes); }
+};
+
+// One launch's tail: shared by the launch's dispatcher thread, the workers and the context (shared_ptr: a worker may still be inside a read when the
+// context moves on or goes away).
+struct TailBatch {
+    DevIndex ix{};          // host view of the index (blocks in host memory)
+    DevParams P{};          // points into *tables
+    std::shared_ptr<const HostTables> tables;
+    const uint8_t* ring = nullptr;  // page-locked records
+    uint32_t stride = 0, cap = 0, lmax = 0;
+
+    std::mutex mu;
+    std::condition_variable cv;
+    std::vector<TailResult> results;
+    uint32_t dispatched = 0, done = 0;
+    uint64_t gpu_pops = 0, host_pops = 0;
+    double t_first = 0.0, t_last = 0.0;  // steady-clock seconds of the first hand-over seen and of the last read finished
+    bool failed = false;
+
+    std::atomic<int64_t> final_count{-1};  // records the launch wrote, known once it has ended
+    std::atomic<bool> cancel{false};
+    std::thread dispatcher;
+
+    static double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+};
+
+// k_mismatch_search for one handed-over read, from scratch, by this thread (search_core.hpp: the kernel's own step, payload cache included).
+inline void tail_map_read(const std::shared_ptr<TailBatch>& tb, const TailRecord* rec) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    (void)tb; (void)rec;  // (the device pass of hipcc parses host functions too; arena pointers carry device address spaces there)
+#else
+    thread_local TailScratch sc;
+    TailResult r;
+    r.read = rec->read;
+    const int L = (int)rec->L;
+    bool ok = sc.ensure(tb->P.stack_limit + 10, tb->P.edit_tree_limit + 10, std::max<uint32_t>(tb->lmax, (uint32_t)L));
+    uint64_t pops = 0;
+    if (ok && !tb->cancel.load(std::memory_order_relaxed)) {
+        const uint8_t* qc = reinterpret_cast<const uint8_t*>(rec) + 16;
+        const float* d = reinterpret_cast<const float*>(reinterpret_cast<const uint8_t*>(rec) + 16 + ((2u * tb->lmax + 15u) & ~15u));
+        Arena A;
+        A.top = sc.top.data() + 1; A.heap = sc.heap + 1; A.nodes = sc.nodes; A.hits = sc.hits.data(); A.hit_ops = sc.hit_ops.data(); A.scratch = sc.scratch.data();
+        A.heap_cap = sc.heap_cap; A.node_cap = sc.node_cap; A.hit_ops_cap = (uint32_t)sc.hit_ops.size();
+        A.pc = sc.pc;
+        const ReadIn rd{qc, d, L, tb->P.reject_thr[L], tb->P.table_base[L]};
+        SearchState st;
+        search_init(tb->ix.n, alignment_start_of(tb->P, L), rd, A, st);
+        pc_clear(A);
+        uint32_t n = 0;
+        if (tb->P.bound_kind == BOUND_CONTINUOUS) { while (search_step<1, true, false, true>(tb->ix, tb->P, rd, A, st, 0, NoGrow())) { if ((++n & 0xFFFFu) == 0 && tb->cancel.load(std::memory_order_relaxed)) break; } }
+        else { while (search_step<1, false, false, true>(tb->ix, tb->P, rd, A, st, 0, NoGrow())) { if ((++n & 0xFFFFu) == 0 && tb->cancel.load(std::memory_order_relaxed)) break; } }
+        r.status = st.status;
+        r.e_search = st.c_esearch; r.n_push = st.c_push; r.n_pop = st.c_pop; r.n_node = st.c_node; r.n_hits = st.c_hits;
+        pops = st.c_pop;
+        r.hits.assign(sc.hits.begin(), sc.hits.begin() + st.n_hits);
+        r.ops.assign(sc.hit_ops.begin(), sc.hit_ops.begin() + st.hit_ops_used);
+        ok = st.status != ST_ARENA_OVERFLOW;  // cannot happen: the arena holds the reference's limits
+    }
+    {
+        std::lock_guard<std::mutex> g(tb->mu);
+        if (!ok) tb->failed = true;
+        tb->results.push_back(std::move(r));
+        tb->done += 1;
+        tb->host_pops += pops;
+        tb->t_last = TailBatch::now_s();
+    }
+    tb->cv.notify_all();
+#endif
+}
+
+// The launch's dispatcher: watches the records appear (in slot order; the kernel claims slots with an atomic counter and marks a record ready behind a
+// system-scope fence) and hands each to the workers, until the launch has ended and every record it wrote has been seen.
+inline void tail_start(const std::shared_ptr<TailBatch>& tb) {
+    tb->dispatcher = std::thread([tb] {
+        uint32_t next = 0, idle = 0;
+        for (;;) {
+            if (tb->cancel.load(std::memory_order_relaxed)) break;
+            const int64_t fin = tb->final_count.load(std::memory_order_acquire);
+            if (fin >= 0 && (int64_t)next >= fin) break;
+            if (next < tb->cap) {
+                const TailRecord* rec = reinterpret_cast<const TailRecord*>(tb->ring + (size_t)next * tb->stride);
+                if (__atomic_load_n(&rec->ready, __ATOMIC_ACQUIRE) == 1u) {
+                    {
+                        std::lock_guard<std::mutex> g(tb->mu);
+                        if (tb->dispatched == 0) tb->t_first = TailBatch::now_s();
+                        tb->dispatched += 1;
+                        tb->gpu_pops += rec->pops;
+                    }
+                    TailWorkers::instance().submit([tb, rec] { tail_map_read(tb, rec); });
+                    next += 1;
+                    idle = 0;
+                    continue;
+                }
+            }
+            // nothing new: back off up to a millisecond (a hand-over is rare, and a read that needs one runs for seconds)
+            idle = idle < 10 ? idle + 1 : 10;
+            std::this_thread::sleep_for(std::chrono::microseconds(100 * idle));
+        }
+    });
+}
+
+// The launch has ended having written `count` records: waits until all of them are mapped.  Returns false if a worker failed.
+inline bool tail_finish(const std::shared_ptr<TailBatch>& tb, uint32_t count) {
+    tb->final_count.store((int64_t)std::min(count, tb->cap), std::memory_order_release);
+    if (tb->dispatcher.joinable()) tb->dispatcher.join();
+    std::unique_lock<std::mutex> l(tb->mu);
+    tb->cv.wait(l, [&] { return tb->done == tb->dispatched; });
+    return !tb->failed;
+}
+// The batch is abandoned (its slot is reused or its context destroyed before the results were collected).
+inline void tail_cancel(const std::shared_ptr<TailBatch>& tb) {
+    tb->cancel.store(true, std::memory_order_relaxed);
+    if (tb->dispatcher.joinable()) tb->dispatcher.join();
+    std::unique_lock<std::mutex> l(tb->mu);
+    tb->cv.wait(l, [&] { return tb->done == tb->dispatched; });  // the ring and the tables stay alive through the shared_ptr, but the ring's memory is the slot's
+}
+
+}  // namespace host
+}  // namespace mapad

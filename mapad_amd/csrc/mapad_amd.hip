@@ -10,6 +10,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -32,6 +33,7 @@
 #include "postproc_core.hpp"
 #include "text_core.hpp"
 #include "search_core.hpp"
+#include "host_tail.hpp"
 
 using namespace mapad;
 
@@ -42,7 +44,7 @@ namespace mapad { namespace gpuidx { void suffix_products(const uint8_t* t_host,
 // ======================================================================================================================
 namespace {
 
-enum : uint32_t { ST_POOL_OVERFLOW = 4, ST_NO_TABLE = 8 };
+enum : uint32_t { ST_POOL_OVERFLOW = 4, ST_NO_TABLE = 8, ST_TAIL = 16 /* handed to the host tail (host_tail.hpp); replaced by the read's final status when its result comes back */ };
 // Launches over a batch (all on the batch's stream):
 //   Q0  search_kernel, every read: one quad per read, a per-slot base arena that GROWS on demand (size classes below).  A read that has outgrown
 //       its base arena is HEAVY: its state moves into the grown arena and the read is suspended (HeavyItem) — the quad takes its next read.
@@ -51,6 +53,11 @@ enum : uint32_t { ST_POOL_OVERFLOW = 4, ST_NO_TABLE = 8 };
 //   Q1  search_kernel again over the reads that gave up waiting for an arena in Q0 (normally none: the launch exits at once), H1 its suspended reads.
 //   F   heavy_kernel from scratch, with arenas that hold the reference's full limits (STACK_LIMIT / EDIT_TREE_LIMIT, mapping.rs:52-54), for the reads
 //       that no size class could hold.
+// Pop budget of a read on the GPU before a host thread takes it over (host_tail.hpp); MAPAD_TAIL_POPS / mapad_ctx_set_tail_pops override, 0 = never.
+// 2^19 pops are ~3 s of one quad's time: no 50 bp read of C1-C4 gets there (heaviest C4 read: see DESIGN.md section 5), the heavy tail of the 35-100 bp mix does.
+#if !defined(MAPAD_DEFAULT_TAIL_POPS)
+#define MAPAD_DEFAULT_TAIL_POPS (1u << 19)
+#endif
 constexpr int kTiers = 2;   // arena pools: growable base arenas, full-limit arenas
 constexpr int kStages = 3;  // hand-over lists: Q0 -> Q1 -> F
 constexpr int kClasses = 10;  // grown arenas: 2x steps above the base arena (16 Ki nodes -> 32 Ki ... ), the last one with the full limits
@@ -59,7 +66,7 @@ constexpr int kKeyBins = kMaxReadLen + 2;
 // handed on.  The two pool cursors are 64-bit (words 0-1 and 2-3): a batch may ask for more than 2^32 op words, which must show up as a pool
 // overflow, not wrap around.
 enum { CUR_HITS = 0, CUR_OPS = 2, CUR_POOL_OVF = 4, CUR_ERR = 5, CUR_WORK = 6, CUR_OVF = 7, CUR_GROWN = 6 + 2 * kStages, CUR_HEAVY_N = CUR_GROWN + 4 /* per quad stage */, CUR_HEAVY_WORK = CUR_GROWN + 6 /* per heavy stage */,
-       CUR_HEAVY_POPS = CUR_GROWN + 8 /* 64-bit */, CUR_HPROF = CUR_GROWN + 10 /* 8 x 64-bit, -DMAPAD_HEAVY_PROF */, CUR_COUNT = CUR_GROWN + 26 };
+       CUR_HEAVY_POPS = CUR_GROWN + 8 /* 64-bit */, CUR_HPROF = CUR_GROWN + 10 /* 8 x 64-bit, -DMAPAD_HEAVY_PROF */, CUR_TAIL = CUR_GROWN + 26 /* reads handed to the host tail */, CUR_COUNT = CUR_GROWN + 28 };
 inline uint64_t cur64(const uint32_t* cur, int k) { return (uint64_t)cur[k] | ((uint64_t)cur[k + 1] << 32); }
 
 struct BatchDev {
@@ -84,6 +91,10 @@ struct BatchDev {
     unsigned long long* prof; // -DMAPAD_PROFILE_SECTIONS builds: section cycle sums (else nullptr)
     struct HeavyItem* heavy;  // [2][heavy_cap] reads suspended by the two quad stages, continued by heavy_kernel (one wavefront each)
     uint32_t heavy_cap;
+    // host tail (host_tail.hpp): a read that has made tail_pops pops is written into a record of this page-locked ring and finished by a host thread
+    uint8_t* tail_ring;
+    uint32_t tail_stride, tail_cap, tail_lmax;
+    uint32_t tail_pops;       // 0xFFFFFFFF: never
 };
 
 // A read that has outgrown its base arena, as the quad stage leaves it: everything else (heap, nodes, hit staging) is in the grown arena.
@@ -588,6 +599,26 @@ __device__ __forceinline__ void suspend_heavy(const BatchDev& B, const GrowPools
     }
 }
 
+// A quad gives its read to the host tail (host_tail.hpp): position data and D array -> record k of the batch's page-locked ring, visible to the host
+// while the kernel runs (fine-grained host memory; the `ready` word follows everything else behind a system-scope fence).
+template <int LPR, bool NL>
+__device__ __forceinline__ void hand_to_host(const BatchDev& B, const ReadInT<NL>& rd, const SearchState& st, uint32_t read, uint32_t k, int w) {
+    uint8_t* rec = B.tail_ring + (size_t)k * B.tail_stride;
+    uint32_t* rq = (uint32_t*)(rec + 16);
+    float* rdd = (float*)(rec + 16 + ((2u * B.tail_lmax + 15u) & ~15u));
+    const typename near_ptr<const uint32_t, NL>::type qc4 = (typename near_ptr<const uint32_t, NL>::type)rd.qc;  // 16-byte aligned (near layout)
+    const uint32_t nq = (2u * (uint32_t)rd.L + 3u) / 4u;
+    for (uint32_t i = w; i < nq; i += LPR) rq[i] = qc4[i];
+    for (uint32_t i = w; i < (uint32_t)rd.L; i += LPR) rdd[i] = rd.d[i];
+    host::TailRecord* h = (host::TailRecord*)rec;
+    if (w == 0) { h->read = read; h->L = (uint32_t)rd.L; h->pops = st.c_pop; }
+    __threadfence_system();
+    if (w == 0) {
+        __hip_atomic_store(&h->ready, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        B.status[read] = ST_TAIL; B.hit_count[read] = 0; B.hit_first[read] = 0;
+    }
+}
+
 // PASS 0: every read, growable arenas (PASS 2: the same code for the retry launches).  PASS 1: the reads that no size class could
 // hold, arenas with the reference's full limits.
 // NL: the near data (heap top, position data) of every read slot is in LDS and addressed with ds_* instructions; otherwise it
@@ -625,6 +656,11 @@ __device__ __forceinline__ T kernarg_reload(size_t off, const T& by_value) {
 #if !defined(MAPAD_KTOP2)
 #define MAPAD_KTOP2 31
 #endif
+// Payload cache (search_core.hpp: search_step<.., PC>): the frames in heap slots 1 and 2 are kept in 64 bytes of LDS per read slot, so that a pop starts its rank
+// queries straight after the look at the heap's top instead of after a trip to the arena for the popped frame's node.  Quads with near data in LDS only.
+#if !defined(MAPAD_PAYLOAD_CACHE)
+#define MAPAD_PAYLOAD_CACHE 1
+#endif
 template <int LPR> struct top_of { static constexpr int value = LPR == 2 ? MAPAD_KTOP2 : kTop; };
 template <int LPR, bool CONT, int PASS, bool NL, bool HEAVY>
 __global__ void __launch_bounds__(64, (LPR == 1 && NL) ? 1 : LPR == 2 ? 2 : MAPAD_MIN_WAVES) search_kernel(DevIndex ix, DevParams P, BatchDev B0, ArenaPool AP0, const GrowPools* GP, uint32_t near_stride, uint32_t near_lmax, int stage) {
@@ -647,11 +683,15 @@ __global__ void __launch_bounds__(64, (LPR == 1 && NL) ? 1 : LPR == 2 ? 2 : MAPA
     A.top = (typename near_ptr<HeapEntry, NL>::type)near + 1;
     const NearBytes near_qc = near + (TOPK + 1) * sizeof(HeapEntry);
     const typename near_ptr<float, NL>::type near_d = (typename near_ptr<float, NL>::type)(near_qc + ((2 * near_lmax + 15) & ~15u));
+    constexpr bool kPC = MAPAD_PAYLOAD_CACHE != 0 && LPR == 4 && NL;
+    if constexpr (kPC) A.pc = (typename near_ptr<uint64_t, NL>::type)(near + (near_stride - 64u));  // the last 64 bytes of the slot's near data (near_bytes)
     uint32_t* work = &cursors[CUR_WORK + 2 * tier];
     // reads of the first stages give up after kMaxWaits fruitless waits for an arena and are restarted by the next stage, when the
     // pools are quiet; the last growable stage waits as long as it takes
     const DeviceGrow<LPR, NL, TOPK> grow{GP, &cursors[CUR_GROWN], slot, w, stage + 2 < kStages || HEAVY};
     const uint32_t wide_copy_nodes = GP->wide_copy_nodes;
+    const uint32_t tail_pops = B0.tail_pops;
+    bool tail_denied = false;  // the ring was full when this read asked: it stays on the GPU
 #if defined(MAPAD_PROFILE_SECTIONS)
     if (lane < 2 * PROF_N + 2) g_prof_lds[lane] = 0;
     g_prof_hist[lane] = 0;
@@ -686,10 +726,12 @@ __global__ void __launch_bounds__(64, (LPR == 1 && NL) ? 1 : LPR == 2 ? 2 : MAPA
                     SearchState tmp;
                     A.n_waits = 0;
                     search_init(kernarg_reload(0, ix).n, alignment_start_of(P, rd.L), rd, A, tmp);
+                    if constexpr (kPC) pc_clear(A);
                     st = tmp;
                     have = true;
-                    drain_memory();  // rare path of the step loop (search_core.hpp: drain_memory)
+                    tail_denied = false;
                 }
+                drain_memory();  // rare path of the step loop (search_core.hpp: drain_memory) — on both arms: the loads of thr / table would otherwise count as pending at the step's first use of them
             }
         }
         MAPAD_MARK(PROF_SETUP);
@@ -701,8 +743,8 @@ __global__ void __launch_bounds__(64, (LPR == 1 && NL) ? 1 : LPR == 2 ? 2 : MAPA
         }
         if (have) {
             bool cont;
-            if constexpr (PASS != 1) cont = search_step<LPR, CONT, NL>(ix, P, rd, A, st, w, grow);
-            else cont = search_step<LPR, CONT, NL>(ix, P, rd, A, st, w, NoGrow());
+            if constexpr (PASS != 1) cont = search_step<LPR, CONT, NL, kPC>(ix, P, rd, A, st, w, grow);
+            else cont = search_step<LPR, CONT, NL, kPC>(ix, P, rd, A, st, w, NoGrow());
             MAPAD_MARK(PROF_TAIL);
             if (!cont) {
                 finalize_read<LPR>(kernarg_reload(kArgOffB, B0), rd, A, st, read, w, tier);
@@ -714,6 +756,22 @@ __global__ void __launch_bounds__(64, (LPR == 1 && NL) ? 1 : LPR == 2 ? 2 : MAPA
                 have = false;
                 drain_memory();
                 MAPAD_MARK(PROF_FINALIZE);
+            } else if (MAPAD_UNLIKELY((st.c_pop >= tail_pops) & !tail_denied)) {
+                // past the pop budget: a host thread maps this read from scratch (host_tail.hpp), the quad takes its next read
+                const BatchDev B = kernarg_reload(kArgOffB, B0);
+                uint32_t k = 0;
+                if (w == 0) k = atomicAdd(&cursors[CUR_TAIL], 1u);
+                k = group_bcast<LPR>(k);
+                if (k < B.tail_cap) {
+                    hand_to_host<LPR, NL>(B, rd, st, read, k, w);
+                    if (PASS != 1 && A.grown) {
+                        release_grown<LPR>(GP, A.grown, w);
+                        const ArenaT<NL, TOPK> base = carve<NL, TOPK>(kernarg_reload(kArgOffAP, AP0), slot);
+                        A.heap = base.heap; A.nodes = base.nodes; A.heap_cap = base.heap_cap; A.node_cap = base.node_cap; A.grown = 0;
+                    }
+                    have = false;
+                } else tail_denied = true;
+                drain_memory();
             } else if constexpr (HEAVY) { if (MAPAD_UNLIKELY(A.grown != 0)) {
                 // The read has outgrown its base arena: it is heavy.  Its state goes into the grown arena (heap top from the near array, hit staging
                 // from the base arena), the read is queued for heavy_kernel — a wavefront of its own — and this quad takes its next read.
@@ -738,6 +796,17 @@ __global__ void __launch_bounds__(64, (LPR == 1 && NL) ? 1 : LPR == 2 ? 2 : MAPA
 }
 
 #include "heavy_kernel.hpp"
+
+// ---- results of the host tail -> the batch's per-read arrays (the hits and edit tracks themselves are copied into the pools) -----------------------
+struct TailUp { uint32_t read, status, hit_count, hit_first, e_search, n_push, n_pop, n_node, n_hits; };
+__global__ void MAPAD_SLIM tail_scatter_kernel(BatchDev B, const TailUp* __restrict__ up, uint32_t n) {
+    const uint32_t i = blockIdx.x * 64u + threadIdx.x;
+    if (i >= n) return;
+    const TailUp u = up[i];
+    B.status[u.read] = u.status; B.hit_count[u.read] = u.hit_count; B.hit_first[u.read] = u.hit_first;
+    ReadCounters* c = B.counters + u.read;  // e_darray stays as the D-array kernel wrote it
+    c->e_search = u.e_search; c->n_push = u.n_push; c->n_pop = u.n_pop; c->n_node = u.n_node; c->n_hits = u.n_hits;
+}
 
 // ---- order-preserving collect (mapping.rs:288) on the device ------------------------------------------------------------------
 // The search writes a read's hits wherever the bump cursors stood when the read finished.  These three kernels lay hits and edit
@@ -855,7 +924,9 @@ struct DevBuf {
 };
 
 // bytes of "near" data per read slot: heap top (32 physical slots), 2 bytes + 4 bytes per read position
-uint32_t near_bytes(uint32_t lmax, uint32_t top = kTop) { return (top + 1) * 8 + ((2 * lmax + 15) & ~15u) + ((4 * lmax + 15) & ~15u); }
+// (+ 64 bytes for the payload cache of heap slots 1 and 2 where the kernel keeps one: quads with their near data in LDS)
+constexpr uint32_t kPcBytes = 64;
+uint32_t near_bytes(uint32_t lmax, uint32_t top = kTop, bool pc = false) { return (top + 1) * 8 + ((2 * lmax + 15) & ~15u) + ((4 * lmax + 15) & ~15u) + (pc ? kPcBytes : 0u); }
 constexpr uint32_t kMaxLdsReadLen = 256;  // longer reads keep their near data in the HBM arena instead of LDS
 
 ArenaPool make_pool_layout(uint32_t heap_cap, uint32_t node_cap, uint32_t hit_ops_cap, uint32_t lmax) {
@@ -871,6 +942,64 @@ ArenaPool make_pool_layout(uint32_t heap_cap, uint32_t node_cap, uint32_t hit_op
     ap.stride = o;
     return ap;
 }
+
+}  // namespace
+
+namespace {
+// Page-locked host memory for everything that crosses PCIe (results out, staged inputs in): DMA at link speed instead of the driver's
+// staged copies of pageable memory.  Pinning is slow (the pages are locked one by one), so blocks are recycled: power-of-two sizes, a few
+// kept per size, process-wide (results may outlive the context they came from).
+class PinnedPool {
+public:
+    static PinnedPool& instance() { static PinnedPool p; return p; }
+    void* take(size_t bytes, size_t& got) {
+        size_t cap = 1 << 16;
+        while (cap < bytes) cap <<= 1;
+        got = cap;
+        {
+            std::lock_guard<std::mutex> g(mu_);
+            auto& fl = free_[cap];
+            if (!fl.empty()) { void* p = fl.back(); fl.pop_back(); return p; }
+        }
+        void* p = nullptr;
+        if (hipHostMalloc(&p, cap, hipHostMallocPortable) != hipSuccess) return nullptr;
+        return p;
+    }
+    void give(void* p, size_t cap) {
+        if (!p) return;
+        {
+            std::lock_guard<std::mutex> g(mu_);
+            auto& fl = free_[cap];
+            if (fl.size() < 6) { fl.push_back(p); return; }
+        }
+        (void)hipHostFree(p);
+    }
+private:
+    std::mutex mu_;
+    std::map<size_t, std::vector<void*>> free_;
+};
+template <class T>
+struct PinnedBuf {
+    T* p = nullptr;
+    size_t n = 0, cap_bytes = 0;
+    PinnedBuf() = default;
+    PinnedBuf(const PinnedBuf&) = delete;
+    PinnedBuf& operator=(const PinnedBuf&) = delete;
+    bool resize(size_t count) {
+        if (count * sizeof(T) > cap_bytes) {
+            PinnedPool::instance().give(p, cap_bytes);
+            p = (T*)PinnedPool::instance().take(std::max<size_t>(count * sizeof(T), 1), cap_bytes);
+            if (!p) { cap_bytes = 0; n = 0; return false; }
+        }
+        n = count;
+        return true;
+    }
+    T* data() { return p; }
+    size_t size() const { return n; }
+    bool empty() const { return n == 0; }
+    T& operator[](size_t i) { return p[i]; }
+    ~PinnedBuf() { PinnedPool::instance().give(p, cap_bytes); }
+};
 
 }  // namespace
 
@@ -903,13 +1032,20 @@ struct BatchSlot {
     uint32_t last_lmax = 0;
     uint32_t launch_info[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     bool ev_valid = false, timed = true;  // timed: its event times are already in the context's history
-    uint64_t gen = 0;                     // counts the launches of this slot: a fetched result knows whether the slot still holds it
+    uint64_t gen = 0;                     // process-wide serial number of this slot's latest launch: a fetched result knows whether the slot still holds it
+    // host tail of the slot's latest launch (host_tail.hpp)
+    PinnedBuf<uint8_t> tail_ring;
+    std::shared_ptr<host::TailBatch> tail;  // set while the launch's handed-over reads have not been merged into its pools
+    DevBuf<uint8_t> d_tail_up;
+    uint64_t tail_info[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // reads, pops on the GPU before the hand-over, pops on the host, host wall microseconds, threads, budget, host E_search, N_push, N_node, -
 
     void release() {
         d_seqs.release(); d_quals.release(); d_offsets.release(); d_darr.release(); d_dscratch.release(); d_counters.release(); d_status.release(); d_hit_count.release();
         d_hit_first.release(); d_ops.release(); d_cursors.release(); d_overflow.release(); d_sort_key.release(); d_key_hist.release(); d_order.release();
         d_hits.release(); d_heavy.release();
         d_c_hit_begin.release(); d_c_ops_begin.release(); d_c_tiles.release(); d_c_hits.release(); d_c_ops.release();
+        if (tail) { host::tail_cancel(tail); tail.reset(); }
+        d_tail_up.release();
         for (auto& e : ev) if (e) { (void)hipEventDestroy(e); e = nullptr; }
         if (ev_in) { (void)hipEventDestroy(ev_in); ev_in = nullptr; }
         if (own_stream && stream) (void)hipStreamDestroy(stream);
@@ -924,6 +1060,8 @@ struct mapad_ctx {
     const mapad_index* index = nullptr;
     host::HostTables tables;
     bool tables_dirty = true;
+    std::shared_ptr<const host::HostTables> tables_snap;  // the tables as uploaded last: what the host tail's threads read (`tables` may grow under them)
+    uint32_t tail_pops = 0;                                // pop budget of a read on the GPU (0: no host tail)
     // index + tables on the device
     DevBuf<uint64_t> d_blocks;
     DevBuf<float> d_sdm, d_thr;
@@ -1017,6 +1155,7 @@ int upload_tables(mapad_ctx* c) {
     d.stack_limit_abort = p.stack_limit_abort;
     d.stack_limit = p.stack_limit ? p.stack_limit : 2000000u;
     d.edit_tree_limit = p.edit_tree_limit ? p.edit_tree_limit : 10000000u;
+    c->tables_snap = c->tail_pops ? std::make_shared<const host::HostTables>(c->tables) : nullptr;
     c->tables_dirty = false;
     return MAPAD_OK;
 }
@@ -1172,6 +1311,7 @@ int record_times(mapad_ctx* c, BatchSlot& S) {
 int acquire_slot(mapad_ctx* c, int k) {
     BatchSlot& S = c->bs[k];
     if (S.ev_valid) { HIP_TRY(hipStreamSynchronize(S.stream)); int rc = record_times(c, S); if (rc) return rc; }
+    if (S.tail) { host::tail_cancel(S.tail); S.tail.reset(); }  // the previous batch of this slot was never collected: its handed-over reads are dropped with it
     if (c->depth == 1) S.stream = c->stream;  // one batch at a time: everything runs on the caller's stream (own_stream stays false)
     else if (!S.stream) { HIP_TRY(hipStreamCreateWithFlags(&S.stream, hipStreamNonBlocking)); S.own_stream = true; }
     if (c->depth > 1) {  // the slot's stream is non-blocking: order it behind whatever the caller has queued on its own stream (async uploads of the inputs)
@@ -1253,8 +1393,29 @@ int launch_batch(mapad_ctx* c, BatchSlot& S, const uint8_t* d_seqs, const uint8_
     HIP_TRY(hipMemsetAsync(c->d_prof.p, 0, (2 * PROF_N + 64) * 8, S.stream));
     B.prof = c->d_prof.p;
 #endif
+    B.tail_ring = nullptr; B.tail_stride = 0; B.tail_cap = 0; B.tail_lmax = 0; B.tail_pops = 0xFFFFFFFFu;
+    if (S.tail) { host::tail_cancel(S.tail); S.tail.reset(); }
+    for (auto& x : S.tail_info) x = 0;
+    if (c->tail_pops && !warm && n_reads) {
+        const uint32_t tl = std::max<uint32_t>(lmax, 1);
+        const uint32_t stride = host::tail_record_stride(tl), cap = (uint32_t)std::min<uint64_t>(n_reads, env_u32("MAPAD_TAIL_RING", 65536));
+        if (!S.tail_ring.resize((size_t)cap * stride)) return MAPAD_ERR_NOMEM;
+        for (uint32_t k = 0; k < cap; ++k) reinterpret_cast<host::TailRecord*>(S.tail_ring.data() + (size_t)k * stride)->ready = 0;
+        auto tb = std::make_shared<host::TailBatch>();
+        tb->ix = c->index->ix.view();
+        tb->tables = c->tables_snap;
+        tb->P = c->dprm;
+        tb->P.sdm_table = tb->tables->sdm.data(); tb->P.table_base = tb->tables->table_base.data(); tb->P.reject_thr = tb->tables->reject_thr.data();
+        tb->ring = S.tail_ring.data(); tb->stride = stride; tb->cap = cap; tb->lmax = tl;
+        host::tail_start(tb);
+        S.tail = tb;
+        B.tail_ring = S.tail_ring.data(); B.tail_stride = stride; B.tail_cap = cap; B.tail_lmax = tl; B.tail_pops = c->tail_pops;
+    }
     S.last = B; S.last_total_bases = total_bases; S.last_lmax = lmax; S.compacted = false;
-    S.gen += 1;
+    // A process-wide launch number, not a per-slot count: a result of a destroyed context must not pass for the batch of a new context that happens to sit at
+    // the same address with the same slot and launch count (mapad_hits_to_coords_gpu's device-resident shortcut compares this number).
+    static std::atomic<uint64_t> launch_serial{0};
+    S.gen = launch_serial.fetch_add(1, std::memory_order_relaxed) + 1;
     if (n_reads == 0 && !warm) return MAPAD_OK;
     const uint32_t lds_lmax = std::max<uint32_t>(lmax, 1);
     size_t lds_bytes = (size_t)16 * lds_lmax * sizeof(float);
@@ -1285,7 +1446,7 @@ int launch_batch(mapad_ctx* c, BatchSlot& S, const uint8_t* d_seqs, const uint8_
     // lanes-per-read 1: 64 read slots per wavefront, near data in LDS while it fits the 64 KB a launch may ask for without an opt-in
     const uint32_t near_top = c->lpr == 2 ? MAPAD_KTOP2 : kTop;
     const bool near_fits = c->lpr == 4 ? near_lmax <= kMaxLdsReadLen : c->lpr == 2 ? (size_t)near_bytes(near_lmax, near_top) * 32 <= 65536 : (size_t)near_bytes(near_lmax) * 64 <= 65536;
-    const uint32_t near_stride = (near_fits && env_u32("MAPAD_NEAR_LDS", 1)) ? near_bytes(near_lmax, near_top) : 0;
+    const uint32_t near_stride = (near_fits && env_u32("MAPAD_NEAR_LDS", 1)) ? near_bytes(near_lmax, near_top, MAPAD_PAYLOAD_CACHE && c->lpr == 4) : 0;
     // LDS per search block: the near data of its read slots — padded, when twelve blocks would fit a CU, to what only eleven fit (see order_scatter_kernel)
     size_t lds = (size_t)near_stride * rpw;
     {
@@ -1293,7 +1454,7 @@ int launch_batch(mapad_ctx* c, BatchSlot& S, const uint8_t* d_seqs, const uint8_
         if (lds) {
             const size_t fit = cu_lds / lds;
             // at least 12 KB of a CU's LDS stay free: one block fewer than fit if the blocks would leave less (quads: 12 x 13.3 KB -> 11; pairs at 50 bp: 8 x 18.4 KB leave 12.8 KB)
-            size_t per_cu = cu_lds - fit * lds < 12 * 1024 ? fit - 1 : fit;
+            size_t per_cu = cu_lds - fit * lds < (size_t)env_u32("MAPAD_LDS_FREE_KB", 12) * 1024 ? fit - 1 : fit;
             per_cu = std::min<size_t>(per_cu, env_u32("MAPAD_SEARCH_BLOCKS_PER_CU", 32));
             if (per_cu >= 1 && per_cu < fit) lds = (cu_lds / (per_cu + 1) + 256) & ~(size_t)255;
         }
@@ -1360,6 +1521,48 @@ int launch_batch(mapad_ctx* c, BatchSlot& S, const uint8_t* d_seqs, const uint8_
     return MAPAD_OK;
 }
 
+// The launch of slot S has ended (`cur` = its cursors): waits for the host threads that map its handed-over reads (host_tail.hpp) and puts their results where
+// the kernel would have put them — hits and edit tracks at the pools' cursors, per-read counts, status and event counters by a scatter kernel.
+int merge_tail(mapad_ctx* c, BatchSlot& S, uint32_t* cur) {
+    std::shared_ptr<host::TailBatch> tb = S.tail;
+    S.tail.reset();
+    const bool ok = host::tail_finish(tb, cur[CUR_TAIL]);
+    if (!ok) { std::fprintf(stderr, "mapad_amd: a read of the host tail could not be mapped (out of host memory?)\n"); return MAPAD_ERR_NOMEM; }
+    std::vector<host::TailResult>& res = tb->results;
+    S.tail_info[0] = res.size(); S.tail_info[1] = tb->gpu_pops; S.tail_info[2] = tb->host_pops;
+    S.tail_info[3] = res.empty() ? 0 : (uint64_t)(std::max(tb->t_last - tb->t_first, 0.0) * 1e6); S.tail_info[4] = host::TailWorkers::instance().size(); S.tail_info[5] = c->tail_pops;
+    for (const auto& r : res) { S.tail_info[6] += r.e_search; S.tail_info[7] += r.n_push; S.tail_info[8] += r.n_node; }
+    if (res.empty()) return MAPAD_OK;
+    std::sort(res.begin(), res.end(), [](const host::TailResult& a, const host::TailResult& b) { return a.read < b.read; });
+    const BatchDev& B = S.last;
+    uint64_t n_hits = 0, n_ops = 0;
+    for (const auto& r : res) { n_hits += r.hits.size(); n_ops += r.ops.size(); }
+    const uint64_t hbase = cur64(cur, CUR_HITS), obase = cur64(cur, CUR_OPS);
+    auto set64 = [&](int k, uint64_t v) { cur[k] = (uint32_t)v; cur[k + 1] = (uint32_t)(v >> 32); };
+    set64(CUR_HITS, hbase + n_hits); set64(CUR_OPS, obase + n_ops);
+    const bool fits = hbase + n_hits <= B.hits_cap && obase + n_ops <= B.ops_cap;
+    if (!fits) cur[CUR_POOL_OVF] = 1;  // the caller re-runs the batch with larger pools (mapad_map_batch), sized by these cursors
+    HIP_TRY(hipMemcpyAsync(B.cursors, cur, (CUR_POOL_OVF + 1) * 4, hipMemcpyHostToDevice, S.stream));
+    if (!fits) { HIP_TRY(hipStreamSynchronize(S.stream)); return MAPAD_OK; }
+    std::vector<HitRec> hits; hits.reserve(n_hits);
+    std::vector<uint32_t> ops; ops.reserve(n_ops);
+    std::vector<TailUp> up; up.reserve(res.size());
+    for (const auto& r : res) {
+        up.push_back(TailUp{r.read, r.status, (uint32_t)r.hits.size(), (uint32_t)(hbase + hits.size()), r.e_search, r.n_push, r.n_pop, r.n_node, r.n_hits});
+        for (HitRec h : r.hits) { h.ops_off += (uint32_t)(obase + ops.size()); hits.push_back(h); }  // like finalize_read: offsets into the global op pool
+        ops.insert(ops.end(), r.ops.begin(), r.ops.end());
+    }
+    int rc;
+    if ((rc = S.d_tail_up.ensure(up.size() * sizeof(TailUp)))) return rc;
+    if (!hits.empty()) HIP_TRY(hipMemcpyAsync(B.hits_pool + hbase, hits.data(), hits.size() * sizeof(HitRec), hipMemcpyHostToDevice, S.stream));
+    if (!ops.empty()) HIP_TRY(hipMemcpyAsync(B.ops_pool + obase, ops.data(), ops.size() * 4, hipMemcpyHostToDevice, S.stream));
+    HIP_TRY(hipMemcpyAsync(S.d_tail_up.p, up.data(), up.size() * sizeof(TailUp), hipMemcpyHostToDevice, S.stream));
+    hipLaunchKernelGGL(tail_scatter_kernel, dim3((uint32_t)((up.size() + 63) / 64)), dim3(64), 0, S.stream, B, (const TailUp*)S.d_tail_up.p, (uint32_t)up.size());
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(S.stream));  // the host vectors go out of scope
+    return MAPAD_OK;
+}
+
 // Lays the last batch's hits out in read order on the device (no-op if already done).  Reports pool overflow / kernel errors like the fetch.
 int compact_last(mapad_ctx* c) {
     BatchSlot& S = c->bs[c->view];
@@ -1369,6 +1572,7 @@ int compact_last(mapad_ctx* c) {
     const uint64_t n = B.n_reads;
     uint32_t cur[CUR_COUNT] = {0};
     if (n) HIP_TRY(hipMemcpy(cur, B.cursors, sizeof cur, hipMemcpyDeviceToHost));
+    if (S.tail) { const int rc_t = merge_tail(c, S, cur); if (rc_t) return rc_t; }
     if (cur[CUR_ERR] & ST_NO_TABLE) { std::fprintf(stderr, "mapad_amd: a read length had no score table (call mapad_ctx_prepare_lengths)\n"); return MAPAD_ERR_INVALID; }
     if (cur[CUR_ERR] & ST_ARENA_OVERFLOW) { std::fprintf(stderr, "mapad_amd: arena overflow in the large-arena pass\n"); return MAPAD_ERR_NOMEM; }
     if (cur[CUR_POOL_OVF]) return MAPAD_ERR_NOMEM;  // mapad_map_batch retries with larger pools
@@ -1389,61 +1593,6 @@ int compact_last(mapad_ctx* c) {
     S.compacted = true;
     return MAPAD_OK;
 }
-
-// Page-locked host memory for everything that crosses PCIe (results out, staged inputs in): DMA at link speed instead of the driver's
-// staged copies of pageable memory.  Pinning is slow (the pages are locked one by one), so blocks are recycled: power-of-two sizes, a few
-// kept per size, process-wide (results may outlive the context they came from).
-class PinnedPool {
-public:
-    static PinnedPool& instance() { static PinnedPool p; return p; }
-    void* take(size_t bytes, size_t& got) {
-        size_t cap = 1 << 16;
-        while (cap < bytes) cap <<= 1;
-        got = cap;
-        {
-            std::lock_guard<std::mutex> g(mu_);
-            auto& fl = free_[cap];
-            if (!fl.empty()) { void* p = fl.back(); fl.pop_back(); return p; }
-        }
-        void* p = nullptr;
-        if (hipHostMalloc(&p, cap, hipHostMallocPortable) != hipSuccess) return nullptr;
-        return p;
-    }
-    void give(void* p, size_t cap) {
-        if (!p) return;
-        {
-            std::lock_guard<std::mutex> g(mu_);
-            auto& fl = free_[cap];
-            if (fl.size() < 6) { fl.push_back(p); return; }
-        }
-        (void)hipHostFree(p);
-    }
-private:
-    std::mutex mu_;
-    std::map<size_t, std::vector<void*>> free_;
-};
-template <class T>
-struct PinnedBuf {
-    T* p = nullptr;
-    size_t n = 0, cap_bytes = 0;
-    PinnedBuf() = default;
-    PinnedBuf(const PinnedBuf&) = delete;
-    PinnedBuf& operator=(const PinnedBuf&) = delete;
-    bool resize(size_t count) {
-        if (count * sizeof(T) > cap_bytes) {
-            PinnedPool::instance().give(p, cap_bytes);
-            p = (T*)PinnedPool::instance().take(std::max<size_t>(count * sizeof(T), 1), cap_bytes);
-            if (!p) { cap_bytes = 0; n = 0; return false; }
-        }
-        n = count;
-        return true;
-    }
-    T* data() { return p; }
-    size_t size() const { return n; }
-    bool empty() const { return n == 0; }
-    T& operator[](size_t i) { return p[i]; }
-    ~PinnedBuf() { PinnedPool::instance().give(p, cap_bytes); }
-};
 
 struct HostResult {
     mapad_batch_result_t pub{};
@@ -1622,6 +1771,7 @@ int mapad_ctx_create(const mapad_index_t* idx, const mapad_params_t* params, int
     c->device = device_id; c->params = *params; c->index = idx; c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     c->tables = host::make_tables(*params);
     c->depth = (int)std::min<uint32_t>(std::max<uint32_t>(env_u32("MAPAD_PIPELINE_DEPTH", 1), 1), kMaxDepth);
+    c->tail_pops = env_u32("MAPAD_TAIL_POPS", MAPAD_DEFAULT_TAIL_POPS);
     int rc;
     if ((rc = c->d_blocks.ensure(idx->ix.blocks.size()))) return rc;
     HIP_TRY(hipMemcpy(c->d_blocks.p, idx->ix.blocks.data(), idx->ix.blocks.size() * 8, hipMemcpyHostToDevice));
@@ -1631,6 +1781,17 @@ int mapad_ctx_create(const mapad_index_t* idx, const mapad_params_t* params, int
     return MAPAD_OK;
 }
 void mapad_ctx_destroy(mapad_ctx_t* ctx) { delete ctx; }
+int mapad_ctx_set_tail_pops(mapad_ctx_t* ctx, uint32_t pops) {
+    if (!ctx) return MAPAD_ERR_INVALID;
+    if ((pops != 0) != (ctx->tail_pops != 0)) ctx->tables_dirty = true;  // the host copy of the tables is taken with the next upload
+    ctx->tail_pops = pops;
+    return MAPAD_OK;
+}
+int mapad_last_tail_info(mapad_ctx_t* ctx, uint64_t out[10]) {
+    if (!ctx || !out) return MAPAD_ERR_INVALID;
+    std::memcpy(out, ctx->bs[ctx->view].tail_info, sizeof ctx->bs[ctx->view].tail_info);
+    return MAPAD_OK;
+}
 int mapad_ctx_set_fetch_d_arrays(mapad_ctx_t* ctx, int on) { if (!ctx) return MAPAD_ERR_INVALID; ctx->fetch_d = on != 0; return MAPAD_OK; }
 int mapad_ctx_set_stream(mapad_ctx_t* ctx, void* s) { if (!ctx) return MAPAD_ERR_INVALID; ctx->stream = (hipStream_t)s; return MAPAD_OK; }
 

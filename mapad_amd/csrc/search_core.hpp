@@ -12,6 +12,8 @@
 // the deletion and match/mismatch nodes of base w; search_step / commit_child).
 // The same source compiles for the host (tests/emu) so that the CPU test-suite can run it against the oracle.
 #pragma once
+#include <type_traits>
+
 #include "fmd_device.hpp"
 
 // Rare paths (a hit is found, limit recovery, read set-up).  Out-of-line variants were measured on MI355X (C2): they shrink the
@@ -61,6 +63,15 @@ namespace mapad {
 // flight" at the join, and the common path then carries a full `s_waitcnt vmcnt(0)` — a drain of every store in flight — in front of the
 // next instruction that touches one of the registers involved.  Rare paths therefore end with an explicit wait of their own, which the pass
 // does model: behind it nothing is pending and the common path keeps only the waits it needs.
+// Marks a loaded value as used here: the wait-count pass then places the wait for it at this point — chosen where younger loads are waited for anyway, so that it
+// costs nothing — instead of carrying "possibly still in flight" around the loop into a full drain in front of the next write of the same register.
+template <class T> MAPAD_HD void consume_here(const T& v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" ::"v"(v));
+#else
+    (void)v;
+#endif
+}
 MAPAD_HD void drain_memory() {
 #if defined(__HIP_DEVICE_COMPILE__)
     __builtin_amdgcn_s_waitcnt(0);  // vmcnt(0) expcnt(0) lgkmcnt(0)
@@ -164,6 +175,7 @@ struct ArenaT {
     MAPAD_GLOBAL HitRec* hits;       // kMaxHits
     MAPAD_GLOBAL uint32_t* hit_ops;  // staging for the hits' edit tracks
     MAPAD_GLOBAL uint16_t* scratch;  // 2 * (Lmax + 1) u16 for the bucket sort of extract_edit_operations
+    typename near_ptr<uint64_t, NL>::type pc = nullptr;  // payload cache of heap slots 1 and 2 (search_step<.., PC = true>): 2 x {1 << 32 | node id, w1, w2, w3}, near data
     uint32_t heap_cap, node_cap, hit_ops_cap;
     uint32_t grown = 0;  // 0: heap/nodes are the slot's base arena; else (class + 1) << 27 | arena index (mapad_amd.hip: DeviceGrow)
     uint32_t wait = 0;   // steps to sit out before asking the pools again
@@ -285,7 +297,7 @@ MAPAD_HD Ancestors load_ancestors(const ArenaT<NL, TOP>& A, uint32_t pos) {
     return a;
 }
 template <bool NL, int TOP>
-MAPAD_HD void mm_bubble_up(const ArenaT<NL, TOP>& A, uint32_t pos, const HeapEntry elt, const Ancestors& an) {  // elt is the new element, destined for slot pos
+MAPAD_HD uint32_t mm_bubble_up(const ArenaT<NL, TOP>& A, uint32_t pos, const HeapEntry elt, const Ancestors& an) {  // elt is the new element, destined for slot pos; returns the slot it ends up in
     // Both compares are evaluated unconditionally (slots that do not exist compare as "stay"): the three entries are then consumed on the main
     // path, where the compiler places the one wait for them, and the outcome is a store of elt plus at most two displaced entries.
     const uint32_t i1 = pos > 0 ? (pos - 1) >> 1 : 0;   // parent
@@ -322,9 +334,10 @@ MAPAD_HD void mm_bubble_up(const ArenaT<NL, TOP>& A, uint32_t pos, const HeapEnt
         }
     } else pos = pos1;
     hp_set(A, pos, elt);
+    return pos;
 }
 template <bool NL, int TOP>
-MAPAD_HD void mm_bubble_up(const ArenaT<NL, TOP>& A, uint32_t pos, const HeapEntry elt) { mm_bubble_up(A, pos, elt, load_ancestors(A, pos)); }
+MAPAD_HD uint32_t mm_bubble_up(const ArenaT<NL, TOP>& A, uint32_t pos, const HeapEntry elt) { return mm_bubble_up(A, pos, elt, load_ancestors(A, pos)); }
 
 // The heap array is stored shifted by one entry (logical index i lives in physical slot i + 1; `v` points at logical 0), so the
 // two children of a node (logical 2p+1, 2p+2) form one 16-byte aligned pair and its four grandchildren (4p+3 .. 4p+6) one
@@ -334,9 +347,15 @@ MAPAD_HD void mm_bubble_up(const ArenaT<NL, TOP>& A, uint32_t pos, const HeapEnt
 // (the arena has slack) but neutralised by an index test.
 // A sift that starts at slot 1 or 2 (every pop_max of a heap with more than two entries) takes its first two strides through levels 1-5, which
 // with kTop = 63 lie in the near array entirely: those strides run without the near / arena selection of the general stride.
-template <bool MAX, bool NL, int TOP>
-MAPAD_HD void mm_trickle_down(const ArenaT<NL, TOP>& A, uint32_t n, uint32_t pos, HeapEntry elt) {
+// `occupant(node)`: for a sift that starts in slots 0-2, called once, as soon as it is known which entry ends up in the slot the sift started from (after
+// the first stride, or at once if that slot has no children): search_step's payload cache fetches that frame while the rest of the sift and the rank
+// queries are in flight.
+struct NoOccupantHook { MAPAD_HD void operator()(uint32_t) const {} };
+template <bool MAX, bool NL, int TOP, class Hook = NoOccupantHook>
+MAPAD_HD void mm_trickle_down(const ArenaT<NL, TOP>& A, uint32_t n, uint32_t pos, HeapEntry elt, Hook&& occupant = Hook()) {
     bool going = true;
+    uint32_t placed_node = elt.node;  // node of the entry that was stored into the slot a stride started from (elt itself if the stride stored nothing there)
+    const uint32_t start = pos;
     // one stride: the hole moves to the best child or grandchild; false = the sift ends at `pos`
     auto stride = [&](const HeapPair& c, const HeapPair& ga, const HeapPair& gb, uint32_t c1, uint32_t g1, auto&& set) -> bool {
         uint32_t best = c1;
@@ -348,6 +367,7 @@ MAPAD_HD void mm_trickle_down(const ArenaT<NL, TOP>& A, uint32_t n, uint32_t pos
         consider(c1 + 1, c.b); consider(g1, ga.a); consider(g1 + 1, ga.b); consider(g1 + 2, gb.a); consider(g1 + 3, gb.b);
         if (!(MAX ? (be.score > elt.score) : (be.score < elt.score))) return false;
         set(pos, be);
+        placed_node = pos == start ? be.node : placed_node;
         pos = best;
         if (best < g1) return false;  // moved to a child: done
         const uint32_t parent = (pos - 1) >> 1;
@@ -365,8 +385,10 @@ MAPAD_HD void mm_trickle_down(const ArenaT<NL, TOP>& A, uint32_t n, uint32_t pos
             const uint32_t c1 = 2 * pos + 1, g1 = 2 * c1 + 1;
             if (!(going & (c1 < n) & (g1 + 3 < (uint32_t)TOP))) break;  // levels below 5, or a sift that started deeper: the general loop
             going = stride(load_pair(A.top + c1), load_pair(A.top + g1), load_pair(A.top + g1 + 2), c1, g1, set_near);
+            if (k == 0) occupant(placed_node);
         }
-    }
+        if (2 * start + 1 >= n) occupant(placed_node);  // no children: elt stays where the sift started
+    } else static_assert(std::is_same<typename std::decay<Hook>::type, NoOccupantHook>::value, "the occupant hook needs the first stride in the near array");
     while (going && 2 * pos + 1 < n) {
         const uint32_t c1 = 2 * pos + 1, g1 = 2 * c1 + 1;
         HeapPair c, ga, gb;  // a level is entirely near or entirely in the arena
@@ -659,7 +681,23 @@ MAPAD_RARE void search_init(uint64_t n_text, int alignment_start, const ReadInT<
 }
 
 // One iteration of the `while let Some(stack_frame) = stack.pop_max()` loop.  Returns false when the search is over.
-template <int LPR, bool CONT, bool NL, class Grow, int TOP, bool NLR>
+// PC: payload cache.  The frame payload (w1..w3 of the node) of the entries in heap slots 1 and 2 — one of which is the next pop_max — is kept next to the
+// quad (A.pc, LDS on the device), keyed by node id, so that a pop does not start with a dependent trip to the arena for its node.  It is filled (a) when a pop's
+// sift puts a new entry into the slot it emptied: that frame's node is fetched behind the rank-query loads of the same step and stored at the end of the step,
+// (b) from registers when a child of this step bubbles up into slot 1 or 2.  Everything else (tiny heaps, the general commit loop, evictions) just misses:
+// a payload is only used if its key equals the node id the heap holds, a live node's payload never changes, and evictions — after which ids are reused — clear
+// the cache.  What leaves the step's dependent chain is one HBM round trip in six.
+#if defined(MAPAD_PC_STATS) && !defined(__HIP_DEVICE_COMPILE__)
+static unsigned long long g_pc_stats[3];
+#endif
+template <bool NL, int TOP>
+MAPAD_HD void pc_store(const ArenaT<NL, TOP>& A, uint32_t s, uint32_t id, uint64_t w1, uint64_t w2, uint64_t w3) {
+    A.pc[4 * s] = (1ull << 32) | id; A.pc[4 * s + 1] = w1; A.pc[4 * s + 2] = w2; A.pc[4 * s + 3] = w3;
+}
+template <bool NL, int TOP>
+MAPAD_HD void pc_clear(const ArenaT<NL, TOP>& A) { A.pc[0] = 0; A.pc[4] = 0; }
+
+template <int LPR, bool CONT, bool NL, bool PC = false, class Grow = NoGrow, int TOP = kTop, bool NLR = NL>
 MAPAD_HD bool search_step(const DevIndex& ix, const DevParams& P, const ReadInT<NLR>& rd, ArenaT<NL, TOP>& A, SearchState& st, int w, const Grow& grow) {
     if (st.heap_len == 0 || st.status != ST_OK) return false;
     if (MAPAD_UNLIKELY(st.tree_len + kStepNodes > A.node_cap || st.heap_len + kStepNodes > A.heap_cap)) {
@@ -683,8 +721,22 @@ MAPAD_HD bool search_step(const DevIndex& ix, const DevParams& P, const ReadInT<
     //   them the repair of the heap (its round trips through the arena levels run while the index loads are in flight) and the window of
     //   ancestors for this step's pushes      3. nothing: counts, gates, children and pushes work on what has arrived.
     const HeapEntry top = mm_find_max(A, st.heap_len, top_idx);
-    const Node top_node = A.nodes[top.node];
-    const HeapEntry last = hp_get(A, st.heap_len - 1);
+    Node top_node;
+    if constexpr (PC) {
+        const uint32_t cs = top_idx == 2 ? 1u : 0u;
+        const uint64_t key = A.pc[4 * cs], c1 = A.pc[4 * cs + 1], c2 = A.pc[4 * cs + 2], c3 = A.pc[4 * cs + 3];
+        const bool hit = (top_idx != 0) & (key == ((1ull << 32) | top.node));
+#if defined(MAPAD_PC_STATS) && !defined(__HIP_DEVICE_COMPILE__)
+        g_pc_stats[hit ? 0 : top_idx == 0 ? 2 : 1] += 1;  // hits, misses, pops of slot 0 (heaps of one entry)
+#endif
+        uint64_t g1 = 0, g2 = 0, g3 = 0;
+        if (MAPAD_UNLIKELY(!hit)) {  // a miss takes the trip to the arena and waits for it here, so that the hit path carries no wait at all (drain_memory)
+            const Node g = A.nodes[top.node];
+            g1 = g.w1; g2 = g.w2; g3 = g.w3;
+            drain_memory();
+        }
+        top_node.w0 = 0; top_node.w1 = hit ? c1 : g1; top_node.w2 = hit ? c2 : g2; top_node.w3 = hit ? c3 : g3;
+    } else top_node = A.nodes[top.node];
     st.c_pop += 1;
     const Frame f = unpack_frame(top_node);
     const float f_score = top.score;
@@ -700,6 +752,17 @@ MAPAD_HD bool search_step(const DevIndex& ix, const DevParams& P, const ReadInT<
     const float lower_bound = d_get(rd.d, L, alignment_start, d_k, d_l);                       // :1195
     if (st.n_hits > 0 && mb_reject_iterative(P, f_score + lower_bound, st.best_score)) { st.heap_len -= 1; return false; }  // :1201-1208 (the frame was popped; the search is over)
     MAPAD_MARK(PROF_NODE);
+    HeapEntry last;
+    {   // The heap's last entry, loaded behind the stop rule above so that every path that issues the load also reaches the point where it counts as used
+        // (consume_here).  Near read (clamped) for every slot, arena load predicated: as one two-armed branch the arms share their destination registers, and
+        // the wait-count pass then puts a full drain in front of the near arm (any wavefront with a slot whose heap is still small).
+        const uint32_t li = st.heap_len - 1;
+        const bool l_near = li < (uint32_t)TOP;
+        const HeapEntry ln = load_entry(A.top + (l_near ? li : 0u));
+        HeapEntry lg = HeapEntry{0.0f, 0u};
+        if (!l_near) lg = load_entry(A.heap + li);
+        last.score = l_near ? ln.score : lg.score; last.node = l_near ? ln.node : lg.node;
+    }
 
     // Extension (:1245); forward extension works on the swapped interval.  Device quads: lane w keeps the extension by base w only.
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -718,7 +781,15 @@ MAPAD_HD bool search_step(const DevIndex& ix, const DevParams& P, const ReadInT<
 #endif
     // pop_max of the crate, second half: the last entry takes the place of the maximum and trickles down
     st.heap_len -= 1;
-    if (top_idx < st.heap_len) mm_trickle_down<true>(A, st.heap_len, top_idx, last);
+    uint64_t pf1 = 0, pf2 = 0, pf3 = 0;  // PC: payload of the frame the sift moves into the emptied slot, fetched behind the rank-query loads
+    uint32_t pf_id = 0;
+    bool pf_valid = false;
+    if constexpr (PC) {
+        auto fetch = [&](uint32_t id) { const Node g = A.nodes[id]; pf1 = g.w1; pf2 = g.w2; pf3 = g.w3; pf_id = id; pf_valid = true; };
+        if (top_idx < st.heap_len) mm_trickle_down<true>(A, st.heap_len, top_idx, last, fetch);
+    } else {
+        if (top_idx < st.heap_len) mm_trickle_down<true>(A, st.heap_len, top_idx, last);
+    }
     MAPAD_MARK(PROF_POP);
     Ext4 e;
     uint64_t my_lower[kBases] = {}, my_lower_rev[kBases] = {}, my_size[kBases] = {};  // kLaneKids: extension by this lane's base(s)
@@ -742,6 +813,7 @@ MAPAD_HD bool search_step(const DevIndex& ix, const DevParams& P, const ReadInT<
         nonempty = (e.size[0] >= 1 ? 1u : 0u) | (e.size[1] >= 1 ? 2u : 0u) | (e.size[2] >= 1 ? 4u : 0u) | (e.size[3] >= 1 ? 8u : 0u);
     }
     st.c_esearch += 1;
+    consume_here(last.score); consume_here(last.node);  // older than the rank-query loads just waited for; a step whose pop needs no sift would leave it "pending" (consume_here)
     MAPAD_MARK(PROF_EXT);
 
     // Static gates of the <= 9 children in commit order: Ins; then for k = T,G,C,A: Del(k), Match/Mismatch(k).
@@ -827,6 +899,9 @@ MAPAD_HD bool search_step(const DevIndex& ix, const DevParams& P, const ReadInT<
             for (int i = 0; i < 4; ++i) if (mm[i] < lim) cand &= ~(4u << (2 * i));
         }
         const uint32_t cand0 = cand, id0 = st.tree_next;  // == tree_entries: the slab grows at its end, child t gets key id0 + (children before t)
+        uint32_t land_t = 0xFFu, land_s = 0;  // PC: the last child of this step that ended up in heap slot 1 or 2 (land_s = slot - 1)
+        Node land_nd{};                       //     ... and its node where the children are not built lane-parallel
+        (void)land_nd;
         while (cand != 0) {
 #if defined(__HIP_DEVICE_COMPILE__)
             const int t = __ffs((int)cand) - 1;
@@ -844,14 +919,41 @@ MAPAD_HD bool search_step(const DevIndex& ix, const DevParams& P, const ReadInT<
             const uint32_t pos = st.heap_len;
             st.heap_len = pos + 1;
             const Ancestors an = load_ancestors(A, pos);
+            Node made{};
+            (void)made;
             if constexpr (!kLaneKids) {
                 const uint64_t xl = k == 0 ? e.lower[0] : k == 1 ? e.lower[1] : k == 2 ? e.lower[2] : e.lower[3];
                 const uint64_t xr = k == 0 ? e.lower_rev[0] : k == 1 ? e.lower_rev[1] : k == 2 ? e.lower_rev[2] : e.lower_rev[3];
                 const uint64_t xs = k == 0 ? e.size[0] : k == 1 ? e.size[1] : k == 2 ? e.size[2] : e.size[3];
-                A.nodes[id] = make_child(t, k, xl, xr, xs);
+                made = make_child(t, k, xl, xr, xs);
+                A.nodes[id] = made;
             }
-            mm_bubble_up(A, pos, HeapEntry{score, id}, an);
+            const uint32_t fin = mm_bubble_up(A, pos, HeapEntry{score, id}, an);
+            if constexpr (PC) {
+                const bool lands = (fin - 1u) < 2u;
+                land_t = lands ? (uint32_t)t : land_t; land_s = lands ? fin - 1u : land_s;
+                if constexpr (!kLaneKids) { if (lands) land_nd = made; }
+            }
             st.c_node += 1; st.c_push += 1;
+        }
+        if constexpr (PC) {
+            // the frame the sift moved into the emptied slot first (its loads have long arrived: they are older than the ancestors the pushes waited for) ...
+            if (pf_valid) pc_store(A, top_idx - 1u, pf_id, pf1, pf2, pf3);
+            pf_valid = false;
+            // ... then the child that bubbled into slot 1 or 2, if any (it may have displaced that frame): the lane that built the child holds its payload
+            if (land_t != 0xFFu) {
+                const uint32_t lid = id0 + (uint32_t)popc32(cand0 & ((1u << land_t) - 1u));
+                if constexpr (kLaneKids) {
+#if defined(__HIP_DEVICE_COMPILE__)
+                    static_assert(kBases == 1, "payload cache: quads");
+                    const uint32_t t_mm = 2u + 2u * (3u - (uint32_t)w), t_del = t_mm - 1u;
+                    const bool is_mm = land_t == t_mm, is_del = land_t == t_del, is_ins = (land_t == 0u) & (w == 0);
+                    const uint64_t v1 = is_mm ? nd_mm[0].w1 : is_del ? nd_del[0].w1 : nd_ins.w1, v2 = is_mm ? nd_mm[0].w2 : is_del ? nd_del[0].w2 : nd_ins.w2,
+                                   v3 = is_mm ? nd_mm[0].w3 : is_del ? nd_del[0].w3 : nd_ins.w3;
+                    if (is_mm | is_del | is_ins) pc_store(A, land_s, lid, v1, v2, v3);
+#endif
+                } else pc_store(A, land_s, lid, land_nd.w1, land_nd.w2, land_nd.w3);
+            }
         }
         if constexpr (kLaneKids) {
             // The nodes of all children in three store groups behind the pushes (a node is only read when its frame is popped, at the earliest
@@ -898,6 +1000,7 @@ MAPAD_HD bool search_step(const DevIndex& ix, const DevParams& P, const ReadInT<
             commit_child<LPR>(P, rd, A, st, alignment_start, score, ngaps, len, make_child(t, k, xl, xr, xs), true, 0);
         }
     }
+    if constexpr (PC) { if (MAPAD_UNLIKELY(pf_valid)) pc_store(A, top_idx - 1u, pf_id, pf1, pf2, pf3); }  // the step went through the general loop only (whose pushes are not tracked: they miss)
     MAPAD_MARK(PROF_COMMIT);
 #if defined(MAPAD_PROFILE_SECTIONS) && defined(__HIP_DEVICE_COMPILE__)
     if (w == 0) atomicAdd(&g_prof_hist[24 + min(st.tree_len - prof_nodes0, 11u)], 1u);
@@ -912,16 +1015,22 @@ MAPAD_HD bool search_step(const DevIndex& ix, const DevParams& P, const ReadInT<
         const int64_t b = (int64_t)st.tree_len - (int64_t)P.edit_tree_limit;
         SearchState tmp = st;
         evict_worst(A, tmp, a > b ? a : b);
+        if constexpr (PC) pc_clear(A);  // slots 1 and 2 may hold other entries now, and the freed node ids will be reused
         drain_memory();
         st = tmp;
     }
     return st.heap_len > 0;
 }
 
+// one read from start to end by one thread (host builds: tests/emu, the host tail of host_tail.hpp); A.pc set = with the payload cache
 template <class Grow = NoGrow>
 MAPAD_HD void search_read(const DevIndex& ix, const DevParams& P, const ReadIn& rd, Arena& A, SearchState& st, int w, const Grow& grow = Grow()) {
     search_init(ix.n, alignment_start_of(P, rd.L), rd, A, st);
-    if (P.bound_kind == BOUND_CONTINUOUS) { while (search_step<1, true, false>(ix, P, rd, A, st, w, grow)) {} }
+    if (A.pc) {
+        pc_clear(A);
+        if (P.bound_kind == BOUND_CONTINUOUS) { while (search_step<1, true, false, true>(ix, P, rd, A, st, w, grow)) {} }
+        else { while (search_step<1, false, false, true>(ix, P, rd, A, st, w, grow)) {} }
+    } else if (P.bound_kind == BOUND_CONTINUOUS) { while (search_step<1, true, false>(ix, P, rd, A, st, w, grow)) {} }
     else { while (search_step<1, false, false>(ix, P, rd, A, st, w, grow)) {} }
 }
 

@@ -94,6 +94,9 @@ summary["traffic_bytes_per_batch"] = traffic
 json.dump(summary, open(os.path.join(ROOT, "profiles", f"{tag}_pmc_summary.json"), "w"), indent=1)
 tp = os.path.join(ROOT, "profiles", "traffic.json")
 tj = json.load(open(tp)) if os.path.exists(tp) else {}
+sys.path.insert(0, ROOT)
+from mapad_amd import build as _build  # noqa: E402
+traffic["kernel_source_sha16"] = _build.source_hash()  # bench.py reports this traffic only while the library is built from these sources
 tj[key] = traffic
 json.dump(tj, open(tp, "w"), indent=1)
 print(json.dumps(summary["traffic_bytes_per_batch"]))

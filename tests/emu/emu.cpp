@@ -4,9 +4,12 @@
 // the same headers with g++ (scalar rank queries on the identical block layout) lets the CPU test-suite (-m "not gpu")
 // check heap / slab / hit-list / D-array logic, the block layout and the score tables against the oracle without a GPU.
 // This library is never loaded by the product (mapad_amd/): it is built into tests/emu/_build by tests/emu_util.py.
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <vector>
+
+#define MAPAD_PC_STATS 1
 
 #include "../../include/mapad_amd.h"
 #include "../../mapad_amd/csrc/darray_core.hpp"
@@ -50,6 +53,11 @@ mapad_batch_result_t* emu_map_batch(const uint64_t* blocks, uint64_t n_blocks, u
     r->hit_begin.assign(n_reads + 1, 0); r->status.resize(n_reads); r->counters.resize(n_reads);
     r->d_arrays.resize(n_reads ? offsets[n_reads] : 0);
     std::vector<HeapEntry> top(kTop + 1 + 8);  // logical slots [0, kTop) shifted by one, plus slack for pair loads
+    // the payload cache of heap slots 1 and 2 (search_step<.., PC>), as the quad kernel runs it; MAPAD_EMU_PAYLOAD_CACHE=0: the plain step
+    const char* pc_env = std::getenv("MAPAD_EMU_PAYLOAD_CACHE");
+    const bool use_pc = !(pc_env && pc_env[0] == '0');
+    uint64_t pc_words[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    g_pc_stats[0] = g_pc_stats[1] = g_pc_stats[2] = 0;
     std::vector<uint8_t> qc(2 * (lmax + 1));
     std::vector<float> dnear(lmax + 1);
     std::vector<float> pen(lmax + 1), chain(lmax + 1);
@@ -95,6 +103,7 @@ mapad_batch_result_t* emu_map_batch(const uint64_t* blocks, uint64_t n_blocks, u
             nodes.assign(std::min<uint32_t>(nc, 1u << 22), Node{});
             A.top = top.data() + 1; A.heap = heap.data() + 1; A.nodes = nodes.data(); A.hits = hits.data(); A.hit_ops = hit_ops.data(); A.scratch = scratch.data();
             A.heap_cap = (uint32_t)heap.size() - 16; A.node_cap = (uint32_t)nodes.size(); A.hit_ops_cap = (uint32_t)hit_ops.size();
+            A.pc = use_pc ? pc_words : nullptr;
             ReadIn rd{qc.data(), dnear.data(), L, P.reject_thr[L], P.table_base[L]};
             if (pass == 0) search_read(ix, P, rd, A, st, 0, grow);
             else search_read(ix, P, rd, A, st, 0);
@@ -112,6 +121,7 @@ mapad_batch_result_t* emu_map_batch(const uint64_t* blocks, uint64_t n_blocks, u
         }
         r->hit_begin[i + 1] = r->hits.size();
     }
+    if (std::getenv("MAPAD_EMU_PC_STATS")) std::fprintf(stderr, "emu payload cache: %llu hits, %llu misses, %llu pops of a one-entry heap\n", g_pc_stats[0], g_pc_stats[1], g_pc_stats[2]);
     r->pub.n_reads = n_reads; r->pub.n_hits = r->hits.size(); r->pub.n_ops = r->ops.size();
     r->pub.hit_begin = r->hit_begin.data(); r->pub.hits = r->hits.data(); r->pub.ops = r->ops.data(); r->pub.status = r->status.data();
     r->pub.counters = r->counters.data(); r->pub.d_arrays = r->d_arrays.data(); r->pub.n_second_pass = migrations; r->pub.n_third_pass = second;

@@ -90,6 +90,30 @@ def test_caller_built_result_goes_through_the_device_post_search():
         ctx.close()
 
 
+def test_result_of_a_destroyed_context_is_not_taken_for_the_new_contexts_batch():
+    """The device-resident shortcut of the post-search recognises "this batch slot still holds that result" by a process-wide launch number.  A result that
+    outlives its context must go the long way (its hits are uploaded) when it is handed to a NEW context — which may sit at the same address, in the same
+    slot, after the same number of launches, holding a different batch."""
+    g = synth.genome(200_000, seed=41)
+    idx = mapad_amd.Index.build([("chr1", g)])
+    params = mapad_amd.make_params(resolve_params(DAMAGE))
+    a_reads = synth.reads(g, 1200, 50, seed=1, qual_range=(20, 40), damage=dict(f=0.5, t=0.5, d=0.02, s=1.0))
+    b_reads = synth.reads(g, 1200, 50, seed=2, qual_range=(20, 40), damage=dict(f=0.5, t=0.5, d=0.02, s=1.0))
+    ctx_a = mapad_amd.Context(idx, params, 0)
+    res_a = ctx_a.map_batch(*a_reads)
+    want = ctx_a.hits_to_records(res_a, *a_reads, seed=3)
+    ctx_a.close()
+    for _ in range(3):  # the allocator usually hands the same block out again at once; a few tries make that likely, none of them may go wrong
+        ctx_b = mapad_amd.Context(idx, params, 0)
+        try:
+            res_b = ctx_b.map_batch(*b_reads)  # slot 0, first launch of this context: the state the old scheme could not tell from ctx_a's
+            assert ctx_b.hits_to_records(res_a, *a_reads, seed=3) == want
+            assert ctx_b.hits_to_records(res_b, *b_reads, seed=3) == mapad_amd.hits_to_records(idx, params, res_b, *b_reads, seed=3)
+        finally:
+            ctx_b.close()
+    assert sum(r["mapped"] for r in want) > 800
+
+
 @pytest.mark.parametrize("text", ["device", "host"])
 def test_device_coordinates_on_contigs_x_runs_and_multi_row_hits(text, monkeypatch):
     """The records kernel (postproc_core.hpp: strand, contig, X0 / X1, XA candidates, PrRange order) against the host restatement on a

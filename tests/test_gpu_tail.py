@@ -1,0 +1,125 @@
+"""GPU tests of the host tail (csrc/host_tail.hpp): reads that pass a pop budget on the GPU are handed — by the running kernel, through page-locked
+records — to the library's host threads, which map them from scratch with the kernel's own search step; their results join the batch before the
+order-preserving collect.  Where a read was finished must not show anywhere: every result is compared bit for bit (hits, BinaryHeap order, score bits,
+edit tracks, D arrays, the six event counters) with the CPU oracle and with the same batch mapped with the tail switched off.
+Reference behaviour at stake: the overflow recovery of src/map/mapping.rs:1358-1380 (the reads that get here at the real limits are those that hit it)."""
+import numpy as np
+import pytest
+
+import mapad_amd
+from mapad_amd import synth
+from oracle import binding as ob
+
+from kat_util import resolve_params
+from parity_util import CONTINUOUS, DAMAGE, NO_DAMAGE, assert_same_as_oracle, split_reads
+
+pytestmark = pytest.mark.gpu
+
+
+def _map(index, params, seqs, quals, offsets, tail_pops):
+    ctx = mapad_amd.Context(index, params, 0)
+    try:
+        ctx.set_tail_pops(tail_pops)
+        res = ctx.map_batch(seqs, quals, offsets)
+        return res, ctx.tail_info()
+    finally:
+        ctx.close()
+
+
+def _same(a, b):
+    assert np.array_equal(a.hit_begin, b.hit_begin) and np.array_equal(a.hits_arr, b.hits_arr) and np.array_equal(a.ops, b.ops)
+    assert np.array_equal(a.status, b.status) and np.array_equal(a.counters, b.counters)
+
+
+@pytest.mark.parametrize("name,prm,kw,n", [
+    ("no_damage", NO_DAMAGE, dict(qual=40), 3000),
+    ("damage_mixed_len_indels", DAMAGE, dict(qual_range=(20, 40), len_range=(35, 100), indel_frac=0.05), 800),
+    ("continuous_bound", CONTINUOUS, dict(qual_range=(20, 40), damage=dict(f=0.5, t=0.5, d=0.02, s=1.0)), 2000),
+])
+def test_reads_finished_on_the_host_equal_the_oracle(name, prm, kw, n):
+    g = synth.genome(300_000, seed=77)
+    seqs, quals, offsets = synth.reads(g, n, 50, seed=3 + len(name), **kw)
+    rp = resolve_params(prm)
+    pidx = mapad_amd.Index.build([("chr1", g)])
+    oidx = ob.OracleIndex.from_bwt(pidx.bwt(), "$ACGTX", 128)
+    params = mapad_amd.make_params(rp)
+    res, info = _map(pidx, params, seqs, quals, offsets, tail_pops=48)  # a budget most reads with a mismatch exceed
+    reads, qs = split_reads(seqs, quals, offsets)
+    ores = oidx.map_batch(ob.make_params(rp), reads, qs, n_threads=8, keep_d=True)
+    assert_same_as_oracle(ores, res, offsets)
+    pops = ores.counters[:, 3]
+    assert info["reads"] == int((pops > 48).sum()) > n // 20  # exactly the reads beyond the budget went to the host, and they are many
+    assert info["host_pops"] == int(pops[pops > 48].sum()) and info["gpu_pops"] >= 48 * info["reads"]
+    assert (res.status & 16).sum() == 0  # no read is left marked "handed over"
+    off, info_off = _map(pidx, params, seqs, quals, offsets, tail_pops=0)
+    assert info_off["reads"] == 0
+    _same(res, off)
+
+
+def test_limit_recovery_and_abort_on_the_host():
+    """Tiny STACK_LIMIT / EDIT_TREE_LIMIT: the reads that reach the host run into the overflow recovery (pop_min eviction, slab key reuse) or the abort there."""
+    g = synth.genome(100_000, seed=5)
+    seqs, quals, offsets = synth.reads(g, 600, 50, seed=11)
+    reads, qs = split_reads(seqs, quals, offsets)
+    pidx = mapad_amd.Index.build([("chr1", g)])
+    oidx = ob.OracleIndex.from_bwt(pidx.bwt(), "$ACGTX", 128)
+    for limits in ({"stack_limit": 40, "edit_tree_limit": 100000}, {"stack_limit": 100000, "edit_tree_limit": 120}, {"stack_limit": 40, "edit_tree_limit": 100000, "stack_limit_abort": 1}):
+        rp = dict(resolve_params(NO_DAMAGE), **limits)
+        res, info = _map(pidx, mapad_amd.make_params(rp), seqs, quals, offsets, tail_pops=30)
+        ores = oidx.map_batch(ob.make_params(rp), reads, qs, n_threads=8, keep_d=True)
+        assert ores.counters[:, 3].max() > 40 and info["reads"] > 20
+        assert_same_as_oracle(ores, res, offsets)
+        if limits.get("stack_limit_abort"):
+            assert (res.status == 2).any()
+
+
+def test_full_ring_leaves_reads_on_the_gpu(monkeypatch):
+    """More reads pass the budget than the ring has records: the rest stays on the GPU; nothing changes."""
+    monkeypatch.setenv("MAPAD_TAIL_RING", "16")
+    g = synth.genome(200_000, seed=9)
+    seqs, quals, offsets = synth.reads(g, 2000, 50, seed=2, qual_range=(20, 40), damage=dict(f=0.5, t=0.5, d=0.02, s=1.0))
+    rp = resolve_params(DAMAGE)
+    pidx = mapad_amd.Index.build([("chr1", g)])
+    oidx = ob.OracleIndex.from_bwt(pidx.bwt(), "$ACGTX", 128)
+    res, info = _map(pidx, mapad_amd.make_params(rp), seqs, quals, offsets, tail_pops=40)
+    reads, qs = split_reads(seqs, quals, offsets)
+    ores = oidx.map_batch(ob.make_params(rp), reads, qs, n_threads=8, keep_d=True)
+    assert info["reads"] == 16 < int((ores.counters[:, 3] > 40).sum())
+    assert_same_as_oracle(ores, res, offsets)
+
+
+def test_tail_with_batches_in_flight_and_an_uncollected_batch():
+    """Three batches in flight, each with reads on the host; the collect of a batch waits for ITS host reads only.  A batch whose slot is reused before anybody
+    collected it is dropped together with its host reads."""
+    g = synth.genome(300_000, seed=31)
+    rp = resolve_params(DAMAGE)
+    pidx = mapad_amd.Index.build([("chr1", g)])
+    oidx = ob.OracleIndex.from_bwt(pidx.bwt(), "$ACGTX", 128)
+    batches = [synth.reads(g, 1500, 50, seed=40 + i, qual_range=(20, 40), damage=dict(f=0.5, t=0.5, d=0.02, s=1.0)) for i in range(5)]
+    ctx = mapad_amd.Context(pidx, mapad_amd.make_params(rp), 0)
+    try:
+        ctx.set_pipeline_depth(3)
+        ctx.set_tail_pops(64)
+        got = {}
+        for i, b in enumerate(batches):
+            ctx.submit_batch(*b)
+            if i >= 2:
+                ctx.select_batch(2)
+                got[i - 2] = (ctx.fetch(), ctx.tail_info())
+                ctx.select_batch(0)
+        for age, i in ((1, 3), (0, 4)):
+            ctx.select_batch(age)
+            got[i] = (ctx.fetch(), ctx.tail_info())
+        # two more batches are submitted and never collected; then the slots are reused
+        for b in batches[:4]:
+            ctx.submit_batch(*b)
+        ctx.select_batch(0)
+        again = ctx.fetch()
+    finally:
+        ctx.close()
+    for i, b in enumerate(batches):
+        reads, qs = split_reads(*b)
+        ores = oidx.map_batch(ob.make_params(rp), reads, qs, n_threads=8, keep_d=True)
+        assert_same_as_oracle(ores, got[i][0], b[2])
+        assert got[i][1]["reads"] == int((ores.counters[:, 3] > 64).sum()) > 20
+    _same(again, got[3][0])
