@@ -17,12 +17,14 @@ Workloads (synthetic genome = i.i.d. ACGT from splitmix64(1234), re
   c5  the read mix of C5 (35-100 bp, 5 % of the reads with an indel, damage model) on the 48 Mbp genome, 1 M reads per step
 One "step" = one pass of the hot path (D-array kernel, ordering, search kernel + its retry / full-limit launches) over the batch;
 reads, index and score tables are resident in HBM before the timed region.  With N > 1 every rank holds a replica of the index, maps
-its own shard (weak scaling) and, inside every step, lays its hits out in read order on the device and sends them to rank 0 (RCCL
-point-to-point over xGMI); after the timed region rank 0 merges the shards and checks them against every rank's own result.
+its own shard (weak scaling) and, inside every step, lays its hits out in read order on the device, turns them into record fields there (coordinates,
+CIGAR / MD / XA text, MAPQ inputs: <= 128 bytes per read) and sends those to rank 0 (RCCL point-to-point over xGMI); after the timed region rank 0 merges
+the shards and checks them against every rank's own copy.
 
 Also on the line: `roofline` (dominant kernel: algorithmic bytes from the kernels' event counters / HIP-event time), `cpu_baseline`
 (the C++ oracle on the host cores over a bounded sample, N = 1 only; its hits must equal the GPU's), `e2e` (host buffers in, host
-results out: H2D + kernels + device-side collect + D2H), `sa_locate` and `post_search` (the next rows of the path).
+results out: H2D + kernels + device-side collect + D2H), `sa_locate` and `post_search` (the next rows of the path), `tail` (reads finished by host threads),
+`secondary` (C4 only: short C2 / C3 runs).
 """
 import argparse
 import ctypes
@@ -104,6 +106,7 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target wall time of the CPU baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the e2e / cli / sa_locate / post_search legs")
+    ap.add_argument("--no-secondary", action="store_true", help="C4 only: skip the short C2 / C3 runs (BASELINE.json configs[1], configs[2]) reported under `secondary`")
     ap.add_argument("--no-cli", action="store_true", help="skip the command-line leg (FASTQ -> BAM; at C4 it writes and re-reads the 3 Gbp index files)")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo: test mode for boxes with one GPU — every rank uses device 0 and the gather goes through host memory")
@@ -112,6 +115,7 @@ def main():
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="N > 1: weak = --reads per GPU (total work grows with N); strong = ONE chunk of --reads reads cut into N contiguous slices (SURVEY 8e)")
     ap.add_argument("--watchdog-s", type=float, default=600.0, help="N > 1: exit 3 if no step or gather completes for this long (a starved transfer must not hang the node)")
+    ap.add_argument("--search-waves-per-cu", type=int, default=0, help="resident search wavefronts per CU (0 = the library's default, the same for every N)")
     ap.add_argument("--own-index", action="store_true", help="N > 1: every rank builds its own index instead of loading the files rank 0 wrote")
     args = ap.parse_args()
     if args.depth is None:
@@ -136,7 +140,7 @@ def main():
 
     import mapad_amd
     from mapad_amd import synth
-    from mapad_amd.distributed import gather_hit_records, merge_gathered
+    from mapad_amd.distributed import gather_hit_records, merge_gathered_records
     from mapad_amd.presets import DAMAGE, NO_DAMAGE, resolve as resolve_params
 
     if not torch.cuda.is_available():
@@ -154,8 +158,10 @@ def main():
     xdev = dev if args.dist_backend == "nccl" else torch.device("cpu")  # where the exchanged tensors live
     # sizes travel over a CPU group: a GPU collective is a kernel that needs wave slots, and the persistent search wavefronts hold them (distributed.py)
     meta_group = dist.new_group(backend="gloo") if world > 1 and args.dist_backend == "nccl" else None
-    if world > 1:  # 8 search wavefronts per CU map as fast as 12 once batches overlap, and leave registers and LDS on every CU for RCCL's kernels
-        os.environ.setdefault("MAPAD_TIER0_WAVES_PER_CU", "8")
+    # (N > 1 runs the search launches like N = 1 — as many wavefronts per CU as fit: a launch leaves 12 KB of LDS and one wavefront's registers free on every CU,
+    #  which is what RCCL's transfer kernels need; --search-waves-per-cu 8 is the fall-back should the watchdog ever report a starved transfer)
+    if args.search_waves_per_cu:
+        os.environ["MAPAD_TIER0_WAVES_PER_CU"] = str(args.search_waves_per_cu)
 
     # ---- watchdog (N > 1): a rank that makes no progress for --watchdog-s seconds ends the job with a fresh exit (never an exec) ---------------
     import threading
@@ -256,18 +262,27 @@ def main():
     d_offsets = torch.from_numpy(offsets.view(np.int64)).to(dev)
     torch.cuda.synchronize(dev)
 
+    gather_bytes = []  # per gathered step: bytes this rank put on the links
+
+    def record_views():
+        """The selected batch's record fields on the device (collect, then the coordinate and text kernels over the device-resident hits): 88-byte records,
+        text pool, MAPQ pairs — as int32 tensors over the library's buffers (the text padded to whole words)."""
+        p_rec, p_text, p_pairs, n_text, n_pairs = ctx.records_device(0)
+        recs = torch.as_tensor(DevArray(p_rec, (n_reads * 22,), "<i4"), device=dev)
+        text = torch.as_tensor(DevArray(p_text, ((n_text + 3) // 4 + 1,), "<i4"), device=dev)[:(n_text + 3) // 4]
+        pairs = torch.as_tensor(DevArray(p_pairs, (max(n_pairs, 1) * 2,), "<i4"), device=dev)[:n_pairs * 2]
+        return recs, text, pairs
+
     def gather_hits():
-        """The only exchange of the path: every rank's read-ordered hit records (device-side collect) go to rank 0."""
+        """The only exchange of the path: every rank's record fields in read order (<= 128 bytes per read once the SA lookup is on the device) go to rank 0."""
         if world == 1:
             return None
-        p_begin, p_hits, p_ops, n_hits, n_ops = ctx.compact_device()
-        begin = torch.as_tensor(DevArray(p_begin, (n_reads + 1,), "<i8"), device=dev).view(torch.int32)
-        hits = torch.as_tensor(DevArray(p_hits, (max(n_hits, 1) * 10,), "<i4"), device=dev)[:n_hits * 10]
-        ops = torch.as_tensor(DevArray(p_ops, (max(n_ops, 1),), "<i4"), device=dev)[:n_ops]
+        recs, text, pairs = record_views()
+        gather_bytes.append(4 * (recs.numel() + text.numel() + pairs.numel()))
         if args.dist_backend == "gloo":
             torch.cuda.synchronize(dev)
-            begin, hits, ops = begin.cpu(), hits.cpu(), ops.cpu()
-        return gather_hit_records(begin, hits, ops, rank, world, device=xdev, meta_group=meta_group)
+            recs, text, pairs = recs.cpu(), text.cpu(), pairs.cpu()
+        return gather_hit_records(recs, text, pairs, rank, world, device=xdev, meta_group=meta_group)
 
     tail_steps = []  # per collected step: the host tail's figures (csrc/host_tail.hpp)
 
@@ -350,16 +365,22 @@ def main():
     # ---- N > 1: rank 0 rebuilds the read-ordered hit list of the whole chunk and checks it against every rank's own result ---------
     gather_check = None
     if world > 1:
-        own = digest(res.hit_begin, res.hits_arr, res.ops)
+        ctx.select_batch(1 if args.depth > 1 else 0)  # the last timed step's batch: still in its slot (the solo launch went to the next one)
+        own = digest(*[t.cpu().numpy() for t in record_views()]) if args.depth > 1 else None
+        ctx.select_batch(0)
+        if own is None:  # depth 1: the slot has been launched again; the solo launch maps the same reads, so its records are the same
+            own = digest(*[t.cpu().numpy() for t in record_views()])
         all_own = [None] * world
         dist.all_gather_object(all_own, own)
         loads = [None] * world
         dist.all_gather_object(loads, None if t_index_load is None else round(t_index_load, 1))
         if rank == 0:
-            hb, hits, ops, per_rank = merge_gathered(gathered)
+            m_recs, m_text, m_pairs, per_rank = merge_gathered_records(gathered)
             ok = [per_rank[r] == all_own[r] for r in range(world)]
-            gather_check = {"world_size_seen": dist.get_world_size(), "ranks_identical_to_own_fetch": int(sum(ok)), "merged_reads": int(len(hb) - 1),
-                            "merged_hits": int(hits.shape[0]), "merged_ops": int(ops.size), "per_rank": rank_rates,
+            gather_check = {"world_size_seen": dist.get_world_size(), "ranks_identical_to_own_fetch": int(sum(ok)), "merged_reads": int(m_recs.shape[0]),
+                            "merged_mapped": int((m_recs[:, 3] != 0).sum()), "merged_text_bytes": int(m_text.size), "merged_pairs": int(m_pairs.size // 2),
+                            "payload": "per read an 88-byte record (position, contig, strand, AS / XS / NM / X0 / X1 / XT, text and pair offsets) + its CIGAR / MD / XA text + the (score, size) pairs of the mapping quality",
+                            "bytes_per_read": round(sum(gather_bytes) / max(len(gather_bytes), 1) / max(n_reads, 1), 1), "per_rank": rank_rates,
                             "exchange": "RCCL point-to-point fan-in to rank 0 over xGMI, issued behind the next step's submission" if args.dist_backend == "nccl" else "gloo through host memory (test mode)",
                             "index": {"built_by": "rank 0, saved, loaded by the others" if shared is not None else "every rank", "save_s": None if t_index_save is None else round(t_index_save, 1), "load_s_per_rank": loads}}
             if not all(ok):
@@ -521,6 +542,23 @@ def main():
     ctx.close()  # the command-line leg below starts a process with a context of its own on the same GPU: this one's 180 GB of pools must be gone
     mapped_fraction = round(float((np.diff(res.hit_begin.astype(np.int64)) > 0).mean()), 4)
     del res
+    # ---- the other single-GPU configurations of BASELINE.json, briefly: C2 (no damage) and C3 (damage model) on the 48 Mbp genome ----------------------
+    # (own processes with contexts of their own, after this one's pools are gone; each line is this script's with --no-extras: reads/s, roofline, parity sample)
+    secondary = None
+    if extras and args.config == "c4" and not args.no_secondary:
+        secondary = {}
+        for cfg in ("c2", "c3"):
+            try:
+                t = time.perf_counter()
+                pr = subprocess.run([sys.executable, os.path.abspath(__file__), "--config", cfg, "--steps", "5", "--warmup", "1", "--no-extras", "--cpu-seconds", "4"],
+                                    stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+                d = json.loads(pr.stdout.strip().splitlines()[-1])
+                r = d["roofline"]
+                secondary[cfg] = {"reads_per_s": d["value"], "ms_per_step": d["ms_per_step"], "steps": d["steps"], "workload": d["config"]["workload"], "batches_in_flight": d["config"]["batches_in_flight"],
+                                  "roofline": {k: r[k] for k in ("kernel", "achieved", "frac", "traffic", "traffic_stale", "kernel_ms", "algorithmic_bytes_per_launch")},
+                                  "solo_launch": r["solo_launch"], "cpu_baseline": d["cpu_baseline"], "parity": d["parity"], "tail": d["tail"], "wall_s": round(time.perf_counter() - t, 1)}
+            except Exception as e:
+                secondary[cfg] = {"skipped": f"{type(e).__name__}: {e}"}
     # ---- the command line end to end: FASTQ in, BAM out (reader, GPU mapping, records, BAM encoding + BGZF, all overlapped) -----------------
     cli = None
     if extras and args.config in ("c2", "c3", "c4") and not args.no_cli:
@@ -601,7 +639,7 @@ def main():
                      "pops_share": round(tail_last["host_pops"] / max(n_pop_all, 1), 5), "gpu_pops_before_hand_over": tail_last["gpu_pops"],
                      "host_s_per_step": round(sum(t["host_us"] for t in tail_timed) / max(len(tail_timed), 1) / 1e6, 3), "budget_pops": tail_last["budget"],
                      "where": f"{tail_last['threads']} host threads, search_core.hpp compiled for the host (the kernel's source; from scratch), overlapped with the GPU's bulk" if tail_last["budget"] else "off"},
-            "e2e": e2e, "cli": cli, "sa_locate": locate, "post_search": post,
+            "secondary": secondary, "e2e": e2e, "cli": cli, "sa_locate": locate, "post_search": post,
         }
         if gather_check is not None:
             line["gather"] = gather_check

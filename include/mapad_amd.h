@@ -271,6 +271,13 @@ int mapad_hits_to_records_gpu(mapad_ctx_t* ctx, const mapad_batch_result_t* res,
  * (which hit is reported, its coordinate, the XA candidates, X0 / X1: one kernel over the hits that are still resident on the device, one small copy back);
  * mapad_coords_to_records() is the host half (flags, CIGAR / MD / XA text, XS / XT, mapping quality) — it needs no context and may run on any thread
  * while the GPU thread goes on submitting and fetching.  Together they return exactly what mapad_hits_to_records_gpu() returns. */
+/* The same products left on the device, for the batch selected by mapad_ctx_select_batch (its collect is done first): per read one 88-byte record
+ * {i64 pos; i32 tid; u32 mapped, reverse; f32 as, xs; i32 nm, x0, x1; u32 has_xs, xt, text_off, cigar_len, md_len, xa_len; f32 best_size; u32 read_len, mq_off, mq_n, error}
+ * (csrc/text_core.hpp: DevRecord), the text pool ([CIGAR][MD][XA] of a read behind its text_off) and the pool of (score, size) f32 pairs the mapping
+ * quality is computed from (mq_n pairs behind mq_off) — what a rank sends to rank 0 in the multi-GPU gather (<= 128 bytes per read; the
+ * reference's ResultSheet return path, src/distributed/dispatcher.rs:223-247).  Valid until the batch slot is launched again.  Flags and MAPQ are
+ * finished on the host (mapad_coords_to_records' arithmetic: glibc exp2f / log10f). */
+int mapad_records_device(mapad_ctx_t* ctx, uint64_t seed, void** d_records, void** d_text, void** d_pairs, uint64_t* text_bytes, uint64_t* n_pairs);
 typedef struct mapad_coords mapad_coords_t;
 int mapad_hits_to_coords_gpu(mapad_ctx_t* ctx, const mapad_batch_result_t* res, uint64_t seed, mapad_coords_t** out);
 int mapad_coords_to_records(const mapad_index_t* idx, const mapad_params_t* params, const mapad_batch_result_t* res, const uint16_t* in_flags,

@@ -131,6 +131,7 @@ SYMBOLS = {
     "mapad_sa_locate": (_i32, [_vp, _vp, _u64, _vp]),
     "mapad_last_locate_info": (_i32, [_vp, C.POINTER(C.c_float), C.POINTER(_u64), C.POINTER(_u64)]),
     "mapad_hits_to_records_gpu": (_i32, [_vp, C.POINTER(BatchResultC), _vp, _vp, _vp, _vp, _u64, C.POINTER(C.POINTER(RecordsC))]),
+    "mapad_records_device": (_i32, [_vp, _u64, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_u64), C.POINTER(_u64)]),
     "mapad_hits_to_coords_gpu": (_i32, [_vp, C.POINTER(BatchResultC), _u64, C.POINTER(_vp)]),
     "mapad_coords_to_records": (_i32, [_vp, _PP, C.POINTER(BatchResultC), _vp, _vp, C.POINTER(C.POINTER(RecordsC))]),
     "mapad_coords_free": (None, [_vp]),
@@ -388,6 +389,13 @@ class Context:
         n = C.c_uint32()
         _check(lib().mapad_kernel_history(self.h, _ptr(out), cap, C.byref(n)), "mapad_kernel_history")
         return out[:min(cap, int(n.value))].copy()
+
+    def records_device(self, seed=0):
+        """record fields of the selected batch on the device: (d_records [n x 88 B], d_text, d_pairs, text_bytes, n_pairs) — what the multi-GPU gather sends"""
+        p = [C.c_void_p() for _ in range(3)]
+        nt, npairs = _u64(), _u64()
+        _check(lib().mapad_records_device(self.h, int(seed), C.byref(p[0]), C.byref(p[1]), C.byref(p[2]), C.byref(nt), C.byref(npairs)), "mapad_records_device")
+        return p[0].value, p[1].value, p[2].value, int(nt.value), int(npairs.value)
 
     def compact_device(self):
         """device-side order-preserving collect of the last batch: (d_hit_begin, d_hits, d_ops, n_hits, n_ops)"""

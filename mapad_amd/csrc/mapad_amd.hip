@@ -658,8 +658,9 @@ __device__ __forceinline__ T kernarg_reload(size_t off, const T& by_value) {
 #endif
 // Payload cache (search_core.hpp: search_step<.., PC>): the frames in heap slots 1 and 2 are kept in 64 bytes of LDS per read slot, so that a pop starts its rank
 // queries straight after the look at the heap's top instead of after a trip to the arena for the popped frame's node.  Quads with near data in LDS only.
+// MEASURED SLOWER (round 4, same-box A/B, profiles/r04/ab_step_levers.txt: C4 -5 ... -7 %, C2 -3 ... -10 %): off by default, kept as a tested build option.
 #if !defined(MAPAD_PAYLOAD_CACHE)
-#define MAPAD_PAYLOAD_CACHE 1
+#define MAPAD_PAYLOAD_CACHE 0
 #endif
 template <int LPR> struct top_of { static constexpr int value = LPR == 2 ? MAPAD_KTOP2 : kTop; };
 template <int LPR, bool CONT, int PASS, bool NL, bool HEAVY>
@@ -1037,6 +1038,11 @@ struct BatchSlot {
     PinnedBuf<uint8_t> tail_ring;
     std::shared_ptr<host::TailBatch> tail;  // set while the launch's handed-over reads have not been merged into its pools
     DevBuf<uint8_t> d_tail_up;
+    // record fields of the slot's batch on the device (mapad_records_device: what the multi-GPU gather sends)
+    DevBuf<CoordRec> d_rec_coords;
+    DevBuf<DevRecord> d_rec_out;
+    DevBuf<char> d_rec_text;
+    DevBuf<float> d_rec_pairs;
     uint64_t tail_info[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // reads, pops on the GPU before the hand-over, pops on the host, host wall microseconds, threads, budget, host E_search, N_push, N_node, -
 
     void release() {
@@ -1046,6 +1052,7 @@ struct BatchSlot {
         d_c_hit_begin.release(); d_c_ops_begin.release(); d_c_tiles.release(); d_c_hits.release(); d_c_ops.release();
         if (tail) { host::tail_cancel(tail); tail.reset(); }
         d_tail_up.release();
+        d_rec_coords.release(); d_rec_out.release(); d_rec_text.release(); d_rec_pairs.release();
         for (auto& e : ev) if (e) { (void)hipEventDestroy(e); e = nullptr; }
         if (ev_in) { (void)hipEventDestroy(ev_in); ev_in = nullptr; }
         if (own_stream && stream) (void)hipStreamDestroy(stream);
@@ -2213,21 +2220,68 @@ struct mapad_coords {
     std::vector<float> pairs;
     uint64_t n = 0;
 };
-static int record_coords_gpu(mapad_ctx_t* ctx, const mapad_batch_result_t* res, uint64_t seed, mapad_coords& co) {
-    std::vector<CoordRec>& coords = co.v;
-    co.n = res->n_reads;
-    const char* tm = std::getenv("MAPAD_RECORDS_TEXT");
-    co.device_text = !(tm && std::strcmp(tm, "host") == 0);
+// The post-search kernels over read-ordered hits on the device: records_kernel (coordinates) and, `device_text`, text_kernel (CIGAR / MD / XA bytes and the pairs
+// of the mapping quality) into the given buffers; used[0] = text bytes, used[1] = pairs.  Synchronises rstream.
+struct RecordBufs {
+    DevBuf<CoordRec>& coords;
+    DevBuf<DevRecord>& out;
+    DevBuf<char>& text;
+    DevBuf<float>& pairs;
+};
+static int run_record_kernels(mapad_ctx_t* ctx, const uint64_t* d_begin, const HitRec* d_hits, const uint32_t* d_ops, uint64_t n, uint64_t seed, hipStream_t rstream, RecordBufs bufs,
+                              bool device_text, unsigned long long used[2]) {
     const host::Index& ix = ctx->index->ix;
     uint32_t shift = 0;
     while ((1ull << shift) < ix.sa_rate) ++shift;
     if ((1ull << shift) != ix.sa_rate || shift < 1 || shift > 8 || ix.extra_rows.size() > 2) return MAPAD_ERR_INVALID;  // the kernels' assumptions
     int rc;
+    used[0] = used[1] = 0;
+    if ((rc = bufs.coords.ensure(n))) return rc;
+    PostIndex Q{};
+    Q.ix = ctx->dix; Q.sa_sample = ctx->d_sa.p; Q.x_counts = ix.x_counts.empty() ? nullptr : ctx->d_xc.p; Q.sa_shift = shift;
+    int k = 0;
+    for (const auto& kv : ix.extra_rows) { Q.extra_row[k] = kv.first; Q.extra_val[k] = kv.second; ++k; }
+    for (; k < 2; ++k) { Q.extra_row[k] = ~0ull; Q.extra_val[k] = 0; }
+    Q.n_contigs = (uint32_t)ix.contigs.size(); Q.contig_start = ctx->d_contigs.p; Q.contig_end = ctx->d_contigs.p + ix.contigs.size();
+    HIP_TRY(hipEventRecord(ctx->lev[0], rstream));
+    hipLaunchKernelGGL(records_kernel, dim3((uint32_t)((n + 63) / 64)), dim3(64), 0, rstream, Q, d_begin, d_hits, d_ops, n, seed, bufs.coords.p);
+    HIP_TRY(hipGetLastError());
+    ctx->last_locate_rows = n; ctx->last_locate_steps = 0;
+    if (!device_text) { HIP_TRY(hipEventRecord(ctx->lev[1], rstream)); return MAPAD_OK; }
+    // the text half on the device: CIGAR / MD / XA bytes and the pairs of the mapping quality into two pools; what leaves the device is one 88-byte record
+    // per read plus the text (typically "50M" + "50": a dozen bytes per read)
+    if ((rc = bufs.out.ensure(n))) return rc;
+    if ((rc = bufs.text.ensure(std::max<size_t>(bufs.text.cap, (size_t)n * 24 + (1u << 16))))) return rc;
+    if ((rc = bufs.pairs.ensure(std::max<size_t>(bufs.pairs.cap, (size_t)n * 2 + 4096)))) return rc;
+    for (int attempt = 0; attempt < 8; ++attempt) {
+        HIP_TRY(hipMemsetAsync(ctx->d_t_cur.p, 0, 16, rstream));
+        TextDev TQ{};
+        TQ.T.os_pos = ctx->d_os_pos.p; TQ.T.os_sym = ctx->d_os_sym.p; TQ.T.n_os = ctx->n_os; TQ.T.name_off = ctx->d_name_off.p; TQ.T.names = (const char*)ctx->d_names.p;
+        TQ.hit_begin = d_begin; TQ.hits = d_hits; TQ.ops = d_ops; TQ.coords = bufs.coords.p; TQ.n_reads = n;
+        TQ.text = bufs.text.p; TQ.pairs = bufs.pairs.p; TQ.cursors = ctx->d_t_cur.p; TQ.text_cap = bufs.text.cap; TQ.pair_cap = bufs.pairs.cap / 2; TQ.out = bufs.out.p;
+        hipLaunchKernelGGL(text_kernel, dim3((uint32_t)((n + 63) / 64)), dim3(64), 0, rstream, TQ);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(used, ctx->d_t_cur.p, 16, hipMemcpyDeviceToHost, rstream));
+        HIP_TRY(hipStreamSynchronize(rstream));
+        if (used[0] <= TQ.text_cap && used[1] <= TQ.pair_cap) break;
+        if (used[0] > 0xFFFFFFFFull || used[1] > 0xFFFFFFFFull) return MAPAD_ERR_INVALID;  // more than 4 GiB of record text in one batch
+        if (attempt == 7) return MAPAD_ERR_NOMEM;
+        if (used[0] > TQ.text_cap && (rc = bufs.text.ensure((size_t)used[0] + (1u << 16)))) return rc;
+        if (used[1] > TQ.pair_cap && (rc = bufs.pairs.ensure((size_t)used[1] * 2 + 4096))) return rc;
+    }
+    HIP_TRY(hipEventRecord(ctx->lev[1], rstream));
+    return MAPAD_OK;
+}
+static int record_coords_gpu(mapad_ctx_t* ctx, const mapad_batch_result_t* res, uint64_t seed, mapad_coords& co) {
+    std::vector<CoordRec>& coords = co.v;
+    co.n = res->n_reads;
+    const char* tm = std::getenv("MAPAD_RECORDS_TEXT");
+    co.device_text = !(tm && std::strcmp(tm, "host") == 0);
+    int rc;
     if ((rc = ensure_sa_uploaded(ctx))) return rc;
     const uint64_t n = res->n_reads;
     if (!co.device_text) coords.resize(n);
     if (!n) return MAPAD_OK;
-    if ((rc = ctx->d_r_out.ensure(n))) return rc;
     // The hits are normally still on the device, laid out in read order by the collect of the fetch that produced `res` (the batch slot has not
     // been launched again since): the kernel reads them where they are.  Otherwise (an older result) they go back over PCIe first.
     const HostResult* hr = LiveResults::get().has(res) ? reinterpret_cast<const HostResult*>(res) : nullptr;  // a result of this library: pub is the first member
@@ -2246,45 +2300,13 @@ static int record_coords_gpu(mapad_ctx_t* ctx, const mapad_batch_result_t* res, 
         if (res->n_ops) HIP_TRY(hipMemcpyAsync(ctx->d_r_ops.p, res->ops, res->n_ops * 4, hipMemcpyHostToDevice, ctx->stream));
         d_begin = ctx->d_r_begin.p; d_hits = ctx->d_r_hits.p; d_ops = ctx->d_r_ops.p;
     }
-    PostIndex Q{};
-    Q.ix = ctx->dix; Q.sa_sample = ctx->d_sa.p; Q.x_counts = ix.x_counts.empty() ? nullptr : ctx->d_xc.p; Q.sa_shift = shift;
-    int k = 0;
-    for (const auto& kv : ix.extra_rows) { Q.extra_row[k] = kv.first; Q.extra_val[k] = kv.second; ++k; }
-    for (; k < 2; ++k) { Q.extra_row[k] = ~0ull; Q.extra_val[k] = 0; }
-    Q.n_contigs = (uint32_t)ix.contigs.size(); Q.contig_start = ctx->d_contigs.p; Q.contig_end = ctx->d_contigs.p + ix.contigs.size();
-    HIP_TRY(hipEventRecord(ctx->lev[0], rstream));
-    hipLaunchKernelGGL(records_kernel, dim3((uint32_t)((n + 63) / 64)), dim3(64), 0, rstream, Q, d_begin, d_hits, d_ops, n, seed, ctx->d_r_out.p);
-    HIP_TRY(hipGetLastError());
-    ctx->last_locate_rows = n; ctx->last_locate_steps = 0;
+    unsigned long long used[2] = {0, 0};
+    if ((rc = run_record_kernels(ctx, d_begin, d_hits, d_ops, n, seed, rstream, RecordBufs{ctx->d_r_out, ctx->d_t_out, ctx->d_t_text, ctx->d_t_pairs}, co.device_text, used))) return rc;
     if (!co.device_text) {
-        HIP_TRY(hipEventRecord(ctx->lev[1], rstream));
         HIP_TRY(hipMemcpyAsync(coords.data(), ctx->d_r_out.p, n * sizeof(CoordRec), hipMemcpyDeviceToHost, rstream));
         HIP_TRY(hipStreamSynchronize(rstream));
         return MAPAD_OK;
     }
-    // the text half on the device: CIGAR / MD / XA bytes and the pairs of the mapping quality into two pools; what crosses PCIe is one 88-byte record
-    // per read plus the text (typically "50M" + "50": a dozen bytes per read)
-    if ((rc = ctx->d_t_out.ensure(n))) return rc;
-    if ((rc = ctx->d_t_text.ensure(std::max<size_t>(ctx->d_t_text.cap, (size_t)n * 24 + (1u << 16))))) return rc;
-    if ((rc = ctx->d_t_pairs.ensure(std::max<size_t>(ctx->d_t_pairs.cap, (size_t)n * 2 + 4096)))) return rc;
-    unsigned long long used[2] = {0, 0};
-    for (int attempt = 0; attempt < 8; ++attempt) {
-        HIP_TRY(hipMemsetAsync(ctx->d_t_cur.p, 0, 16, rstream));
-        TextDev TQ{};
-        TQ.T.os_pos = ctx->d_os_pos.p; TQ.T.os_sym = ctx->d_os_sym.p; TQ.T.n_os = ctx->n_os; TQ.T.name_off = ctx->d_name_off.p; TQ.T.names = (const char*)ctx->d_names.p;
-        TQ.hit_begin = d_begin; TQ.hits = d_hits; TQ.ops = d_ops; TQ.coords = ctx->d_r_out.p; TQ.n_reads = n;
-        TQ.text = ctx->d_t_text.p; TQ.pairs = ctx->d_t_pairs.p; TQ.cursors = ctx->d_t_cur.p; TQ.text_cap = ctx->d_t_text.cap; TQ.pair_cap = ctx->d_t_pairs.cap / 2; TQ.out = ctx->d_t_out.p;
-        hipLaunchKernelGGL(text_kernel, dim3((uint32_t)((n + 63) / 64)), dim3(64), 0, rstream, TQ);
-        HIP_TRY(hipGetLastError());
-        HIP_TRY(hipMemcpyAsync(used, ctx->d_t_cur.p, 16, hipMemcpyDeviceToHost, rstream));
-        HIP_TRY(hipStreamSynchronize(rstream));
-        if (used[0] <= TQ.text_cap && used[1] <= TQ.pair_cap) break;
-        if (used[0] > 0xFFFFFFFFull || used[1] > 0xFFFFFFFFull) return MAPAD_ERR_INVALID;  // more than 4 GiB of record text in one batch
-        if (attempt == 7) return MAPAD_ERR_NOMEM;
-        if (used[0] > TQ.text_cap && (rc = ctx->d_t_text.ensure((size_t)used[0] + (1u << 16)))) return rc;
-        if (used[1] > TQ.pair_cap && (rc = ctx->d_t_pairs.ensure((size_t)used[1] * 2 + 4096))) return rc;
-    }
-    HIP_TRY(hipEventRecord(ctx->lev[1], rstream));
     co.recs.resize(n); co.text.resize(used[0]); co.pairs.resize(2 * used[1]);
     HIP_TRY(hipMemcpyAsync(co.recs.data(), ctx->d_t_out.p, n * sizeof(DevRecord), hipMemcpyDeviceToHost, rstream));
     if (used[0]) HIP_TRY(hipMemcpyAsync(co.text.data(), ctx->d_t_text.p, used[0], hipMemcpyDeviceToHost, rstream));
@@ -2295,6 +2317,20 @@ static int record_coords_gpu(mapad_ctx_t* ctx, const mapad_batch_result_t* res, 
 static mapad_records_t* records_from(const host::Index& ix, const mapad_params_t& prm, const mapad_batch_result_t& res, const uint16_t* in_flags, const mapad_coords& co) {
     if (co.device_text) return host::records_from_device_text(prm, res.n_reads, in_flags, co.recs.data(), co.text.data(), co.text.size(), co.pairs.data());
     return host::records_from_coords(ix, prm, res, in_flags, co.v.data());
+}
+
+int mapad_records_device(mapad_ctx_t* ctx, uint64_t seed, void** d_records, void** d_text, void** d_pairs, uint64_t* text_bytes, uint64_t* n_pairs) {
+    if (!ctx || !d_records || !d_text || !d_pairs || !text_bytes || !n_pairs) return MAPAD_ERR_INVALID;
+    if (hipSetDevice(ctx->device) != hipSuccess) return MAPAD_ERR_NO_DEVICE;
+    int rc;
+    if ((rc = compact_last(ctx))) return rc;
+    if ((rc = ensure_sa_uploaded(ctx))) return rc;
+    BatchSlot& S = ctx->bs[ctx->view];
+    const uint64_t n = S.last.n_reads;
+    unsigned long long used[2] = {0, 0};
+    if (n && (rc = run_record_kernels(ctx, S.d_c_hit_begin.p, S.d_c_hits.p, S.d_c_ops.p, n, seed, S.stream, RecordBufs{S.d_rec_coords, S.d_rec_out, S.d_rec_text, S.d_rec_pairs}, true, used))) return rc;
+    *d_records = S.d_rec_out.p; *d_text = S.d_rec_text.p; *d_pairs = S.d_rec_pairs.p; *text_bytes = used[0]; *n_pairs = used[1];
+    return MAPAD_OK;
 }
 
 int mapad_hits_to_records_gpu(mapad_ctx_t* ctx, const mapad_batch_result_t* res, const uint8_t* seqs, const uint8_t* quals, const uint64_t* offsets,

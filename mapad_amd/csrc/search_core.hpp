@@ -688,7 +688,7 @@ MAPAD_RARE void search_init(uint64_t n_text, int alignment_start, const ReadInT<
 // a payload is only used if its key equals the node id the heap holds, a live node's payload never changes, and evictions — after which ids are reused — clear
 // the cache.  What leaves the step's dependent chain is one HBM round trip in six.
 #if defined(MAPAD_PC_STATS) && !defined(__HIP_DEVICE_COMPILE__)
-static unsigned long long g_pc_stats[3];
+static unsigned long long g_pc_stats[5];
 #endif
 template <bool NL, int TOP>
 MAPAD_HD void pc_store(const ArenaT<NL, TOP>& A, uint32_t s, uint32_t id, uint64_t w1, uint64_t w2, uint64_t w3) {
@@ -737,6 +737,8 @@ MAPAD_HD bool search_step(const DevIndex& ix, const DevParams& P, const ReadInT<
         }
         top_node.w0 = 0; top_node.w1 = hit ? c1 : g1; top_node.w2 = hit ? c2 : g2; top_node.w3 = hit ? c3 : g3;
     } else top_node = A.nodes[top.node];
+    HeapEntry last;
+    if constexpr (!PC) last = hp_get(A, st.heap_len - 1);  // with the node: both trips are needed before anything else can start
     st.c_pop += 1;
     const Frame f = unpack_frame(top_node);
     const float f_score = top.score;
@@ -752,8 +754,17 @@ MAPAD_HD bool search_step(const DevIndex& ix, const DevParams& P, const ReadInT<
     const float lower_bound = d_get(rd.d, L, alignment_start, d_k, d_l);                       // :1195
     if (st.n_hits > 0 && mb_reject_iterative(P, f_score + lower_bound, st.best_score)) { st.heap_len -= 1; return false; }  // :1201-1208 (the frame was popped; the search is over)
     MAPAD_MARK(PROF_NODE);
-    HeapEntry last;
-    {   // The heap's last entry, loaded behind the stop rule above so that every path that issues the load also reaches the point where it counts as used
+#if defined(MAPAD_EXP_NOPS) && defined(__HIP_DEVICE_COMPILE__)
+    {   // experiment ("what bounds the step"): MAPAD_EXP_NOPS extra vector instructions per step that do nothing
+        uint32_t dummy = st.c_pop;
+        asm volatile(".rept %1\n\tv_mov_b32 %0, %0\n\t.endr" : "+v"(dummy) : "n"(MAPAD_EXP_NOPS));
+    }
+#endif
+#if defined(MAPAD_EXP_LOADS) && defined(__HIP_DEVICE_COMPILE__)
+    // experiment: one more random 8-byte request per pop (a node of this read's slab), used nowhere; counted as arrived where the rank queries are (consume_here)
+    const uint64_t exp_word = A.nodes[(uint32_t)(((uint64_t)top.node * 2654435761ull) % st.tree_entries)].w0;
+#endif
+    if constexpr (PC) {   // The heap's last entry, loaded behind the stop rule above so that every path that issues the load also reaches the point where it counts as used
         // (consume_here).  Near read (clamped) for every slot, arena load predicated: as one two-armed branch the arms share their destination registers, and
         // the wait-count pass then puts a full drain in front of the near arm (any wavefront with a slot whose heap is still small).
         const uint32_t li = st.heap_len - 1;
@@ -785,7 +796,12 @@ MAPAD_HD bool search_step(const DevIndex& ix, const DevParams& P, const ReadInT<
     uint32_t pf_id = 0;
     bool pf_valid = false;
     if constexpr (PC) {
-        auto fetch = [&](uint32_t id) { const Node g = A.nodes[id]; pf1 = g.w1; pf2 = g.w2; pf3 = g.w3; pf_id = id; pf_valid = true; };
+        auto fetch = [&](uint32_t id) {
+#if defined(MAPAD_PC_STATS) && !defined(__HIP_DEVICE_COMPILE__)
+            g_pc_stats[3] += 1;  // nodes fetched ahead
+#endif
+            const Node g = A.nodes[id]; pf1 = g.w1; pf2 = g.w2; pf3 = g.w3; pf_id = id; pf_valid = true;
+        };
         if (top_idx < st.heap_len) mm_trickle_down<true>(A, st.heap_len, top_idx, last, fetch);
     } else {
         if (top_idx < st.heap_len) mm_trickle_down<true>(A, st.heap_len, top_idx, last);
@@ -813,7 +829,10 @@ MAPAD_HD bool search_step(const DevIndex& ix, const DevParams& P, const ReadInT<
         nonempty = (e.size[0] >= 1 ? 1u : 0u) | (e.size[1] >= 1 ? 2u : 0u) | (e.size[2] >= 1 ? 4u : 0u) | (e.size[3] >= 1 ? 8u : 0u);
     }
     st.c_esearch += 1;
-    consume_here(last.score); consume_here(last.node);  // older than the rank-query loads just waited for; a step whose pop needs no sift would leave it "pending" (consume_here)
+#if defined(MAPAD_EXP_LOADS) && defined(__HIP_DEVICE_COMPILE__)
+    consume_here(exp_word);
+#endif
+    if constexpr (PC) { consume_here(last.score); consume_here(last.node); }  // older than the rank-query loads just waited for; a step whose pop needs no sift would leave it "pending" (consume_here)
     MAPAD_MARK(PROF_EXT);
 
     // Static gates of the <= 9 children in commit order: Ins; then for k = T,G,C,A: Del(k), Match/Mismatch(k).
@@ -942,6 +961,9 @@ MAPAD_HD bool search_step(const DevIndex& ix, const DevParams& P, const ReadInT<
             pf_valid = false;
             // ... then the child that bubbled into slot 1 or 2, if any (it may have displaced that frame): the lane that built the child holds its payload
             if (land_t != 0xFFu) {
+#if defined(MAPAD_PC_STATS) && !defined(__HIP_DEVICE_COMPILE__)
+                g_pc_stats[4] += 1;  // steps in which a child ended up in slot 1 or 2
+#endif
                 const uint32_t lid = id0 + (uint32_t)popc32(cand0 & ((1u << land_t) - 1u));
                 if constexpr (kLaneKids) {
 #if defined(__HIP_DEVICE_COMPILE__)

@@ -16,7 +16,9 @@ def shard_bounds(n_reads, world, rank):
 
 
 def gather_hit_records(hit_count, hits, ops, rank, world, device=None, meta_group=None):
-    """Gathers (hit_begin as int32 view of uint64[n_reads_local + 1], hits int32[n_hits_local * 10], ops int32[n_ops_local]) on rank 0.
+    """Gathers three int32 buffers per rank on rank 0: either the hit records (hit_begin as int32 view of uint64[n_reads_local + 1], hits
+    int32[n_hits_local * 10], ops int32[n_ops_local]) or — what bench.py sends since round 4 — the compact record fields of mapad_records_device
+    (records int32[n_reads_local * 22], text bytes padded to int32, MAPQ pairs as int32 views of f32), see merge_gathered_records.
 
     Tensors may live on the GPU (nccl/RCCL) or the CPU (gloo).  Returns on rank 0 a list, indexed by source rank, of
     (hit_count, hits, ops) tensors; None elsewhere.  Sizes are exchanged first (all_gather of three int64), then every peer
@@ -99,3 +101,34 @@ def merge_gathered(parts):
         hits.append(h)
         ops.append(o)
     return np.concatenate(begins), np.concatenate(hits), np.concatenate(ops), digests
+
+
+RECORD_WORDS = 22  # csrc/text_core.hpp: DevRecord, 88 bytes
+_REC_TEXT_OFF, _REC_MQ_OFF = 13, 19  # word indices of text_off and mq_off
+
+
+def merge_gathered_records(parts):
+    """rank-ordered (records int32[n_r * 22], text as int32 (bytes padded to a multiple of 4), pairs as int32 views of f32[2 * n_pairs_r]) of read-ordered
+    shards -> the chunk's records (n x 22 int32, text_off / mq_off rebased into the concatenated pools), text bytes, pairs (float32) and the sha256 of
+    each rank's part (which must equal the digest of that rank's own copy).  <= 128 bytes per read cross the links."""
+    import hashlib
+    recs, texts, pairs, digests = [], [], [], []
+    text_base = pair_base = 0
+    for r, t, p in parts:
+        r = np.ascontiguousarray(np.asarray(r.cpu())).reshape(-1, RECORD_WORDS)
+        t = np.ascontiguousarray(np.asarray(t.cpu()))
+        p = np.ascontiguousarray(np.asarray(p.cpu()))
+        dg = hashlib.sha256()
+        for a in (r, t, p):
+            dg.update(a.tobytes())
+        digests.append(dg.hexdigest())
+        r = r.copy()
+        mapped = r[:, 3] != 0
+        r[mapped, _REC_TEXT_OFF] += text_base
+        r[mapped, _REC_MQ_OFF] += pair_base
+        text_base += int(t.size) * 4
+        pair_base += int(p.size) // 2
+        recs.append(r)
+        texts.append(t.view(np.uint8))
+        pairs.append(p.view(np.float32))
+    return np.concatenate(recs), np.concatenate(texts), np.concatenate(pairs), digests

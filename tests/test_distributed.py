@@ -97,6 +97,74 @@ def test_two_rank_sharding_and_gather_matches_single_process(tmp_path):
     assert hb[-1] > 50
 
 
+def _fake_records(n, seed):
+    """n record structs in the layout of csrc/text_core.hpp: DevRecord (22 words) with their text and pair pools, as a rank's mapad_records_device leaves them."""
+    rng = np.random.default_rng(seed)
+    recs = np.zeros((n, 22), np.int32)
+    text, pairs = bytearray(), []
+    for i in range(n):
+        if rng.random() < 0.2:
+            recs[i, 0:2] = -1; recs[i, 2] = -1  # unmapped: pos -1, tid -1, offsets 0
+            continue
+        cig, md, xa = b"%dM" % rng.integers(30, 100), b"%d" % rng.integers(30, 100), (b"chr1,+%d,50M,50,0,1,-1.50;" % rng.integers(1, 10 ** 6)) if rng.random() < 0.3 else b""
+        recs[i, 0] = rng.integers(0, 1 << 30); recs[i, 2] = 0; recs[i, 3] = 1
+        recs[i, 13] = len(text); recs[i, 14:17] = (len(cig), len(md), len(xa))
+        text += cig + md + xa
+        k = int(rng.integers(0, 3))
+        recs[i, 19] = len(pairs) // 2; recs[i, 20] = k
+        pairs += [float(x) for x in rng.normal(size=2 * k)]
+    text += b"\0" * (-len(text) % 4)
+    return recs, np.frombuffer(bytes(text), np.uint8).view(np.int32).copy(), np.array(pairs, np.float32).view(np.int32).copy()
+
+
+def _text_of(recs, text, i):
+    o, c, m, x = (int(v) for v in recs[i, 13:17])
+    return bytes(text[o:o + c + m + x])
+
+
+def _records_worker(rank, world, port, out_path):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sys.path.insert(0, ROOT)
+    import hashlib
+    from mapad_amd.distributed import gather_hit_records, merge_gathered_records
+    own = _fake_records(300 + 17 * rank, seed=5 + rank)
+    own_digest = hashlib.sha256(b"".join(np.ascontiguousarray(a).tobytes() for a in own)).hexdigest()
+    meta = dist.new_group(backend="gloo")
+    parts = gather_hit_records(torch.from_numpy(own[0].reshape(-1)), torch.from_numpy(own[1]), torch.from_numpy(own[2]), rank, world, meta_group=meta)
+    digests = [None] * world
+    dist.all_gather_object(digests, own_digest)
+    if rank == 0:
+        recs, text, pairs, per_rank = merge_gathered_records(parts)
+        assert per_rank == digests
+        np.savez(out_path, recs=recs, text=text, pairs=pairs)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gather_of_compact_records(tmp_path):
+    """What bench.py sends since round 4: per read an 88-byte record plus its text and MAPQ pairs (<= 128 bytes per read).  Rank 0's merge must
+    rebase every shard's text and pair offsets so that each read still finds its own CIGAR / MD / XA bytes and pairs."""
+    out = str(tmp_path / "records.npz")
+    mp.spawn(_records_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    got = np.load(out)
+    shards = [_fake_records(300, seed=5), _fake_records(317, seed=6)]
+    assert got["recs"].shape == (617, 22)
+    base = 0
+    for recs, text, pairs in shards:
+        tb, pf = text.view(np.uint8), pairs.view(np.float32)
+        for i in range(recs.shape[0]):
+            g = got["recs"][base + i]
+            assert np.array_equal(np.delete(g, [13, 19]), np.delete(recs[i], [13, 19]))
+            if recs[i, 3]:
+                assert _text_of(got["recs"], got["text"], base + i) == _text_of(recs, tb, i)
+                k = int(recs[i, 20])
+                assert np.array_equal(got["pairs"][2 * int(g[19]):2 * int(g[19]) + 2 * k], pf[2 * int(recs[i, 19]):2 * int(recs[i, 19]) + 2 * k])
+        base += recs.shape[0]
+    per_read = (got["recs"].nbytes + got["text"].nbytes + got["pairs"].nbytes) / 617
+    assert per_read <= 128
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("scaling", ["weak", "strong"])
 def test_bench_two_ranks_on_one_gpu_over_gloo(scaling):
@@ -116,5 +184,6 @@ def test_bench_two_ranks_on_one_gpu_over_gloo(scaling):
     g = line["gather"]
     assert line["n_gpus"] == 2 and line["scaling"] == scaling and g["world_size_seen"] == 2 and g["ranks_identical_to_own_fetch"] == 2
     assert g["merged_reads"] == (120000 if scaling == "weak" else 60000)
+    assert g["bytes_per_read"] <= 128 and g["merged_mapped"] > 0.8 * g["merged_reads"]  # compact records on the links, not hit intervals + edit tracks
     assert g["index"]["built_by"].startswith("rank 0") and g["index"]["load_s_per_rank"][1] is not None
     assert len(g["per_rank"]) == 2 and sum(r["reads"] for r in g["per_rank"]) == g["merged_reads"]

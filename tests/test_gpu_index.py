@@ -165,6 +165,7 @@ def test_index_beyond_2_pow_32_rows_maps_like_the_oracle(monkeypatch):
         rp = dict(resolve_params(DAMAGE), **c5_limits)
         monkeypatch.setenv("MAPAD_CLASS_COUNTS", os.environ.get("MAPAD_TEST_C5_CLASS_COUNTS", "8192,4096,2048,1024,0,0,0,0,0,0"))
         ctx = mapad_amd.Context(pidx, mapad_amd.make_params(rp), 0)
+        ctx.set_tail_pops(0)  # this case is about the GPU's own stages (growth through the size classes, the full-limit stage): nothing goes to the host tail
         t5 = time.time()
         res = ctx.map_batch(seqs, quals, offsets)
         t6 = time.time()
@@ -177,3 +178,38 @@ def test_index_beyond_2_pow_32_rows_maps_like_the_oracle(monkeypatch):
         assert_same_as_oracle(ores, res, offsets)
         if "MAPAD_TEST_C5_CLASS_COUNTS" not in os.environ and n_c5 >= 20_000 and n > 2 ** 32:
             assert res.n_third_pass > 0 and res.n_second_pass > 0  # the knobs above did send reads through growth and through the full-limit stage
+    # C5 at the reference's REAL limits (STACK_LIMIT 2 000 000 / EDIT_TREE_LIMIT 10 000 000, mapping.rs:52-54,1358-1380; stack_limit / edit_tree_limit left at 0 =
+    # the defaults): the heaviest reads of a larger sample of the mix — those that search under eviction for millions of pops — as a batch of their own,
+    # bit for bit against the oracle incl. the event counters.  Past the pop budget they are finished by the library's host threads (csrc/host_tail.hpp).
+    n_pre = int(os.environ.get("MAPAD_TEST_C5_PRESELECT", 100_000))
+    n_heavy = int(os.environ.get("MAPAD_TEST_C5_HEAVY", 2_000))
+    if n_pre and n > 2 ** 32:
+        monkeypatch.delenv("MAPAD_CLASS_COUNTS", raising=False)
+        seqs, quals, offsets = synth.reads(g, n_pre, 50, seed=4328, qual_range=(20, 40), damage=dict(f=0.5, t=0.5, d=0.02, s=1.0), len_range=(35, 100), indel_frac=0.05)
+        rp = resolve_params(DAMAGE)
+        ctx = mapad_amd.Context(pidx, mapad_amd.make_params(rp), 0)
+        t5 = time.time()
+        res = ctx.map_batch(seqs, quals, offsets)
+        info = ctx.tail_info()
+        t6 = time.time()
+        pops = res.counters["n_pop"].astype(np.int64)
+        heavy = np.sort(np.argsort(pops)[-n_heavy:])
+        lens = np.diff(offsets.astype(np.int64))
+        h_off = np.zeros(len(heavy) + 1, np.uint64)
+        h_off[1:] = np.cumsum(lens[heavy])
+        h_seqs = np.concatenate([seqs[int(offsets[i]):int(offsets[i + 1])] for i in heavy])
+        h_quals = np.concatenate([quals[int(offsets[i]):int(offsets[i + 1])] for i in heavy])
+        hres = ctx.map_batch(h_seqs, h_quals, h_off)
+        hinfo = ctx.tail_info()
+        t7 = time.time()
+        ctx.close()
+        reads, qs = split_reads(h_seqs, h_quals, h_off)
+        ores = oidx.map_batch(ob.make_params(rp), reads, qs, n_threads=os.cpu_count() or 8, keep_d=True)
+        t8 = time.time()
+        print(f"C5 at the real limits: {n_pre} reads in {t6 - t5:.1f} s ({info['reads']} finished on the host, {info['host_pops'] / max(pops.sum(), 1):.1%} of the pops); the {len(heavy)} heaviest "
+              f"(pops {pops[heavy].min()} .. {pops[heavy].max()}) again in {t7 - t6:.1f} s ({hinfo['reads']} on the host), oracle {t8 - t7:.1f} s; "
+              f"{int((pops[heavy] >= 2_000_000).sum())} reads with >= 2 M pops")
+        assert_same_as_oracle(ores, hres, h_off)
+        assert np.array_equal(hres.counters["n_pop"], res.counters["n_pop"][heavy]) and np.array_equal(np.diff(hres.hit_begin.astype(np.int64)), np.diff(res.hit_begin.astype(np.int64))[heavy])
+        if n_pre >= 100_000:
+            assert hinfo["reads"] > 0 and pops[heavy].max() > 2_000_000  # reads at the limits were in the batch, and the host tail took the heaviest
