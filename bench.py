@@ -140,7 +140,7 @@ def main():
 
     import mapad_amd
     from mapad_amd import synth
-    from mapad_amd.distributed import gather_hit_records, merge_gathered_records
+    from mapad_amd.distributed import gather_hit_records, merge_gathered_records, records_digest
     from mapad_amd.presets import DAMAGE, NO_DAMAGE, resolve as resolve_params
 
     if not torch.cuda.is_available():
@@ -366,10 +366,11 @@ def main():
     gather_check = None
     if world > 1:
         ctx.select_batch(1 if args.depth > 1 else 0)  # the last timed step's batch: still in its slot (the solo launch went to the next one)
-        own = digest(*[t.cpu().numpy() for t in record_views()]) if args.depth > 1 else None
+        # (a digest of the records' content: where a read's text sits in the pools differs from run to run of the text kernel)
+        own = records_digest(*[t.cpu().numpy() for t in record_views()]) if args.depth > 1 else None
         ctx.select_batch(0)
         if own is None:  # depth 1: the slot has been launched again; the solo launch maps the same reads, so its records are the same
-            own = digest(*[t.cpu().numpy() for t in record_views()])
+            own = records_digest(*[t.cpu().numpy() for t in record_views()])
         all_own = [None] * world
         dist.all_gather_object(all_own, own)
         loads = [None] * world
@@ -569,12 +570,12 @@ def main():
         tmp = tempfile.mkdtemp(prefix="mapad_cli_")
         try:
             n_src = min(n_reads, 4_000_000)
-            n_cli = n_src * max(1, 8_000_000 // n_src)  # the batch's first reads, repeated up to 8 M: 32 chunks of 250 000, so that the fill and drain of the pipeline are a small part of the run
+            n_cli = n_src * max(1, (24_000_000 if genome_bp >= 1_000_000_000 else 8_000_000) // n_src)  # (3 Gbp: 24 launches of 1 M reads, below)  # the batch's first reads, repeated up to 8 M: 32 chunks of 250 000, so that the fill and drain of the pipeline are a small part of the run
             fa, fq, bam = os.path.join(tmp, "ref.fa"), os.path.join(tmp, "reads.fastq"), os.path.join(tmp, "out.bam")
-            rec = np.empty((n_cli, 114), np.uint8)  # "@rNNNNNNN\n" + 50 bases + "\n+\n" + 50 qualities + "\n"
-            rec[:, 0] = ord("@"); rec[:, 1] = ord("r")
+            rec = np.empty((n_cli, 114), np.uint8)  # "@NNNNNNNN\n" + 50 bases + "\n+\n" + 50 qualities + "\n"
+            rec[:, 0] = ord("@")
             ids = np.arange(n_cli)
-            for k in range(7):
+            for k in range(8):
                 rec[:, 8 - k] = 48 + (ids // 10 ** k) % 10
             reps = n_cli // n_src
             rec[:, 9] = 10; rec[:, 10:60] = np.tile(seqs[:50 * n_src].reshape(n_src, 50), (reps, 1)); rec[:, 60] = 10; rec[:, 61] = ord("+"); rec[:, 62] = 10
@@ -612,7 +613,7 @@ def main():
                    "index_files_bytes": index_bytes,
                    "stage_busy_s": (lambda mm: {"reader": float(mm.group(1)), "device_worker": float(mm.group(2)), "writer": float(mm.group(3))} if mm else None)(
                        re.search(r"reader ([0-9.]+) s, device worker 0 ([0-9.]+) s, writer ([0-9.]+) s", pr.stderr)),
-                   "what": "mapad-amd map: FASTQ -> BAM, --batch_size 250000 (the reference's default), up to 4 chunks (8 on a 3 Gbp index) in flight on one GPU; reader, MAPQ and BGZF on host threads, coordinates and record text on the GPU"}
+                   "what": "mapad-amd map: FASTQ -> BAM, --batch_size 250000 (the reference's default; on a 3 Gbp index four chunks go to the device as one launch), up to 4 launches in flight on one GPU; reader, MAPQ and BGZF on host threads, coordinates and record text on the GPU"}
         except Exception as e:  # the leg is a report, not the metric: say why it is missing
             cli = {"skipped": f"{type(e).__name__}: {e}"}
         finally:

@@ -5,7 +5,7 @@
 //   mapad-amd [--seed N] [--devices K] index -g ref.fa
 //   mapad-amd [--devices K] worker --host H [--port 3130] [--dry_run]
 //   mapad-amd [--seed N] [--devices 0-7 | 0,1,...] map -r reads.{bam,cram,fastq,fastq.gz} -g ref.fa -o out.bam -l single_stranded|double_stranded
-//             -p 0.03 | (-c CUTOFF [-e EXP]) -f F -t T -d D -s S [-D 0.02] -i I [-x 1.0] [--batch_size 250000] [--in_flight 4 (8 on a text of >= 2^31 rows)] [--ignore_base_quality]
+//             -p 0.03 | (-c CUTOFF [-e EXP]) -f F -t T -d D -s S [-D 0.02] -i I [-x 1.0] [--batch_size 250000] [--coalesce 1 (4 on a text of >= 2^31 rows)] [--in_flight 4] [--ignore_base_quality]
 //             [--gap_dist_ends 5] [--max_num_gaps_open 2] [--no_search_limit_recovery] [--force_overwrite] [-R ID]
 #include <atomic>
 #include <chrono>
@@ -185,6 +185,7 @@ struct Slice {
 };
 struct Chunk {
     uint64_t no = 0;
+    uint64_t first_read = 0;         // mapped reads of the run before this chunk: read k of the chunk is read first_read + k of the run (the records' seeds count in reads of the run)
     std::vector<InRecord> in;        // every input record, in input order
     std::vector<int64_t> read_of;    // per input record: its index among the mapped reads, -1 if it cannot be mapped (empty / longer than the device limit)
     PinnedBytes seqs, quals;         // mapped reads, concatenated
@@ -240,7 +241,14 @@ int cmd_map(const Args& a, uint64_t seed, const std::vector<int>& devices, const
     check(mapad_index_open(a.get("reference").c_str(), &idx), "mapad_index_open");
     // chunks in flight per device: the serial tail of a chunk (its few heaviest reads) runs beside the bulk of the following ones.  On a text of >= 2^31
     // rows a read costs three times the pops and a chunk's tail is longer: 8 in flight map 8 % more reads/s than 4 there (3 Gbp, 8 M reads; 16 are slower again)
-    const char* in_flight_default = mapad_index_text_len(idx) >= (1ull << 31) ? "8" : "4";
+    // Launches per chunk.  On a text of >= 2^31 rows a read costs three times the pops, and a launch is not over before its heaviest read is (a serial chain of up to
+    // ~0.5 s at 50 bp) while its bulk needs a tenth of that: every launch leaves wavefronts behind that idle on their last reads.  There --coalesce 4 (the default)
+    // hands the device four chunks of --batch_size reads as ONE launch; the records do not depend on it (one seed per read of the run, below), only the XD tag's
+    // granularity does (chunk wall time / reads, mapping.rs:912-918).
+    const bool big_text = mapad_index_text_len(idx) >= (1ull << 31);
+    const uint64_t coalesce = std::max<uint64_t>(1, std::min<uint64_t>(std::strtoull(a.get("coalesce", big_text ? "4" : "1").c_str(), nullptr, 10), 64));
+    const uint64_t chunk_reads = prm.chunk_size * coalesce;
+    const char* in_flight_default = "4";
     const int in_flight = std::max(1, std::min(std::atoi(a.get("in_flight", in_flight_default).c_str()), 16));
     const size_t n_dev = devices.size();
     std::vector<mapad_ctx_t*> ctxs(n_dev, nullptr);
@@ -248,7 +256,7 @@ int cmd_map(const Args& a, uint64_t seed, const std::vector<int>& devices, const
         check(mapad_ctx_create(idx, &prm, devices[d], &ctxs[d]), "mapad_ctx_create");
         check(mapad_ctx_set_fetch_d_arrays(ctxs[d], 0), "mapad_ctx_set_fetch_d_arrays");
         check(mapad_ctx_set_pipeline_depth(ctxs[d], in_flight), "mapad_ctx_set_pipeline_depth");
-        const uint64_t per_dev = (prm.chunk_size + n_dev - 1) / n_dev;  // both batch slots' buffers up front (typical short reads; longer ones grow them)
+        const uint64_t per_dev = (chunk_reads + n_dev - 1) / n_dev;  // both batch slots' buffers up front (typical short reads; longer ones grow them)
         check(mapad_ctx_reserve(ctxs[d], per_dev, per_dev * 64, 128, 1), "mapad_ctx_reserve");
     }
     const double t_load = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
@@ -286,12 +294,13 @@ int cmd_map(const Args& a, uint64_t seed, const std::vector<int>& devices, const
     // ---- reader ----
     std::thread reader([&] {
         try {
-            uint64_t chunk_no = 0;
+            uint64_t chunk_no = 0, reads_so_far = 0;
             bool more = true;
             while (more && !failed) {
                 const uint64_t t_r0 = now_us();
                 auto c = std::make_shared<Chunk>();
                 c->no = chunk_no;
+                c->first_read = reads_so_far;
                 c->offsets.assign(1, 0);
                 size_t bases = 0;
                 auto admit = [&](InRecord&& r, bool copy) {
@@ -309,7 +318,7 @@ int cmd_map(const Args& a, uint64_t seed, const std::vector<int>& devices, const
                     c->in.push_back(std::move(r));
                 };
                 std::vector<std::pair<uint32_t, uint32_t>> lines;
-                const char* block = src.fastq_block(prm.chunk_size, lines);
+                const char* block = src.fastq_block(chunk_reads, lines);
                 bool block_done = false;
                 if (block && !lines.empty() && lines.size() % 4 == 0) {
                     // FASTQ fast path: the chunk's lines are cut sequentially (one memchr per line), the records are parsed by several threads
@@ -336,7 +345,7 @@ int cmd_map(const Args& a, uint64_t seed, const std::vector<int>& devices, const
                                 std::memcpy(c->quals.p + c->offsets[(size_t)k], r.qual.data(), r.seq.size());
                             }
                         });
-                        more = lines.size() == 4 * prm.chunk_size;
+                        more = lines.size() == 4 * chunk_reads;
                         block_done = true;
                     }
                 }
@@ -345,16 +354,16 @@ int cmd_map(const Args& a, uint64_t seed, const std::vector<int>& devices, const
                     size_t i = 0;
                     while (i < lines.size()) {
                         if (lines[i].second == 0) { ++i; continue; }
-                        if (i + 4 > lines.size()) { if (lines.size() == 4 * prm.chunk_size) src.fastq_unread_from(lines[i].first); break; }  // a cut record goes back
+                        if (i + 4 > lines.size()) { if (lines.size() == 4 * chunk_reads) src.fastq_unread_from(lines[i].first); break; }  // a cut record goes back
                         InRecord r;
                         if (ReadSource::parse_fastq_record(block, &lines[i], r)) admit(std::move(r), true);
                         else std::fprintf(stderr, "Skip record due to an error: malformed FASTQ record\n");
                         i += 4;
                     }
-                    more = lines.size() == 4 * prm.chunk_size;
+                    more = lines.size() == 4 * chunk_reads;
                 } else if (!block) {
                     InRecord r;
-                    while (c->in.size() < prm.chunk_size && (more = src.next(r))) admit(std::move(r), true);
+                    while (c->in.size() < chunk_reads && (more = src.next(r))) admit(std::move(r), true);
                 }
                 if (c->in.empty()) { if (more) continue; break; }  // a whole block of blank / malformed records: keep reading
                 const uint64_t n_reads = c->offsets.size() - 1;
@@ -371,6 +380,7 @@ int cmd_map(const Args& a, uint64_t seed, const std::vector<int>& devices, const
                 c->t_submit = std::chrono::steady_clock::now();
                 for (size_t d = 0; d < n_dev; ++d) dev_q[d]->push(c);
                 chunk_no += 1;
+                reads_so_far += n_reads;
             }
         } catch (const std::exception& e) { fail(e.what()); }
         for (auto& q : dev_q) q->close();
@@ -391,8 +401,8 @@ int cmd_map(const Args& a, uint64_t seed, const std::vector<int>& devices, const
             const uint64_t t0 = now_us();
             // The device half of intervals_to_bam (reported hit, coordinates, XA candidates, X0 / X1) from the hits still resident on this GPU; the
             // strings and mapping qualities are the records thread's work, so that this thread goes straight back to submitting and fetching.
-            // One seed per read of the run, whichever device maps it: the chunk's seed advanced to the slice's first read.
-            check(mapad_hits_to_coords_gpu(ctx, sl.res, mapad_records_seed_at(seed + c->no, sl.lo), &sl.coords), "mapad_hits_to_coords_gpu");
+            // One seed per read of the run, whichever device maps it and however the input is cut into chunks: the run's seed advanced to the slice's first read.
+            check(mapad_hits_to_coords_gpu(ctx, sl.res, mapad_records_seed_at(seed, c->first_read + sl.lo), &sl.coords), "mapad_hits_to_coords_gpu");
             if (d == 0) us_records += now_us() - t0;
             if (--c->pending == 0) {
                 c->per_read_s = std::chrono::duration<float>(std::chrono::steady_clock::now() - c->t_submit).count() / (float)std::max<size_t>(c->in.size(), 1);

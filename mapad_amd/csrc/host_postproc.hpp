@@ -27,93 +27,8 @@
 namespace mapad {
 namespace host {
 
-// ---- PrRange: Lehmer-LCG lazy permutation of an SA interval (src/map/prrange.rs) ------------------------------------------
-class PrRange {
-public:
-    static bool make(uint64_t start, uint64_t end, uint64_t seed, PrRange& out) {  // try_new :43-71
-        const uint64_t l = end > start ? end - start : 0;
-        if (l == 0) return false;
-        const uint64_t m = next_prime(l);
-        uint64_t a = 2;
-        for (;;) {
-            bool overflow = false;
-            if (is_primitive_root(a, m, overflow)) break;
-            if (overflow) return false;
-            a += 1;
-        }
-        const uint64_t s = std::max<uint64_t>(seed % l, 1);
-        out.start_ = start; out.l_ = l; out.m_ = m; out.a_ = a; out.x_ = s; out.seed_ = s; out.count_ = 0;
-        return true;
-    }
-    bool next(uint64_t& out) {  // :19-35
-        if (count_ == 0 && l_ == 1) { count_ = 1; out = start_; return true; }
-        for (;;) {
-            const uint64_t prev = x_;
-            x_ = (a_ * x_) % m_;
-            if (count_ > 0 && prev == seed_) return false;
-            if (prev <= l_) { count_ += 1; out = prev - 1 + start_; return true; }
-        }
-    }
-
-private:
-    uint64_t start_ = 0, l_ = 0, m_ = 0, a_ = 0, x_ = 0, seed_ = 0, count_ = 0;
-    static bool is_prime(uint64_t n) {
-        if (n <= 1) return false;
-        if (n <= 3) return true;
-        if (n % 2 == 0 || n % 3 == 0) return false;
-        for (uint64_t i = 5; i * i <= n; i += 6) if (n % i == 0 || n % (i + 2) == 0) return false;
-        return true;
-    }
-    static uint64_t next_prime(uint64_t n) {
-        uint64_t p = n + 1;
-        if (p <= 2) return 2;
-        if (p % 2 == 0) p += 1;
-        while (!is_prime(p)) p += 2;
-        return p;
-    }
-    static bool pow_mod(uint64_t base, uint64_t e, uint64_t mod, uint64_t& out) {  // checked_pow_mod :170-184
-        if (mod == 1) { out = 0; return true; }
-        if (((unsigned __int128)(mod - 1) * (mod - 1)) >> 64) return false;
-        uint64_t r = 1;
-        base %= mod;
-        while (e > 0) {
-            if (e & 1) r = (r * base) % mod;
-            e >>= 1;
-            base = (base * base) % mod;
-        }
-        out = r;
-        return true;
-    }
-    // PrimeFactorIterator (:126-165): distinct prime factors by resumable trial division
-    struct Factors {
-        uint64_t rest, i = 2, step = 1, last = 0;
-        explicit Factors(uint64_t n) : rest(n) {}
-        bool next(uint64_t& f) {
-            if (rest <= 3) return false;
-            while (i * i <= rest) {
-                while (rest > 1) {
-                    while (rest % i == 0) {
-                        if (i > last) { f = last = i; return true; }
-                        rest /= i;
-                    }
-                    i += step;
-                    step = 2;
-                }
-            }
-            return false;
-        }
-    };
-    static bool is_primitive_root(uint64_t a, uint64_t n, bool& overflow) {  // :113-121
-        const uint64_t phi = n - 1;
-        Factors fs(phi);
-        uint64_t f, r;
-        while (fs.next(f)) {
-            if (!pow_mod(a, phi / f, n, r)) { overflow = true; return false; }
-            if (r == 1) return false;
-        }
-        return true;
-    }
-};
+// ---- PrRange: Lehmer-LCG lazy permutation of an SA interval (src/map/prrange.rs): the one restatement, shared with the records kernel (postproc_core.hpp) ----
+using PrRange = PrRangeHD;
 
 // ---- edit track helpers (record.rs:269-449) -----------------------------------------------------------------------------------
 struct Track {

@@ -103,7 +103,9 @@ struct TailScratch {
     std::vector<uint16_t> scratch;
     uint64_t pc[8];
     bool ensure(uint32_t hc, uint32_t nc, uint32_t lm) {
-        if (hc > heap_cap) { std::free(heap); heap = (HeapEntry*)std::malloc(((size_t)hc + 32) * sizeof(HeapEntry)); heap_cap = heap ? hc : 0; }
+        // a sift loads the grandchildren of its hole before it looks at the heap's length (search_core.hpp: mm_trickle_down): slots up to 2 * heap_len + 6 are
+        // read (and ignored), so the allocation is twice the capacity — on the device those reads fall into the arena's node area
+        if (hc > heap_cap) { std::free(heap); heap = (HeapEntry*)std::malloc((2 * (size_t)hc + 64) * sizeof(HeapEntry)); heap_cap = heap ? hc : 0; }
         if (nc > node_cap) { std::free(nodes); nodes = (Node*)std::aligned_alloc(64, (((size_t)nc + 1) * sizeof(Node) + 63) & ~(size_t)63); node_cap = nodes ? nc : 0; }
         if (!heap || !nodes) return false;
         if (lm > lmax || top.empty()) {

@@ -107,21 +107,46 @@ RECORD_WORDS = 22  # csrc/text_core.hpp: DevRecord, 88 bytes
 _REC_TEXT_OFF, _REC_MQ_OFF = 13, 19  # word indices of text_off and mq_off
 
 
+def records_digest(recs, text, pairs):
+    """sha256 of a shard's records that does not depend on where the text kernel put a read's bytes in its pools (wavefronts claim pool space with atomic
+    adds, so two runs over the same batch lay the pools out differently): the records with text_off / mq_off zeroed, then every mapped read's
+    [CIGAR][MD][XA] bytes and its (score, size) pairs, in read order."""
+    import hashlib
+    r = np.ascontiguousarray(np.asarray(recs)).reshape(-1, RECORD_WORDS)
+    t = np.ascontiguousarray(np.asarray(text)).view(np.uint8)
+    p = np.ascontiguousarray(np.asarray(pairs)).view(np.uint32)
+    mapped = r[:, 3] != 0
+
+    def in_read_order(pool, starts, lens):
+        lens = np.where(mapped, lens, 0).astype(np.int64)
+        total = int(lens.sum())
+        if total == 0:
+            return pool[:0]
+        first = np.cumsum(lens) - lens  # where a read's piece starts in the output
+        idx = np.repeat(starts.astype(np.int64) - first, lens) + np.arange(total, dtype=np.int64)
+        return pool[idx]
+
+    canon = r.copy()
+    canon[:, _REC_TEXT_OFF] = 0
+    canon[:, _REC_MQ_OFF] = 0
+    h = hashlib.sha256()
+    h.update(canon.tobytes())
+    h.update(in_read_order(t, r[:, _REC_TEXT_OFF].view(np.uint32), r[:, 14].astype(np.int64) + r[:, 15] + r[:, 16]).tobytes())
+    h.update(in_read_order(p, 2 * r[:, _REC_MQ_OFF].view(np.uint32).astype(np.int64), 2 * r[:, 20].astype(np.int64)).tobytes())
+    return h.hexdigest()
+
+
 def merge_gathered_records(parts):
     """rank-ordered (records int32[n_r * 22], text as int32 (bytes padded to a multiple of 4), pairs as int32 views of f32[2 * n_pairs_r]) of read-ordered
-    shards -> the chunk's records (n x 22 int32, text_off / mq_off rebased into the concatenated pools), text bytes, pairs (float32) and the sha256 of
-    each rank's part (which must equal the digest of that rank's own copy).  <= 128 bytes per read cross the links."""
-    import hashlib
+    shards -> the chunk's records (n x 22 int32, text_off / mq_off rebased into the concatenated pools), text bytes, pairs (float32) and the
+    records_digest of each rank's part (which must equal the digest of that rank's own copy).  <= 128 bytes per read cross the links."""
     recs, texts, pairs, digests = [], [], [], []
     text_base = pair_base = 0
     for r, t, p in parts:
         r = np.ascontiguousarray(np.asarray(r.cpu())).reshape(-1, RECORD_WORDS)
         t = np.ascontiguousarray(np.asarray(t.cpu()))
         p = np.ascontiguousarray(np.asarray(p.cpu()))
-        dg = hashlib.sha256()
-        for a in (r, t, p):
-            dg.update(a.tobytes())
-        digests.append(dg.hexdigest())
+        digests.append(records_digest(r, t, p))
         r = r.copy()
         mapped = r[:, 3] != 0
         r[mapped, _REC_TEXT_OFF] += text_base

@@ -76,7 +76,7 @@ mapad_batch_result_t* emu_map_batch(const uint64_t* blocks, uint64_t n_blocks, u
             const uint32_t cls = A.grown >> 27;
             if (cls >= 2) return GROW_NEVER;
             const uint32_t hc = std::min<uint64_t>((uint64_t)A.heap_cap * 4, stack_cap), nc = std::min<uint64_t>((uint64_t)A.node_cap * 4, tree_cap);
-            gheap[cls].assign(hc + 16, HeapEntry{});
+            gheap[cls].assign(2 * (size_t)hc + 64, HeapEntry{});
             gnodes[cls].assign(nc, Node{});
             HeapEntry* nheap = gheap[cls].data() + 1;
             for (uint32_t i = kTop; i < st.heap_len; ++i) nheap[i] = A.heap[i];
@@ -99,10 +99,10 @@ mapad_batch_result_t* emu_map_batch(const uint64_t* blocks, uint64_t n_blocks, u
             const uint32_t hc = pass == 0 ? heap_cap : P.stack_limit + 10, nc = pass == 0 ? node_cap : P.edit_tree_limit + 10;
             // lazily grown backing stores keep the host emulation cheap even with the reference's 2M / 10M limits
             Arena A;
-            heap.assign(std::min<uint32_t>(hc, 1u << 22) + 16, HeapEntry{});
+            heap.assign(2 * (size_t)std::min<uint32_t>(hc, 1u << 22) + 64, HeapEntry{});  // a sift reads (and ignores) slots up to 2 * heap_len + 6: twice the capacity, as in host_tail.hpp
             nodes.assign(std::min<uint32_t>(nc, 1u << 22), Node{});
             A.top = top.data() + 1; A.heap = heap.data() + 1; A.nodes = nodes.data(); A.hits = hits.data(); A.hit_ops = hit_ops.data(); A.scratch = scratch.data();
-            A.heap_cap = (uint32_t)heap.size() - 16; A.node_cap = (uint32_t)nodes.size(); A.hit_ops_cap = (uint32_t)hit_ops.size();
+            A.heap_cap = std::min<uint32_t>(hc, 1u << 22); A.node_cap = (uint32_t)nodes.size(); A.hit_ops_cap = (uint32_t)hit_ops.size();
             A.pc = use_pc ? pc_words : nullptr;
             ReadIn rd{qc.data(), dnear.data(), L, P.reject_thr[L], P.table_base[L]};
             if (pass == 0) search_read(ix, P, rd, A, st, 0, grow);

@@ -126,10 +126,9 @@ def _records_worker(rank, world, port, out_path):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     sys.path.insert(0, ROOT)
-    import hashlib
-    from mapad_amd.distributed import gather_hit_records, merge_gathered_records
+    from mapad_amd.distributed import gather_hit_records, merge_gathered_records, records_digest
     own = _fake_records(300 + 17 * rank, seed=5 + rank)
-    own_digest = hashlib.sha256(b"".join(np.ascontiguousarray(a).tobytes() for a in own)).hexdigest()
+    own_digest = records_digest(*own)
     meta = dist.new_group(backend="gloo")
     parts = gather_hit_records(torch.from_numpy(own[0].reshape(-1)), torch.from_numpy(own[1]), torch.from_numpy(own[2]), rank, world, meta_group=meta)
     digests = [None] * world
@@ -163,6 +162,23 @@ def test_two_rank_gather_of_compact_records(tmp_path):
         base += recs.shape[0]
     per_read = (got["recs"].nbytes + got["text"].nbytes + got["pairs"].nbytes) / 617
     assert per_read <= 128
+    # the digest follows the records' content, not the pools' layout: the same reads with their text and pairs laid out in another order hash alike
+    from mapad_amd.distributed import records_digest
+    recs, text, pairs = shards[0]
+    tb, pf = text.view(np.uint8), pairs.view(np.float32)
+    r2, t2, p2 = recs.copy(), bytearray(), []
+    for i in reversed(range(recs.shape[0])):
+        if not recs[i, 3]:
+            continue
+        piece = _text_of(recs, tb, i)
+        r2[i, 13] = len(t2); t2 += piece
+        k = int(recs[i, 20])
+        r2[i, 19] = len(p2) // 2
+        p2 += list(pf[2 * int(recs[i, 19]):2 * int(recs[i, 19]) + 2 * k])
+    t2 += b"\0" * (-len(t2) % 4)
+    assert records_digest(r2, np.frombuffer(bytes(t2), np.uint8).view(np.int32), np.array(p2, np.float32).view(np.int32)) == records_digest(recs, text, pairs)
+    r2[5, 0] ^= 1
+    assert records_digest(r2, np.frombuffer(bytes(t2), np.uint8).view(np.int32), np.array(p2, np.float32).view(np.int32)) != records_digest(recs, text, pairs)
 
 
 @pytest.mark.gpu
