@@ -75,6 +75,24 @@ def spawn_ranks(n, same_device=False):
     sys.exit(subprocess.call(cmd))
 
 
+def host_cpus():
+    """CPUs this process may really use: os.cpu_count() capped by the cgroup's CPU-time quota (the GPU boxes show 256 CPUs and grant 16)."""
+    n = os.cpu_count() or 1
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = min(n, max(1, round(int(q) / int(p))))
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, round(q / p)))
+        except Exception:
+            pass
+    return n
+
+
 def digest(*arrays):
     h = hashlib.sha256()
     for a in arrays:
@@ -162,6 +180,9 @@ def main():
     #  which is what RCCL's transfer kernels need; --search-waves-per-cu 8 is the fall-back should the watchdog ever report a starved transfer)
     if args.search_waves_per_cu:
         os.environ["MAPAD_TIER0_WAVES_PER_CU"] = str(args.search_waves_per_cu)
+    if world > 1 and args.dist_backend == "gloo":  # test mode: the ranks share ONE GPU — each takes its share of the chip's wavefront slots and of the HBM for its pools
+        os.environ.setdefault("MAPAD_TIER0_WAVES_PER_CU", str(max(2, 12 // world)))
+        os.environ.setdefault("MAPAD_POOL_BUDGET_GB", str(max(4, 64 // world)))
 
     # ---- watchdog (N > 1): a rank that makes no progress for --watchdog-s seconds ends the job with a fresh exit (never an exec) ---------------
     import threading
@@ -438,7 +459,7 @@ def main():
     parity = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import binding as ob  # the checker / CPU baseline: only ever used in this leg
-        cores = 1 if args.config == "c1" else (os.cpu_count() or 1)  # C1 is the single-thread figure
+        cores = 1 if args.config == "c1" else host_cpus()  # C1 is the single-thread figure
         oidx = ob.OracleIndex.from_bwt(index.bwt(), "$ACGTX", 128)  # byte BWT + Occ k = 128 like the reference (indexing.rs:188)
         op = ob.make_params(rp)
 
@@ -456,7 +477,7 @@ def main():
         ores, dt = run(n_sample)
         cpu = {"value": round(n_sample / dt, 1), "unit": "reads/s", "cores": cores, "kind": "port",
                "sample": f"first {n_sample} reads of the same batch, {dt:.1f} s wall, C++ oracle (restatement of the reference algorithm: byte BWT, "
-                         f"Occ k=128, min-max heap, slab tree), {cores} thread(s)"}
+                         f"Occ k=128, min-max heap, slab tree), {cores} thread(s) = the CPUs this process may use ({os.cpu_count()} visible)"}
         # parity of the GPU result on that sample: hit counts, intervals, f32 score bits, edit tracks
         hb = res.hit_begin[:n_sample + 1]
         nh = int(hb[-1])

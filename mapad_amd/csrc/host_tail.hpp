@@ -14,6 +14,7 @@
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
+#include <cstdio>
 #include <cstdlib>
 #include <deque>
 #include <functional>
@@ -46,7 +47,7 @@ struct TailResult {
 };
 
 // Worker threads shared by every context of the process (a read at the reference's limits keeps a thread busy for seconds and its arena is 336 MB, so
-// there is one pool, as wide as the machine: MAPAD_TAIL_THREADS overrides).  Started with the first task.
+// there is one pool, as wide as the machine — or as this process's CPU share of it: MAPAD_TAIL_THREADS overrides).  Started with the first task.
 class TailWorkers {
 public:
     static TailWorkers& instance() { static TailWorkers* w = new TailWorkers(); return *w; }  // never destroyed: workers may outlive static destructors
@@ -63,9 +64,34 @@ public:
         return threads_.empty() ? wanted() : (unsigned)threads_.size();
     }
 private:
+    // CPUs this process may really use: a container often shows every CPU of the machine and limits the CPU TIME of its cgroup (the round-4 GPU box:
+    // 256 CPUs visible, cpu.max = 16 CPUs' worth) — threads beyond that share are throttled together and thrash each other's caches (measured: 256 threads
+    // 1.5 x slower than 16 there).
+    static unsigned cpu_share() {
+        unsigned n = std::thread::hardware_concurrency();
+        if (!n) n = 8;
+        auto read2 = [](const char* path, double& a, double& b) -> bool {
+            FILE* f = std::fopen(path, "r");
+            if (!f) return false;
+            char q[64] = {0}, per[64] = {0};
+            const int k = std::fscanf(f, "%63s %63s", q, per);
+            std::fclose(f);
+            if (k < 1 || q[0] == 'm' /* "max" */) return false;
+            a = std::atof(q); b = k == 2 ? std::atof(per) : 0.0;
+            return a > 0;
+        };
+        double quota = 0, period = 0;
+        if (read2("/sys/fs/cgroup/cpu.max", quota, period) && period > 0) n = std::min<unsigned>(n, (unsigned)std::max(1.0, quota / period + 0.5));
+        else {
+            double q1 = 0, p1 = 0, dummy = 0;
+            if (read2("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", q1, dummy) && read2("/sys/fs/cgroup/cpu/cpu.cfs_period_us", p1, dummy) && p1 > 0)
+                n = std::min<unsigned>(n, (unsigned)std::max(1.0, q1 / p1 + 0.5));
+        }
+        return n;
+    }
     static unsigned wanted() {
         const char* e = std::getenv("MAPAD_TAIL_THREADS");
-        unsigned n = e && e[0] ? (unsigned)std::strtoul(e, nullptr, 10) : std::thread::hardware_concurrency();
+        const unsigned n = e && e[0] ? (unsigned)std::strtoul(e, nullptr, 10) : cpu_share();
         return n ? n : 8;
     }
     void start() {

@@ -338,6 +338,15 @@ MAPAD_HD uint32_t mm_bubble_up(const ArenaT<NL, TOP>& A, uint32_t pos, const Hea
 }
 template <bool NL, int TOP>
 MAPAD_HD uint32_t mm_bubble_up(const ArenaT<NL, TOP>& A, uint32_t pos, const HeapEntry elt) { return mm_bubble_up(A, pos, elt, load_ancestors(A, pos)); }
+// Would mm_bubble_up leave `elt` in slot pos (neither of its first two compares moves it)?  Such a push stores one entry and touches no other slot.
+MAPAD_HD bool mm_push_stays(uint32_t pos, const HeapEntry elt, const Ancestors& an) {
+    const bool min_level = mm_is_min_level(pos);
+    const uint32_t flip1 = min_level ? 0u : 0x80000000u;
+    const bool moved = (pos > 0) & (flip_sign(elt.score, flip1) > flip_sign(an.e1.score, flip1));
+    const uint32_t flip2 = min_level ? 0x80000000u : 0u;  // not moved: the grandparent chain of the other kind of level
+    const bool moved2 = (pos > 2) & (flip_sign(elt.score, flip2) > flip_sign(an.e2.score, flip2));
+    return !moved & !moved2;
+}
 
 // The heap array is stored shifted by one entry (logical index i lives in physical slot i + 1; `v` points at logical 0), so the
 // two children of a node (logical 2p+1, 2p+2) form one 16-byte aligned pair and its four grandchildren (4p+3 .. 4p+6) one
@@ -689,6 +698,7 @@ MAPAD_RARE void search_init(uint64_t n_text, int alignment_start, const ReadInT<
 // the cache.  What leaves the step's dependent chain is one HBM round trip in six.
 #if defined(MAPAD_PC_STATS) && !defined(__HIP_DEVICE_COMPILE__)
 static unsigned long long g_pc_stats[5];
+static unsigned long long g_commit_stats[8];  // steps with children, children, movers, steps without a mover, steps with >= 3 children, ... of those without a mover, movers in those
 #endif
 template <bool NL, int TOP>
 MAPAD_HD void pc_store(const ArenaT<NL, TOP>& A, uint32_t s, uint32_t id, uint64_t w1, uint64_t w2, uint64_t w3) {
@@ -697,6 +707,17 @@ MAPAD_HD void pc_store(const ArenaT<NL, TOP>& A, uint32_t s, uint32_t id, uint64
 template <bool NL, int TOP>
 MAPAD_HD void pc_clear(const ArenaT<NL, TOP>& A) { A.pc[0] = 0; A.pc[4] = 0; }
 
+// MAPAD_PAR_COMMIT (device quads): the children of a frame are pushed by the quad's four lanes side by side instead of one after the other.  A push that stays
+// where it is appended (mm_push_stays: 70 % of them with the no-damage model, where ties are the rule) writes its own slot and nothing else, and it stays a stayer
+// whatever its siblings do: a sibling that moves up along the max levels only ever RAISES the entries of max-level slots, one that moves along the min levels only
+// lowers min-level entries, and "stays" means not above the max-level ancestor and not below the min-level one.  So every lane loads the ancestors of its own child
+// (slot heap_len + rank), the stayers are stored at once, and only the movers go one after the other, in commit order, each by the lane that holds it — the first
+// with the ancestors it already has (stayers changed none of them), later ones with fresh loads.  One memory round trip per frame where the sequential loop made one
+// per child; with 16 read slots in lockstep that loop ran 4 trips in 73 % of the wavefront steps (section profile, C4: 47 % of the wave time) although two thirds of
+// the frames have one child.  Same heap, entry for entry, as the sequential pushes (children cannot be each other's ancestors once the heap has 16 entries).
+#if !defined(MAPAD_PAR_COMMIT)
+#define MAPAD_PAR_COMMIT 1
+#endif
 template <int LPR, bool CONT, bool NL, bool PC = false, class Grow = NoGrow, int TOP = kTop, bool NLR = NL>
 MAPAD_HD bool search_step(const DevIndex& ix, const DevParams& P, const ReadInT<NLR>& rd, ArenaT<NL, TOP>& A, SearchState& st, int w, const Grow& grow) {
     if (st.heap_len == 0 || st.status != ST_OK) return false;
@@ -918,9 +939,84 @@ MAPAD_HD bool search_step(const DevIndex& ix, const DevParams& P, const ReadInT<
             for (int i = 0; i < 4; ++i) if (mm[i] < lim) cand &= ~(4u << (2 * i));
         }
         const uint32_t cand0 = cand, id0 = st.tree_next;  // == tree_entries: the slab grows at its end, child t gets key id0 + (children before t)
+#if defined(__HIP_DEVICE_COMPILE__)
+        if constexpr (MAPAD_PAR_COMMIT != 0 && LPR == 4 && !PC) {
+            if (st.heap_len >= 16u) {
+                const uint32_t n0 = st.heap_len, kids = (uint32_t)__popc(cand0);
+                uint32_t rest = cand0;
+                for (uint32_t base = 0; base < kids; base += 4) {  // four children per round (a frame has at most nine)
+                    // commit-order rank base + w -> which child (bit of cand0)
+                    int t = 0;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) { const int tq = rest ? __ffs((int)rest) - 1 : 0; rest &= rest - 1; t = q == w ? tq : t; }
+                    const uint32_t r = base + (uint32_t)w;
+                    const bool act = r < kids;
+                    const bool is_ins = t == 0, is_del = (t & 1) != 0;
+                    const int i = is_ins ? 0 : (t - 1) >> 1;
+                    float score = mm[3];
+                    score = i == 2 ? mm[2] : score; score = i == 1 ? mm[1] : score; score = i == 0 ? mm[0] : score;
+                    score = is_del ? deletion_score : score; score = is_ins ? insertion_score : score;
+                    const uint32_t pos = n0 + (act ? r : 0u);
+                    const HeapEntry elt{score, id0 + r};
+                    const Ancestors an = load_ancestors(A, pos);
+                    const bool stays = mm_push_stays(pos, elt, an);
+                    if (act & stays) hp_set(A, pos, elt);
+                    // the movers of this round, in commit order, each by its own lane
+                    uint32_t movers = (uint32_t)(__ballot(act & !stays) >> (threadIdx.x & 60u)) & 15u;  // this quad's four lanes
+                    bool fresh = true;  // the ancestors loaded above are still what the heap holds (only stayers have been stored)
+                    while (movers) {
+                        const int m = __ffs((int)movers) - 1;
+                        movers &= movers - 1;
+                        if (w == m) {
+                            if (fresh) mm_bubble_up(A, pos, elt, an);
+                            else mm_bubble_up(A, pos, elt);
+                        }
+                        fresh = false;
+                    }
+                }
+                st.tree_next = id0 + kids; st.tree_entries = id0 + kids; st.tree_len += kids; st.heap_len = n0 + kids;
+                st.c_node += kids; st.c_push += kids;
+                cand = 0;
+            }
+        }
+#elif defined(MAPAD_PAR_COMMIT_EMU)
+        // the same scheme on the host, lane by lane (tests/emu: the CPU suite checks the argument above on every read it maps)
+        if (!PC && st.heap_len >= 16u) {
+            const uint32_t n0 = st.heap_len, kids = (uint32_t)__builtin_popcount(cand0);
+            uint32_t rest = cand0;
+            for (uint32_t base = 0; base < kids; base += 4) {
+                HeapEntry elt4[4]; Ancestors an4[4]; uint32_t pos4[4], movers = 0; int t4[4];
+                for (int wv = 0; wv < 4 && base + wv < kids; ++wv) {
+                    const int t = __builtin_ctz(rest); rest &= rest - 1; t4[wv] = t;
+                    const bool is_ins = t == 0, is_del = (t & 1) != 0;
+                    const int i = is_ins ? 0 : (t - 1) >> 1, k = 3 - i;
+                    const float score = is_ins ? insertion_score : is_del ? deletion_score : mm[i];
+                    pos4[wv] = n0 + base + wv; elt4[wv] = HeapEntry{score, id0 + base + (uint32_t)wv};
+                    an4[wv] = load_ancestors(A, pos4[wv]);
+                    const uint64_t xl = e.lower[k], xr = e.lower_rev[k], xs = e.size[k];
+                    A.nodes[elt4[wv].node] = make_child(t, k, xl, xr, xs);
+                }
+                for (int wv = 0; wv < 4 && base + wv < kids; ++wv) {  // all decisions against the heap as it was, stayers stored
+                    if (mm_push_stays(pos4[wv], elt4[wv], an4[wv])) hp_set(A, pos4[wv], elt4[wv]); else movers |= 1u << wv;
+                }
+                bool fresh = true;
+                for (int wv = 0; wv < 4; ++wv) if ((movers >> wv) & 1u) {
+                    if (fresh) mm_bubble_up(A, pos4[wv], elt4[wv], an4[wv]); else mm_bubble_up(A, pos4[wv], elt4[wv]);
+                    fresh = false;
+                }
+                (void)t4;
+            }
+            st.tree_next = id0 + kids; st.tree_entries = id0 + kids; st.tree_len += kids; st.heap_len = n0 + kids;
+            st.c_node += kids; st.c_push += kids;
+            cand = 0;
+        }
+#endif
         uint32_t land_t = 0xFFu, land_s = 0;  // PC: the last child of this step that ended up in heap slot 1 or 2 (land_s = slot - 1)
         Node land_nd{};                       //     ... and its node where the children are not built lane-parallel
         (void)land_nd;
+#if defined(MAPAD_PC_STATS) && !defined(__HIP_DEVICE_COMPILE__)
+        int stat_k = 0, stat_movers = 0;
+#endif
         while (cand != 0) {
 #if defined(__HIP_DEVICE_COMPILE__)
             const int t = __ffs((int)cand) - 1;
@@ -948,6 +1044,9 @@ MAPAD_HD bool search_step(const DevIndex& ix, const DevParams& P, const ReadInT<
                 A.nodes[id] = made;
             }
             const uint32_t fin = mm_bubble_up(A, pos, HeapEntry{score, id}, an);
+#if defined(MAPAD_PC_STATS) && !defined(__HIP_DEVICE_COMPILE__)
+            stat_k += 1; stat_movers += fin != pos;
+#endif
             if constexpr (PC) {
                 const bool lands = (fin - 1u) < 2u;
                 land_t = lands ? (uint32_t)t : land_t; land_s = lands ? fin - 1u : land_s;
@@ -955,6 +1054,10 @@ MAPAD_HD bool search_step(const DevIndex& ix, const DevParams& P, const ReadInT<
             }
             st.c_node += 1; st.c_push += 1;
         }
+#if defined(MAPAD_PC_STATS) && !defined(__HIP_DEVICE_COMPILE__)
+        if (stat_k) { g_commit_stats[0] += 1; g_commit_stats[1] += stat_k; g_commit_stats[2] += stat_movers; g_commit_stats[3] += stat_movers == 0; g_commit_stats[4] += stat_k >= 3; g_commit_stats[5] += (stat_k >= 3) & (stat_movers == 0);
+                      g_commit_stats[6] += (stat_k >= 3) ? stat_movers : 0; }
+#endif
         if constexpr (PC) {
             // the frame the sift moved into the emptied slot first (its loads have long arrived: they are older than the ancestors the pushes waited for) ...
             if (pf_valid) pc_store(A, top_idx - 1u, pf_id, pf1, pf2, pf3);

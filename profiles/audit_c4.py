@@ -51,7 +51,7 @@ def main():
 
     oidx = ob.OracleIndex.from_bwt(index.bwt(), "$ACGTX", 128)
     op = ob.make_params(rp)
-    cores = os.cpu_count() or 1
+    cores = bench.host_cpus()
     h_gpu, h_ora = hashlib.sha256(), hashlib.sha256()
     bad_reads, first_bad, checked, hits_ge_2_32 = 0, [], 0, 0
     t_oracle = 0.0

@@ -10,6 +10,7 @@
 #include <vector>
 
 #define MAPAD_PC_STATS 1
+#define MAPAD_PAR_COMMIT_EMU 1  // the lane-parallel commit of the quad kernel, emulated lane by lane (search_core.hpp); runs when the payload cache is off
 
 #include "../../include/mapad_amd.h"
 #include "../../mapad_amd/csrc/darray_core.hpp"
@@ -58,6 +59,7 @@ mapad_batch_result_t* emu_map_batch(const uint64_t* blocks, uint64_t n_blocks, u
     const bool use_pc = !(pc_env && pc_env[0] == '0');
     uint64_t pc_words[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     g_pc_stats[0] = g_pc_stats[1] = g_pc_stats[2] = g_pc_stats[3] = g_pc_stats[4] = 0;
+    for (auto& x : g_commit_stats) x = 0;
     std::vector<uint8_t> qc(2 * (lmax + 1));
     std::vector<float> dnear(lmax + 1);
     std::vector<float> pen(lmax + 1), chain(lmax + 1);
@@ -121,6 +123,8 @@ mapad_batch_result_t* emu_map_batch(const uint64_t* blocks, uint64_t n_blocks, u
         }
         r->hit_begin[i + 1] = r->hits.size();
     }
+    if (std::getenv("MAPAD_EMU_PC_STATS")) std::fprintf(stderr, "emu commit loop: %llu steps with children, %llu children, %llu movers, %llu steps without a mover; >= 3 children: %llu steps, %llu without a mover, %llu movers\n",
+                                                       g_commit_stats[0], g_commit_stats[1], g_commit_stats[2], g_commit_stats[3], g_commit_stats[4], g_commit_stats[5], g_commit_stats[6]);
     if (std::getenv("MAPAD_EMU_PC_STATS")) std::fprintf(stderr, "emu payload cache: %llu hits, %llu misses, %llu pops of a one-entry heap; %llu nodes fetched ahead, %llu steps with a child landing in slot 1 / 2\n", g_pc_stats[0], g_pc_stats[1], g_pc_stats[2], g_pc_stats[3], g_pc_stats[4]);
     r->pub.n_reads = n_reads; r->pub.n_hits = r->hits.size(); r->pub.n_ops = r->ops.size();
     r->pub.hit_begin = r->hit_begin.data(); r->pub.hits = r->hits.data(); r->pub.ops = r->ops.data(); r->pub.status = r->status.data();

@@ -41,3 +41,16 @@ def algorithmic_bytes(counters_sum, total_bases):
     """256*(E_search + E_darray) + 40*(N_push + N_pop) + 8*N_node + 6*L"""
     e_search, e_darray, n_push, n_pop, n_node = [int(x) for x in counters_sum[:5]]
     return 256 * (e_search + e_darray) + 40 * (n_push + n_pop) + 8 * n_node + 6 * int(total_bases)
+
+
+def oracle_threads():
+    """Threads for the oracle: the CPUs this process may really use (os.cpu_count() capped by the cgroup's CPU-time quota)."""
+    import os
+    n = os.cpu_count() or 8
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = min(n, max(1, round(int(q) / int(p))))
+    except Exception:
+        pass
+    return n

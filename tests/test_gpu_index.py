@@ -12,7 +12,7 @@ from mapad_amd import synth
 from oracle import binding as ob
 
 from kat_util import resolve_params
-from parity_util import DAMAGE, NO_DAMAGE, assert_same_as_oracle, split_reads
+from parity_util import oracle_threads, DAMAGE, NO_DAMAGE, assert_same_as_oracle, split_reads
 
 pytestmark = pytest.mark.gpu
 
@@ -155,7 +155,7 @@ def test_index_beyond_2_pow_32_rows_maps_like_the_oracle(monkeypatch):
         ctx.close()
         reads, qs = split_reads(seqs, quals, offsets)
         t5 = time.time()
-        ores = oidx.map_batch(ob.make_params(rp), reads, qs, n_threads=os.cpu_count() or 8, keep_d=True)
+        ores = oidx.map_batch(ob.make_params(rp), reads, qs, n_threads=oracle_threads(), keep_d=True)
         print(f"oracle mapped {len(reads)} reads in {time.time() - t5:.1f} s; hits above 2^32: {(res.hits_arr['lower'] >= 2 ** 32).sum()} of {res.n_hits}")
         assert_same_as_oracle(ores, res, offsets)
         if n > 2 ** 32:
@@ -171,7 +171,7 @@ def test_index_beyond_2_pow_32_rows_maps_like_the_oracle(monkeypatch):
         t6 = time.time()
         ctx.close()
         reads, qs = split_reads(seqs, quals, offsets)
-        ores = oidx.map_batch(ob.make_params(rp), reads, qs, n_threads=os.cpu_count() or 8, keep_d=True)
+        ores = oidx.map_batch(ob.make_params(rp), reads, qs, n_threads=oracle_threads(), keep_d=True)
         pops = res.counters["n_pop"].astype(np.int64)
         print(f"C5 mix: {n_c5} reads of 35-100 bp on the GPU in {t6 - t5:.1f} s, oracle in {time.time() - t6:.1f} s; pops mean {pops.mean():.0f} max {pops.max()}, "
               f"{res.n_second_pass} arena migrations, {res.n_third_pass} reads through the full-limit stage, {int((pops > c5_limits['edit_tree_limit']).sum())} reads past the tree limit")
@@ -204,7 +204,7 @@ def test_index_beyond_2_pow_32_rows_maps_like_the_oracle(monkeypatch):
         t7 = time.time()
         ctx.close()
         reads, qs = split_reads(h_seqs, h_quals, h_off)
-        ores = oidx.map_batch(ob.make_params(rp), reads, qs, n_threads=os.cpu_count() or 8, keep_d=True)
+        ores = oidx.map_batch(ob.make_params(rp), reads, qs, n_threads=oracle_threads(), keep_d=True)
         t8 = time.time()
         print(f"C5 at the real limits: {n_pre} reads in {t6 - t5:.1f} s ({info['reads']} finished on the host, {info['host_pops'] / max(pops.sum(), 1):.1%} of the pops); the {len(heavy)} heaviest "
               f"(pops {pops[heavy].min()} .. {pops[heavy].max()}) again in {t7 - t6:.1f} s ({hinfo['reads']} on the host), oracle {t8 - t7:.1f} s; "

@@ -219,7 +219,11 @@ def test_kernel_logic_search_kat(case):
     ("double_stranded", DOUBLE_STRANDED, dict(qual_range=(20, 40), damage=dict(f=0.5, t=0.5, d=0.02, s=1.0)), 300),
     ("ignore_base_quality", IGNORE_BQ, dict(qual_range=(2, 40), damage=dict(f=0.5, t=0.5, d=0.02, s=1.0)), 300),
 ])
-def test_kernel_logic_synthetic(name, prm, kw, n):
+@pytest.mark.parametrize("step", ["lane_parallel_commit", "payload_cache"])
+def test_kernel_logic_synthetic(name, prm, kw, n, step, monkeypatch):
+    # the two build options of the search step that change how a frame's children reach the heap (search_core.hpp): the quad kernel's default — children pushed
+    # side by side, emulated lane by lane here — and the payload cache of heap slots 1 and 2 with the sequential pushes
+    monkeypatch.setenv("MAPAD_EMU_PAYLOAD_CACHE", "1" if step == "payload_cache" else "0")
     g = synth.genome(150_000, seed=99)
     seqs, quals, offsets = synth.reads(g, n, 50, seed=7 + len(name), **kw)
     rp = resolve_params(prm)
@@ -231,7 +235,9 @@ def test_kernel_logic_synthetic(name, prm, kw, n):
     assert_same_as_oracle(ores, res, offsets)
 
 
-def test_kernel_logic_second_pass_and_limit_recovery():
+@pytest.mark.parametrize("step", ["lane_parallel_commit", "payload_cache"])
+def test_kernel_logic_second_pass_and_limit_recovery(step, monkeypatch):
+    monkeypatch.setenv("MAPAD_EMU_PAYLOAD_CACHE", "1" if step == "payload_cache" else "0")
     g = synth.genome(60_000, seed=5)
     seqs, quals, offsets = synth.reads(g, 150, 50, seed=11)
     reads, qs = split_reads(seqs, quals, offsets)
