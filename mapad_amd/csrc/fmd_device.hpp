@@ -176,6 +176,10 @@ __device__ __forceinline__ uint64_t quad_pick64(uint64_t v, int k) {  // value o
     const uint64_t a = quad_bcast64<0>(v), b = quad_bcast64<1>(v), c = quad_bcast64<2>(v), d = quad_bcast64<3>(v);
     return k == 0 ? a : k == 1 ? b : k == 2 ? c : d;
 }
+__device__ __forceinline__ uint32_t quad_pick32(uint32_t v, int k) {  // value of lane k (k quad-uniform, dynamic)
+    const uint32_t a = dpp_quad<0 * 0x55>(v), b = dpp_quad<1 * 0x55>(v), c = dpp_quad<2 * 0x55>(v), d = dpp_quad<3 * 0x55>(v);
+    return k == 0 ? a : k == 1 ? b : k == 2 ? c : d;
+}
 // The same in two halves, so that a caller can put other memory traffic (the repair of the heap) between issuing the four loads and using them.
 struct ExtLoads { OccLoads lo, hi; };
 __device__ __forceinline__ ExtLoads ext4_quad_issue(const DevIndex& ix, uint64_t lower, uint64_t size, int w) {

@@ -296,8 +296,15 @@ MAPAD_HD Ancestors load_ancestors(const ArenaT<NL, TOP>& A, uint32_t pos) {
     a.e1 = i1 < (uint32_t)TOP ? n1 : g1; a.e2 = i2 < (uint32_t)TOP ? n2 : g2; a.e3 = i3 < (uint32_t)TOP ? n3 : g3;
     return a;
 }
+// What a bubble-up stored into slots other than the new element's own: at most two (slot, entry) pairs unless it climbed beyond the second grandparent (`far`).
+// The lane-parallel commit forwards these to the siblings that are pushed behind it instead of sending them back to memory for their ancestors.
+struct BubbleWrites {
+    uint32_t slot_a = 0xFFFFFFFFu, slot_b = 0xFFFFFFFFu;
+    HeapEntry a{0.0f, 0u}, b{0.0f, 0u};
+    uint32_t far = 0;
+};
 template <bool NL, int TOP>
-MAPAD_HD uint32_t mm_bubble_up(const ArenaT<NL, TOP>& A, uint32_t pos, const HeapEntry elt, const Ancestors& an) {  // elt is the new element, destined for slot pos; returns the slot it ends up in
+MAPAD_HD uint32_t mm_bubble_up(const ArenaT<NL, TOP>& A, uint32_t pos, const HeapEntry elt, const Ancestors& an, BubbleWrites* bw = nullptr) {  // elt is the new element, destined for slot pos; returns the slot it ends up in
     // Both compares are evaluated unconditionally (slots that do not exist compare as "stay"): the three entries are then consumed on the main
     // path, where the compiler places the one wait for them, and the outcome is a store of elt plus at most two displaced entries.
     const uint32_t i1 = pos > 0 ? (pos - 1) >> 1 : 0;   // parent
@@ -314,6 +321,7 @@ MAPAD_HD uint32_t mm_bubble_up(const ArenaT<NL, TOP>& A, uint32_t pos, const Hea
 #if defined(MAPAD_PROFILE_SECTIONS) && defined(__HIP_DEVICE_COMPILE__)
     if (__ballot(moved) != 0xFFFFFFFFFFFFFFFFull || e2.score != e3.score) MAPAD_MARK(PROF_C_LOAD);  // forces the wait for the three entries before the mark
 #endif
+    const uint32_t pos0 = pos;
     const uint32_t pos1 = moved ? i1 : pos;
     const HeapEntry ge = moved ? e3 : e2;
     const uint32_t gp = moved ? i3 : i2;
@@ -329,11 +337,17 @@ MAPAD_HD uint32_t mm_bubble_up(const ArenaT<NL, TOP>& A, uint32_t pos, const Hea
                 if (!(elt_key > flip_sign(g.score, flip2))) break;
                 hp_set(A, pos, g);
                 pos = g2;
+                if (bw) bw->far = 1;
             }
             drain_memory();
         }
     } else pos = pos1;
     hp_set(A, pos, elt);
+    if (bw) {
+        const bool both = moved & moved2;  // the parent's slot took the grandparent's entry
+        bw->slot_a = both ? i1 : 0xFFFFFFFFu; bw->a.score = ge.score; bw->a.node = ge.node;
+        bw->slot_b = pos != pos0 ? pos : 0xFFFFFFFFu; bw->b.score = elt.score; bw->b.node = elt.node;
+    }
     return pos;
 }
 template <bool NL, int TOP>
@@ -963,15 +977,29 @@ MAPAD_HD bool search_step(const DevIndex& ix, const DevParams& P, const ReadInT<
                     if (act & stays) hp_set(A, pos, elt);
                     // the movers of this round, in commit order, each by its own lane
                     uint32_t movers = (uint32_t)(__ballot(act & !stays) >> (threadIdx.x & 60u)) & 15u;  // this quad's four lanes
-                    bool fresh = true;  // the ancestors loaded above are still what the heap holds (only stayers have been stored)
+                    Ancestors my_an = an;
+                    bool my_fresh = true;  // my_an is what the heap holds for this lane's child (stayers changed no ancestor; movers' writes are forwarded below)
                     while (movers) {
                         const int m = __ffs((int)movers) - 1;
                         movers &= movers - 1;
+                        BubbleWrites bw;
                         if (w == m) {
-                            if (fresh) mm_bubble_up(A, pos, elt, an);
-                            else mm_bubble_up(A, pos, elt);
+                            if (MAPAD_UNLIKELY(!my_fresh)) { my_an = load_ancestors(A, pos); drain_memory(); }
+                            mm_bubble_up(A, pos, elt, my_an, &bw);
                         }
-                        fresh = false;
+                        if (movers) {  // siblings behind this one: they see what it stored, from its registers (a trip to memory each otherwise)
+                            const uint32_t sa = quad_pick32(bw.slot_a, m), sb = quad_pick32(bw.slot_b, m), far = quad_pick32(bw.far, m);
+                            const uint32_t a_s = quad_pick32(__float_as_uint(bw.a.score), m), a_n = quad_pick32(bw.a.node, m);
+                            const uint32_t b_s = quad_pick32(__float_as_uint(bw.b.score), m), b_n = quad_pick32(bw.b.node, m);
+                            const uint32_t i1 = pos > 0 ? (pos - 1) >> 1 : 0, i2 = pos > 2 ? (pos - 3) >> 2 : 0, i3 = i1 > 2 ? (i1 - 3) >> 2 : 0;
+                            auto patch = [&](HeapEntry& e, uint32_t idx) {
+                                const bool ha = idx == sa, hb = idx == sb;  // slot_b is written last (the new element's final slot): it wins if both name the slot
+                                e.score = hb ? __uint_as_float(b_s) : ha ? __uint_as_float(a_s) : e.score;
+                                e.node = hb ? b_n : ha ? a_n : e.node;
+                            };
+                            patch(my_an.e1, i1); patch(my_an.e2, i2); patch(my_an.e3, i3);
+                            my_fresh = my_fresh & (far == 0u);  // it climbed past its second grandparent: whoever comes behind reloads
+                        }
                     }
                 }
                 st.tree_next = id0 + kids; st.tree_entries = id0 + kids; st.tree_len += kids; st.heap_len = n0 + kids;
@@ -999,10 +1027,17 @@ MAPAD_HD bool search_step(const DevIndex& ix, const DevParams& P, const ReadInT<
                 for (int wv = 0; wv < 4 && base + wv < kids; ++wv) {  // all decisions against the heap as it was, stayers stored
                     if (mm_push_stays(pos4[wv], elt4[wv], an4[wv])) hp_set(A, pos4[wv], elt4[wv]); else movers |= 1u << wv;
                 }
-                bool fresh = true;
+                bool fresh4[4] = {true, true, true, true};
                 for (int wv = 0; wv < 4; ++wv) if ((movers >> wv) & 1u) {
-                    if (fresh) mm_bubble_up(A, pos4[wv], elt4[wv], an4[wv]); else mm_bubble_up(A, pos4[wv], elt4[wv]);
-                    fresh = false;
+                    BubbleWrites bw;
+                    if (!fresh4[wv]) an4[wv] = load_ancestors(A, pos4[wv]);
+                    mm_bubble_up(A, pos4[wv], elt4[wv], an4[wv], &bw);
+                    for (int u = wv + 1; u < 4 && base + u < kids; ++u) {  // forwarded to the lanes behind (search_step: device path)
+                        const uint32_t pos = pos4[u], i1 = pos > 0 ? (pos - 1) >> 1 : 0, i2 = pos > 2 ? (pos - 3) >> 2 : 0, i3 = i1 > 2 ? (i1 - 3) >> 2 : 0;
+                        auto patch = [&](HeapEntry& en, uint32_t idx) { if (idx == bw.slot_b) en = bw.b; else if (idx == bw.slot_a) en = bw.a; };
+                        patch(an4[u].e1, i1); patch(an4[u].e2, i2); patch(an4[u].e3, i3);
+                        if (bw.far) fresh4[u] = false;
+                    }
                 }
                 (void)t4;
             }
