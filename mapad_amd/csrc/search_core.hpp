@@ -28,6 +28,13 @@
 #define MAPAD_RARE inline
 #endif
 
+// MAPAD_QUAD_LOADS=1: values every lane of a quad needs (popped node, score row, the heap's last entry, heap entries stored) are requested / stored by one lane
+// each and handed round by DPP, instead of four lanes issuing the same address.  Bit-identical and MEASURED SLOWER (round 4, same-box A/B: C4 -9 %, C2 -9 %,
+// C3 -5 %, profiles/r04/ab_step_levers.txt): four lanes with one address cost the memory pipeline no more than one lane does, the DPP moves and exec masks do cost.  Off.
+#if !defined(MAPAD_QUAD_LOADS)
+#define MAPAD_QUAD_LOADS 0
+#endif
+
 // -DMAPAD_PROFILE_SECTIONS: wave time and lane time per section of the search loop (s_memtime deltas accumulated in LDS, dumped by the kernel).
 // A diagnostic build: the marks cost a few percent and the numbers are relative.
 #if defined(MAPAD_PROFILE_SECTIONS) && defined(__HIPCC__)
@@ -237,6 +244,17 @@ template <bool NL, int TOP> MAPAD_HD void hp_set(const ArenaT<NL, TOP>& A, uint3
     if (i < (uint32_t)TOP) store_entry(A.top + i, e);
     else store_entry(A.heap + i, e);
 }
+// the same where all lanes of a quad hold the same (i, e): the arena store by the quad's first lane only (lane-parallel callers use hp_set: their lanes differ)
+template <int LPR, bool NL, int TOP> MAPAD_HD void hp_set_uniform(const ArenaT<NL, TOP>& A, uint32_t i, const HeapEntry e) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if constexpr (MAPAD_QUAD_LOADS != 0 && LPR == 4) {
+        if (i < (uint32_t)TOP) store_entry(A.top + i, e);
+        else if ((threadIdx.x & 3u) == 0u) store_entry(A.heap + i, e);
+        return;
+    }
+#endif
+    hp_set(A, i, e);
+}
 template <bool NL, int TOP> MAPAD_HD HeapPair hp_pair(const ArenaT<NL, TOP>& A, uint32_t i) { if (i < (uint32_t)TOP) return load_pair(A.top + i); return load_pair(A.heap + i); }
 
 struct SearchState {
@@ -374,7 +392,8 @@ MAPAD_HD bool mm_push_stays(uint32_t pos, const HeapEntry elt, const Ancestors& 
 // the first stride, or at once if that slot has no children): search_step's payload cache fetches that frame while the rest of the sift and the rank
 // queries are in flight.
 struct NoOccupantHook { MAPAD_HD void operator()(uint32_t) const {} };
-template <bool MAX, bool NL, int TOP, class Hook = NoOccupantHook>
+// QL = 4: the caller is a quad whose four lanes run this sift with identical arguments (arena stores then go out once per quad: hp_set_uniform).
+template <bool MAX, bool NL, int TOP, class Hook = NoOccupantHook, int QL = 1>
 MAPAD_HD void mm_trickle_down(const ArenaT<NL, TOP>& A, uint32_t n, uint32_t pos, HeapEntry elt, Hook&& occupant = Hook()) {
     bool going = true;
     uint32_t placed_node = elt.node;  // node of the entry that was stored into the slot a stride started from (elt itself if the stride stored nothing there)
@@ -400,7 +419,7 @@ MAPAD_HD void mm_trickle_down(const ArenaT<NL, TOP>& A, uint32_t n, uint32_t pos
         return true;
     };
     auto set_near = [&](uint32_t i, const HeapEntry e) { store_entry(A.top + i, e); };
-    auto set_any = [&](uint32_t i, const HeapEntry e) { hp_set(A, i, e); };
+    auto set_any = [&](uint32_t i, const HeapEntry e) { hp_set_uniform<QL>(A, i, e); };
     if constexpr (TOP >= 63) {
         constexpr int kNearStrides = TOP >= 1023 ? 4 : TOP >= 255 ? 3 : 2;  // strides that stay inside the near levels when the sift starts at slot 1 or 2
 #pragma unroll
@@ -414,6 +433,17 @@ MAPAD_HD void mm_trickle_down(const ArenaT<NL, TOP>& A, uint32_t n, uint32_t pos
     } else static_assert(std::is_same<typename std::decay<Hook>::type, NoOccupantHook>::value, "the occupant hook needs the first stride in the near array");
     while (going && 2 * pos + 1 < n) {
         const uint32_t c1 = 2 * pos + 1, g1 = 2 * c1 + 1;
+#if !defined(__HIP_DEVICE_COMPILE__)
+        // host build (the host tail's deep heaps: 2 M entries, 16 MB): whichever grandchild the hole moves to, the next stride looks at slots 2 g + 1 ... 2 g + 2 and
+        // 4 g + 3 ... 4 g + 6 for g in [g1, g1 + 3] — two short contiguous runs; asked for now, they arrive while this stride is decided (a sift is otherwise a
+        // chain of ten cache misses, each waiting for the one before)
+        if (g1 >= (uint32_t)TOP) {
+            const HeapEntry* nc = A.heap + (2 * g1 + 1);  // 8 entries
+            const HeapEntry* ng = A.heap + (4 * g1 + 3);  // 16 entries
+            __builtin_prefetch(nc); __builtin_prefetch(nc + 7);
+            __builtin_prefetch(ng); __builtin_prefetch(ng + 8); __builtin_prefetch(ng + 15);
+        }
+#endif
         HeapPair c, ga, gb;  // a level is entirely near or entirely in the arena
         {   // near reads for every slot (clamped), arena loads predicated and back to back: one wait per level for the whole wavefront
             const bool c_near = c1 < (uint32_t)TOP, g_near = g1 + 3 < (uint32_t)TOP;
@@ -426,7 +456,7 @@ MAPAD_HD void mm_trickle_down(const ArenaT<NL, TOP>& A, uint32_t n, uint32_t pos
         }
         going = stride(c, ga, gb, c1, g1, set_any);
     }
-    hp_set(A, pos, elt);
+    hp_set_uniform<QL>(A, pos, elt);
 }
 
 // pop_max of the crate in two steps so that the caller can start loading the popped frame's node before the sift's stores:
@@ -732,6 +762,16 @@ MAPAD_HD void pc_clear(const ArenaT<NL, TOP>& A) { A.pc[0] = 0; A.pc[4] = 0; }
 #if !defined(MAPAD_PAR_COMMIT)
 #define MAPAD_PAR_COMMIT 1
 #endif
+// MAPAD_FORWARD_MOVERS=1: a mover's writes (mm_bubble_up: BubbleWrites) are handed to the siblings behind it through DPP instead of memory.  Bit-identical,
+// measured 0 ... -3 % (C4 / C2, C3: profiles/r04/ab_step_levers.txt): second movers are too rare to pay for the hand-over on every first one.  Off.
+#if !defined(MAPAD_FORWARD_MOVERS)
+#define MAPAD_FORWARD_MOVERS 0
+#endif
+// MAPAD_EARLY_ANCESTORS=1: the ancestors of the slots a frame's children will be appended to are requested as soon as the heap is repaired, before the rank
+// queries are finished and the children scored.  Bit-identical, measured +-0 (C2, C3, C4): off.
+#if !defined(MAPAD_EARLY_ANCESTORS)
+#define MAPAD_EARLY_ANCESTORS 0
+#endif
 template <int LPR, bool CONT, bool NL, bool PC = false, class Grow = NoGrow, int TOP = kTop, bool NLR = NL>
 MAPAD_HD bool search_step(const DevIndex& ix, const DevParams& P, const ReadInT<NLR>& rd, ArenaT<NL, TOP>& A, SearchState& st, int w, const Grow& grow) {
     if (st.heap_len == 0 || st.status != ST_OK) return false;
@@ -771,9 +811,33 @@ MAPAD_HD bool search_step(const DevIndex& ix, const DevParams& P, const ReadInT<
             drain_memory();
         }
         top_node.w0 = 0; top_node.w1 = hit ? c1 : g1; top_node.w2 = hit ? c2 : g2; top_node.w3 = hit ? c3 : g3;
-    } else top_node = A.nodes[top.node];
+    } else {
+#if defined(__HIP_DEVICE_COMPILE__)
+        if constexpr (MAPAD_QUAD_LOADS != 0 && LPR == 4) {
+            // One request per quad, not four: lane w asks for word w of the node (lane 0's word — edit operation and parent — is not needed to extend the frame) and
+            // DPP hands the words round.  Four lanes asking for the same 32 bytes are one cache request but four lanes' worth of address and data-return
+            // cycles in the CU's memory pipeline, which is what this kernel saturates (what bounds the step).
+            const MAPAD_GLOBAL uint64_t* np = (const MAPAD_GLOBAL uint64_t*)(A.nodes + top.node);
+            uint64_t word = 0;
+            if (w != 0) word = np[w];
+            top_node.w0 = 0; top_node.w1 = quad_bcast64<1>(word); top_node.w2 = quad_bcast64<2>(word); top_node.w3 = quad_bcast64<3>(word);
+        } else
+#endif
+        top_node = A.nodes[top.node];
+    }
     HeapEntry last;
-    if constexpr (!PC) last = hp_get(A, st.heap_len - 1);  // with the node: both trips are needed before anything else can start
+    if constexpr (!PC) {  // with the node: both trips are needed before anything else can start
+#if defined(__HIP_DEVICE_COMPILE__)
+        if constexpr (MAPAD_QUAD_LOADS != 0 && LPR == 4) {
+            const uint32_t li = st.heap_len - 1;
+            HeapEntry le{0.0f, 0u};
+            if (li < (uint32_t)TOP) le = load_entry(A.top + li);  // (an LDS read of one address by four lanes is one access)
+            else if (w == 0) le = load_entry(A.heap + li);
+            last.score = __uint_as_float(dpp_quad<0>(__float_as_uint(le.score))); last.node = dpp_quad<0>(le.node);
+        } else
+#endif
+        last = hp_get(A, st.heap_len - 1);
+    }
     st.c_pop += 1;
     const Frame f = unpack_frame(top_node);
     const float f_score = top.score;
@@ -781,7 +845,17 @@ MAPAD_HD bool search_step(const DevIndex& ix, const DevParams& P, const ReadInT<
     const int j = forward ? f.start + f.len : f.start - 1;
     const int d_k = forward ? f.start : f.start - 1, d_l = forward ? f.start + f.len : f.start + f.len - 1;
     const int to_class = rd.qc[2 * j];
-    const Float4 row = sdm_row_at(P, rd.table, j, rd.qc[2 * j + 1], to_class);  // shared score table: hot in L1/L2; consumed after the rank queries
+    Float4 row;  // shared score table: hot in L1/L2; consumed after the rank queries
+#if defined(__HIP_DEVICE_COMPILE__)
+    if constexpr (MAPAD_QUAD_LOADS != 0 && LPR == 4) {  // lane w asks for the row's element w
+        const int qi = P.nq == 1 ? 0 : (int)rd.qc[2 * j + 1];
+        const float* e4 = P.sdm_table + 4 * ((size_t)rd.table + ((size_t)j * P.nq + qi) * 5 + to_class);
+        const uint32_t mine = __float_as_uint(e4[w]);
+        row.a = __uint_as_float(dpp_quad<0 * 0x55>(mine)); row.c = __uint_as_float(dpp_quad<1 * 0x55>(mine));
+        row.g = __uint_as_float(dpp_quad<2 * 0x55>(mine)); row.t = __uint_as_float(dpp_quad<3 * 0x55>(mine));
+    } else
+#endif
+    row = sdm_row_at(P, rd.table, j, rd.qc[2 * j + 1], to_class);
     const uint32_t gap_side = forward ? f.gap_f : f.gap_b;
     const float insertion_score = (gap_side == GAP_INS ? P.gap_extend : open_ext) + f_score;  // :1127-1136,1165-1174
     const float deletion_score = (gap_side == GAP_DEL ? P.gap_extend : open_ext) + f_score;
@@ -839,8 +913,15 @@ MAPAD_HD bool search_step(const DevIndex& ix, const DevParams& P, const ReadInT<
         };
         if (top_idx < st.heap_len) mm_trickle_down<true>(A, st.heap_len, top_idx, last, fetch);
     } else {
-        if (top_idx < st.heap_len) mm_trickle_down<true>(A, st.heap_len, top_idx, last);
+        if (top_idx < st.heap_len) mm_trickle_down<true, NL, TOP, NoOccupantHook, LPR == 4 ? 4 : 1>(A, st.heap_len, top_idx, last);
     }
+#if defined(__HIP_DEVICE_COMPILE__)
+    // MAPAD_EARLY_ANCESTORS: lane w's child, if the frame has that many, will be appended at slot heap_len + w — its ancestors are requested here, as soon as the
+    // heap is repaired, and travel while the rank queries are finished and the children are scored (the lane-parallel commit below would request them only then)
+    Ancestors early_an{};
+    constexpr bool kEarlyAn = MAPAD_PAR_COMMIT != 0 && MAPAD_EARLY_ANCESTORS != 0 && LPR == 4 && !PC;
+    if constexpr (kEarlyAn) early_an = load_ancestors(A, st.heap_len + (uint32_t)w);
+#endif
     MAPAD_MARK(PROF_POP);
     Ext4 e;
     uint64_t my_lower[kBases] = {}, my_lower_rev[kBases] = {}, my_size[kBases] = {};  // kLaneKids: extension by this lane's base(s)
@@ -972,7 +1053,9 @@ MAPAD_HD bool search_step(const DevIndex& ix, const DevParams& P, const ReadInT<
                     score = is_del ? deletion_score : score; score = is_ins ? insertion_score : score;
                     const uint32_t pos = n0 + (act ? r : 0u);
                     const HeapEntry elt{score, id0 + r};
-                    const Ancestors an = load_ancestors(A, pos);
+                    Ancestors an;
+                    if (kEarlyAn && base == 0) an = early_an;  // requested behind the sift (slot n0 + w; an inactive lane's are not looked at)
+                    else an = load_ancestors(A, pos);
                     const bool stays = mm_push_stays(pos, elt, an);
                     if (act & stays) hp_set(A, pos, elt);
                     // the movers of this round, in commit order, each by its own lane
@@ -987,7 +1070,8 @@ MAPAD_HD bool search_step(const DevIndex& ix, const DevParams& P, const ReadInT<
                             if (MAPAD_UNLIKELY(!my_fresh)) { my_an = load_ancestors(A, pos); drain_memory(); }
                             mm_bubble_up(A, pos, elt, my_an, &bw);
                         }
-                        if (movers) {  // siblings behind this one: they see what it stored, from its registers (a trip to memory each otherwise)
+                        if (MAPAD_FORWARD_MOVERS == 0) my_fresh = false;  // (default) whoever moves behind this one reloads its ancestors
+                        else if (movers) {  // siblings behind this one: they see what it stored, from its registers (a trip to memory each otherwise)
                             const uint32_t sa = quad_pick32(bw.slot_a, m), sb = quad_pick32(bw.slot_b, m), far = quad_pick32(bw.far, m);
                             const uint32_t a_s = quad_pick32(__float_as_uint(bw.a.score), m), a_n = quad_pick32(bw.a.node, m);
                             const uint32_t b_s = quad_pick32(__float_as_uint(bw.b.score), m), b_n = quad_pick32(bw.b.node, m);
