@@ -23,6 +23,8 @@
 #include <thread>
 #include <vector>
 
+#include <sys/mman.h>
+
 #include "host_models.hpp"
 #include "search_core.hpp"
 
@@ -131,8 +133,18 @@ struct TailScratch {
     bool ensure(uint32_t hc, uint32_t nc, uint32_t lm) {
         // a sift loads the grandchildren of its hole before it looks at the heap's length (search_core.hpp: mm_trickle_down): slots up to 2 * heap_len + 6 are
         // read (and ignored), so the allocation is twice the capacity — on the device those reads fall into the arena's node area
-        if (hc > heap_cap) { std::free(heap); heap = (HeapEntry*)std::malloc((2 * (size_t)hc + 64) * sizeof(HeapEntry)); heap_cap = heap ? hc : 0; }
-        if (nc > node_cap) { std::free(nodes); nodes = (Node*)std::aligned_alloc(64, (((size_t)nc + 1) * sizeof(Node) + 63) & ~(size_t)63); node_cap = nodes ? nc : 0; }
+        // (2 MB alignment + MADV_HUGEPAGE: a sift over a 2 M-entry heap and the node lookups behind evictions are random accesses over 16 MB and 320 MB; with 4 KB
+        //  pages nearly every one of them also misses the TLB)
+        auto big = [](size_t bytes) -> void* {
+            const size_t sz = (bytes + ((size_t)2 << 20) - 1) & ~(((size_t)2 << 20) - 1);
+            void* p = std::aligned_alloc((size_t)2 << 20, sz);
+#if defined(MADV_HUGEPAGE)
+            if (p) (void)madvise(p, sz, MADV_HUGEPAGE);
+#endif
+            return p;
+        };
+        if (hc > heap_cap) { std::free(heap); heap = (HeapEntry*)big((2 * (size_t)hc + 64) * sizeof(HeapEntry)); heap_cap = heap ? hc : 0; }
+        if (nc > node_cap) { std::free(nodes); nodes = (Node*)big(((size_t)nc + 1) * sizeof(Node)); node_cap = nodes ? nc : 0; }
         if (!heap || !nodes) return false;
         if (lm > lmax || top.empty()) {
             lmax = std::max(lm, lmax);

@@ -104,7 +104,9 @@ def merge_gathered(parts):
 
 
 RECORD_WORDS = 22  # csrc/text_core.hpp: DevRecord, 88 bytes
-_REC_TEXT_OFF, _REC_MQ_OFF = 13, 19  # word indices of text_off and mq_off
+# word indices: i64 pos (0-1), tid 2, mapped 3, reverse 4, as 5, xs 6, nm 7, x0 8, x1 9, has_xs 10, xt 11, text_off 12, cigar_len 13, md_len 14, xa_len 15,
+# best_size 16, read_len 17, mq_off 18, mq_n 19, error 20, (padding 21)
+_REC_TEXT_OFF, _REC_CIGAR_LEN, _REC_MQ_OFF, _REC_MQ_N = 12, 13, 18, 19
 
 
 def records_digest(recs, text, pairs):
@@ -131,8 +133,8 @@ def records_digest(recs, text, pairs):
     canon[:, _REC_MQ_OFF] = 0
     h = hashlib.sha256()
     h.update(canon.tobytes())
-    h.update(in_read_order(t, r[:, _REC_TEXT_OFF].view(np.uint32), r[:, 14].astype(np.int64) + r[:, 15] + r[:, 16]).tobytes())
-    h.update(in_read_order(p, 2 * r[:, _REC_MQ_OFF].view(np.uint32).astype(np.int64), 2 * r[:, 20].astype(np.int64)).tobytes())
+    h.update(in_read_order(t, r[:, _REC_TEXT_OFF].view(np.uint32), r[:, _REC_CIGAR_LEN].astype(np.int64) + r[:, _REC_CIGAR_LEN + 1] + r[:, _REC_CIGAR_LEN + 2]).tobytes())
+    h.update(in_read_order(p, 2 * r[:, _REC_MQ_OFF].view(np.uint32).astype(np.int64), 2 * r[:, _REC_MQ_N].astype(np.int64)).tobytes())
     return h.hexdigest()
 
 
