@@ -100,10 +100,14 @@ def main():
         checked = hi
         hits_ge_2_32 += int((g_hits["lower"] >= 2 ** 32).sum())
         print(f"  reads [{lo}, {hi}): {'identical' if same else 'DIFFERENT'}; oracle {t_oracle:.0f} s so far", file=sys.stderr, flush=True)
+        os.makedirs(os.path.dirname(args.out), exist_ok=True)  # progress on disk: a run that is cut short still says how far it got
+        json.dump({"partial": True, "reads_checked": checked, "reads_that_differ": bad_reads, "first_reads_that_differ": first_bad, "oracle_s": round(t_oracle, 1),
+                   "sha256_gpu_so_far": h_gpu.hexdigest(), "sha256_oracle_so_far": h_ora.hexdigest()}, open(args.out, "w"), indent=1)
     out = {"config": f"C4: synthetic genome ({args.genome_bp} bp, n = {len(index)} BWT rows), {args.reads} x 50 bp reads (seed 4321 + 4: the batch of bench.py --config c4), -p 0.03, no-damage model",
            "reads_checked": checked, "reads_that_differ": bad_reads, "first_reads_that_differ": first_bad, "hits": int(res.n_hits), "hit_intervals_at_or_above_2^32": hits_ge_2_32,
            "compared": "per read: hit count, BinaryHeap array order, lower, lower_rev, size, f32 score bits, edit tracks, the six event counters",
            "sha256_gpu": h_gpu.hexdigest(), "sha256_oracle": h_ora.hexdigest(), "digests_equal": h_gpu.hexdigest() == h_ora.hexdigest(),
+           "pops_per_read": {"mean": round(float(res.counters["n_pop"].mean()), 1), "max": int(res.counters["n_pop"].max()), "reads_above_2^17": int((res.counters["n_pop"] > (1 << 17)).sum())},
            "gpu_map_batch_s": round(t_gpu, 1), "oracle_s": round(t_oracle, 1), "oracle_threads": cores, "index_s": round(t_index, 1), "host_tail_reads": tail["reads"],
            "oracle": "oracle/mapad_oracle.hpp (CPU restatement of the reference algorithm; test infrastructure), byte BWT + Occ k = 128 over the product index's BWT"}
     os.makedirs(os.path.dirname(args.out), exist_ok=True)

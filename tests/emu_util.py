@@ -22,7 +22,8 @@ def lib():
             os.makedirs(os.path.dirname(_OUT), exist_ok=True)
             subprocess.check_call(["g++", "-O2", "-g", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math", "-fno-builtin-log2f", "-fno-builtin-powf",
                                    "-fno-builtin-expf", "-fno-builtin-exp2f", "-fno-builtin-log10f", "-Wall",
-                                   "-Wno-unused-function", "-Wno-unknown-pragmas", "-o", _OUT, _SRC])
+                                   "-Wno-unused-function", "-Wno-unknown-pragmas", "-o", _OUT + f".tmp{os.getpid()}", _SRC])
+            os.replace(_OUT + f".tmp{os.getpid()}", _OUT)  # atomically: the two ranks of test_distributed may both find the library stale
         L = C.CDLL(_OUT)
         L.emu_map_batch.restype = C.POINTER(mb.BatchResultC)
         L.emu_map_batch.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p, C.POINTER(mb.Params), C.c_void_p, C.c_void_p,

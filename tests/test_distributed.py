@@ -89,6 +89,9 @@ def test_two_rank_sharding_and_gather_matches_single_process(tmp_path):
         assert b[0][0] == 0 and b[-1][1] == n and all(b[i][1] == b[i + 1][0] for i in range(w - 1))
         assert max(hi - lo for lo, hi in b) - min(hi - lo for lo, hi in b) <= 1
     out = str(tmp_path / "merged.npz")
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import emu_util
+    emu_util.lib()  # built once here, not by both ranks at the same time
     mp.spawn(_worker, args=(2, _free_port(), out), nprocs=2, join=True)
     got = np.load(out)
     hb, hits, ops = _map_slice(0, 101)
