@@ -1038,6 +1038,11 @@ struct BatchSlot {
     PinnedBuf<uint8_t> tail_ring;
     std::shared_ptr<host::TailBatch> tail;  // set while the launch's handed-over reads have not been merged into its pools
     DevBuf<uint8_t> d_tail_up;
+    // Page-locked landing place of this slot's small device-to-host copies (cursors, a batch's base count).  A copy into pageable memory is staged by a copy
+    // KERNEL, and beside a search launch that kernel waits for wave slots the persistent wavefronts do not give up: rocprofv3 showed one such copy of 120 bytes
+    // taking 3.0 s, and every second search launch of the C4 bench starting 135 ms late behind it.  Page-locked destinations go through the SDMA engines.
+    PinnedBuf<uint32_t> h_small;
+    PinnedBuf<uint8_t> h_tail_stage;  // the host tail's results on their way into the pools (page-locked for the same reason)
     // record fields of the slot's batch on the device (mapad_records_device: what the multi-GPU gather sends)
     DevBuf<CoordRec> d_rec_coords;
     DevBuf<DevRecord> d_rec_out;
@@ -1106,6 +1111,7 @@ struct mapad_ctx {
     DevBuf<char> d_t_text;
     DevBuf<float> d_t_pairs;
     DevBuf<unsigned long long> d_t_cur;
+    PinnedBuf<unsigned long long> h_t_used;  // page-locked landing place of the text kernel's two cursors (see BatchSlot::h_small)
     uint64_t n_os = 0;
     DevBuf<unsigned long long> d_steps;
     bool sa_uploaded = false;
@@ -1549,24 +1555,31 @@ int merge_tail(mapad_ctx* c, BatchSlot& S, uint32_t* cur) {
     set64(CUR_HITS, hbase + n_hits); set64(CUR_OPS, obase + n_ops);
     const bool fits = hbase + n_hits <= B.hits_cap && obase + n_ops <= B.ops_cap;
     if (!fits) cur[CUR_POOL_OVF] = 1;  // the caller re-runs the batch with larger pools (mapad_map_batch), sized by these cursors
-    HIP_TRY(hipMemcpyAsync(B.cursors, cur, (CUR_POOL_OVF + 1) * 4, hipMemcpyHostToDevice, S.stream));
+    if (!S.h_small.resize(CUR_COUNT + 8)) return MAPAD_ERR_NOMEM;
+    std::memcpy(S.h_small.data(), cur, (CUR_POOL_OVF + 1) * 4);
+    HIP_TRY(hipMemcpyAsync(B.cursors, S.h_small.data(), (CUR_POOL_OVF + 1) * 4, hipMemcpyHostToDevice, S.stream));
     if (!fits) { HIP_TRY(hipStreamSynchronize(S.stream)); return MAPAD_OK; }
-    std::vector<HitRec> hits; hits.reserve(n_hits);
-    std::vector<uint32_t> ops; ops.reserve(n_ops);
-    std::vector<TailUp> up; up.reserve(res.size());
+    // staged in page-locked memory: [TailUp x reads][HitRec x n_hits][u32 x n_ops]
+    const size_t off_hits = (res.size() * sizeof(TailUp) + 63) & ~(size_t)63, off_ops = (off_hits + n_hits * sizeof(HitRec) + 63) & ~(size_t)63;
+    if (!S.h_tail_stage.resize(off_ops + n_ops * 4 + 64)) return MAPAD_ERR_NOMEM;
+    TailUp* up = reinterpret_cast<TailUp*>(S.h_tail_stage.data());
+    HitRec* hits = reinterpret_cast<HitRec*>(S.h_tail_stage.data() + off_hits);
+    uint32_t* ops = reinterpret_cast<uint32_t*>(S.h_tail_stage.data() + off_ops);
+    size_t k_up = 0, k_hits = 0, k_ops = 0;
     for (const auto& r : res) {
-        up.push_back(TailUp{r.read, r.status, (uint32_t)r.hits.size(), (uint32_t)(hbase + hits.size()), r.e_search, r.n_push, r.n_pop, r.n_node, r.n_hits});
-        for (HitRec h : r.hits) { h.ops_off += (uint32_t)(obase + ops.size()); hits.push_back(h); }  // like finalize_read: offsets into the global op pool
-        ops.insert(ops.end(), r.ops.begin(), r.ops.end());
+        up[k_up++] = TailUp{r.read, r.status, (uint32_t)r.hits.size(), (uint32_t)(hbase + k_hits), r.e_search, r.n_push, r.n_pop, r.n_node, r.n_hits};
+        for (HitRec h : r.hits) { h.ops_off += (uint32_t)(obase + k_ops); hits[k_hits++] = h; }  // like finalize_read: offsets into the global op pool
+        std::memcpy(ops + k_ops, r.ops.data(), r.ops.size() * 4);
+        k_ops += r.ops.size();
     }
     int rc;
-    if ((rc = S.d_tail_up.ensure(up.size() * sizeof(TailUp)))) return rc;
-    if (!hits.empty()) HIP_TRY(hipMemcpyAsync(B.hits_pool + hbase, hits.data(), hits.size() * sizeof(HitRec), hipMemcpyHostToDevice, S.stream));
-    if (!ops.empty()) HIP_TRY(hipMemcpyAsync(B.ops_pool + obase, ops.data(), ops.size() * 4, hipMemcpyHostToDevice, S.stream));
-    HIP_TRY(hipMemcpyAsync(S.d_tail_up.p, up.data(), up.size() * sizeof(TailUp), hipMemcpyHostToDevice, S.stream));
-    hipLaunchKernelGGL(tail_scatter_kernel, dim3((uint32_t)((up.size() + 63) / 64)), dim3(64), 0, S.stream, B, (const TailUp*)S.d_tail_up.p, (uint32_t)up.size());
+    if ((rc = S.d_tail_up.ensure(res.size() * sizeof(TailUp)))) return rc;
+    if (n_hits) HIP_TRY(hipMemcpyAsync(B.hits_pool + hbase, hits, n_hits * sizeof(HitRec), hipMemcpyHostToDevice, S.stream));
+    if (n_ops) HIP_TRY(hipMemcpyAsync(B.ops_pool + obase, ops, n_ops * 4, hipMemcpyHostToDevice, S.stream));
+    HIP_TRY(hipMemcpyAsync(S.d_tail_up.p, up, res.size() * sizeof(TailUp), hipMemcpyHostToDevice, S.stream));
+    hipLaunchKernelGGL(tail_scatter_kernel, dim3((uint32_t)((res.size() + 63) / 64)), dim3(64), 0, S.stream, B, (const TailUp*)S.d_tail_up.p, (uint32_t)res.size());
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipStreamSynchronize(S.stream));  // the host vectors go out of scope
+    HIP_TRY(hipStreamSynchronize(S.stream));
     return MAPAD_OK;
 }
 
@@ -1578,7 +1591,12 @@ int compact_last(mapad_ctx* c) {
     const BatchDev& B = S.last;
     const uint64_t n = B.n_reads;
     uint32_t cur[CUR_COUNT] = {0};
-    if (n) HIP_TRY(hipMemcpy(cur, B.cursors, sizeof cur, hipMemcpyDeviceToHost));
+    if (n) {
+        if (!S.h_small.resize(CUR_COUNT + 8)) return MAPAD_ERR_NOMEM;
+        HIP_TRY(hipMemcpyAsync(S.h_small.data(), B.cursors, sizeof cur, hipMemcpyDeviceToHost, S.stream));
+        HIP_TRY(hipStreamSynchronize(S.stream));
+        std::memcpy(cur, S.h_small.data(), sizeof cur);
+    }
     if (S.tail) { const int rc_t = merge_tail(c, S, cur); if (rc_t) return rc_t; }
     if (cur[CUR_ERR] & ST_NO_TABLE) { std::fprintf(stderr, "mapad_amd: a read length had no score table (call mapad_ctx_prepare_lengths)\n"); return MAPAD_ERR_INVALID; }
     if (cur[CUR_ERR] & ST_ARENA_OVERFLOW) { std::fprintf(stderr, "mapad_amd: arena overflow in the large-arena pass\n"); return MAPAD_ERR_NOMEM; }
@@ -1823,8 +1841,13 @@ int mapad_map_batch_device(mapad_ctx_t* ctx, const void* d_seqs, const void* d_q
     // the batch's base count, read on the slot's own (idle) stream: a copy on the caller's stream would wait for whatever that stream orders
     // itself behind (the legacy default stream: every blocking stream)
     uint64_t total = 0;
-    if (n_reads) HIP_TRY(hipMemcpyAsync(&total, (const uint64_t*)d_offsets + n_reads, 8, hipMemcpyDeviceToHost, ctx->bs[ctx->cur].stream));
-    if (n_reads) HIP_TRY(hipStreamSynchronize(ctx->bs[ctx->cur].stream));
+    if (n_reads) {
+        BatchSlot& S = ctx->bs[ctx->cur];
+        if (!S.h_small.resize(CUR_COUNT + 8)) return MAPAD_ERR_NOMEM;
+        HIP_TRY(hipMemcpyAsync(S.h_small.data() + CUR_COUNT, (const uint64_t*)d_offsets + n_reads, 8, hipMemcpyDeviceToHost, S.stream));  // (page-locked: no copy kernel, BatchSlot::h_small)
+        HIP_TRY(hipStreamSynchronize(S.stream));
+        std::memcpy(&total, S.h_small.data() + CUR_COUNT, 8);
+    }
     return launch_batch(ctx, ctx->bs[ctx->cur], (const uint8_t*)d_seqs, (const uint8_t*)d_quals, (const uint64_t*)d_offsets, n_reads, total, max_read_len);
 }
 
@@ -1838,7 +1861,10 @@ int mapad_fetch_result(mapad_ctx_t* ctx, mapad_batch_result_t** out) {
     const uint64_t n = B.n_reads;
     auto r = std::make_unique<HostResult>();
     uint32_t cur[CUR_COUNT] = {0};
-    if (n) HIP_TRY(hipMemcpyAsync(cur, B.cursors, sizeof cur, hipMemcpyDeviceToHost, S.stream));
+    if (n) {
+        if (!S.h_small.resize(CUR_COUNT + 8)) return MAPAD_ERR_NOMEM;
+        HIP_TRY(hipMemcpyAsync(S.h_small.data(), B.cursors, sizeof cur, hipMemcpyDeviceToHost, S.stream));
+    }
     // order-preserving collect (mapping.rs:288): hits in read order, BinaryHeap array order inside a read — laid out by the device
     bool ok = r->status.resize(n) && r->counters.resize(n) && r->hit_begin.resize(n + 1) && r->hits.resize(S.c_n_hits) && r->ops.resize(S.c_n_ops);
     if (ctx->fetch_d) ok = ok && r->d_arrays.resize(S.last_total_bases);
@@ -1854,6 +1880,7 @@ int mapad_fetch_result(mapad_ctx_t* ctx, mapad_batch_result_t** out) {
         if (ctx->fetch_d && S.last_total_bases) HIP_TRY(hipMemcpyAsync(r->d_arrays.data(), B.d_arrays, S.last_total_bases * 4, hipMemcpyDeviceToHost, S.stream));
     }
     HIP_TRY(hipStreamSynchronize(S.stream));
+    if (n) std::memcpy(cur, S.h_small.data(), sizeof cur);
     if (r->hit_begin[n] != r->hits.size()) { std::fprintf(stderr, "mapad_amd: compacted hit count does not match the pool cursor\n"); return MAPAD_ERR_DEVICE; }
     uint64_t sums[6] = {0, 0, 0, 0, 0, 0};
     for (uint64_t i = 0; i < n; ++i) {
@@ -2261,8 +2288,10 @@ static int run_record_kernels(mapad_ctx_t* ctx, const uint64_t* d_begin, const H
         TQ.text = bufs.text.p; TQ.pairs = bufs.pairs.p; TQ.cursors = ctx->d_t_cur.p; TQ.text_cap = bufs.text.cap; TQ.pair_cap = bufs.pairs.cap / 2; TQ.out = bufs.out.p;
         hipLaunchKernelGGL(text_kernel, dim3((uint32_t)((n + 63) / 64)), dim3(64), 0, rstream, TQ);
         HIP_TRY(hipGetLastError());
-        HIP_TRY(hipMemcpyAsync(used, ctx->d_t_cur.p, 16, hipMemcpyDeviceToHost, rstream));
+        if (!ctx->h_t_used.resize(2)) return MAPAD_ERR_NOMEM;
+        HIP_TRY(hipMemcpyAsync(ctx->h_t_used.data(), ctx->d_t_cur.p, 16, hipMemcpyDeviceToHost, rstream));
         HIP_TRY(hipStreamSynchronize(rstream));
+        used[0] = ctx->h_t_used[0]; used[1] = ctx->h_t_used[1];
         if (used[0] <= TQ.text_cap && used[1] <= TQ.pair_cap) break;
         if (used[0] > 0xFFFFFFFFull || used[1] > 0xFFFFFFFFull) return MAPAD_ERR_INVALID;  // more than 4 GiB of record text in one batch
         if (attempt == 7) return MAPAD_ERR_NOMEM;
