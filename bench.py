@@ -307,11 +307,21 @@ def main():
 
     tail_steps = []  # per collected step: the host tail's figures (csrc/host_tail.hpp)
 
+    host_trace = []  # (what, seconds) of the library calls of the step loop, when MAPAD_BENCH_TRACE is set: where the host thread waits
+
+    def timed(what, fn, *a):
+        if not os.environ.get("MAPAD_BENCH_TRACE"):
+            return fn(*a)
+        t = time.perf_counter()
+        r = fn(*a)
+        host_trace.append((what, round(time.perf_counter() - t, 4)))
+        return r
+
     def collect_step():
         """The selected batch's order-preserving collect on the device — which first waits for the host threads that finish the reads the GPU handed
         over (none for the 50 bp workloads) — and, N > 1, the gather of its records."""
         if world == 1:
-            ctx.compact_device()
+            timed("collect", ctx.compact_device)
             g = None
         else:
             g = gather_hits()
@@ -323,7 +333,7 @@ def main():
         the gather of its records) is issued behind the submission of step i + 1."""
         last = None
         for i in range(k):
-            ctx.map_batch_device(d_seqs.data_ptr(), d_quals.data_ptr(), d_offsets.data_ptr(), n_reads, max_len)
+            timed("submit", ctx.map_batch_device, d_seqs.data_ptr(), d_quals.data_ptr(), d_offsets.data_ptr(), n_reads, max_len)
             heartbeat(f"step {i} submitted")
             if i > 0 and args.depth > 1:
                 ctx.select_batch(1)
@@ -344,7 +354,10 @@ def main():
         dist.barrier()
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
+    host_trace.clear()
     gathered = run_steps(args.steps)
+    if host_trace:
+        log("[host trace] " + " ".join(f"{w}:{t}" for w, t in host_trace[:24]))
     tail_timed = list(tail_steps)
     torch.cuda.synchronize(dev)
     if world > 1:

@@ -798,6 +798,22 @@ __global__ void __launch_bounds__(64, (LPR == 1 && NL) ? 1 : LPR == 2 ? 2 : MAPA
 
 #include "heavy_kernel.hpp"
 
+// ---- a few words from device memory into page-locked host memory, by a one-wavefront kernel ---------------------------------------------------------------
+// What the host needs to read back between launches (a batch's cursors, its base count, the text kernel's pool cursors) is a hundred bytes — and a hipMemcpy of
+// a hundred bytes is a copy KERNEL of the runtime whose workgroups do not fit beside a search launch: host trace of the C4 bench, round 4: 1.2-1.8 s per such
+// copy, waiting for the persistent wavefronts to thin out, every second search launch 135 ms late.  This kernel is one wavefront like the other kernels around
+// the search, which the launches leave room for.
+// The same for clearing a batch's buffers: hipMemsetAsync is a fill kernel of the runtime with large workgroups, and in front of a batch's D-array kernel it kept the
+// whole batch waiting for the running search to thin out (launch marks of the C4 bench: the next batch's preparation started 3 s late whenever it was submitted
+// a few milliseconds after the search beside it had filled the chip).
+__global__ void MAPAD_SLIM zero_words_kernel(uint32_t* __restrict__ p, uint64_t n) {
+    for (uint64_t i = (uint64_t)blockIdx.x * 64 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 64) p[i] = 0u;
+}
+__global__ void MAPAD_SLIM publish_words_kernel(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst_host, uint32_t n) {
+    for (uint32_t i = threadIdx.x; i < n; i += 64) dst_host[i] = src[i];
+    __threadfence_system();
+}
+
 // ---- results of the host tail -> the batch's per-read arrays (the hits and edit tracks themselves are copied into the pools) -----------------------
 struct TailUp { uint32_t read, status, hit_count, hit_first, e_search, n_push, n_pop, n_node, n_hits; };
 __global__ void MAPAD_SLIM tail_scatter_kernel(BatchDev B, const TailUp* __restrict__ up, uint32_t n) {
@@ -1002,6 +1018,25 @@ struct PinnedBuf {
     ~PinnedBuf() { PinnedPool::instance().give(p, cap_bytes); }
 };
 
+}  // namespace
+
+namespace {
+// clears `bytes` bytes (a multiple of 4) at p on stream st with one-wavefront blocks (zero_words_kernel)
+int zero_async(hipStream_t st, void* p, size_t bytes) {
+    const uint64_t n = bytes / 4;
+    if (!n) return MAPAD_OK;
+    const uint32_t grid = (uint32_t)std::min<uint64_t>((n + 255) / 256, 4096);
+    hipLaunchKernelGGL(zero_words_kernel, dim3(grid), dim3(64), 0, st, (uint32_t*)p, n);
+    HIP_TRY(hipGetLastError());
+    return MAPAD_OK;
+}
+// n words at d_src -> h[word_off ...] on stream st (publish_words_kernel), then waits for the stream
+int read_back_words(hipStream_t st, const void* d_src, PinnedBuf<uint32_t>& h, size_t word_off, uint32_t n_words) {
+    hipLaunchKernelGGL(publish_words_kernel, dim3(1), dim3(64), 0, st, (const uint32_t*)d_src, h.data() + word_off, n_words);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(st));
+    return MAPAD_OK;
+}
 }  // namespace
 
 // Everything one batch in flight owns: its stream, result and scratch buffers, per-read-slot base arenas.  A context keeps `depth` of
@@ -1388,9 +1423,9 @@ int launch_batch(mapad_ctx* c, BatchSlot& S, const uint8_t* d_seqs, const uint8_
     const bool ordered = env_u32("MAPAD_ORDER", 1) != 0;
     const uint32_t order_shift = order_shift_for(nr);
     const uint32_t n_chunks = (uint32_t)((nr + (1ull << order_shift) - 1) >> order_shift);
-    if (ordered) HIP_TRY(hipMemsetAsync(S.d_key_hist.p, 0, (size_t)n_chunks * kKeyBins * 4, S.stream));
-    HIP_TRY(hipMemsetAsync(S.d_cursors.p, 0, CUR_COUNT * 4, S.stream));
-    HIP_TRY(hipMemsetAsync(S.d_status.p, 0, nr * 4, S.stream));
+    if (ordered && (rc = zero_async(S.stream, S.d_key_hist.p, (size_t)n_chunks * kKeyBins * 4))) return rc;
+    if ((rc = zero_async(S.stream, S.d_cursors.p, CUR_COUNT * 4))) return rc;
+    if ((rc = zero_async(S.stream, S.d_status.p, nr * 4))) return rc;
     BatchDev B{};
     B.seqs = d_seqs; B.quals = d_quals; B.offsets = d_offsets; B.n_reads = (uint32_t)n_reads;
     B.d_arrays = S.d_darr.p; B.counters = S.d_counters.p; B.status = S.d_status.p;
@@ -1593,8 +1628,7 @@ int compact_last(mapad_ctx* c) {
     uint32_t cur[CUR_COUNT] = {0};
     if (n) {
         if (!S.h_small.resize(CUR_COUNT + 8)) return MAPAD_ERR_NOMEM;
-        HIP_TRY(hipMemcpyAsync(S.h_small.data(), B.cursors, sizeof cur, hipMemcpyDeviceToHost, S.stream));
-        HIP_TRY(hipStreamSynchronize(S.stream));
+        { const int rc_p = read_back_words(S.stream, B.cursors, S.h_small, 0, CUR_COUNT); if (rc_p) return rc_p; }
         std::memcpy(cur, S.h_small.data(), sizeof cur);
     }
     if (S.tail) { const int rc_t = merge_tail(c, S, cur); if (rc_t) return rc_t; }
@@ -1844,8 +1878,7 @@ int mapad_map_batch_device(mapad_ctx_t* ctx, const void* d_seqs, const void* d_q
     if (n_reads) {
         BatchSlot& S = ctx->bs[ctx->cur];
         if (!S.h_small.resize(CUR_COUNT + 8)) return MAPAD_ERR_NOMEM;
-        HIP_TRY(hipMemcpyAsync(S.h_small.data() + CUR_COUNT, (const uint64_t*)d_offsets + n_reads, 8, hipMemcpyDeviceToHost, S.stream));  // (page-locked: no copy kernel, BatchSlot::h_small)
-        HIP_TRY(hipStreamSynchronize(S.stream));
+        if ((rc = read_back_words(S.stream, (const uint64_t*)d_offsets + n_reads, S.h_small, CUR_COUNT, 2))) return rc;
         std::memcpy(&total, S.h_small.data() + CUR_COUNT, 8);
     }
     return launch_batch(ctx, ctx->bs[ctx->cur], (const uint8_t*)d_seqs, (const uint8_t*)d_quals, (const uint64_t*)d_offsets, n_reads, total, max_read_len);
@@ -1863,7 +1896,8 @@ int mapad_fetch_result(mapad_ctx_t* ctx, mapad_batch_result_t** out) {
     uint32_t cur[CUR_COUNT] = {0};
     if (n) {
         if (!S.h_small.resize(CUR_COUNT + 8)) return MAPAD_ERR_NOMEM;
-        HIP_TRY(hipMemcpyAsync(S.h_small.data(), B.cursors, sizeof cur, hipMemcpyDeviceToHost, S.stream));
+        hipLaunchKernelGGL(publish_words_kernel, dim3(1), dim3(64), 0, S.stream, (const uint32_t*)B.cursors, S.h_small.data(), (uint32_t)CUR_COUNT);
+        HIP_TRY(hipGetLastError());
     }
     // order-preserving collect (mapping.rs:288): hits in read order, BinaryHeap array order inside a read — laid out by the device
     bool ok = r->status.resize(n) && r->counters.resize(n) && r->hit_begin.resize(n + 1) && r->hits.resize(S.c_n_hits) && r->ops.resize(S.c_n_ops);
@@ -2281,7 +2315,7 @@ static int run_record_kernels(mapad_ctx_t* ctx, const uint64_t* d_begin, const H
     if ((rc = bufs.text.ensure(std::max<size_t>(bufs.text.cap, (size_t)n * 24 + (1u << 16))))) return rc;
     if ((rc = bufs.pairs.ensure(std::max<size_t>(bufs.pairs.cap, (size_t)n * 2 + 4096)))) return rc;
     for (int attempt = 0; attempt < 8; ++attempt) {
-        HIP_TRY(hipMemsetAsync(ctx->d_t_cur.p, 0, 16, rstream));
+        if ((rc = zero_async(rstream, ctx->d_t_cur.p, 16))) return rc;
         TextDev TQ{};
         TQ.T.os_pos = ctx->d_os_pos.p; TQ.T.os_sym = ctx->d_os_sym.p; TQ.T.n_os = ctx->n_os; TQ.T.name_off = ctx->d_name_off.p; TQ.T.names = (const char*)ctx->d_names.p;
         TQ.hit_begin = d_begin; TQ.hits = d_hits; TQ.ops = d_ops; TQ.coords = bufs.coords.p; TQ.n_reads = n;
@@ -2289,7 +2323,8 @@ static int run_record_kernels(mapad_ctx_t* ctx, const uint64_t* d_begin, const H
         hipLaunchKernelGGL(text_kernel, dim3((uint32_t)((n + 63) / 64)), dim3(64), 0, rstream, TQ);
         HIP_TRY(hipGetLastError());
         if (!ctx->h_t_used.resize(2)) return MAPAD_ERR_NOMEM;
-        HIP_TRY(hipMemcpyAsync(ctx->h_t_used.data(), ctx->d_t_cur.p, 16, hipMemcpyDeviceToHost, rstream));
+        hipLaunchKernelGGL(publish_words_kernel, dim3(1), dim3(64), 0, rstream, (const uint32_t*)ctx->d_t_cur.p, (uint32_t*)ctx->h_t_used.data(), 4u);
+        HIP_TRY(hipGetLastError());
         HIP_TRY(hipStreamSynchronize(rstream));
         used[0] = ctx->h_t_used[0]; used[1] = ctx->h_t_used[1];
         if (used[0] <= TQ.text_cap && used[1] <= TQ.pair_cap) break;
