@@ -1446,7 +1446,9 @@ int launch_batch(mapad_ctx* c, BatchSlot& S, const uint8_t* d_seqs, const uint8_
     for (auto& x : S.tail_info) x = 0;
     if (c->tail_pops && !warm && n_reads) {
         const uint32_t tl = std::max<uint32_t>(lmax, 1);
-        const uint32_t stride = host::tail_record_stride(tl), cap = (uint32_t)std::min<uint64_t>(n_reads, env_u32("MAPAD_TAIL_RING", 65536));
+        // (records of long reads are big — 6 bytes per base: the ring never takes more than 1 GB of page-locked memory; reads that find it full stay on the GPU)
+        const uint32_t stride = host::tail_record_stride(tl);
+        const uint32_t cap = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(std::min<uint64_t>(n_reads, env_u32("MAPAD_TAIL_RING", 65536)), (1ull << 30) / stride));
         if (!S.tail_ring.resize((size_t)cap * stride)) return MAPAD_ERR_NOMEM;
         for (uint32_t k = 0; k < cap; ++k) reinterpret_cast<host::TailRecord*>(S.tail_ring.data() + (size_t)k * stride)->ready = 0;
         auto tb = std::make_shared<host::TailBatch>();

@@ -764,6 +764,11 @@ MAPAD_HD void pc_clear(const ArenaT<NL, TOP>& A) { A.pc[0] = 0; A.pc[4] = 0; }
 #endif
 // MAPAD_FORWARD_MOVERS=1: a mover's writes (mm_bubble_up: BubbleWrites) are handed to the siblings behind it through DPP instead of memory.  Bit-identical,
 // measured 0 ... -3 % (C4 / C2, C3: profiles/r04/ab_step_levers.txt): second movers are too rare to pay for the hand-over on every first one.  Off.
+// MAPAD_NODES_FIRST=1: the children's node stores go out in front of the lane-parallel commit's wait instead of behind the pushes.  Measured +-0 (C2, C3, C4): store
+// completions are not what the next step's first wait waits for.  Off.
+#if !defined(MAPAD_NODES_FIRST)
+#define MAPAD_NODES_FIRST 0
+#endif
 #if !defined(MAPAD_FORWARD_MOVERS)
 #define MAPAD_FORWARD_MOVERS 0
 #endif
@@ -1034,9 +1039,26 @@ MAPAD_HD bool search_step(const DevIndex& ix, const DevParams& P, const ReadInT<
             for (int i = 0; i < 4; ++i) if (mm[i] < lim) cand &= ~(4u << (2 * i));
         }
         const uint32_t cand0 = cand, id0 = st.tree_next;  // == tree_entries: the slab grows at its end, child t gets key id0 + (children before t)
+        bool nodes_stored = false;
 #if defined(__HIP_DEVICE_COMPILE__)
+        // The nodes of all children in three store groups (a node is only read when its frame is popped, at the earliest in the next step): lane w stores the
+        // match / mismatch and the deletion child of base w, lane 0 the insertion child.
+        auto store_child_nodes = [&]() {
+            if constexpr (kLaneKids) {
+#pragma unroll
+                for (int b = 0; b < kBases; ++b) {
+                    const uint32_t t_mm = 2u + 2u * (3u - (uint32_t)(kBases * w + b)), t_del = t_mm - 1u;
+                    if ((cand0 >> t_mm) & 1u) A.nodes[id0 + (uint32_t)__popc(cand0 & ((1u << t_mm) - 1u))] = nd_mm[b];
+                    if ((cand0 >> t_del) & 1u) A.nodes[id0 + (uint32_t)__popc(cand0 & ((1u << t_del) - 1u))] = nd_del[b];
+                }
+                if ((cand0 & 1u) && w == 0) A.nodes[id0] = nd_ins;
+            }
+        };
         if constexpr (MAPAD_PAR_COMMIT != 0 && LPR == 4 && !PC) {
             if (st.heap_len >= 16u) {
+                // MAPAD_NODES_FIRST: with one wait for the whole frame's pushes the node stores go out IN FRONT of it (their keys are known: id0 + rank) — the wait for the
+                // ancestors covers them while they travel, and the next step's first wait (the popped node) does not begin behind 32-byte stores to fresh lines
+                if (MAPAD_NODES_FIRST != 0) { store_child_nodes(); nodes_stored = true; }
                 const uint32_t n0 = st.heap_len, kids = (uint32_t)__popc(cand0);
                 uint32_t rest = cand0;
                 for (uint32_t base = 0; base < kids; base += 4) {  // four children per round (a frame has at most nine)
@@ -1200,19 +1222,12 @@ MAPAD_HD bool search_step(const DevIndex& ix, const DevParams& P, const ReadInT<
             }
         }
         if constexpr (kLaneKids) {
-            // The nodes of all children in three store groups behind the pushes (a node is only read when its frame is popped, at the earliest
-            // in the next step): lane w stores the match/mismatch and the deletion child of base w, lane 0 the insertion child.  Inside the loop
-            // the stores sat between a push's loads and its wait, which then had to cover them as well.
+            // Behind the sequential loop: inside it the stores sat between a push's loads and its wait, which then had to cover them as well (round 2).
 #if defined(__HIP_DEVICE_COMPILE__)
-#pragma unroll
-            for (int b = 0; b < kBases; ++b) {
-                const uint32_t t_mm = 2u + 2u * (3u - (uint32_t)(kBases * w + b)), t_del = t_mm - 1u;
-                if ((cand0 >> t_mm) & 1u) A.nodes[id0 + (uint32_t)__popc(cand0 & ((1u << t_mm) - 1u))] = nd_mm[b];
-                if ((cand0 >> t_del) & 1u) A.nodes[id0 + (uint32_t)__popc(cand0 & ((1u << t_del) - 1u))] = nd_del[b];
-            }
+            if (!nodes_stored) store_child_nodes();
 #endif
-            if ((cand0 & 1u) && w == 0) A.nodes[id0] = nd_ins;
         }
+        (void)nodes_stored;
     }
     while (cand != 0 && st.status == ST_OK) {
 #if defined(__HIP_DEVICE_COMPILE__)
