@@ -329,20 +329,21 @@ def main():
         return g
 
     def run_steps(k):
-        """k steps back to back.  With depth > 1 step i + 1 is submitted while step i's tail is still running; the collect of step i (and, N > 1,
-        the gather of its records) is issued behind the submission of step i + 1."""
+        """k steps back to back, `depth` batches in flight: behind the submission of step i the oldest batch in flight (step i - depth + 1) is collected
+        (and, N > 1, its records gathered)."""
         last = None
+        d = args.depth
         for i in range(k):
             timed("submit", ctx.map_batch_device, d_seqs.data_ptr(), d_quals.data_ptr(), d_offsets.data_ptr(), n_reads, max_len)
             heartbeat(f"step {i} submitted")
-            if i > 0 and args.depth > 1:
-                ctx.select_batch(1)
+            if i >= d - 1:  # `depth` batches are in flight: collect the oldest (the host waits for it — and for its host tail — while the others map)
+                ctx.select_batch(d - 1)
                 last = collect_step()
                 ctx.select_batch(0)
-            elif args.depth == 1:
-                last = collect_step()
-        if args.depth > 1:
+        for age in range(min(d - 1, k) - 1, -1, -1):  # drain, oldest first
+            ctx.select_batch(age)
             last = collect_step()
+        ctx.select_batch(0)
         heartbeat("steps done")
         return last
 
