@@ -360,6 +360,8 @@ def main():
     if host_trace:
         log("[host trace] " + " ".join(f"{w}:{t}" for w, t in host_trace[:24]))
     tail_timed = list(tail_steps)
+    if args.config in ("c1", "c2", "c3", "c4") and any(t["reads"] for t in tail_timed):
+        log(f"[rank {rank}] NOTE: {sum(t['reads'] for t in tail_timed)} reads of a 50 bp workload passed the pop budget and were finished on the host (none are expected to)")
     torch.cuda.synchronize(dev)
     if world > 1:
         dist.barrier()

@@ -88,6 +88,22 @@ def test_full_ring_leaves_reads_on_the_gpu(monkeypatch):
     assert_same_as_oracle(ores, res, offsets)
 
 
+def test_hit_pools_too_small_for_the_hosts_results_are_grown_and_the_batch_rerun(monkeypatch):
+    """The host's hits are appended to the batch's device pools; when they do not fit (here: pools of 64 hits), the collect reports it like a kernel-side overflow and
+    mapad_map_batch re-runs the batch — GPU stages and host tail — with pools sized for everything."""
+    monkeypatch.setenv("MAPAD_HIT_POOL", "64")
+    g = synth.genome(200_000, seed=13)
+    seqs, quals, offsets = synth.reads(g, 1500, 50, seed=4, qual_range=(20, 40), damage=dict(f=0.5, t=0.5, d=0.02, s=1.0))
+    rp = resolve_params(DAMAGE)
+    pidx = mapad_amd.Index.build([("chr1", g)])
+    oidx = ob.OracleIndex.from_bwt(pidx.bwt(), "$ACGTX", 128)
+    res, info = _map(pidx, mapad_amd.make_params(rp), seqs, quals, offsets, tail_pops=40)
+    reads, qs = split_reads(seqs, quals, offsets)
+    ores = oidx.map_batch(ob.make_params(rp), reads, qs, n_threads=8, keep_d=True)
+    assert res.n_hits > 64 and info["reads"] == int((ores.counters[:, 3] > 40).sum()) > 50
+    assert_same_as_oracle(ores, res, offsets)
+
+
 def test_tail_with_batches_in_flight_and_an_uncollected_batch():
     """Three batches in flight, each with reads on the host; the collect of a batch waits for ITS host reads only.  A batch whose slot is reused before anybody
     collected it is dropped together with its host reads."""
