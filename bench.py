@@ -180,9 +180,11 @@ def main():
     #  which is what RCCL's transfer kernels need; --search-waves-per-cu 8 is the fall-back should the watchdog ever report a starved transfer)
     if args.search_waves_per_cu:
         os.environ["MAPAD_TIER0_WAVES_PER_CU"] = str(args.search_waves_per_cu)
+    if world > 1:  # rank 0 receives every rank's records into buffers of its own (1.1 GB per rank and step at C4): the size-class pools leave room for them on every GPU
+        os.environ.setdefault("MAPAD_POOL_BUDGET_GB", "48")
     if world > 1 and args.dist_backend == "gloo":  # test mode: the ranks share ONE GPU — each takes its share of the chip's wavefront slots and of the HBM for its pools
         os.environ.setdefault("MAPAD_TIER0_WAVES_PER_CU", str(max(2, 12 // world)))
-        os.environ.setdefault("MAPAD_POOL_BUDGET_GB", str(max(4, 64 // world)))
+        os.environ["MAPAD_POOL_BUDGET_GB"] = str(max(4, 64 // world))
 
     # ---- watchdog (N > 1): a rank that makes no progress for --watchdog-s seconds ends the job with a fresh exit (never an exec) ---------------
     import threading
