@@ -128,7 +128,7 @@ def main():
     ap.add_argument("--no-cli", action="store_true", help="skip the command-line leg (FASTQ -> BAM; at C4 it writes and re-reads the 3 Gbp index files)")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo: test mode for boxes with one GPU — every rank uses device 0 and the gather goes through host memory")
-    ap.add_argument("--depth", type=int, default=None, help="batches in flight (1 = every step runs alone on the stream); default 3, C4: 2 (its 10 M-read launches "
+    ap.add_argument("--depth", type=int, default=None, help="batches in flight (1 = every step runs alone on the stream); default 4 (round 4, C2 / C3 at 3 / 4 / 6 in flight: 5.71 / 6.01 / 5.98 M and 2.47 / 2.53 / 2.56 M reads/s), C4: 2 (its 10 M-read launches "
                     "run one after the other, the next batch's D arrays beside the search), C5: 6 (heavy-tailed reads: more tails to overlap)")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="N > 1: weak = --reads per GPU (total work grows with N); strong = ONE chunk of --reads reads cut into N contiguous slices (SURVEY 8e)")
@@ -137,7 +137,7 @@ def main():
     ap.add_argument("--own-index", action="store_true", help="N > 1: every rank builds its own index instead of loading the files rank 0 wrote")
     args = ap.parse_args()
     if args.depth is None:
-        args.depth = {"c4": 2, "c5": 6}.get(args.config, 3)
+        args.depth = {"c4": 2, "c5": 6}.get(args.config, 4)
     genome_bp = args.genome_bp or CONFIGS[args.config][0]
     n_reads = args.reads or CONFIGS[args.config][1]
 
