@@ -345,7 +345,8 @@ def main():
         for age in range(min(d - 1, k) - 1, -1, -1):  # drain, oldest first
             ctx.select_batch(age)
             last = collect_step()
-        ctx.select_batch(0)
+        if k:
+            ctx.select_batch(0)
         heartbeat("steps done")
         return last
 
