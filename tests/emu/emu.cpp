@@ -133,4 +133,45 @@ mapad_batch_result_t* emu_map_batch(const uint64_t* blocks, uint64_t n_blocks, u
 }
 void emu_result_free(mapad_batch_result_t* r) { if (r) delete reinterpret_cast<EmuResult*>(r); }
 
+// Property check of the lane-parallel commit (search_core.hpp: MAPAD_PAR_COMMIT) on random heaps: `trials` times a min-max heap of n0 in [16, max_n] entries is
+// built by sequential pushes of scores drawn from `levels` distinct values (few levels = many ties, the common case of the no-damage model), then k in [1, 9]
+// children are pushed (a) one after the other (the reference's order) and (b) by the scheme — four at a time: every child decides against the heap as it stands
+// whether it stays (mm_push_stays), the stayers are stored, the movers follow in commit order with freshly loaded ancestors.  Returns the number of trials in
+// which the two heaps differ in any slot (must be 0).
+uint64_t emu_par_commit_selftest(uint64_t seed, uint32_t trials, uint32_t max_n, uint32_t levels) {
+    uint64_t x = seed * 0x9E3779B97F4A7C15ull + 1, bad = 0;
+    auto rnd = [&]() { x ^= x << 13; x ^= x >> 7; x ^= x << 17; return x; };
+    std::vector<HeapEntry> top_a(kTop + 9), top_b(kTop + 9), heap_a(2 * (size_t)max_n + 128), heap_b(2 * (size_t)max_n + 128);
+    for (uint32_t t = 0; t < trials; ++t) {
+        Arena A, B;
+        A.top = top_a.data() + 1; A.heap = heap_a.data() + 1; B.top = top_b.data() + 1; B.heap = heap_b.data() + 1;
+        const uint32_t n0 = 16 + (uint32_t)(rnd() % (max_n - 15));
+        auto score = [&]() { return -(float)(rnd() % levels) * 0.75f; };
+        uint32_t n = 0;
+        for (uint32_t i = 0; i < n0; ++i) { mm_bubble_up(A, n, HeapEntry{score(), i}); n += 1; }
+        for (uint32_t i = 0; i < n0; ++i) hp_set(B, i, hp_get(A, i));
+        const uint32_t k = 1 + (uint32_t)(rnd() % 9);
+        HeapEntry kid[9];
+        for (uint32_t i = 0; i < k; ++i) kid[i] = HeapEntry{score(), n0 + i};
+        for (uint32_t i = 0; i < k; ++i) mm_bubble_up(A, n0 + i, kid[i]);                     // (a)
+        for (uint32_t base = 0; base < k; base += 4) {                                         // (b)
+            Ancestors an[4];
+            uint32_t movers = 0;
+            for (uint32_t w = 0; w < 4 && base + w < k; ++w) an[w] = load_ancestors(B, n0 + base + w);
+            for (uint32_t w = 0; w < 4 && base + w < k; ++w) {
+                if (mm_push_stays(n0 + base + w, kid[base + w], an[w])) hp_set(B, n0 + base + w, kid[base + w]); else movers |= 1u << w;
+            }
+            bool fresh = true;
+            for (uint32_t w = 0; w < 4; ++w) if ((movers >> w) & 1u) {
+                if (fresh) mm_bubble_up(B, n0 + base + w, kid[base + w], an[w]); else mm_bubble_up(B, n0 + base + w, kid[base + w]);
+                fresh = false;
+            }
+        }
+        bool same = true;
+        for (uint32_t i = 0; i < n0 + k && same; ++i) { const HeapEntry a = hp_get(A, i), b = hp_get(B, i); same = a.score == b.score && a.node == b.node; }
+        bad += same ? 0 : 1;
+    }
+    return bad;
+}
+
 }  // extern "C"

@@ -277,6 +277,15 @@ def test_kernel_logic_long_and_degenerate_reads():
     assert [len(res.hits(i)) for i in range(len(reads))][3:] == [1, 1, 1, 1]
 
 
+@pytest.mark.parametrize("max_n,levels", [(40, 3), (300, 2), (300, 7), (5000, 4), (5000, 1000), (70000, 25)])
+def test_lane_parallel_commit_equals_sequential_pushes_on_random_heaps(max_n, levels):
+    """The quad kernel pushes a frame's children side by side (search_core.hpp: MAPAD_PAR_COMMIT): stayers stored at once, movers in order.  The argument that this
+    leaves the heap of the sequential pushes (a stayer stays whatever its siblings do) is checked here slot by slot on random min-max heaps — few score levels
+    (ties everywhere, like the no-damage model), many (like the damage model), heaps that straddle the near / arena boundary (63 slots) and level boundaries."""
+    for seed in range(4):
+        assert emu_util.lib().emu_par_commit_selftest(seed + 17 * levels, 4000, max_n, levels) == 0
+
+
 # ---- post-search ----------------------------------------------------------------------------------------------------------
 def check_integration_records(k, recs):
     """shared_expectation of tests/integration_tests.rs:464-868 on decoded record fields."""
