@@ -445,7 +445,7 @@ def main():
     dominant = "search_kernel" if ms_search >= ms_darray else "darray_kernel"
     dom_bytes, dom_ms = (bytes_search, ms_search) if dominant == "search_kernel" else (bytes_darray, ms_darray)
     achieved = dom_bytes / (dom_ms * 1e-3) / 1e9
-    # HBM traffic of the PMC passes (profiles/collect.sh) — reported only while the library is built from the sources those passes ran with
+    # HBM traffic of the PMC passes (profiles/collect.sh) — reported only while the library's gfx950 machine code is the code those passes ran
     traffic, traffic_stale = None, None
     tp = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tp):
@@ -453,7 +453,10 @@ def main():
             from mapad_amd import build as mbuild_
             entry = json.load(open(tp)).get(f"{args.config}:{genome_bp}:{n_reads}", {})
             if entry.get(dominant) is not None:
-                traffic_stale = entry.get("kernel_source_sha16") != mbuild_.source_hash()
+                if entry.get("kernel_code_sha16"):  # the device machine code of the loaded library is the code the PMC passes ran
+                    traffic_stale = entry["kernel_code_sha16"] != mbuild_.kernel_code_hash()
+                else:
+                    traffic_stale = entry.get("kernel_source_sha16") != mbuild_.source_hash()
                 traffic = None if traffic_stale else entry.get(dominant)
         except Exception:
             traffic = None

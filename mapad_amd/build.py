@@ -42,8 +42,7 @@ def _deps():
 
 
 def source_hash():
-    """sha256 (16 hex digits) over the sources the library is built from: ties measurements that are not taken live (the PMC traffic of
-    profiles/traffic.json) to the kernels they were taken with."""
+    """sha256 (16 hex digits) over the sources the library is built from (host and device parts alike); recorded beside kernel_code_hash()."""
     import hashlib
     h = hashlib.sha256()
     for path in sorted(p for p in _deps() if p.endswith((".hip", ".hpp", ".h"))):
@@ -51,6 +50,58 @@ def source_hash():
         with open(path, "rb") as f:
             h.update(f.read())
     return h.hexdigest()[:16]
+
+
+def _elf_sections(b, base=0):
+    import struct
+    shoff, = struct.unpack_from("<Q", b, base + 0x28)
+    shentsize, shnum, shstrndx = struct.unpack_from("<HHH", b, base + 0x3A)
+    sh = lambda i: struct.unpack_from("<IIQQQQIIQQ", b, base + shoff + i * shentsize)  # noqa: E731
+    stro = sh(shstrndx)[4]
+    out = {}
+    for i in range(shnum):
+        s = sh(i)
+        name = b[base + stro + s[0]:b.index(b"\0", base + stro + s[0])].decode()
+        out.setdefault(name, []).append((base + s[4], s[5], s[1]))
+    return out
+
+
+def kernel_code_hash(lib=None):
+    """sha256 (16 hex digits) over the gfx950 machine code of the built library: the .text and .rodata sections of every amdgcn code object in its
+    `.hip_fatbin` offload bundles.  This is what ties measurements that are not taken live (the PMC traffic of profiles/traffic.json) to the kernels
+    they were taken with: it changes with any change of the device code (sources, flags, compiler) and with nothing else — the symbol tables and bundle
+    ids, which differ from build to build, and the host code are not in it.  None when the library is not built."""
+    import hashlib
+    import struct
+    lib = lib or LIB
+    if not os.path.exists(lib):
+        return None
+    with open(lib, "rb") as f:
+        b = f.read()
+    h, n = hashlib.sha256(), 0
+    for off, size, _ in _elf_sections(b).get(".hip_fatbin", []):
+        pos, end = off, off + size
+        while pos < end:
+            j = b.find(b"__CLANG_OFFLOAD_BUNDLE__", pos, end)
+            if j < 0:
+                break
+            count, = struct.unpack_from("<Q", b, j + 24)
+            p, nxt = j + 32, j + 32
+            for _ in range(count):
+                eo, es, tl = struct.unpack_from("<QQQ", b, p)
+                triple = b[p + 24:p + 24 + tl].decode()
+                p += 24 + tl
+                nxt = max(nxt, j + eo + es)
+                if "amdgcn" in triple and es:
+                    secs = _elf_sections(b, j + eo)
+                    for name in (".text", ".rodata"):
+                        for o, s, t in secs.get(name, []):
+                            if t != 8:  # not SHT_NOBITS
+                                h.update(name.encode())
+                                h.update(b[o:o + s])
+                                n += s
+            pos = nxt
+    return h.hexdigest()[:16] if n else None
 
 
 def needs_build():

@@ -96,7 +96,8 @@ tp = os.path.join(ROOT, "profiles", "traffic.json")
 tj = json.load(open(tp)) if os.path.exists(tp) else {}
 sys.path.insert(0, ROOT)
 from mapad_amd import build as _build  # noqa: E402
-traffic["kernel_source_sha16"] = _build.source_hash()  # bench.py reports this traffic only while the library is built from these sources
+traffic["kernel_source_sha16"] = _build.source_hash()
+traffic["kernel_code_sha16"] = _build.kernel_code_hash()  # bench.py reports this traffic only while the library's gfx950 machine code is this code
 tj[key] = traffic
 json.dump(tj, open(tp, "w"), indent=1)
 print(json.dumps(summary["traffic_bytes_per_batch"]))

@@ -36,3 +36,18 @@ def test_bench_gpus_n_without_n_devices_is_an_error():
 def test_bench_world_size_must_match_gpus():
     p = _run(["--gpus", "1"], env={"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"})
     assert p.returncode == 2 and "WORLD_SIZE" in p.stderr
+
+
+def test_committed_traffic_is_tied_to_the_machine_code_of_the_library():
+    """roofline.traffic comes from PMC passes run earlier (profiles/collect.sh); bench.py reports it only while the library's gfx950 machine code is the code
+    those passes ran.  The tie is a hash of the device code itself (mapad_amd/build.py: kernel_code_hash) — it must exist for the built library, be the same
+    for two reads of it, and every entry that feeds the default line must carry it."""
+    import json
+    from mapad_amd import build
+    build.build()
+    h = build.kernel_code_hash()
+    assert h and len(h) == 16 and int(h, 16) >= 0 and h == build.kernel_code_hash()
+    assert build.kernel_code_hash(os.path.join(ROOT, "no_such_library.so")) is None
+    traffic = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+    for key in ("c4:3000000000:10000000", "c2:48000000:1000000", "c3:48000000:1000000"):
+        assert len(traffic[key].get("kernel_code_sha16", "")) == 16 and traffic[key]["search_kernel"] > 0
