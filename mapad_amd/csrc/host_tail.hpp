@@ -23,7 +23,11 @@
 #include <thread>
 #include <vector>
 
+#include <pthread.h>
+#include <sched.h>
 #include <sys/mman.h>
+#include <map>
+#include <string>
 
 #include "host_models.hpp"
 #include "search_core.hpp"
@@ -47,6 +51,49 @@ struct TailResult {
     std::vector<HitRec> hits;   // BinaryHeap array order; ops_off relative to `ops`
     std::vector<uint32_t> ops;
 };
+
+// Worker i of the process is kept inside one last-level-cache domain of the machine (on the round-4 GPU box: 16 CCDs of 8 cores and 32 MB L3 each — with 16
+// workers one per CCD, so a read's 16 MB heap has an L3 to itself), chosen round-robin over the domains this process may run on; memory a worker touches first is
+// then local to its socket and stays so.  Left to the scheduler, 16 threads under a CPU-time quota wander over 256 hardware threads and two sockets.
+// MAPAD_TAIL_PIN=0 leaves the threads unpinned; a machine with one domain (or an unreadable topology) is left alone.
+inline void tail_pin_worker(unsigned i) {
+    const char* e = std::getenv("MAPAD_TAIL_PIN");
+    if (e && e[0] == '0') return;
+    static const std::vector<cpu_set_t> domains = [] {
+        std::vector<cpu_set_t> out;
+        cpu_set_t allowed;
+        CPU_ZERO(&allowed);
+        if (sched_getaffinity(0, sizeof allowed, &allowed) != 0) return out;
+        std::map<std::string, size_t> seen;
+        for (int c = 0; c < CPU_SETSIZE; ++c) {
+            if (!CPU_ISSET(c, &allowed)) continue;
+            char path[128], key[256] = {0};
+            std::snprintf(path, sizeof path, "/sys/devices/system/cpu/cpu%d/cache/index3/shared_cpu_list", c);
+            FILE* f = std::fopen(path, "r");
+            if (!f) return std::vector<cpu_set_t>();
+            const bool ok = std::fgets(key, sizeof key, f) != nullptr;
+            std::fclose(f);
+            if (!ok) return std::vector<cpu_set_t>();
+            auto it = seen.find(key);
+            if (it == seen.end()) { it = seen.emplace(key, out.size()).first; cpu_set_t z; CPU_ZERO(&z); out.push_back(z); }
+            CPU_SET(c, &out[it->second]);
+        }
+        return out;
+    }();
+    if (domains.size() < 2) return;
+    (void)pthread_setaffinity_np(pthread_self(), sizeof(cpu_set_t), &domains[i % domains.size()]);
+}
+// MAPAD_TAIL_PREFETCH (search_core.hpp: HostPrefetch), read once
+inline void tail_read_prefetch_env() {
+#if !defined(__HIP_DEVICE_COMPILE__)
+    static const bool once = [] {
+        const char* e = std::getenv("MAPAD_TAIL_PREFETCH");
+        if (e && e[0] >= '0' && e[0] <= '1') { g_host_prefetch.sift_lookahead = e[0] - '0'; if (e[1] == '0' || e[1] == '1') g_host_prefetch.next_pop = e[1] == '1'; }
+        return true;
+    }();
+    (void)once;
+#endif
+}
 
 // Worker threads shared by every context of the process (a read at the reference's limits keeps a thread busy for seconds and its arena is 336 MB, so
 // there is one pool, as wide as the machine — or as this process's CPU share of it: MAPAD_TAIL_THREADS overrides).  Started with the first task.
@@ -98,8 +145,10 @@ private:
     }
     void start() {
         const unsigned n = wanted();
+        tail_read_prefetch_env();
         for (unsigned i = 0; i < n; ++i) {
-            threads_.emplace_back([this] {
+            threads_.emplace_back([this, i] {
+                tail_pin_worker(i);
                 for (;;) {
                     std::function<void()> f;
                     {
@@ -138,7 +187,7 @@ struct TailScratch {
         auto big = [](size_t bytes) -> void* {
             const size_t sz = (bytes + ((size_t)2 << 20) - 1) & ~(((size_t)2 << 20) - 1);
             void* p = std::aligned_alloc((size_t)2 << 20, sz);
-#if defined(MADV_HUGEPAGE)
+#if defined(MADV_HUGEPAGE) && !defined(MAPAD_TAIL_NO_HUGEPAGE)
             if (p) (void)madvise(p, sz, MADV_HUGEPAGE);
 #endif
             return p;
@@ -182,6 +231,21 @@ struct TailBatch {
     static double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 };
 
+// The search of one read on a host thread: search_core.hpp's step (the kernel's own source, payload cache on) until the read is done, `max_pops` pops are
+// made (0: no bound; the timing harness uses one) or `cancel` is raised.
+inline void tail_search(const DevIndex& ix, const DevParams& P, const ReadIn& rd, Arena& A, SearchState& st, uint64_t max_pops, const std::atomic<bool>* cancel) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    (void)ix; (void)P; (void)rd; (void)A; (void)st; (void)max_pops; (void)cancel;
+#else
+    search_init(ix.n, alignment_start_of(P, rd.L), rd, A, st);
+    pc_clear(A);
+    uint32_t n = 0;
+    auto check = [&]() { return (++n & 0xFFFFu) == 0 && ((cancel && cancel->load(std::memory_order_relaxed)) || (max_pops && st.c_pop >= max_pops)); };
+    if (P.bound_kind == BOUND_CONTINUOUS) { while (search_step<1, true, false, true>(ix, P, rd, A, st, 0, NoGrow())) { if (check()) break; } }
+    else { while (search_step<1, false, false, true>(ix, P, rd, A, st, 0, NoGrow())) { if (check()) break; } }
+#endif
+}
+
 // k_mismatch_search for one handed-over read, from scratch, by this thread (search_core.hpp: the kernel's own step, payload cache included).
 inline void tail_map_read(const std::shared_ptr<TailBatch>& tb, const TailRecord* rec) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -190,6 +254,7 @@ inline void tail_map_read(const std::shared_ptr<TailBatch>& tb, const TailRecord
     thread_local TailScratch sc;
     TailResult r;
     r.read = rec->read;
+    const double t_begin = TailBatch::now_s();
     const int L = (int)rec->L;
     bool ok = sc.ensure(tb->P.stack_limit + 10, tb->P.edit_tree_limit + 10, std::max<uint32_t>(tb->lmax, (uint32_t)L));
     uint64_t pops = 0;
@@ -202,11 +267,7 @@ inline void tail_map_read(const std::shared_ptr<TailBatch>& tb, const TailRecord
         A.pc = sc.pc;
         const ReadIn rd{qc, d, L, tb->P.reject_thr[L], tb->P.table_base[L]};
         SearchState st;
-        search_init(tb->ix.n, alignment_start_of(tb->P, L), rd, A, st);
-        pc_clear(A);
-        uint32_t n = 0;
-        if (tb->P.bound_kind == BOUND_CONTINUOUS) { while (search_step<1, true, false, true>(tb->ix, tb->P, rd, A, st, 0, NoGrow())) { if ((++n & 0xFFFFu) == 0 && tb->cancel.load(std::memory_order_relaxed)) break; } }
-        else { while (search_step<1, false, false, true>(tb->ix, tb->P, rd, A, st, 0, NoGrow())) { if ((++n & 0xFFFFu) == 0 && tb->cancel.load(std::memory_order_relaxed)) break; } }
+        tail_search(tb->ix, tb->P, rd, A, st, 0, &tb->cancel);
         r.status = st.status;
         r.e_search = st.c_esearch; r.n_push = st.c_push; r.n_pop = st.c_pop; r.n_node = st.c_node; r.n_hits = st.c_hits;
         pops = st.c_pop;
@@ -217,6 +278,12 @@ inline void tail_map_read(const std::shared_ptr<TailBatch>& tb, const TailRecord
     {
         std::lock_guard<std::mutex> g(tb->mu);
         if (!ok) tb->failed = true;
+        if (const char* log = std::getenv("MAPAD_TAIL_LOG")) {  // diagnostics: one line per read the host finished (read, length, pops, start relative to the first hand-over, seconds, cpu)
+            if (FILE* f = std::fopen(log, "a")) {
+                std::fprintf(f, "%u %d %llu %.3f %.3f %d\n", r.read, L, (unsigned long long)pops, t_begin - tb->t_first, TailBatch::now_s() - t_begin, sched_getcpu());
+                std::fclose(f);
+            }
+        }
         tb->results.push_back(std::move(r));
         tb->done += 1;
         tb->host_pops += pops;

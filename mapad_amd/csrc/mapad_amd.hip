@@ -55,8 +55,15 @@ enum : uint32_t { ST_POOL_OVERFLOW = 4, ST_NO_TABLE = 8, ST_TAIL = 16 /* handed 
 //       that no size class could hold.
 // Pop budget of a read on the GPU before a host thread takes it over (host_tail.hpp); MAPAD_TAIL_POPS / mapad_ctx_set_tail_pops override, 0 = never.
 // 2^19 pops are ~3 s of one quad's time: no 50 bp read of C1-C4 gets there (heaviest C4 read: see DESIGN.md section 5), the heavy tail of the 35-100 bp mix does.
+// On a large index (>= 2^31 rows: the 3 Gbp genome) the budget is 2^17: there a read that is still going after 2^17 pops has grown into arena classes HBM holds few
+// of, and the launch then waits for such reads one after the other — measured on 1 M reads of the C5 mix at the real limits: with 2^19 the GPU handed reads over
+// for 370 s while the host threads (41 s of work for 16) sat idle; with 2^18 for > 250 s; with 2^17 the batch takes 125 s, bound by the 16 host CPUs.
+// No 50 bp read of C4 gets to 2^17 either (heaviest of 10 M: 76 272 pops).
 #if !defined(MAPAD_DEFAULT_TAIL_POPS)
 #define MAPAD_DEFAULT_TAIL_POPS (1u << 19)
+#endif
+#if !defined(MAPAD_DEFAULT_TAIL_POPS_LARGE_INDEX)
+#define MAPAD_DEFAULT_TAIL_POPS_LARGE_INDEX (1u << 17)
 #endif
 constexpr int kTiers = 2;   // arena pools: growable base arenas, full-limit arenas
 constexpr int kStages = 3;  // hand-over lists: Q0 -> Q1 -> F
@@ -1832,7 +1839,7 @@ int mapad_ctx_create(const mapad_index_t* idx, const mapad_params_t* params, int
     c->device = device_id; c->params = *params; c->index = idx; c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     c->tables = host::make_tables(*params);
     c->depth = (int)std::min<uint32_t>(std::max<uint32_t>(env_u32("MAPAD_PIPELINE_DEPTH", 1), 1), kMaxDepth);
-    c->tail_pops = env_u32("MAPAD_TAIL_POPS", MAPAD_DEFAULT_TAIL_POPS);
+    c->tail_pops = env_u32("MAPAD_TAIL_POPS", idx->ix.n >= (1ull << 31) ? MAPAD_DEFAULT_TAIL_POPS_LARGE_INDEX : MAPAD_DEFAULT_TAIL_POPS);
     int rc;
     if ((rc = c->d_blocks.ensure(idx->ix.blocks.size()))) return rc;
     HIP_TRY(hipMemcpy(c->d_blocks.p, idx->ix.blocks.data(), idx->ix.blocks.size() * 8, hipMemcpyHostToDevice));

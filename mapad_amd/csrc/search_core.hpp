@@ -392,6 +392,19 @@ MAPAD_HD bool mm_push_stays(uint32_t pos, const HeapEntry elt, const Ancestors& 
 // the first stride, or at once if that slot has no children): search_step's payload cache fetches that frame while the rest of the sift and the rank
 // queries are in flight.
 struct NoOccupantHook { MAPAD_HD void operator()(uint32_t) const {} };
+#if !defined(__HIP_DEVICE_COMPILE__)
+// Host builds (the host tail of host_tail.hpp, tests/emu): what a step asks memory for ahead of time.  A read at the reference's limits walks a 16 MB heap and a
+// 320 MB slab at random; its step is a chain of cache misses — the pop's sift, then one pop_min sift per evicted frame.  Results never depend on these requests.
+// Measured on the round-4 GPU box (EPYC 9575F, 16 threads, 16 reads at the limits on the 3 Gbp index; profiles/r04/host_tail_ab.txt): no prefetch 0.400 us per pop,
+// sift lookahead alone 0.413, with the next pop's node and index blocks 0.372; a second stride of sift lookahead (32 + 64 more entries per stride) 0.378: not kept.
+// MAPAD_TAIL_PREFETCH=<sift lookahead 0|1><next pop 0|1> overrides (default "11").
+struct HostPrefetch {
+    int sift_lookahead = 1;  // a deep sift requests the next stride's candidates (8 + 16 entries) while the current stride is decided
+    bool next_pop = true;    // before / between the evictions of a step: the node of the frame the next step will pop, then its two index blocks
+};
+inline HostPrefetch g_host_prefetch;
+#endif
+
 // QL = 4: the caller is a quad whose four lanes run this sift with identical arguments (arena stores then go out once per quad: hp_set_uniform).
 template <bool MAX, bool NL, int TOP, class Hook = NoOccupantHook, int QL = 1>
 MAPAD_HD void mm_trickle_down(const ArenaT<NL, TOP>& A, uint32_t n, uint32_t pos, HeapEntry elt, Hook&& occupant = Hook()) {
@@ -437,7 +450,7 @@ MAPAD_HD void mm_trickle_down(const ArenaT<NL, TOP>& A, uint32_t n, uint32_t pos
         // host build (the host tail's deep heaps: 2 M entries, 16 MB): whichever grandchild the hole moves to, the next stride looks at slots 2 g + 1 ... 2 g + 2 and
         // 4 g + 3 ... 4 g + 6 for g in [g1, g1 + 3] — two short contiguous runs; asked for now, they arrive while this stride is decided (a sift is otherwise a
         // chain of ten cache misses, each waiting for the one before)
-        if (g1 >= (uint32_t)TOP) {
+        if (g1 >= (uint32_t)TOP && g_host_prefetch.sift_lookahead >= 1) {
             const HeapEntry* nc = A.heap + (2 * g1 + 1);  // 8 entries
             const HeapEntry* ng = A.heap + (4 * g1 + 3);  // 16 entries
             __builtin_prefetch(nc); __builtin_prefetch(nc + 7);
@@ -1273,6 +1286,23 @@ MAPAD_HD bool search_step(const DevIndex& ix, const DevParams& P, const ReadInT<
         const int64_t a = (int64_t)st.heap_len - (int64_t)P.stack_limit;
         const int64_t b = (int64_t)st.tree_len - (int64_t)P.edit_tree_limit;
         SearchState tmp = st;
+#if !defined(__HIP_DEVICE_COMPILE__)
+        if (g_host_prefetch.next_pop && tmp.heap_len > 8) {
+            // The next step pops slot 1 or 2 (evictions touch them only when the entry that takes the root's place beats a max-level one: rare) and starts with two
+            // dependent misses: the frame's node — the payload cache is cleared below — and then its index blocks.  Asked for here, the node travels during the
+            // first eviction's sift and the index blocks during the others.
+            __builtin_prefetch(&A.nodes[A.top[1].node]); __builtin_prefetch(&A.nodes[A.top[2].node]);
+            evict_worst(A, tmp, 1);
+            uint32_t ni;
+            const HeapEntry nt = mm_find_max(A, tmp.heap_len, ni);
+            const Frame nf = unpack_frame(A.nodes[nt.node]);
+            const uint64_t nx = (nf.start <= L - nf.start - nf.len) ? nf.lower_rev : nf.lower;
+            const char* b0 = (const char*)(ix.blocks + ((nx ? nx - 1 : 0) >> 8) * 16);
+            const char* b1 = (const char*)(ix.blocks + ((nx + nf.size - 1) >> 8) * 16);
+            __builtin_prefetch(b0); __builtin_prefetch(b0 + 64); __builtin_prefetch(b1); __builtin_prefetch(b1 + 64);
+            evict_worst(A, tmp, (a > b ? a : b) - 1);
+        } else
+#endif
         evict_worst(A, tmp, a > b ? a : b);
         if constexpr (PC) pc_clear(A);  // slots 1 and 2 may hold other entries now, and the freed node ids will be reused
         drain_memory();

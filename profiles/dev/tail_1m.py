@@ -1,0 +1,72 @@
+#!/usr/bin/env python3
+"""Dev: the C5 read mix on the 3 Gbp index at the reference's real limits, one batch through the C ABI, with the host tail's per-read log (MAPAD_TAIL_LOG) and
+the process's per-thread CPU times — where the host's time goes.  python profiles/dev/tail_1m.py [--reads N] [--genome-bp G]"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+
+
+def cg(name):
+    try:
+        return open("/sys/fs/cgroup/" + name).read().strip().replace("\n", "; ")
+    except Exception as e:
+        return f"({e})"
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--reads", type=int, default=1_000_000)
+    ap.add_argument("--genome-bp", type=int, default=3_000_000_000)
+    ap.add_argument("--log", default=os.path.join(ROOT, "gpurun_out", "tail_reads.log"))
+    ap.add_argument("--budgets", default="", help="comma-separated pop budgets (mapad_ctx_set_tail_pops) to map the batch with, one after the other; default: the library's")
+    args = ap.parse_args()
+    os.makedirs(os.path.dirname(args.log), exist_ok=True)
+    import mapad_amd
+    from mapad_amd import synth
+    from mapad_amd.presets import DAMAGE, resolve
+    t0 = time.time()
+    genome = synth.genome(args.genome_bp, seed=1234)
+    index = mapad_amd.Index.build([("chr1", genome)], seed=1234, device=0)
+    print(f"genome + index {time.time() - t0:.1f} s", flush=True)
+    seqs, quals, offsets = synth.reads(genome, args.reads, 50, seed=4321 + 5, qual_range=(20, 40), damage=dict(f=0.5, t=0.5, d=0.02, s=1.0), len_range=(35, 100), indel_frac=0.05)
+    ctx = mapad_amd.Context(index, mapad_amd.make_params(resolve(DAMAGE)), 0)
+    ctx.set_fetch_d_arrays(False)
+    import hashlib
+    for budget in ([int(b) for b in args.budgets.split(",")] if args.budgets else [None]):
+        log_path = args.log + (f".{budget}" if budget is not None else "")
+        if os.path.exists(log_path):
+            os.remove(log_path)
+        os.environ["MAPAD_TAIL_LOG"] = log_path
+        if budget is not None:
+            ctx.set_tail_pops(budget)
+        print("memory before:", cg("memory.current"), "max", cg("memory.max"), flush=True)
+        cpu0 = cg("cpu.stat")
+        t1 = time.time()
+        res = ctx.map_batch(seqs, quals, offsets)
+        wall = time.time() - t1
+        info = ctx.tail_info()
+        h = hashlib.sha256()
+        for a in (res.hit_begin, res.hits_arr, res.ops, res.status, res.counters):
+            h.update(np.ascontiguousarray(a).tobytes())
+        print(json.dumps({"budget": budget, "reads": args.reads, "wall_s": round(wall, 2), "hits": int(res.n_hits), "results_sha256": h.hexdigest()[:16], "tail": info}), flush=True)
+        print("cpu.stat before:", cpu0)
+        print("cpu.stat after: ", cg("cpu.stat"))
+        log = np.loadtxt(log_path, ndmin=2) if os.path.exists(log_path) else np.zeros((0, 6))
+        if log.size:
+            pops, secs = log[:, 2], log[:, 4]
+            print(f"host reads {len(log)}: pops {int(pops.sum())}, thread seconds {secs.sum():.1f}, mean {secs.sum() / max(pops.sum(), 1) * 1e6:.3f} us/pop; last read ends {float((log[:, 3] + secs).max()):.1f} s after the first hand-over")
+            h_, e_ = np.histogram(log[:, 3], bins=[0, 5, 10, 15, 20, 30, 45, 60, 90, 120, 180, 240, 300, 400, 1000])
+            print("  hand-overs by start time:", {f"{e_[i]:.0f}-{e_[i + 1]:.0f}": int(h_[i]) for i in range(len(h_)) if h_[i]}, flush=True)
+        del res
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()
