@@ -123,7 +123,7 @@ void mapad_ctx_destroy(mapad_ctx_t* ctx);
 int mapad_ctx_set_stream(mapad_ctx_t* ctx, void* hip_stream);
 
 /* The heavy tail.  The reference absorbs the reads that run into STACK_LIMIT / EDIT_TREE_LIMIT (src/map/mapping.rs:52-54,1358-1380) on its rayon threads; here a
- * read that has made `pops` pops on the GPU (default 2^19, MAPAD_TAIL_POPS; 0 = never) is handed — by the kernel, while it runs — to the library's host
+ * read that has made `pops` pops on the GPU (default 2^19, on an index of >= 2^31 rows 2^17; MAPAD_TAIL_POPS; 0 = never) is handed — by the kernel, while it runs — to the library's host
  * threads, which map it from scratch with the kernel's own search step compiled for the host (csrc/host_tail.hpp; MAPAD_TAIL_THREADS threads, default
  * all).  Their results join the batch before its order-preserving collect: nothing a caller sees depends on where a read was finished. */
 int mapad_ctx_set_tail_pops(mapad_ctx_t* ctx, uint32_t pops);
