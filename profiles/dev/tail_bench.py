@@ -50,15 +50,8 @@ def main():
     from mapad_amd import binding as mb, synth
     from mapad_amd.presets import DAMAGE, resolve
 
-    src = os.path.join(ROOT, "tests", "emu", "tail_bench.cpp")
-    out = os.path.join(ROOT, "tests", "emu", "_build", "libtail_bench.so")
-    os.makedirs(os.path.dirname(out), exist_ok=True)
-    subprocess.check_call(["g++", "-O3", "-g", "-std=c++17", "-fPIC", "-shared", "-pthread", "-ffp-contract=off", "-fno-fast-math", "-fno-builtin-log2f", "-fno-builtin-powf",
-                           "-fno-builtin-expf", "-fno-builtin-exp2f", "-fno-builtin-log10f", "-Wno-unused-function", "-Wno-unknown-pragmas"] + args.flags.split() + ["-o", out, src])
-    L = C.CDLL(out)
-    L.tail_bench.restype = C.c_double
-    L.tail_bench.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p, C.POINTER(mb.Params), C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64,
-                             C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    import emu_util
+    L = emu_util.tail_bench_lib(tuple(args.flags.split()))
 
     prefix = f"/tmp/tail_bench_{args.genome_bp}"
     genome = synth.genome(args.genome_bp, seed=1234)

@@ -46,3 +46,45 @@ def map_batch(index, params, seqs, quals, offsets, node_cap=4096, heap_cap=4096)
                             seqs.ctypes.data_as(C.c_void_p), quals.ctypes.data_as(C.c_void_p), offsets.ctypes.data_as(C.c_void_p),
                             offsets.size - 1, node_cap, heap_cap)
     return mb.BatchResult(r, lib().emu_result_free)
+
+
+_TB_SRC = os.path.join(_HERE, "emu", "tail_bench.cpp")
+_TB_OUT = os.path.join(_HERE, "emu", "_build", "libtail_bench.so")
+_tb = None
+
+
+def tail_bench_lib(extra_flags=()):
+    """tests/emu/tail_bench.cpp: the host tail's search (mapad_amd/csrc/host_tail.hpp: tail_search, worker pinning, prefetch settings) on host threads without a GPU."""
+    global _tb
+    if _tb is None or extra_flags:
+        csrc = os.path.join(_HERE, "..", "mapad_amd", "csrc")
+        deps = [_TB_SRC] + [os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith((".hpp", ".hip"))]
+        if extra_flags or not os.path.exists(_TB_OUT) or any(os.path.getmtime(d) > os.path.getmtime(_TB_OUT) for d in deps):
+            os.makedirs(os.path.dirname(_TB_OUT), exist_ok=True)
+            subprocess.check_call(["g++", "-O3", "-g", "-std=c++17", "-fPIC", "-shared", "-pthread", "-ffp-contract=off", "-fno-fast-math", "-fno-builtin-log2f", "-fno-builtin-powf",
+                                   "-fno-builtin-expf", "-fno-builtin-exp2f", "-fno-builtin-log10f", "-Wno-unused-function", "-Wno-unknown-pragmas", *extra_flags,
+                                   "-o", _TB_OUT + f".tmp{os.getpid()}", _TB_SRC])
+            os.replace(_TB_OUT + f".tmp{os.getpid()}", _TB_OUT)
+        L = C.CDLL(_TB_OUT)
+        L.tail_bench.restype = C.c_double
+        L.tail_bench.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p, C.POINTER(mb.Params), C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64,
+                                 C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        _tb = L
+    return _tb
+
+
+def tail_search(index, params, seqs, quals, offsets, sel, threads=4, max_pops=0):
+    """Maps the reads `sel` of the batch from scratch the way a host-tail worker does.  Returns (seconds, pops, status, digest, seconds per read); `digest` is an FNV
+    hash per read over status, the five search counters, every hit (interval, score bits, track length) and the edit tracks."""
+    blocks, nb, less, sent = index.device_view()
+    seqs = np.ascontiguousarray(seqs, dtype=np.uint8)
+    quals = np.ascontiguousarray(quals, dtype=np.uint8)
+    offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+    sel = np.ascontiguousarray(sel, dtype=np.uint32)
+    pops = np.zeros(sel.size, dtype=np.uint64)
+    status = np.zeros(sel.size, dtype=np.uint32)
+    dig = np.zeros(sel.size, dtype=np.uint64)
+    rs = np.zeros(sel.size, dtype=np.float64)
+    secs = tail_bench_lib().tail_bench(blocks, nb, len(index), less.ctypes.data, sent.ctypes.data, C.byref(params), seqs.ctypes.data, quals.ctypes.data, offsets.ctypes.data,
+                                       offsets.size - 1, sel.ctypes.data, sel.size, threads, max_pops, 1, pops.ctypes.data, status.ctypes.data, dig.ctypes.data, rs.ctypes.data)
+    return secs, pops, status, dig, rs

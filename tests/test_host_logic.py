@@ -258,6 +258,36 @@ def test_kernel_logic_second_pass_and_limit_recovery(step, monkeypatch):
             assert (res.status == 2).any()
 
 
+def test_host_tail_search_on_host_threads(monkeypatch):
+    """The search of a host-tail worker (csrc/host_tail.hpp: tail_search — search_core.hpp's step with the payload cache, worker pinning, the prefetches between
+    evictions) on four threads, without a GPU: pops and status of every read equal the oracle's — with limits small enough that reads go on under pop_min eviction and
+    with the abort switch — and nothing a read gets back (status, counters, hits, score bits, edit tracks: one digest per read) moves with the prefetch settings or the
+    pinning."""
+    g = synth.genome(80_000, seed=21)
+    seqs, quals, offsets = synth.reads(g, 300, 50, seed=12, qual_range=(20, 40), damage=dict(f=0.5, t=0.5, d=0.02, s=1.0), len_range=(35, 100), indel_frac=0.05)
+    reads, qs = split_reads(seqs, quals, offsets)
+    pidx = mapad_amd.Index.build([("chr1", g)])
+    oidx = ob.OracleIndex.from_bwt(pidx.bwt(), "$ACGTX", 128)
+    sel = np.arange(len(reads))
+    for limits in ({}, {"stack_limit": 60, "edit_tree_limit": 100000}, {"stack_limit": 100000, "edit_tree_limit": 150}, {"stack_limit": 60, "edit_tree_limit": 100000, "stack_limit_abort": 1}):
+        rp = dict(resolve_params(DAMAGE), **limits)
+        ores = oidx.map_batch(ob.make_params(rp), reads, qs, n_threads=8)
+        digests = []
+        for pin, prefetch in (("1", "11"), ("0", "00"), ("1", "10"), ("0", "01")):
+            monkeypatch.setenv("MAPAD_TAIL_PIN", pin)
+            monkeypatch.setenv("MAPAD_TAIL_PREFETCH", prefetch)
+            _, pops, status, dig, _ = emu_util.tail_search(pidx, mapad_amd.make_params(rp), seqs, quals, offsets, sel)
+            assert np.array_equal(pops, ores.counters[:, 3]), (limits, prefetch)
+            digests.append(dig)
+            if limits.get("stack_limit_abort"):
+                assert (status == 2).any() and set(status.tolist()) <= {0, 2}
+            else:
+                assert not status.any()
+        assert all(np.array_equal(digests[0], d) for d in digests[1:])
+        if limits:
+            assert ores.counters[:, 3].max() >= 100  # the searches run long enough to get to the limits
+
+
 def test_kernel_logic_long_and_degenerate_reads():
     g = synth.genome(50_000, seed=3)
     long_read = g[5000:5300].copy()
