@@ -2100,7 +2100,7 @@ struct HostBlockCache {
         (void)hipHostFree(p);
     }
 };
-HostBlockCache& host_blocks() { static HostBlockCache* c = new HostBlockCache(); return *c; }  // never destroyed: the runtime may be gone at exit
+extern "C++" HostBlockCache& host_blocks() { static HostBlockCache* c = new HostBlockCache(); return *c; }  // never destroyed: the runtime may be gone at exit
 }  // namespace
 void* mapad_host_alloc(size_t bytes) { return host_blocks().alloc(bytes ? bytes : 1); }
 void mapad_host_free(void* p) { if (p) host_blocks().release(p); }
