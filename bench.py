@@ -681,7 +681,9 @@ def main():
             # the heavy tail (csrc/host_tail.hpp): reads past the pop budget on the GPU, finished by host threads with the kernel's own search step; inside the timed region
             "tail": {"reads": int(sum(t["reads"] for t in tail_timed)), "reads_per_step": round(sum(t["reads"] for t in tail_timed) / max(len(tail_timed), 1), 1),
                      "pops_share": round(tail_last["host_pops"] / max(n_pop_all, 1), 5), "gpu_pops_before_hand_over": tail_last["gpu_pops"],
-                     "host_s_per_step": round(sum(t["host_us"] for t in tail_timed) / max(len(tail_timed), 1) / 1e6, 3), "budget_pops": tail_last["budget"],
+                     "host_s_per_step": round(sum(t["host_us"] for t in tail_timed) / max(len(tail_timed), 1) / 1e6, 3),
+                     # thread-seconds inside the reads: far below host_s x threads = the host waited for the GPU's hand-overs; close to it = the host's CPUs set the pace
+                     "host_thread_s_per_step": round(sum(t.get("host_thread_us", 0) for t in tail_timed) / max(len(tail_timed), 1) / 1e6, 3), "budget_pops": tail_last["budget"],
                      "where": f"{tail_last['threads']} host threads, search_core.hpp compiled for the host (the kernel's source; from scratch), overlapped with the GPU's bulk" if tail_last["budget"] else "off"},
             "secondary": secondary, "e2e": e2e, "cli": cli, "sa_locate": locate, "post_search": post,
         }

@@ -129,7 +129,7 @@ int mapad_ctx_set_stream(mapad_ctx_t* ctx, void* hip_stream);
 int mapad_ctx_set_tail_pops(mapad_ctx_t* ctx, uint32_t pops);
 /* the batch selected by mapad_ctx_select_batch, after its collect / fetch: {reads finished on the host, pops the GPU had spent on them, pops on the host,
  * host wall-clock microseconds from the first hand-over to the last result, host threads, pop budget, and the host reads' E_search, N_push, N_node sums
- * (SURVEY 8d events the kernel did not execute), 0} */
+ * (SURVEY 8d events the kernel did not execute), microseconds the host threads spent inside these reads, summed over the threads} */
 int mapad_last_tail_info(mapad_ctx_t* ctx, uint64_t out[10]);
 /* whether mapad_fetch_result()/mapad_map_batch() also copy the D arrays back (default on; bench.py turns it off) */
 int mapad_ctx_set_fetch_d_arrays(mapad_ctx_t* ctx, int on);

@@ -425,10 +425,10 @@ class Context:
         _check(lib().mapad_ctx_set_tail_pops(self.h, int(pops)), "mapad_ctx_set_tail_pops")
 
     def tail_info(self):
-        """{reads, gpu_pops, host_pops, host_us, threads, budget} of the selected batch's host tail (after its collect / fetch)."""
+        """{reads, gpu_pops, host_pops, host_us (wall), threads, budget, ..., host_thread_us (summed over the threads)} of the selected batch's host tail (after its collect / fetch)."""
         out = np.zeros(10, np.uint64)
         _check(lib().mapad_last_tail_info(self.h, _ptr(out)), "mapad_last_tail_info")
-        return dict(zip(("reads", "gpu_pops", "host_pops", "host_us", "threads", "budget", "host_e_search", "host_n_push", "host_n_node"), (int(x) for x in out)))
+        return dict(zip(("reads", "gpu_pops", "host_pops", "host_us", "threads", "budget", "host_e_search", "host_n_push", "host_n_node", "host_thread_us"), (int(x) for x in out)))
 
     def launch_info(self):
         out = np.zeros(8, np.uint32)

@@ -221,6 +221,7 @@ struct TailBatch {
     std::vector<TailResult> results;
     uint32_t dispatched = 0, done = 0;
     uint64_t gpu_pops = 0, host_pops = 0;
+    double host_thread_s = 0.0;  // seconds workers spent inside the reads of this batch, summed: against (t_last - t_first) x threads it says whether the host or the GPU's hand-overs set the pace
     double t_first = 0.0, t_last = 0.0;  // steady-clock seconds of the first hand-over seen and of the last read finished
     bool failed = false;
 
@@ -287,6 +288,7 @@ inline void tail_map_read(const std::shared_ptr<TailBatch>& tb, const TailRecord
         tb->results.push_back(std::move(r));
         tb->done += 1;
         tb->host_pops += pops;
+        tb->host_thread_s += TailBatch::now_s() - t_begin;
         tb->t_last = TailBatch::now_s();
     }
     tb->cv.notify_all();

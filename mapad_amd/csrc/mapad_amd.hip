@@ -1090,7 +1090,7 @@ struct BatchSlot {
     DevBuf<DevRecord> d_rec_out;
     DevBuf<char> d_rec_text;
     DevBuf<float> d_rec_pairs;
-    uint64_t tail_info[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // reads, pops on the GPU before the hand-over, pops on the host, host wall microseconds, threads, budget, host E_search, N_push, N_node, -
+    uint64_t tail_info[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // reads, pops on the GPU before the hand-over, pops on the host, host wall microseconds, threads, budget, host E_search, N_push, N_node, host thread microseconds
 
     void release() {
         d_seqs.release(); d_quals.release(); d_offsets.release(); d_darr.release(); d_dscratch.release(); d_counters.release(); d_status.release(); d_hit_count.release();
@@ -1589,6 +1589,7 @@ int merge_tail(mapad_ctx* c, BatchSlot& S, uint32_t* cur) {
     S.tail_info[0] = res.size(); S.tail_info[1] = tb->gpu_pops; S.tail_info[2] = tb->host_pops;
     S.tail_info[3] = res.empty() ? 0 : (uint64_t)(std::max(tb->t_last - tb->t_first, 0.0) * 1e6); S.tail_info[4] = host::TailWorkers::instance().size(); S.tail_info[5] = c->tail_pops;
     for (const auto& r : res) { S.tail_info[6] += r.e_search; S.tail_info[7] += r.n_push; S.tail_info[8] += r.n_node; }
+    S.tail_info[9] = (uint64_t)(tb->host_thread_s * 1e6);
     if (res.empty()) return MAPAD_OK;
     std::sort(res.begin(), res.end(), [](const host::TailResult& a, const host::TailResult& b) { return a.read < b.read; });
     const BatchDev& B = S.last;

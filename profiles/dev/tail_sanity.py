@@ -26,7 +26,7 @@ for limits in ({}, {"stack_limit": 60, "edit_tree_limit": 100000}):
         ctx.close()
     a, b = out[(bool(limits), 0)][0], out[(bool(limits), 48)][0]
     same = all(np.array_equal(getattr(a, k), getattr(b, k)) for k in ("hit_begin", "hits_arr", "ops", "status", "counters"))
-    print(f"limits {limits or 'default'}: host tail took {out[(bool(limits), 48)][1]['reads']} reads ({out[(bool(limits), 48)][1]['host_pops']} pops, {out[(bool(limits), 48)][1]['threads']} threads); "
+    print(f"limits {limits or 'default'}: host tail took {out[(bool(limits), 48)][1]['reads']} reads ({out[(bool(limits), 48)][1]['host_pops']} pops, {out[(bool(limits), 48)][1]['threads']} threads, {out[(bool(limits), 48)][1]['host_thread_us'] / 1e6:.3f} thread-s in {out[(bool(limits), 48)][1]['host_us'] / 1e6:.3f} s); "
           f"{a.n_hits} hits; identical to the GPU-only batch: {same}", flush=True)
     assert same and out[(bool(limits), 48)][1]["reads"] > 100 and out[(bool(limits), 0)][1]["reads"] == 0
 print(f"OK in {time.time() - t0:.1f} s")
