@@ -146,9 +146,10 @@ def lib():
     if _lib is None:
         path = os.environ.get("MAPAD_AMD_LIB")  # an alternative build of the library (profiling / A-B variants)
         if not path:
-            path = _build.LIB
-            if _build.needs_build():
-                path = _build.build()
+            hv = _build.selected_variant()  # MAPAD_HEAP_VARIANT=1..3: the library built with another reading of the heap's tie rules (csrc/heap_core.hpp)
+            path = _build.lib_path(hv)
+            if _build.needs_build(hv):
+                path = _build.build(heap_variant=hv)
         L = C.CDLL(path)
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(L, name)  # AttributeError = the library does not export what the header declares

@@ -104,21 +104,46 @@ def kernel_code_hash(lib=None):
     return h.hexdigest()[:16] if n else None
 
 
-def needs_build():
-    if not os.path.exists(LIB):
+def lib_path(heap_variant=0):
+    """The library of one reading of the frontier heap's tie rules (csrc/heap_core.hpp: MAPAD_HEAP_VARIANT); 0 = the default library."""
+    return LIB if not heap_variant else os.path.join(HERE, f"libmapad_amd.hv{int(heap_variant)}.so")
+
+
+def selected_variant():
+    """MAPAD_HEAP_VARIANT in the environment picks the library a process loads (binding.lib()); default 0."""
+    v = int(os.environ.get("MAPAD_HEAP_VARIANT", "0") or 0)
+    if not 0 <= v <= 3:
+        raise ValueError("MAPAD_HEAP_VARIANT must be 0..3")
+    return v
+
+
+def needs_build(heap_variant=0):
+    lib = lib_path(heap_variant)
+    if not os.path.exists(lib):
         return True
-    t = os.path.getmtime(LIB)
+    t = os.path.getmtime(lib)
     return any(os.path.getmtime(p) > t for p in _deps())
 
 
-def build(force=False, verbose=False):
-    if not force and not needs_build():
-        return LIB
-    cmd = [HIPCC] + FLAGS + os.environ.get("MAPAD_EXTRA_FLAGS", "").split() + ["-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
+def build(force=False, verbose=False, heap_variant=0):
+    lib = lib_path(heap_variant)
+    if not force and not needs_build(heap_variant):
+        return lib
+    extra = [f"-DMAPAD_HEAP_VARIANT={int(heap_variant)}"] if heap_variant else []
+    tmp = lib + f".tmp{os.getpid()}"
+    cmd = [HIPCC] + FLAGS + extra + os.environ.get("MAPAD_EXTRA_FLAGS", "").split() + ["-o", tmp] + [os.path.join(CSRC, s) for s in SOURCES]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)
-    return LIB
+    os.replace(tmp, lib)
+    return lib
+
+
+def build_all(force=False, verbose=False, variants=(0, 1, 2, 3)):
+    """The default library and the three other readings of the heap's tie rules, side by side (one hipcc each; they share nothing but the sources)."""
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        return list(ex.map(lambda v: build(force=force, verbose=verbose, heap_variant=v), variants))
 
 
 if __name__ == "__main__":

@@ -107,9 +107,6 @@ MAPAD_HD void ext4_scalar(const DevIndex& ix, uint64_t lower, uint64_t lower_rev
     finish_ext4(ix, lower, lower_rev, size, lo, hi, out);
 }
 
-#if !defined(MAPAD_SAME_BLOCK)
-#define MAPAD_SAME_BLOCK 0  // search step: one pair of index loads when both rows of a rank-query pair lie in the same 256-row block (measured: DESIGN.md section 4)
-#endif
 #if defined(__HIPCC__)
 // ---- quad-cooperative versions (gfx950) ----------------------------------------------------------------------------
 // DPP quad_perm controls: [1,0,3,2] = 0xB1, [2,3,0,1] = 0x4E, broadcast lane k = k*0x55.
@@ -186,14 +183,7 @@ __device__ __forceinline__ ExtLoads ext4_quad_issue(const DevIndex& ix, uint64_t
     const uint64_t r_lo = lower == 0 ? 0 : lower - 1, r_hi = lower + size - 1;
     ExtLoads l;
     l.lo = quad_occ_issue(ix, r_lo, w);
-#if MAPAD_SAME_BLOCK
-    // both rows in one 256-row block (every interval narrower than 256 rows that does not straddle a block boundary): the second pair of loads would fetch
-    // the same 128-byte line again — predicated off, the finish takes the first pair for both masks
-    l.hi = OccLoads{};
-    if ((r_lo >> 8) != (r_hi >> 8)) l.hi = quad_occ_issue(ix, r_hi, w);
-#else
     l.hi = quad_occ_issue(ix, r_hi, w);
-#endif
     return l;
 }
 // lane_less = ix.less[w + 1], picked once per kernel by the caller: as a select over the kernel arguments inside the step it came out as nested
@@ -203,16 +193,7 @@ __device__ __forceinline__ void ext4_quad_lane_finish(const DevIndex& ix, const 
                                                       ExtLane& out) {
     const uint64_t r_lo = lower == 0 ? 0 : lower - 1, r_hi = lower + size - 1;
     const uint64_t occ_lo = quad_occ_finish(l.lo, r_lo, w);
-#if MAPAD_SAME_BLOCK
-    OccLoads h;
-    {
-        const bool same = (r_lo >> 8) == (r_hi >> 8);
-        h.v0.x = same ? l.lo.v0.x : l.hi.v0.x; h.v0.y = same ? l.lo.v0.y : l.hi.v0.y; h.v1.x = same ? l.lo.v1.x : l.hi.v1.x; h.v1.y = same ? l.lo.v1.y : l.hi.v1.y;
-    }
-    const uint64_t my_hi = quad_occ_finish(h, r_hi, w);
-#else
     const uint64_t my_hi = quad_occ_finish(l.hi, r_hi, w);
-#endif
     const uint64_t my_lo = lower == 0 ? 0 : occ_lo;
     const uint64_t my_size = my_hi - my_lo;
     const uint64_t s0 = quad_bcast64<0>(my_size), s1 = quad_bcast64<1>(my_size), s2 = quad_bcast64<2>(my_size), s3 = quad_bcast64<3>(my_size);

@@ -47,7 +47,7 @@ __device__ __forceinline__ uint32_t heap_level(uint32_t p) { return 31u - (uint3
 // One stride of a trickle-down (the `stride` of search_core.hpp's mm_trickle_down: candidates in the order child 1, child 2, grandchildren 1-4, a
 // later one wins only if strictly better) with the six candidates in six lanes: lane i < 6 reads its candidate from `base` (logical index
 // c1b + i for the children, g1b + i - 2 for the grandchildren; c1 / g1 are their heap slots), the best is found by a three-step DPP reduction of
-// 64-bit keys (score in sortable form, then 7 - i so that the earlier candidate wins a tie) over the first eight lanes.
+// 64-bit keys (score in sortable form, then 7 - scan rank so that the earlier candidate wins a tie) over the first eight lanes.
 // The hole `pos` moves to the best candidate; returns false when the sift ends at `pos`.  set(slot, entry) stores.
 __device__ __forceinline__ uint32_t sortable_f32(float x) {  // unsigned order == float order (no NaNs; -0.0 is folded into +0.0 first)
     const uint32_t u = __builtin_bit_cast(uint32_t, x + 0.0f);
@@ -61,7 +61,9 @@ __device__ __forceinline__ bool heavy_stride(Ptr base, uint32_t c1b, uint32_t g1
     const bool valid = (i < 6) & (slot < n);
     const HeapEntry e = load_entry(base + (child ? c1b + i : g1b + i - 2));  // lanes 6, 7 (and invalid slots) read an in-range neighbour: discarded
     const uint32_t s = sortable_f32(e.score);
-    uint32_t k_hi = valid ? (MAX ? s : ~s) : 0u, k_lo = 7u - i;
+    // scan rank of candidate i (child 1, child 2, grandchildren 1-4): ascending index, or family order with MAPAD_HEAP_VARIANT bit 0 (child 1, its two children, child 2, its two)
+    const uint32_t rank = (MAPAD_HEAP_VARIANT & 1) ? ((0x00542130u >> (4u * i)) & 7u) : i;  // family order: i = 0..5 -> 0, 3, 1, 2, 4, 5
+    uint32_t k_hi = valid ? (MAX ? s : ~s) : 0u, k_lo = ((7u - rank) << 3) | i;
     auto step = [&](auto ctrl) {
         constexpr int C = decltype(ctrl)::value;
         const uint32_t o_hi = dpp_quad<C>(k_hi), o_lo = dpp_quad<C>(k_lo);
@@ -71,7 +73,7 @@ __device__ __forceinline__ bool heavy_stride(Ptr base, uint32_t c1b, uint32_t g1
     step(std::integral_constant<int, 0xB1>{});   // quad_perm [1,0,3,2]
     step(std::integral_constant<int, 0x4E>{});   // quad_perm [2,3,0,1]
     step(std::integral_constant<int, 0x141>{});  // row_half_mirror: the other quad of the first eight lanes
-    const uint32_t win = 7u - ((uint32_t)__builtin_amdgcn_readfirstlane((int)k_lo) & 7u);  // lane 0 holds the maximum of lanes 0-7
+    const uint32_t win = (uint32_t)__builtin_amdgcn_readfirstlane((int)k_lo) & 7u;  // lane 0 holds the maximum of lanes 0-7: the candidate's number rides in the key's low bits
     HeapEntry be;
     be.score = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, e.score), (int)win));
     be.node = (uint32_t)__builtin_amdgcn_readlane((int)e.node, (int)win);

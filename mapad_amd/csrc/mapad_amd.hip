@@ -663,12 +663,6 @@ __device__ __forceinline__ T kernarg_reload(size_t off, const T& by_value) {
 #if !defined(MAPAD_KTOP2)
 #define MAPAD_KTOP2 31
 #endif
-// Payload cache (search_core.hpp: search_step<.., PC>): the frames in heap slots 1 and 2 are kept in 64 bytes of LDS per read slot, so that a pop starts its rank
-// queries straight after the look at the heap's top instead of after a trip to the arena for the popped frame's node.  Quads with near data in LDS only.
-// MEASURED SLOWER (round 4, same-box A/B, profiles/r04/ab_step_levers.txt: C4 -5 ... -7 %, C2 -3 ... -10 %): off by default, kept as a tested build option.
-#if !defined(MAPAD_PAYLOAD_CACHE)
-#define MAPAD_PAYLOAD_CACHE 0
-#endif
 template <int LPR> struct top_of { static constexpr int value = LPR == 2 ? MAPAD_KTOP2 : kTop; };
 template <int LPR, bool CONT, int PASS, bool NL, bool HEAVY>
 __global__ void __launch_bounds__(64, (LPR == 1 && NL) ? 1 : LPR == 2 ? 2 : MAPAD_MIN_WAVES) search_kernel(DevIndex ix, DevParams P, BatchDev B0, ArenaPool AP0, const GrowPools* GP, uint32_t near_stride, uint32_t near_lmax, int stage) {
@@ -691,8 +685,6 @@ __global__ void __launch_bounds__(64, (LPR == 1 && NL) ? 1 : LPR == 2 ? 2 : MAPA
     A.top = (typename near_ptr<HeapEntry, NL>::type)near + 1;
     const NearBytes near_qc = near + (TOPK + 1) * sizeof(HeapEntry);
     const typename near_ptr<float, NL>::type near_d = (typename near_ptr<float, NL>::type)(near_qc + ((2 * near_lmax + 15) & ~15u));
-    constexpr bool kPC = MAPAD_PAYLOAD_CACHE != 0 && LPR == 4 && NL;
-    if constexpr (kPC) A.pc = (typename near_ptr<uint64_t, NL>::type)(near + (near_stride - 64u));  // the last 64 bytes of the slot's near data (near_bytes)
     uint32_t* work = &cursors[CUR_WORK + 2 * tier];
     // reads of the first stages give up after kMaxWaits fruitless waits for an arena and are restarted by the next stage, when the
     // pools are quiet; the last growable stage waits as long as it takes
@@ -734,7 +726,6 @@ __global__ void __launch_bounds__(64, (LPR == 1 && NL) ? 1 : LPR == 2 ? 2 : MAPA
                     SearchState tmp;
                     A.n_waits = 0;
                     search_init(kernarg_reload(0, ix).n, alignment_start_of(P, rd.L), rd, A, tmp);
-                    if constexpr (kPC) pc_clear(A);
                     st = tmp;
                     have = true;
                     tail_denied = false;
@@ -751,8 +742,8 @@ __global__ void __launch_bounds__(64, (LPR == 1 && NL) ? 1 : LPR == 2 ? 2 : MAPA
         }
         if (have) {
             bool cont;
-            if constexpr (PASS != 1) cont = search_step<LPR, CONT, NL, kPC>(ix, P, rd, A, st, w, grow);
-            else cont = search_step<LPR, CONT, NL, kPC>(ix, P, rd, A, st, w, NoGrow());
+            if constexpr (PASS != 1) cont = search_step<LPR, CONT, NL>(ix, P, rd, A, st, w, grow);
+            else cont = search_step<LPR, CONT, NL>(ix, P, rd, A, st, w, NoGrow());
             MAPAD_MARK(PROF_TAIL);
             if (!cont) {
                 finalize_read<LPR>(kernarg_reload(kArgOffB, B0), rd, A, st, read, w, tier);
@@ -949,8 +940,7 @@ struct DevBuf {
 
 // bytes of "near" data per read slot: heap top (32 physical slots), 2 bytes + 4 bytes per read position
 // (+ 64 bytes for the payload cache of heap slots 1 and 2 where the kernel keeps one: quads with their near data in LDS)
-constexpr uint32_t kPcBytes = 64;
-uint32_t near_bytes(uint32_t lmax, uint32_t top = kTop, bool pc = false) { return (top + 1) * 8 + ((2 * lmax + 15) & ~15u) + ((4 * lmax + 15) & ~15u) + (pc ? kPcBytes : 0u); }
+uint32_t near_bytes(uint32_t lmax, uint32_t top = kTop) { return (top + 1) * 8 + ((2 * lmax + 15) & ~15u) + ((4 * lmax + 15) & ~15u); }
 constexpr uint32_t kMaxLdsReadLen = 256;  // longer reads keep their near data in the HBM arena instead of LDS
 
 ArenaPool make_pool_layout(uint32_t heap_cap, uint32_t node_cap, uint32_t hit_ops_cap, uint32_t lmax) {
@@ -1503,7 +1493,7 @@ int launch_batch(mapad_ctx* c, BatchSlot& S, const uint8_t* d_seqs, const uint8_
     // lanes-per-read 1: 64 read slots per wavefront, near data in LDS while it fits the 64 KB a launch may ask for without an opt-in
     const uint32_t near_top = c->lpr == 2 ? MAPAD_KTOP2 : kTop;
     const bool near_fits = c->lpr == 4 ? near_lmax <= kMaxLdsReadLen : c->lpr == 2 ? (size_t)near_bytes(near_lmax, near_top) * 32 <= 65536 : (size_t)near_bytes(near_lmax) * 64 <= 65536;
-    const uint32_t near_stride = (near_fits && env_u32("MAPAD_NEAR_LDS", 1)) ? near_bytes(near_lmax, near_top, MAPAD_PAYLOAD_CACHE && c->lpr == 4) : 0;
+    const uint32_t near_stride = (near_fits && env_u32("MAPAD_NEAR_LDS", 1)) ? near_bytes(near_lmax, near_top) : 0;
     // LDS per search block: the near data of its read slots — padded, when twelve blocks would fit a CU, to what only eleven fit (see order_scatter_kernel)
     size_t lds = (size_t)near_stride * rpw;
     {

@@ -12,250 +12,9 @@
 // the deletion and match/mismatch nodes of base w; search_step / commit_child).
 // The same source compiles for the host (tests/emu) so that the CPU test-suite can run it against the oracle.
 #pragma once
-#include <type_traits>
-
-#include "fmd_device.hpp"
-
-// Rare paths (a hit is found, limit recovery, read set-up).  Out-of-line variants were measured on MI355X (C2): they shrink the
-// kernel by 30 % of its instructions but cost 5-10 % run time and +25 % memory traffic (call-site spills through scratch),
-// so they are inlined by default; -DMAPAD_OUTLINE_RARE builds the out-of-line variant.
-#define MAPAD_UNLIKELY(x) __builtin_expect(!!(x), 0)
-#if defined(__HIPCC__) && defined(MAPAD_OUTLINE_RARE)
-#define MAPAD_RARE __host__ __device__ __attribute__((noinline))
-#elif defined(__HIPCC__)
-#define MAPAD_RARE __host__ __device__ __forceinline__
-#else
-#define MAPAD_RARE inline
-#endif
-
-// MAPAD_QUAD_LOADS=1: values every lane of a quad needs (popped node, score row, the heap's last entry, heap entries stored) are requested / stored by one lane
-// each and handed round by DPP, instead of four lanes issuing the same address.  Bit-identical and MEASURED SLOWER (round 4, same-box A/B: C4 -9 %, C2 -9 %,
-// C3 -5 %, profiles/r04/ab_step_levers.txt): four lanes with one address cost the memory pipeline no more than one lane does, the DPP moves and exec masks do cost.  Off.
-#if !defined(MAPAD_QUAD_LOADS)
-#define MAPAD_QUAD_LOADS 0
-#endif
-
-// -DMAPAD_PROFILE_SECTIONS: wave time and lane time per section of the search loop (s_memtime deltas accumulated in LDS, dumped by the kernel).
-// A diagnostic build: the marks cost a few percent and the numbers are relative.
-#if defined(MAPAD_PROFILE_SECTIONS) && defined(__HIPCC__)
-enum { PROF_POP = 0, PROF_NODE = 1, PROF_EXT = 2, PROF_GATES = 3, PROF_COMMIT = 4, PROF_TAIL = 5, PROF_SETUP = 6, PROF_FINALIZE = 7, PROF_GROW = 8, PROF_HIT = 9, PROF_LOOP = 10, PROF_C_PRE = 11, PROF_C_LOAD = 12, PROF_N = 14 };
-__shared__ unsigned long long g_prof_lds[2 * PROF_N + 2];  // [k] wave cycles, [PROF_N + k] lane cycles, [2 PROF_N] last stamp
-__shared__ unsigned int g_prof_hist[64];  // [0..23] log2(heap_len) at pop, [24..35] children committed by a pop, [36..47] commit-loop trips of a wave step, [48..63] trickle levels
-__device__ __forceinline__ void prof_mark(int k) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    const unsigned long long t = __builtin_amdgcn_s_memtime();
-    const unsigned long long act = __ballot(1);
-    if ((int)__builtin_amdgcn_mbcnt_hi((unsigned)(act >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)act, 0)) == 0) {  // first active lane
-        const unsigned long long dt = t - g_prof_lds[2 * PROF_N];
-        g_prof_lds[2 * PROF_N] = t;
-        g_prof_lds[k] += dt;
-        g_prof_lds[PROF_N + k] += dt * (unsigned long long)__popcll(act);
-    }
-#else
-    (void)k;
-#endif
-}
-#if defined(__HIP_DEVICE_COMPILE__)
-#define MAPAD_MARK(k) prof_mark(k)
-#else
-#define MAPAD_MARK(k) ((void)0)
-#endif
-#else
-#define MAPAD_MARK(k) ((void)0)
-#endif
+#include "heap_core.hpp"
 
 namespace mapad {
-
-// The compiler's wait-count pass is not path sensitive: a load or store issued on a RARE path of the search loop counts as "possibly still in
-// flight" at the join, and the common path then carries a full `s_waitcnt vmcnt(0)` — a drain of every store in flight — in front of the
-// next instruction that touches one of the registers involved.  Rare paths therefore end with an explicit wait of their own, which the pass
-// does model: behind it nothing is pending and the common path keeps only the waits it needs.
-// Marks a loaded value as used here: the wait-count pass then places the wait for it at this point — chosen where younger loads are waited for anyway, so that it
-// costs nothing — instead of carrying "possibly still in flight" around the loop into a full drain in front of the next write of the same register.
-template <class T> MAPAD_HD void consume_here(const T& v) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    asm volatile("" ::"v"(v));
-#else
-    (void)v;
-#endif
-}
-MAPAD_HD void drain_memory() {
-#if defined(__HIP_DEVICE_COMPILE__)
-    __builtin_amdgcn_s_waitcnt(0);  // vmcnt(0) expcnt(0) lgkmcnt(0)
-#endif
-}
-
-enum : uint32_t { GAP_INS = 0, GAP_DEL = 1, GAP_CLOSED = 2 };  // src/map/mod.rs:93-98
-
-struct HeapEntry {
-    float score;
-    uint32_t node;
-};
-
-// 32-byte tree node + frame payload (MismatchSearchStackFrame, src/map/mod.rs:105-137, minus the score that lives in the heap)
-//   w0 = op | parent << 32          (vacant slot: parent = next free key)
-//   w1 = lower (40 bit) | start << 40 (15 bit: reads up to i16::MAX, record.rs:144-150)
-//   w2 = lower_rev (40 bit) | gap_f << 40 | gap_b << 42 | ngaps << 44 (8 bit) | occupied << 52
-//   w3 = size (40 bit) | len << 40 (15 bit)
-struct alignas(16) Node {
-    uint64_t w0, w1, w2, w3;
-};
-static_assert(sizeof(Node) == 32, "node + frame payload is 32 bytes");
-constexpr uint64_t kMask40 = (1ull << 40) - 1;
-
-struct Frame {
-    uint64_t lower, lower_rev, size;
-    int32_t start, len;
-    uint32_t gap_f, gap_b, ngaps;
-};
-MAPAD_HD Node pack_node(uint32_t op, uint32_t parent, const Frame& f) {
-    Node n;
-    n.w0 = (uint64_t)op | ((uint64_t)parent << 32);
-    n.w1 = f.lower | ((uint64_t)(uint32_t)f.start << 40);
-    n.w2 = f.lower_rev | ((uint64_t)f.gap_f << 40) | ((uint64_t)f.gap_b << 42) | ((uint64_t)f.ngaps << 44) | (1ull << 52);
-    n.w3 = f.size | ((uint64_t)(uint32_t)f.len << 40);
-    return n;
-}
-MAPAD_HD Frame unpack_frame(const Node& n) {
-    Frame f;
-    f.lower = n.w1 & kMask40; f.start = (int32_t)(n.w1 >> 40);
-    f.lower_rev = n.w2 & kMask40; f.gap_f = (uint32_t)(n.w2 >> 40) & 3; f.gap_b = (uint32_t)(n.w2 >> 42) & 3; f.ngaps = (uint32_t)(n.w2 >> 44) & 0xFF;
-    f.size = n.w3 & kMask40; f.len = (int32_t)(n.w3 >> 40);
-    return f;
-}
-// word-wise selects: a conditional expression on whole structs selects an ADDRESS and copies from it, which pins all three nodes in scratch memory
-MAPAD_HD Node pick_node(bool first, bool second, const Node& a, const Node& b, const Node& c) {
-    Node n;
-    n.w0 = first ? a.w0 : second ? b.w0 : c.w0; n.w1 = first ? a.w1 : second ? b.w1 : c.w1;
-    n.w2 = first ? a.w2 : second ? b.w2 : c.w2; n.w3 = first ? a.w3 : second ? b.w3 : c.w3;
-    return n;
-}
-MAPAD_HD uint32_t node_op(const Node& n) { return (uint32_t)n.w0; }
-MAPAD_HD uint32_t node_parent(const Node& n) { return (uint32_t)(n.w0 >> 32); }
-MAPAD_HD bool node_occupied(const Node& n) { return (n.w2 >> 52) & 1; }
-
-struct HitRec {  // 40 bytes; the public hit record (include/mapad_amd.h: mapad_hit_t)
-    uint64_t lower, lower_rev, size;
-    float score;
-    uint32_t n_ops;
-    uint32_t ops_off;  // into the per-read staging area, later into the global ops pool
-    uint32_t pad;
-};
-static_assert(sizeof(HitRec) == 40, "hit record is 40 bytes");
-
-// Per-read position data kept next to the quad (LDS on the device; MAPAD_MAX_LDS_READ_LEN and shorter reads):
-//   qc[2j] = read-base class (0..3 = ACGT, 4 otherwise), qc[2j+1] = Phred quality  -> one shared score-table row per pop
-//   d[j]   = BiDArray::d_composite[j] (written by darray_kernel)
-#if !defined(MAPAD_KTOP)
-#define MAPAD_KTOP 63
-#endif
-constexpr int kTop = MAPAD_KTOP;  // logical heap slots 0..kTop-1 (63: levels 0-5) live in the `top` array (LDS on the device); must be 2^k - 1
-
-constexpr int kMaxHits = 20;  // a pop adds <= 9 hits and the search returns once more than 9 exist (mapping.rs:1348)
-
-enum : uint32_t { ST_OK = 0, ST_ARENA_OVERFLOW = 1, ST_LIMIT_ABORT = 2 };
-
-// "Near" data of a read slot (heap top, position data) is addressed through LDS-typed pointers on the device when NL is set, so the
-// compiler emits ds_* instructions for it and global_* for the arena (a pointer that may be either would force flat_* accesses,
-// which occupy the texture addresser and make every wait a full vmcnt(0)+lgkmcnt(0) wait).  NL = false: plain pointers (host build,
-// very long reads whose near data stays in the HBM arena).
-// The arena pointers of a grown read come out of a descriptor in memory, so their address space must be spelled out as well: left
-// generic they turn every heap and node access into a flat_* instruction, which counts against both vmcnt and lgkmcnt and so
-// serialises the LDS and the HBM halves of every sift.
-#if defined(__HIP_DEVICE_COMPILE__)
-#define MAPAD_LDS __attribute__((address_space(3)))
-#define MAPAD_GLOBAL __attribute__((address_space(1)))
-#else
-#define MAPAD_LDS
-#define MAPAD_GLOBAL
-#endif
-template <class T, bool NL> struct near_ptr { using type = T*; };
-template <class T> struct near_ptr<T, true> { using type = MAPAD_LDS T*; };
-
-// TOP = logical heap slots kept in the near array (2^k - 1): 63 for a quad's read slot, 1023 for a read that has a wavefront to itself (heavy_core.hpp)
-template <bool NL, int TOP = kTop>
-struct ArenaT {
-    static constexpr int kTopN = TOP;
-    typename near_ptr<HeapEntry, NL>::type top;  // logical heap slots [0, TOP), shifted by one entry like `heap`
-    MAPAD_GLOBAL HeapEntry* heap;    // logical heap slots [TOP, ..) are used from here
-    MAPAD_GLOBAL Node* nodes;
-    MAPAD_GLOBAL HitRec* hits;       // kMaxHits
-    MAPAD_GLOBAL uint32_t* hit_ops;  // staging for the hits' edit tracks
-    MAPAD_GLOBAL uint16_t* scratch;  // 2 * (Lmax + 1) u16 for the bucket sort of extract_edit_operations
-    typename near_ptr<uint64_t, NL>::type pc = nullptr;  // payload cache of heap slots 1 and 2 (search_step<.., PC = true>): 2 x {1 << 32 | node id, w1, w2, w3}, near data
-    uint32_t heap_cap, node_cap, hit_ops_cap;
-    uint32_t grown = 0;  // 0: heap/nodes are the slot's base arena; else (class + 1) << 27 | arena index (mapad_amd.hip: DeviceGrow)
-    uint32_t wait = 0;   // steps to sit out before asking the pools again
-    uint32_t n_waits = 0;  // fruitless requests of the current read
-};
-
-using Arena = ArenaT<false>;
-
-template <bool NL>
-struct ReadInT {
-    typename near_ptr<const uint8_t, NL>::type qc;  // 2 bytes per position: base class, quality
-    typename near_ptr<const float, NL>::type d;     // D array
-    int L;
-    float thr;          // DevParams::reject_thr[L]
-    int32_t table;      // DevParams::table_base[L]
-    uint64_t lane_less = 0;  // device quads: Less of the base this lane extends by (DevIndex::less[w + 1]), picked once per kernel; pairs: of base 2w
-    uint64_t lane_less1 = 0; // device pairs (lanes-per-read 2): Less of this lane's second base, 2w + 1
-};
-using ReadIn = ReadInT<false>;
-
-struct alignas(16) HeapPair { HeapEntry a, b; };
-MAPAD_HD HeapPair load_pair(const HeapEntry* p) {  // p is 16-byte aligned
-#if defined(__HIP_DEVICE_COMPILE__)
-    const uint4 q = *reinterpret_cast<const uint4*>(p);
-    HeapPair r;
-    r.a.score = __uint_as_float(q.x); r.a.node = q.y; r.b.score = __uint_as_float(q.z); r.b.node = q.w;
-    return r;
-#else
-    HeapPair r;
-    std::memcpy(&r, p, sizeof r);
-    return r;
-#endif
-}
-#if defined(__HIP_DEVICE_COMPILE__)
-__device__ __forceinline__ HeapPair load_pair(const MAPAD_GLOBAL HeapEntry* p) {
-    const uint4 q = *(const MAPAD_GLOBAL uint4*)p;
-    HeapPair r;
-    r.a.score = __uint_as_float(q.x); r.a.node = q.y; r.b.score = __uint_as_float(q.z); r.b.node = q.w;
-    return r;
-}
-__device__ __forceinline__ HeapPair load_pair(const MAPAD_LDS HeapEntry* p) {
-    const uint4 q = *(const MAPAD_LDS uint4*)p;
-    HeapPair r;
-    r.a.score = __uint_as_float(q.x); r.a.node = q.y; r.b.score = __uint_as_float(q.z); r.b.node = q.w;
-    return r;
-}
-#endif
-
-// heap slot i of this read: the top levels sit in the near array (LDS), the rest in the HBM arena
-// Entries are moved field by field: copying the struct would bind the source to a reference in the generic address space, and after
-// the near/arena branches are merged the access would stay a flat_* instruction (vmcnt and lgkmcnt, no overlap with anything).
-template <class P> MAPAD_HD HeapEntry load_entry(P p) { HeapEntry e; e.score = p->score; e.node = p->node; return e; }
-template <class P> MAPAD_HD void store_entry(P p, const HeapEntry e) { p->score = e.score; p->node = e.node; }
-template <bool NL, int TOP> MAPAD_HD HeapEntry hp_get(const ArenaT<NL, TOP>& A, uint32_t i) {
-    if (i < (uint32_t)TOP) return load_entry(A.top + i);
-    return load_entry(A.heap + i);
-}
-template <bool NL, int TOP> MAPAD_HD void hp_set(const ArenaT<NL, TOP>& A, uint32_t i, const HeapEntry e) {
-    if (i < (uint32_t)TOP) store_entry(A.top + i, e);
-    else store_entry(A.heap + i, e);
-}
-// the same where all lanes of a quad hold the same (i, e): the arena store by the quad's first lane only (lane-parallel callers use hp_set: their lanes differ)
-template <int LPR, bool NL, int TOP> MAPAD_HD void hp_set_uniform(const ArenaT<NL, TOP>& A, uint32_t i, const HeapEntry e) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    if constexpr (MAPAD_QUAD_LOADS != 0 && LPR == 4) {
-        if (i < (uint32_t)TOP) store_entry(A.top + i, e);
-        else if ((threadIdx.x & 3u) == 0u) store_entry(A.heap + i, e);
-        return;
-    }
-#endif
-    hp_set(A, i, e);
-}
-template <bool NL, int TOP> MAPAD_HD HeapPair hp_pair(const ArenaT<NL, TOP>& A, uint32_t i) { if (i < (uint32_t)TOP) return load_pair(A.top + i); return load_pair(A.heap + i); }
 
 struct SearchState {
     uint32_t c_esearch, c_push, c_pop, c_node, c_hits;  // event counters of the read (identical on the oracle: itself a parity check)
@@ -278,226 +37,6 @@ MAPAD_HD void ext4_any(const DevIndex& ix, uint64_t lower, uint64_t lower_rev, u
     (void)w;
     ext4_scalar(ix, lower, lower_rev, size, out);
 #endif
-}
-
-// ---- min-max heap (index 0 = min; even levels are min levels) ----------------------------------------------------
-MAPAD_HD bool mm_is_min_level(uint32_t pos) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    return (__clz((int)(pos + 1)) & 1) == 1;
-#else
-    return (__builtin_clz(pos + 1) & 1) == 1;
-#endif
-}
-
-// "a beats b" on a min level means a > b, on a max level a < b.  Flipping the sign bit of both operands reverses the order of two floats
-// (scores are never NaN), so one compare serves both cases: the two-sided form `(min & (a > b)) | (!min & (a < b))` came out as two compares,
-// two materialised booleans, a select and a third compare.
-MAPAD_HD float flip_sign(float x, uint32_t mask) { return __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, x) ^ mask); }
-
-// The first two compares of a bubble-up (parent, then the grandparent of wherever the element sits after the first compare) decide
-// 98 % of all pushes (measured, C2/C3); their three possible slots are known from `pos` alone, so they are loaded together and the
-// dependent chain of a push is one memory round trip instead of two.
-struct Ancestors { HeapEntry e1, e2, e3; };  // parent, grandparent of pos, grandparent of the parent (slot 0 where there is none)
-template <bool NL, int TOP>
-MAPAD_HD Ancestors load_ancestors(const ArenaT<NL, TOP>& A, uint32_t pos) {
-    const uint32_t i1 = pos > 0 ? (pos - 1) >> 1 : 0, i2 = pos > 2 ? (pos - 3) >> 2 : 0, i3 = i1 > 2 ? (i1 - 3) >> 2 : 0;
-    Ancestors a;  // i3 <= i2 <= i1
-    // The read slots of a wavefront are at different heap sizes: a four-way branch on where the three entries live runs its cases one after
-    // the other, each with its own wait for memory.  Here every slot reads the near array (index clamped into it) and only the arena loads
-    // are predicated, back to back, so that a wavefront waits for memory once.
-    const uint32_t k1 = i1 < (uint32_t)TOP ? i1 : 0, k2 = i2 < (uint32_t)TOP ? i2 : 0, k3 = i3 < (uint32_t)TOP ? i3 : 0;
-    const HeapEntry n1 = load_entry(A.top + k1), n2 = load_entry(A.top + k2), n3 = load_entry(A.top + k3);
-    HeapEntry g1 = HeapEntry{0.0f, 0u}, g2 = HeapEntry{0.0f, 0u}, g3 = HeapEntry{0.0f, 0u};
-    if (i1 >= (uint32_t)TOP) g1 = load_entry(A.heap + i1);
-    if (i2 >= (uint32_t)TOP) g2 = load_entry(A.heap + i2);
-    if (i3 >= (uint32_t)TOP) g3 = load_entry(A.heap + i3);
-    a.e1 = i1 < (uint32_t)TOP ? n1 : g1; a.e2 = i2 < (uint32_t)TOP ? n2 : g2; a.e3 = i3 < (uint32_t)TOP ? n3 : g3;
-    return a;
-}
-// What a bubble-up stored into slots other than the new element's own: at most two (slot, entry) pairs unless it climbed beyond the second grandparent (`far`).
-// The lane-parallel commit forwards these to the siblings that are pushed behind it instead of sending them back to memory for their ancestors.
-struct BubbleWrites {
-    uint32_t slot_a = 0xFFFFFFFFu, slot_b = 0xFFFFFFFFu;
-    HeapEntry a{0.0f, 0u}, b{0.0f, 0u};
-    uint32_t far = 0;
-};
-template <bool NL, int TOP>
-MAPAD_HD uint32_t mm_bubble_up(const ArenaT<NL, TOP>& A, uint32_t pos, const HeapEntry elt, const Ancestors& an, BubbleWrites* bw = nullptr) {  // elt is the new element, destined for slot pos; returns the slot it ends up in
-    // Both compares are evaluated unconditionally (slots that do not exist compare as "stay"): the three entries are then consumed on the main
-    // path, where the compiler places the one wait for them, and the outcome is a store of elt plus at most two displaced entries.
-    const uint32_t i1 = pos > 0 ? (pos - 1) >> 1 : 0;   // parent
-    const uint32_t i2 = pos > 2 ? (pos - 3) >> 2 : 0;   // grandparent of pos
-    const uint32_t i3 = i1 > 2 ? (i1 - 3) >> 2 : 0;     // grandparent of the parent
-    const HeapEntry e1 = an.e1, e2 = an.e2, e3 = an.e3;
-    const bool min_level = mm_is_min_level(pos);
-    // (bitwise on purpose: short-circuit forms of these predicates come out as nested branches on the device)
-    const uint32_t flip1 = min_level ? 0u : 0x80000000u;
-    const bool moved = (pos > 0) & (flip_sign(elt.score, flip1) > flip_sign(e1.score, flip1));
-    const bool greater = min_level == moved;            // which grandparent chain to follow
-    const uint32_t flip2 = greater ? 0u : 0x80000000u;
-    const float elt_key = flip_sign(elt.score, flip2);  // along the chain: climbs while its key is greater
-#if defined(MAPAD_PROFILE_SECTIONS) && defined(__HIP_DEVICE_COMPILE__)
-    if (__ballot(moved) != 0xFFFFFFFFFFFFFFFFull || e2.score != e3.score) MAPAD_MARK(PROF_C_LOAD);  // forces the wait for the three entries before the mark
-#endif
-    const uint32_t pos0 = pos;
-    const uint32_t pos1 = moved ? i1 : pos;
-    const HeapEntry ge = moved ? e3 : e2;
-    const uint32_t gp = moved ? i3 : i2;
-    const bool moved2 = (pos1 > 2) & (elt_key > flip_sign(ge.score, flip2));
-    if (moved) hp_set(A, pos, e1);
-    if (moved2) {
-        hp_set(A, pos1, ge);
-        pos = gp;
-        if (MAPAD_UNLIKELY(pos > 2)) {  // 2 % of the pushes climb further
-            while (pos > 2) {
-                const uint32_t g2 = (pos - 3) >> 2;
-                const HeapEntry g = hp_get(A, g2);
-                if (!(elt_key > flip_sign(g.score, flip2))) break;
-                hp_set(A, pos, g);
-                pos = g2;
-                if (bw) bw->far = 1;
-            }
-            drain_memory();
-        }
-    } else pos = pos1;
-    hp_set(A, pos, elt);
-    if (bw) {
-        const bool both = moved & moved2;  // the parent's slot took the grandparent's entry
-        bw->slot_a = both ? i1 : 0xFFFFFFFFu; bw->a.score = ge.score; bw->a.node = ge.node;
-        bw->slot_b = pos != pos0 ? pos : 0xFFFFFFFFu; bw->b.score = elt.score; bw->b.node = elt.node;
-    }
-    return pos;
-}
-template <bool NL, int TOP>
-MAPAD_HD uint32_t mm_bubble_up(const ArenaT<NL, TOP>& A, uint32_t pos, const HeapEntry elt) { return mm_bubble_up(A, pos, elt, load_ancestors(A, pos)); }
-// Would mm_bubble_up leave `elt` in slot pos (neither of its first two compares moves it)?  Such a push stores one entry and touches no other slot.
-MAPAD_HD bool mm_push_stays(uint32_t pos, const HeapEntry elt, const Ancestors& an) {
-    const bool min_level = mm_is_min_level(pos);
-    const uint32_t flip1 = min_level ? 0u : 0x80000000u;
-    const bool moved = (pos > 0) & (flip_sign(elt.score, flip1) > flip_sign(an.e1.score, flip1));
-    const uint32_t flip2 = min_level ? 0x80000000u : 0u;  // not moved: the grandparent chain of the other kind of level
-    const bool moved2 = (pos > 2) & (flip_sign(elt.score, flip2) > flip_sign(an.e2.score, flip2));
-    return !moved & !moved2;
-}
-
-// The heap array is stored shifted by one entry (logical index i lives in physical slot i + 1; `v` points at logical 0), so the
-// two children of a node (logical 2p+1, 2p+2) form one 16-byte aligned pair and its four grandchildren (4p+3 .. 4p+6) one
-// 32-byte aligned group: a trickle-down level is three 16-byte loads instead of six 8-byte ones and touches at most 2 lines.
-// candidates scanned in ascending index order (child1, child2, grandchildren); a later one wins only if strictly better.
-// `elt` is the element being placed, starting at the hole `pos`.  Entries at or beyond n are stale memory: they are loaded
-// (the arena has slack) but neutralised by an index test.
-// A sift that starts at slot 1 or 2 (every pop_max of a heap with more than two entries) takes its first two strides through levels 1-5, which
-// with kTop = 63 lie in the near array entirely: those strides run without the near / arena selection of the general stride.
-// `occupant(node)`: for a sift that starts in slots 0-2, called once, as soon as it is known which entry ends up in the slot the sift started from (after
-// the first stride, or at once if that slot has no children): search_step's payload cache fetches that frame while the rest of the sift and the rank
-// queries are in flight.
-struct NoOccupantHook { MAPAD_HD void operator()(uint32_t) const {} };
-#if !defined(__HIP_DEVICE_COMPILE__)
-// Host builds (the host tail of host_tail.hpp, tests/emu): what a step asks memory for ahead of time.  A read at the reference's limits walks a 16 MB heap and a
-// 320 MB slab at random; its step is a chain of cache misses — the pop's sift, then one pop_min sift per evicted frame.  Results never depend on these requests.
-// Measured on the round-4 GPU box (EPYC 9575F, 16 threads, 16 reads at the limits on the 3 Gbp index; profiles/r04/host_tail_ab.txt): no prefetch 0.400 us per pop,
-// sift lookahead alone 0.413, with the next pop's node and index blocks 0.372; a second stride of sift lookahead (32 + 64 more entries per stride) 0.378: not kept.
-// MAPAD_TAIL_PREFETCH=<sift lookahead 0|1><next pop 0|1> overrides (default "11").
-struct HostPrefetch {
-    int sift_lookahead = 1;  // a deep sift requests the next stride's candidates (8 + 16 entries) while the current stride is decided
-    bool next_pop = true;    // before / between the evictions of a step: the node of the frame the next step will pop, then its two index blocks
-};
-inline HostPrefetch g_host_prefetch;
-#endif
-
-// QL = 4: the caller is a quad whose four lanes run this sift with identical arguments (arena stores then go out once per quad: hp_set_uniform).
-template <bool MAX, bool NL, int TOP, class Hook = NoOccupantHook, int QL = 1>
-MAPAD_HD void mm_trickle_down(const ArenaT<NL, TOP>& A, uint32_t n, uint32_t pos, HeapEntry elt, Hook&& occupant = Hook()) {
-    bool going = true;
-    uint32_t placed_node = elt.node;  // node of the entry that was stored into the slot a stride started from (elt itself if the stride stored nothing there)
-    const uint32_t start = pos;
-    // one stride: the hole moves to the best child or grandchild; false = the sift ends at `pos`
-    auto stride = [&](const HeapPair& c, const HeapPair& ga, const HeapPair& gb, uint32_t c1, uint32_t g1, auto&& set) -> bool {
-        uint32_t best = c1;
-        HeapEntry be = c.a;
-        auto consider = [&](uint32_t idx, const HeapEntry cand) {  // a later candidate wins only if strictly better; plain selects
-            const bool take = (idx < n) & (MAX ? (cand.score > be.score) : (cand.score < be.score));
-            best = take ? idx : best; be.score = take ? cand.score : be.score; be.node = take ? cand.node : be.node;
-        };
-        consider(c1 + 1, c.b); consider(g1, ga.a); consider(g1 + 1, ga.b); consider(g1 + 2, gb.a); consider(g1 + 3, gb.b);
-        if (!(MAX ? (be.score > elt.score) : (be.score < elt.score))) return false;
-        set(pos, be);
-        placed_node = pos == start ? be.node : placed_node;
-        pos = best;
-        if (best < g1) return false;  // moved to a child: done
-        const uint32_t parent = (pos - 1) >> 1;
-        HeapEntry pe;  // the parent of a grandchild is one of the two children just loaded
-        pe.score = parent == c1 ? c.a.score : c.b.score; pe.node = parent == c1 ? c.a.node : c.b.node;
-        if (MAX ? (pe.score > elt.score) : (pe.score < elt.score)) { set(parent, elt); elt = pe; }
-        return true;
-    };
-    auto set_near = [&](uint32_t i, const HeapEntry e) { store_entry(A.top + i, e); };
-    auto set_any = [&](uint32_t i, const HeapEntry e) { hp_set_uniform<QL>(A, i, e); };
-    if constexpr (TOP >= 63) {
-        constexpr int kNearStrides = TOP >= 1023 ? 4 : TOP >= 255 ? 3 : 2;  // strides that stay inside the near levels when the sift starts at slot 1 or 2
-#pragma unroll
-        for (int k = 0; k < kNearStrides; ++k) {
-            const uint32_t c1 = 2 * pos + 1, g1 = 2 * c1 + 1;
-            if (!(going & (c1 < n) & (g1 + 3 < (uint32_t)TOP))) break;  // levels below 5, or a sift that started deeper: the general loop
-            going = stride(load_pair(A.top + c1), load_pair(A.top + g1), load_pair(A.top + g1 + 2), c1, g1, set_near);
-            if (k == 0) occupant(placed_node);
-        }
-        if (2 * start + 1 >= n) occupant(placed_node);  // no children: elt stays where the sift started
-    } else static_assert(std::is_same<typename std::decay<Hook>::type, NoOccupantHook>::value, "the occupant hook needs the first stride in the near array");
-    while (going && 2 * pos + 1 < n) {
-        const uint32_t c1 = 2 * pos + 1, g1 = 2 * c1 + 1;
-#if !defined(__HIP_DEVICE_COMPILE__)
-        // host build (the host tail's deep heaps: 2 M entries, 16 MB): whichever grandchild the hole moves to, the next stride looks at slots 2 g + 1 ... 2 g + 2 and
-        // 4 g + 3 ... 4 g + 6 for g in [g1, g1 + 3] — two short contiguous runs; asked for now, they arrive while this stride is decided (a sift is otherwise a
-        // chain of ten cache misses, each waiting for the one before)
-        if (g1 >= (uint32_t)TOP && g_host_prefetch.sift_lookahead >= 1) {
-            const HeapEntry* nc = A.heap + (2 * g1 + 1);  // 8 entries
-            const HeapEntry* ng = A.heap + (4 * g1 + 3);  // 16 entries
-            __builtin_prefetch(nc); __builtin_prefetch(nc + 7);
-            __builtin_prefetch(ng); __builtin_prefetch(ng + 8); __builtin_prefetch(ng + 15);
-        }
-#endif
-        HeapPair c, ga, gb;  // a level is entirely near or entirely in the arena
-        {   // near reads for every slot (clamped), arena loads predicated and back to back: one wait per level for the whole wavefront
-            const bool c_near = c1 < (uint32_t)TOP, g_near = g1 + 3 < (uint32_t)TOP;
-            const uint32_t kc = c_near ? c1 : 1u, kg = g_near ? g1 : 3u;  // clamped indices keep the 16-byte alignment of a pair (odd logical index)
-            const HeapPair nc = load_pair(A.top + kc), nga = load_pair(A.top + kg), ngb = load_pair(A.top + kg + 2);
-            HeapPair hc = HeapPair{}, hga = HeapPair{}, hgb = HeapPair{};
-            if (!c_near) hc = load_pair(A.heap + c1);
-            if (!g_near) { hga = load_pair(A.heap + g1); hgb = load_pair(A.heap + g1 + 2); }
-            c = c_near ? nc : hc; ga = g_near ? nga : hga; gb = g_near ? ngb : hgb;
-        }
-        going = stride(c, ga, gb, c1, g1, set_any);
-    }
-    hp_set_uniform<QL>(A, pos, elt);
-}
-
-// pop_max of the crate in two steps so that the caller can start loading the popped frame's node before the sift's stores:
-// mm_find_max() says which slot holds the maximum (slot 2 wins a tie between slots 1 and 2), mm_remove_at() removes it.
-template <bool NL, int TOP>
-MAPAD_HD HeapEntry mm_find_max(const ArenaT<NL, TOP>& A, uint32_t n, uint32_t& idx) {
-    const HeapPair p = load_pair(A.top + 1);  // logical slots 1 and 2 (stale if n < 3, handled below)
-    const HeapEntry first = A.top[0];
-    // selects, not branches: n >= 3 -> the larger of slots 1 and 2 (slot 2 on a tie); n == 2 -> slot 1; n == 1 -> slot 0
-    const bool use_a = (n == 2) | ((n >= 3) & (p.a.score > p.b.score));
-    const bool use_b = (n >= 3) & !(p.a.score > p.b.score);
-    idx = use_a ? 1u : use_b ? 2u : 0u;
-    HeapEntry r = first;
-    r.score = use_a ? p.a.score : use_b ? p.b.score : r.score;
-    r.node = use_a ? p.a.node : use_b ? p.b.node : r.node;
-    return r;
-}
-template <bool MAX, bool NL, int TOP>
-MAPAD_HD void mm_remove_at(const ArenaT<NL, TOP>& A, uint32_t& n, uint32_t idx) {
-    const HeapEntry last = hp_get(A, n - 1);
-    n -= 1;
-    if (idx < n) mm_trickle_down<MAX>(A, n, idx, last);
-}
-template <bool NL, int TOP>
-MAPAD_HD HeapEntry mm_pop_min(const ArenaT<NL, TOP>& A, uint32_t& n) {
-    const HeapEntry item = A.top[0];
-    mm_remove_at<false>(A, n, 0);
-    return item;
 }
 
 // ---- slab tree ----------------------------------------------------------------------------------------------------
@@ -775,21 +314,6 @@ MAPAD_HD void pc_clear(const ArenaT<NL, TOP>& A) { A.pc[0] = 0; A.pc[4] = 0; }
 #if !defined(MAPAD_PAR_COMMIT)
 #define MAPAD_PAR_COMMIT 1
 #endif
-// MAPAD_FORWARD_MOVERS=1: a mover's writes (mm_bubble_up: BubbleWrites) are handed to the siblings behind it through DPP instead of memory.  Bit-identical,
-// measured 0 ... -3 % (C4 / C2, C3: profiles/r04/ab_step_levers.txt): second movers are too rare to pay for the hand-over on every first one.  Off.
-// MAPAD_NODES_FIRST=1: the children's node stores go out in front of the lane-parallel commit's wait instead of behind the pushes.  Measured +-0 (C2, C3, C4): store
-// completions are not what the next step's first wait waits for.  Off.
-#if !defined(MAPAD_NODES_FIRST)
-#define MAPAD_NODES_FIRST 0
-#endif
-#if !defined(MAPAD_FORWARD_MOVERS)
-#define MAPAD_FORWARD_MOVERS 0
-#endif
-// MAPAD_EARLY_ANCESTORS=1: the ancestors of the slots a frame's children will be appended to are requested as soon as the heap is repaired, before the rank
-// queries are finished and the children scored.  Bit-identical, measured +-0 (C2, C3, C4): off.
-#if !defined(MAPAD_EARLY_ANCESTORS)
-#define MAPAD_EARLY_ANCESTORS 0
-#endif
 template <int LPR, bool CONT, bool NL, bool PC = false, class Grow = NoGrow, int TOP = kTop, bool NLR = NL>
 MAPAD_HD bool search_step(const DevIndex& ix, const DevParams& P, const ReadInT<NLR>& rd, ArenaT<NL, TOP>& A, SearchState& st, int w, const Grow& grow) {
     if (st.heap_len == 0 || st.status != ST_OK) return false;
@@ -830,30 +354,10 @@ MAPAD_HD bool search_step(const DevIndex& ix, const DevParams& P, const ReadInT<
         }
         top_node.w0 = 0; top_node.w1 = hit ? c1 : g1; top_node.w2 = hit ? c2 : g2; top_node.w3 = hit ? c3 : g3;
     } else {
-#if defined(__HIP_DEVICE_COMPILE__)
-        if constexpr (MAPAD_QUAD_LOADS != 0 && LPR == 4) {
-            // One request per quad, not four: lane w asks for word w of the node (lane 0's word — edit operation and parent — is not needed to extend the frame) and
-            // DPP hands the words round.  Four lanes asking for the same 32 bytes are one cache request but four lanes' worth of address and data-return
-            // cycles in the CU's memory pipeline, which is what this kernel saturates (what bounds the step).
-            const MAPAD_GLOBAL uint64_t* np = (const MAPAD_GLOBAL uint64_t*)(A.nodes + top.node);
-            uint64_t word = 0;
-            if (w != 0) word = np[w];
-            top_node.w0 = 0; top_node.w1 = quad_bcast64<1>(word); top_node.w2 = quad_bcast64<2>(word); top_node.w3 = quad_bcast64<3>(word);
-        } else
-#endif
         top_node = A.nodes[top.node];
     }
     HeapEntry last;
     if constexpr (!PC) {  // with the node: both trips are needed before anything else can start
-#if defined(__HIP_DEVICE_COMPILE__)
-        if constexpr (MAPAD_QUAD_LOADS != 0 && LPR == 4) {
-            const uint32_t li = st.heap_len - 1;
-            HeapEntry le{0.0f, 0u};
-            if (li < (uint32_t)TOP) le = load_entry(A.top + li);  // (an LDS read of one address by four lanes is one access)
-            else if (w == 0) le = load_entry(A.heap + li);
-            last.score = __uint_as_float(dpp_quad<0>(__float_as_uint(le.score))); last.node = dpp_quad<0>(le.node);
-        } else
-#endif
         last = hp_get(A, st.heap_len - 1);
     }
     st.c_pop += 1;
@@ -864,15 +368,6 @@ MAPAD_HD bool search_step(const DevIndex& ix, const DevParams& P, const ReadInT<
     const int d_k = forward ? f.start : f.start - 1, d_l = forward ? f.start + f.len : f.start + f.len - 1;
     const int to_class = rd.qc[2 * j];
     Float4 row;  // shared score table: hot in L1/L2; consumed after the rank queries
-#if defined(__HIP_DEVICE_COMPILE__)
-    if constexpr (MAPAD_QUAD_LOADS != 0 && LPR == 4) {  // lane w asks for the row's element w
-        const int qi = P.nq == 1 ? 0 : (int)rd.qc[2 * j + 1];
-        const float* e4 = P.sdm_table + 4 * ((size_t)rd.table + ((size_t)j * P.nq + qi) * 5 + to_class);
-        const uint32_t mine = __float_as_uint(e4[w]);
-        row.a = __uint_as_float(dpp_quad<0 * 0x55>(mine)); row.c = __uint_as_float(dpp_quad<1 * 0x55>(mine));
-        row.g = __uint_as_float(dpp_quad<2 * 0x55>(mine)); row.t = __uint_as_float(dpp_quad<3 * 0x55>(mine));
-    } else
-#endif
     row = sdm_row_at(P, rd.table, j, rd.qc[2 * j + 1], to_class);
     const uint32_t gap_side = forward ? f.gap_f : f.gap_b;
     const float insertion_score = (gap_side == GAP_INS ? P.gap_extend : open_ext) + f_score;  // :1127-1136,1165-1174
@@ -881,16 +376,6 @@ MAPAD_HD bool search_step(const DevIndex& ix, const DevParams& P, const ReadInT<
     const float lower_bound = d_get(rd.d, L, alignment_start, d_k, d_l);                       // :1195
     if (st.n_hits > 0 && mb_reject_iterative(P, f_score + lower_bound, st.best_score)) { st.heap_len -= 1; return false; }  // :1201-1208 (the frame was popped; the search is over)
     MAPAD_MARK(PROF_NODE);
-#if defined(MAPAD_EXP_NOPS) && defined(__HIP_DEVICE_COMPILE__)
-    {   // experiment ("what bounds the step"): MAPAD_EXP_NOPS extra vector instructions per step that do nothing
-        uint32_t dummy = st.c_pop;
-        asm volatile(".rept %1\n\tv_mov_b32 %0, %0\n\t.endr" : "+v"(dummy) : "n"(MAPAD_EXP_NOPS));
-    }
-#endif
-#if defined(MAPAD_EXP_LOADS) && defined(__HIP_DEVICE_COMPILE__)
-    // experiment: one more random 8-byte request per pop (a node of this read's slab), used nowhere; counted as arrived where the rank queries are (consume_here)
-    const uint64_t exp_word = A.nodes[(uint32_t)(((uint64_t)top.node * 2654435761ull) % st.tree_entries)].w0;
-#endif
     if constexpr (PC) {   // The heap's last entry, loaded behind the stop rule above so that every path that issues the load also reaches the point where it counts as used
         // (consume_here).  Near read (clamped) for every slot, arena load predicated: as one two-armed branch the arms share their destination registers, and
         // the wait-count pass then puts a full drain in front of the near arm (any wavefront with a slot whose heap is still small).
@@ -931,15 +416,8 @@ MAPAD_HD bool search_step(const DevIndex& ix, const DevParams& P, const ReadInT<
         };
         if (top_idx < st.heap_len) mm_trickle_down<true>(A, st.heap_len, top_idx, last, fetch);
     } else {
-        if (top_idx < st.heap_len) mm_trickle_down<true, NL, TOP, NoOccupantHook, LPR == 4 ? 4 : 1>(A, st.heap_len, top_idx, last);
+        if (top_idx < st.heap_len) mm_trickle_down<true>(A, st.heap_len, top_idx, last);
     }
-#if defined(__HIP_DEVICE_COMPILE__)
-    // MAPAD_EARLY_ANCESTORS: lane w's child, if the frame has that many, will be appended at slot heap_len + w — its ancestors are requested here, as soon as the
-    // heap is repaired, and travel while the rank queries are finished and the children are scored (the lane-parallel commit below would request them only then)
-    Ancestors early_an{};
-    constexpr bool kEarlyAn = MAPAD_PAR_COMMIT != 0 && MAPAD_EARLY_ANCESTORS != 0 && LPR == 4 && !PC;
-    if constexpr (kEarlyAn) early_an = load_ancestors(A, st.heap_len + (uint32_t)w);
-#endif
     MAPAD_MARK(PROF_POP);
     Ext4 e;
     uint64_t my_lower[kBases] = {}, my_lower_rev[kBases] = {}, my_size[kBases] = {};  // kLaneKids: extension by this lane's base(s)
@@ -963,9 +441,6 @@ MAPAD_HD bool search_step(const DevIndex& ix, const DevParams& P, const ReadInT<
         nonempty = (e.size[0] >= 1 ? 1u : 0u) | (e.size[1] >= 1 ? 2u : 0u) | (e.size[2] >= 1 ? 4u : 0u) | (e.size[3] >= 1 ? 8u : 0u);
     }
     st.c_esearch += 1;
-#if defined(MAPAD_EXP_LOADS) && defined(__HIP_DEVICE_COMPILE__)
-    consume_here(exp_word);
-#endif
     if constexpr (PC) { consume_here(last.score); consume_here(last.node); }  // older than the rank-query loads just waited for; a step whose pop needs no sift would leave it "pending" (consume_here)
     MAPAD_MARK(PROF_EXT);
 
@@ -1052,7 +527,6 @@ MAPAD_HD bool search_step(const DevIndex& ix, const DevParams& P, const ReadInT<
             for (int i = 0; i < 4; ++i) if (mm[i] < lim) cand &= ~(4u << (2 * i));
         }
         const uint32_t cand0 = cand, id0 = st.tree_next;  // == tree_entries: the slab grows at its end, child t gets key id0 + (children before t)
-        bool nodes_stored = false;
 #if defined(__HIP_DEVICE_COMPILE__)
         // The nodes of all children in three store groups (a node is only read when its frame is popped, at the earliest in the next step): lane w stores the
         // match / mismatch and the deletion child of base w, lane 0 the insertion child.
@@ -1067,11 +541,8 @@ MAPAD_HD bool search_step(const DevIndex& ix, const DevParams& P, const ReadInT<
                 if ((cand0 & 1u) && w == 0) A.nodes[id0] = nd_ins;
             }
         };
-        if constexpr (MAPAD_PAR_COMMIT != 0 && LPR == 4 && !PC) {
+        if constexpr (MAPAD_PAR_COMMIT != 0 && LPR == 4) {
             if (st.heap_len >= 16u) {
-                // MAPAD_NODES_FIRST: with one wait for the whole frame's pushes the node stores go out IN FRONT of it (their keys are known: id0 + rank) — the wait for the
-                // ancestors covers them while they travel, and the next step's first wait (the popped node) does not begin behind 32-byte stores to fresh lines
-                if (MAPAD_NODES_FIRST != 0) { store_child_nodes(); nodes_stored = true; }
                 const uint32_t n0 = st.heap_len, kids = (uint32_t)__popc(cand0);
                 uint32_t rest = cand0;
                 for (uint32_t base = 0; base < kids; base += 4) {  // four children per round (a frame has at most nine)
@@ -1088,37 +559,21 @@ MAPAD_HD bool search_step(const DevIndex& ix, const DevParams& P, const ReadInT<
                     score = is_del ? deletion_score : score; score = is_ins ? insertion_score : score;
                     const uint32_t pos = n0 + (act ? r : 0u);
                     const HeapEntry elt{score, id0 + r};
-                    Ancestors an;
-                    if (kEarlyAn && base == 0) an = early_an;  // requested behind the sift (slot n0 + w; an inactive lane's are not looked at)
-                    else an = load_ancestors(A, pos);
+                    const Ancestors an = load_ancestors(A, pos);
                     const bool stays = mm_push_stays(pos, elt, an);
                     if (act & stays) hp_set(A, pos, elt);
                     // the movers of this round, in commit order, each by its own lane
                     uint32_t movers = (uint32_t)(__ballot(act & !stays) >> (threadIdx.x & 60u)) & 15u;  // this quad's four lanes
-                    Ancestors my_an = an;
-                    bool my_fresh = true;  // my_an is what the heap holds for this lane's child (stayers changed no ancestor; movers' writes are forwarded below)
+                    bool first = true;  // the first mover's ancestors are what the heap holds (stayers changed none of them); whoever moves behind it reloads
                     while (movers) {
                         const int m = __ffs((int)movers) - 1;
                         movers &= movers - 1;
-                        BubbleWrites bw;
                         if (w == m) {
-                            if (MAPAD_UNLIKELY(!my_fresh)) { my_an = load_ancestors(A, pos); drain_memory(); }
-                            mm_bubble_up(A, pos, elt, my_an, &bw);
+                            Ancestors my_an = an;
+                            if (MAPAD_UNLIKELY(!first)) { my_an = load_ancestors(A, pos); drain_memory(); }
+                            mm_bubble_up(A, pos, elt, my_an);
                         }
-                        if (MAPAD_FORWARD_MOVERS == 0) my_fresh = false;  // (default) whoever moves behind this one reloads its ancestors
-                        else if (movers) {  // siblings behind this one: they see what it stored, from its registers (a trip to memory each otherwise)
-                            const uint32_t sa = quad_pick32(bw.slot_a, m), sb = quad_pick32(bw.slot_b, m), far = quad_pick32(bw.far, m);
-                            const uint32_t a_s = quad_pick32(__float_as_uint(bw.a.score), m), a_n = quad_pick32(bw.a.node, m);
-                            const uint32_t b_s = quad_pick32(__float_as_uint(bw.b.score), m), b_n = quad_pick32(bw.b.node, m);
-                            const uint32_t i1 = pos > 0 ? (pos - 1) >> 1 : 0, i2 = pos > 2 ? (pos - 3) >> 2 : 0, i3 = i1 > 2 ? (i1 - 3) >> 2 : 0;
-                            auto patch = [&](HeapEntry& e, uint32_t idx) {
-                                const bool ha = idx == sa, hb = idx == sb;  // slot_b is written last (the new element's final slot): it wins if both name the slot
-                                e.score = hb ? __uint_as_float(b_s) : ha ? __uint_as_float(a_s) : e.score;
-                                e.node = hb ? b_n : ha ? a_n : e.node;
-                            };
-                            patch(my_an.e1, i1); patch(my_an.e2, i2); patch(my_an.e3, i3);
-                            my_fresh = my_fresh & (far == 0u);  // it climbed past its second grandparent: whoever comes behind reloads
-                        }
+                        first = false;
                     }
                 }
                 st.tree_next = id0 + kids; st.tree_entries = id0 + kids; st.tree_len += kids; st.heap_len = n0 + kids;
@@ -1132,9 +587,9 @@ MAPAD_HD bool search_step(const DevIndex& ix, const DevParams& P, const ReadInT<
             const uint32_t n0 = st.heap_len, kids = (uint32_t)__builtin_popcount(cand0);
             uint32_t rest = cand0;
             for (uint32_t base = 0; base < kids; base += 4) {
-                HeapEntry elt4[4]; Ancestors an4[4]; uint32_t pos4[4], movers = 0; int t4[4];
+                HeapEntry elt4[4]; Ancestors an4[4]; uint32_t pos4[4], movers = 0;
                 for (int wv = 0; wv < 4 && base + wv < kids; ++wv) {
-                    const int t = __builtin_ctz(rest); rest &= rest - 1; t4[wv] = t;
+                    const int t = __builtin_ctz(rest); rest &= rest - 1;
                     const bool is_ins = t == 0, is_del = (t & 1) != 0;
                     const int i = is_ins ? 0 : (t - 1) >> 1, k = 3 - i;
                     const float score = is_ins ? insertion_score : is_del ? deletion_score : mm[i];
@@ -1146,19 +601,12 @@ MAPAD_HD bool search_step(const DevIndex& ix, const DevParams& P, const ReadInT<
                 for (int wv = 0; wv < 4 && base + wv < kids; ++wv) {  // all decisions against the heap as it was, stayers stored
                     if (mm_push_stays(pos4[wv], elt4[wv], an4[wv])) hp_set(A, pos4[wv], elt4[wv]); else movers |= 1u << wv;
                 }
-                bool fresh4[4] = {true, true, true, true};
+                bool first = true;
                 for (int wv = 0; wv < 4; ++wv) if ((movers >> wv) & 1u) {
-                    BubbleWrites bw;
-                    if (!fresh4[wv]) an4[wv] = load_ancestors(A, pos4[wv]);
-                    mm_bubble_up(A, pos4[wv], elt4[wv], an4[wv], &bw);
-                    for (int u = wv + 1; u < 4 && base + u < kids; ++u) {  // forwarded to the lanes behind (search_step: device path)
-                        const uint32_t pos = pos4[u], i1 = pos > 0 ? (pos - 1) >> 1 : 0, i2 = pos > 2 ? (pos - 3) >> 2 : 0, i3 = i1 > 2 ? (i1 - 3) >> 2 : 0;
-                        auto patch = [&](HeapEntry& en, uint32_t idx) { if (idx == bw.slot_b) en = bw.b; else if (idx == bw.slot_a) en = bw.a; };
-                        patch(an4[u].e1, i1); patch(an4[u].e2, i2); patch(an4[u].e3, i3);
-                        if (bw.far) fresh4[u] = false;
-                    }
+                    if (!first) an4[wv] = load_ancestors(A, pos4[wv]);
+                    mm_bubble_up(A, pos4[wv], elt4[wv], an4[wv]);
+                    first = false;
                 }
-                (void)t4;
             }
             st.tree_next = id0 + kids; st.tree_entries = id0 + kids; st.tree_len += kids; st.heap_len = n0 + kids;
             st.c_node += kids; st.c_push += kids;
@@ -1222,25 +670,15 @@ MAPAD_HD bool search_step(const DevIndex& ix, const DevParams& P, const ReadInT<
                 g_pc_stats[4] += 1;  // steps in which a child ended up in slot 1 or 2
 #endif
                 const uint32_t lid = id0 + (uint32_t)popc32(cand0 & ((1u << land_t) - 1u));
-                if constexpr (kLaneKids) {
-#if defined(__HIP_DEVICE_COMPILE__)
-                    static_assert(kBases == 1, "payload cache: quads");
-                    const uint32_t t_mm = 2u + 2u * (3u - (uint32_t)w), t_del = t_mm - 1u;
-                    const bool is_mm = land_t == t_mm, is_del = land_t == t_del, is_ins = (land_t == 0u) & (w == 0);
-                    const uint64_t v1 = is_mm ? nd_mm[0].w1 : is_del ? nd_del[0].w1 : nd_ins.w1, v2 = is_mm ? nd_mm[0].w2 : is_del ? nd_del[0].w2 : nd_ins.w2,
-                                   v3 = is_mm ? nd_mm[0].w3 : is_del ? nd_del[0].w3 : nd_ins.w3;
-                    if (is_mm | is_del | is_ins) pc_store(A, land_s, lid, v1, v2, v3);
-#endif
-                } else pc_store(A, land_s, lid, land_nd.w1, land_nd.w2, land_nd.w3);
+                pc_store(A, land_s, lid, land_nd.w1, land_nd.w2, land_nd.w3);
             }
         }
         if constexpr (kLaneKids) {
             // Behind the sequential loop: inside it the stores sat between a push's loads and its wait, which then had to cover them as well (round 2).
 #if defined(__HIP_DEVICE_COMPILE__)
-            if (!nodes_stored) store_child_nodes();
+            store_child_nodes();
 #endif
         }
-        (void)nodes_stored;
     }
     while (cand != 0 && st.status == ST_OK) {
 #if defined(__HIP_DEVICE_COMPILE__)

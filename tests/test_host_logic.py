@@ -235,6 +235,41 @@ def test_kernel_logic_synthetic(name, prm, kw, n, step, monkeypatch):
     assert_same_as_oracle(ores, res, offsets)
 
 
+@pytest.mark.parametrize("variant", [1, 2, 3])
+@pytest.mark.parametrize("step", ["lane_parallel_commit", "payload_cache"])
+def test_kernel_logic_heap_variants_follow_the_matching_oracle_variant(variant, step, monkeypatch):
+    # csrc/heap_core.hpp: MAPAD_HEAP_VARIANT — the readings of the min-max-heap crate's tie rules that the reference's tests cannot tell apart (scan order of a
+    # trickle-down stride, pop_max on a tie of slots 1 and 2).  The product built with reading v equals the oracle run with reading v: every KAT that searches,
+    # and the 35-100 bp mix with indels (where the readings differ from one another in edit tracks and event counters), incl. the eviction path.
+    monkeypatch.setenv("MAPAD_EMU_PAYLOAD_CACHE", "1" if step == "payload_cache" else "0")
+    for case in KATS["cases"]:
+        ref = KATS["ref10k"] if case["reference"] == "@ref10k" else case["reference"]
+        rp = resolve_params(case["params"])
+        pidx = mapad_amd.Index.build([("ref", ref.encode())])
+        q = quals_for(case["pattern"], case["qual"])
+        seqs = np.frombuffer(case["pattern"].encode(), dtype=np.uint8)
+        offsets = np.array([0, len(seqs)], dtype=np.uint64)
+        res = emu_util.map_batch(pidx, mapad_amd.make_params(rp), seqs, q, offsets, heap_variant=variant)
+        ores = ob.OracleIndex.from_text(ref.encode(), "$ACGTX", 128).map_batch(ob.make_params(dict(rp, heap_variant=variant)), [case["pattern"].encode()], [q], keep_d=True)
+        assert_same_as_oracle(ores, res, offsets)
+    g = synth.genome(150_000, seed=99)
+    pidx = mapad_amd.Index.build([("chr1", g)])
+    oidx = ob.OracleIndex.from_bwt(pidx.bwt(), "$ACGTX", 128)
+    differs = 0
+    for prm, kw, n, limits in ((DAMAGE, dict(qual_range=(20, 40), len_range=(35, 100), indel_frac=0.05), 200, {}),
+                               (NO_DAMAGE, dict(qual=40), 300, {}),
+                               (DAMAGE, dict(qual_range=(20, 40), len_range=(35, 100), indel_frac=0.05), 60, {"stack_limit": 60, "edit_tree_limit": 400})):
+        seqs, quals, offsets = synth.reads(g, n, 50, seed=21 + n, **kw)
+        rp = dict(resolve_params(prm), **limits)
+        reads, qs = split_reads(seqs, quals, offsets)
+        res = emu_util.map_batch(pidx, mapad_amd.make_params(rp), seqs, quals, offsets, heap_variant=variant)
+        ores = oidx.map_batch(ob.make_params(dict(rp, heap_variant=variant)), reads, qs, n_threads=8, keep_d=True)
+        assert_same_as_oracle(ores, res, offsets)
+        o0 = oidx.map_batch(ob.make_params(rp), reads, qs, n_threads=8)
+        differs += int((o0.counters != ores.counters).any(axis=1).sum())
+    assert differs > 0  # the readings are not the same algorithm: the switch does something
+
+
 @pytest.mark.parametrize("step", ["lane_parallel_commit", "payload_cache"])
 def test_kernel_logic_second_pass_and_limit_recovery(step, monkeypatch):
     monkeypatch.setenv("MAPAD_EMU_PAYLOAD_CACHE", "1" if step == "payload_cache" else "0")
