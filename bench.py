@@ -24,7 +24,7 @@ the shards and checks them against every rank's own copy.
 Also on the line: `roofline` (dominant kernel: algorithmic bytes from the kernels' event counters / HIP-event time), `cpu_baseline`
 (the C++ oracle on the host cores over a bounded sample, N = 1 only; its hits must equal the GPU's), `e2e` (host buffers in, host
 results out: H2D + kernels + device-side collect + D2H), `sa_locate` and `post_search` (the next rows of the path), `tail` (reads finished by host threads),
-`secondary` (C4 only: short C2 / C3 runs).
+`secondary` (C4 only: short C2 / C3 runs as processes of their own, and C5's read mix — 200 000 reads at the reference's real limits — on this run's 3 Gbp index).
 """
 import argparse
 import ctypes
@@ -446,7 +446,7 @@ def main():
     dom_bytes, dom_ms = (bytes_search, ms_search) if dominant == "search_kernel" else (bytes_darray, ms_darray)
     achieved = dom_bytes / (dom_ms * 1e-3) / 1e9
     # HBM traffic of the PMC passes (profiles/collect.sh) — reported only while the library's gfx950 machine code is the code those passes ran
-    traffic, traffic_stale = None, None
+    traffic, traffic_stale, traffic_darray = None, None, None
     tp = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tp):
         try:
@@ -458,6 +458,7 @@ def main():
                 else:
                     traffic_stale = entry.get("kernel_source_sha16") != mbuild_.source_hash()
                 traffic = None if traffic_stale else entry.get(dominant)
+                traffic_darray = None if traffic_stale else entry.get("darray_kernel")
         except Exception:
             traffic = None
     roofline = {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
@@ -468,10 +469,15 @@ def main():
                 "launch_marks_ms": [[round(float(x), 2) for x in row] for row in hist],  # per launch: D-array start, search start, search end, last-pass end
                 "solo_launch": {"darray_ms": round(solo_ms[0], 4), "search_ms": round(solo_ms[1], 4), "search_GB/s": round(bytes_search / (solo_ms[1] * 1e-3) / 1e9, 2),
                                 "frac": round(bytes_search / (solo_ms[1] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5), "what": "one launch alone on the chip, nothing else in flight (what rocprofv3 --stats sees with --depth 1)"},
-                "all_kernels": {"darray_kernel": {"ms": round(float(ms_darray), 4), "bytes": bytes_darray, "GB/s": round(bytes_darray / (ms_darray * 1e-3) / 1e9, 2)},
+                # darray_kernel: its SURVEY 8(d) byte count is NOT a bandwidth (the top levels of every read's D-array chains hit the same index blocks: cache
+                # resident, `algorithmic_GB/s` can exceed the HBM peak) — what it moves through HBM is the PMC traffic, and `hbm_GB/s` = that over its solo duration;
+                # `ms` is its phase in the pipelined loop (beside the previous batch's search), `solo_ms` the same launch alone on the chip
+                "all_kernels": {"darray_kernel": {"ms": round(float(ms_darray), 4), "solo_ms": round(solo_ms[0], 4), "algorithmic_bytes": bytes_darray,
+                                                  "algorithmic_GB/s": round(bytes_darray / (solo_ms[0] * 1e-3) / 1e9, 2) if solo_ms[0] else None, "not_a_bandwidth": True,
+                                                  "traffic": traffic_darray, "hbm_GB/s": round(traffic_darray / (solo_ms[0] * 1e-3) / 1e9, 2) if traffic_darray and solo_ms[0] else None,
+                                                  "bound": "L2 / instruction issue (the index blocks of the first extensions are shared by all reads)"},
                                 "search_kernel": {"ms": round(float(ms_search), 4), "bytes": bytes_search, "GB/s": round(bytes_search / (ms_search * 1e-3) / 1e9, 2)},
                                 "search_kernel_last_pass": {"ms": round(float(ms_pass2), 4), "arena_migrations": res.n_second_pass, "reads": res.n_third_pass}},
-                "whole_step_GB/s": round((bytes_darray + bytes_search) / ((ms_darray + ms_search + ms_pass2) * 1e-3) / 1e9, 2),
                 # secondary bound of SURVEY 8(d): dependent random 128-byte index lines per second (2 per extension)
                 "index_lines_per_s": {"search_kernel": round(2 * e_search / (ms_search * 1e-3), 1), "darray_kernel": round(2 * e_darray / (ms_darray * 1e-3), 1)},
                 "events": {"E_search": e_search, "E_darray": e_darray, "N_push": n_push, "N_pop": n_pop, "N_node": n_node}}
@@ -516,7 +522,8 @@ def main():
                   "hit_intervals_at_or_above_2^32": int((res.hits_arr["lower"][:nh] >= 2 ** 32).sum())}
         if not (ok and ok_c):
             log("PARITY FAILURE: GPU hits differ from the oracle on the sample")
-        del oidx
+        if not (args.config == "c4" and not args.no_extras and not args.no_secondary):
+            del oidx  # (kept for the C5 leg of `secondary`, which checks its sample against the same oracle index)
 
     extras = rank == 0 and world == 1 and not args.no_extras
     # ---- end to end through the host entry point: pageable host buffers in, host result out --------------------------------------
@@ -591,6 +598,71 @@ def main():
     secondary = None
     if extras and args.config == "c4" and not args.no_secondary:
         secondary = {}
+        # C5's read mix (35-100 bp, 5 % of the reads with an indel, damage model, Phred 20-40) on the 3 Gbp index of this run at the reference's real limits
+        # (STACK_LIMIT 2 M frames, EDIT_TREE_LIMIT 10 M nodes): one batch of 200 000 reads through mapad_map_batch, i.e. GPU stages + host tail + collect + fetch.
+        # The search cost of such reads is heavy-tailed (a few per thousand make millions of pops): what the line shows is how the GPU and the host threads share them.
+        try:
+            t = time.perf_counter()
+            n5 = int(os.environ.get("MAPAD_BENCH_C5_READS", "200000"))
+            s5, q5, o5 = make_reads(synth, genome, n5, 4321 + 5, qual_range=(20, 40), damage=dict(f=0.5, t=0.5, d=0.02, s=1.0), len_range=(35, 100), indel_frac=0.05)
+            rp5 = resolve_params(DAMAGE)
+            ctx5 = mapad_amd.Context(index, mapad_amd.make_params(rp5), local_rank)
+            ctx5.set_fetch_d_arrays(False)
+            ctx5.prepare_lengths(sorted(set(np.diff(o5.astype(np.int64)).tolist())))
+            t1 = time.perf_counter()
+            res5 = ctx5.map_batch(s5, q5, o5)
+            dt5 = time.perf_counter() - t1
+            ti5 = ctx5.tail_info()
+            k5 = [float(x) for x in ctx5.kernel_ms()]
+            c5 = [int(x) for x in ctx5.last_counters()]
+            ctx5.close()
+            pops_all = c5[3]
+            ev = {"E_search": c5[0] - ti5["host_e_search"], "N_push": c5[2] - ti5["host_n_push"], "N_pop": c5[3] - ti5["host_pops"], "N_node": c5[4] - ti5["host_n_node"]}
+            b5 = 256 * ev["E_search"] + 40 * (ev["N_push"] + ev["N_pop"]) + 8 * ev["N_node"]
+            leg = {"reads_per_s": round(n5 / dt5, 1), "wall_s": round(dt5, 3), "reads": n5, "steps": 1,
+                   "workload": f"C5 read mix: {n5} x 35-100 bp reads, 5 % with an indel, ss 50% deamination model, Phred 20-40, -p 0.03, on the {genome_bp} bp index of this run; "
+                               "STACK_LIMIT / EDIT_TREE_LIMIT at the reference's values (2 000 000 / 10 000 000); one mapad_map_batch call (H2D, D arrays, search stages, host tail, collect, D2H)",
+                   "pops_per_read": round(pops_all / n5, 1),
+                   "roofline": {"kernel": "search_kernel", "kernel_ms": round(k5[1], 2), "algorithmic_bytes_per_launch": b5, "achieved": round(b5 / (k5[1] * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBPS,
+                                "unit": "GB/s", "frac": round(b5 / (k5[1] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5), "traffic": None,
+                                "note": "events of the reads the host finished are not the kernel's and are left out; the launch lasts as long as its slowest read (a serial chain at ~5.5 us per pop)"},
+                   "tail": {"reads": ti5["reads"], "pops_share": round(ti5["host_pops"] / max(pops_all, 1), 5), "gpu_pops_before_hand_over": ti5["gpu_pops"], "host_s_per_step": round(ti5["host_us"] / 1e6, 3),
+                            "host_thread_s_per_step": round(ti5["host_thread_us"] / 1e6, 3), "threads": ti5["threads"], "budget_pops": ti5["budget"], "reads_dry_class": ti5["reads_dry_class"],
+                            "reads_full_limit": ti5["reads_full_limit"], "seen_while_launch_ran": ti5["seen_live"]},
+                   "arena_migrations": res5.n_second_pass}
+            if not args.no_cpu_baseline:
+                reads5 = [s5[int(o5[i]):int(o5[i + 1])].tobytes() for i in range(n5)]
+                quals5 = [q5[int(o5[i]):int(o5[i + 1])] for i in range(n5)]
+                op5 = ob.make_params(rp5)
+                n0 = min(n5, 4 * cores + 256)
+                t2 = time.perf_counter()
+                oidx.map_batch(op5, reads5[:n0], quals5[:n0], n_threads=cores)
+                n_s = int(min(n5, max(n0, n0 / max(time.perf_counter() - t2, 1e-3) * 6.0)))
+                t2 = time.perf_counter()
+                o5r = oidx.map_batch(op5, reads5[:n_s], quals5[:n_s], n_threads=cores)
+                dto = time.perf_counter() - t2
+                hb = res5.hit_begin[:n_s + 1]
+                nh, no = int(hb[-1]), int(o5r.op_offsets[-1])
+                ok5 = (np.array_equal(hb, o5r.hit_offsets) and np.array_equal(res5.hits_arr["lower"][:nh], o5r.intervals[:, 0]) and np.array_equal(res5.hits_arr["lower_rev"][:nh], o5r.intervals[:, 1])
+                       and np.array_equal(res5.hits_arr["size"][:nh], o5r.intervals[:, 2]) and np.array_equal(res5.hits_arr["score"][:nh].view(np.uint32), o5r.scores.view(np.uint32))
+                       and np.array_equal(res5.ops[:no], o5r.ops))
+                cc = res5.counters[:n_s]
+                got5 = np.stack([cc["e_search"], cc["e_darray"], cc["n_push"], cc["n_pop"], cc["n_node"], cc["n_hits"]], axis=1).astype(np.uint64)
+                st5 = res5.status[:n_s]
+                leg["cpu_baseline"] = {"value": round(n_s / dto, 1), "unit": "reads/s", "cores": cores, "kind": "port", "sample": f"first {n_s} reads of the batch, {dto:.1f} s wall, C++ oracle"}
+                leg["parity"] = {"reads_checked": n_s, "bit_identical_hits": bool(ok5), "identical_event_counters": bool(np.array_equal(got5, o5r.counters)),
+                                 "heaviest_read_checked_pops": int(o5r.counters[:, 3].max()), "status_words_clean": bool(((st5 & 16) == 0).all())}
+                if not (ok5 and leg["parity"]["identical_event_counters"]):
+                    log("PARITY FAILURE (C5 leg): GPU + host-tail hits differ from the oracle on the sample")
+            del res5
+            leg["wall_s_leg"] = round(time.perf_counter() - t, 1)
+            secondary["c5"] = leg
+        except Exception as e:
+            secondary["c5"] = {"skipped": f"{type(e).__name__}: {e}"}
+        try:
+            del oidx
+        except Exception:
+            pass
         for cfg in ("c2", "c3"):
             try:
                 t = time.perf_counter()
@@ -684,6 +756,9 @@ def main():
                      "host_s_per_step": round(sum(t["host_us"] for t in tail_timed) / max(len(tail_timed), 1) / 1e6, 3),
                      # thread-seconds inside the reads: far below host_s x threads = the host waited for the GPU's hand-overs; close to it = the host's CPUs set the pace
                      "host_thread_s_per_step": round(sum(t.get("host_thread_us", 0) for t in tail_timed) / max(len(tail_timed), 1) / 1e6, 3), "budget_pops": tail_last["budget"],
+                     # why reads went to the host: past the pop budget; their arena class was dry while the host had room (round 5); no growable arena could hold them
+                     "reads_dry_class": int(sum(t.get("reads_dry_class", 0) for t in tail_timed)), "reads_full_limit": int(sum(t.get("reads_full_limit", 0) for t in tail_timed)),
+                     "seen_while_launch_ran": int(sum(t.get("seen_live", 0) for t in tail_timed)),
                      "where": f"{tail_last['threads']} host threads, search_core.hpp compiled for the host (the kernel's source; from scratch), overlapped with the GPU's bulk" if tail_last["budget"] else "off"},
             "secondary": secondary, "e2e": e2e, "cli": cli, "sa_locate": locate, "post_search": post,
         }

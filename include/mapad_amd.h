@@ -123,14 +123,18 @@ void mapad_ctx_destroy(mapad_ctx_t* ctx);
 int mapad_ctx_set_stream(mapad_ctx_t* ctx, void* hip_stream);
 
 /* The heavy tail.  The reference absorbs the reads that run into STACK_LIMIT / EDIT_TREE_LIMIT (src/map/mapping.rs:52-54,1358-1380) on its rayon threads; here a
- * read that has made `pops` pops on the GPU (default 2^19, on an index of >= 2^31 rows 2^17; MAPAD_TAIL_POPS; 0 = never) is handed — by the kernel, while it runs — to the library's host
- * threads, which map it from scratch with the kernel's own search step compiled for the host (csrc/host_tail.hpp; MAPAD_TAIL_THREADS threads, default
- * all).  Their results join the batch before its order-preserving collect: nothing a caller sees depends on where a read was finished. */
+ * read is handed — by the kernel, while it runs, through host-coherent page-locked memory — to the library's host threads when (a) it has made `pops` pops on the
+ * GPU (default 2^19; MAPAD_TAIL_POPS; 0 = the host tail is off), (b) it needs a grown arena of a class the GPU has few of and every one is taken, while the host
+ * threads have little waiting (MAPAD_TAIL_MIN_CLASS, MAPAD_TAIL_BACKLOG), or (c) no growable arena can hold it (the reads the full-limit stage would restart).
+ * The host threads map it from scratch with the kernel's own search step compiled for the host (csrc/host_tail.hpp; MAPAD_TAIL_THREADS threads, default this
+ * process's share of the CPUs, divided by LOCAL_WORLD_SIZE when several ranks share a node).  Their results join the batch before its order-preserving collect:
+ * nothing a caller sees depends on where a read was finished. */
 int mapad_ctx_set_tail_pops(mapad_ctx_t* ctx, uint32_t pops);
 /* the batch selected by mapad_ctx_select_batch, after its collect / fetch: {reads finished on the host, pops the GPU had spent on them, pops on the host,
  * host wall-clock microseconds from the first hand-over to the last result, host threads, pop budget, and the host reads' E_search, N_push, N_node sums
- * (SURVEY 8d events the kernel did not execute), microseconds the host threads spent inside these reads, summed over the threads} */
-int mapad_last_tail_info(mapad_ctx_t* ctx, uint64_t out[10]);
+ * (SURVEY 8d events the kernel did not execute), microseconds the host threads spent inside these reads, summed over the threads,
+ * [10] hand-overs the host saw while the launch was still running, [11] reads handed over for reason (b), [12] for reason (c), [13] smallest class of (b), [14-15] 0} */
+int mapad_last_tail_info(mapad_ctx_t* ctx, uint64_t out[16]);
 /* whether mapad_fetch_result()/mapad_map_batch() also copy the D arrays back (default on; bench.py turns it off) */
 int mapad_ctx_set_fetch_d_arrays(mapad_ctx_t* ctx, int on);
 /* Score tables are built lazily per read length.  mapad_map_batch() does this itself; before mapad_map_batch_device()
@@ -183,6 +187,9 @@ int mapad_submit_batch(mapad_ctx_t* ctx, const uint8_t* seqs, const uint8_t* qua
  * chunk loop that allocates per chunk cannot afford. */
 void* mapad_host_alloc(size_t bytes);
 void mapad_host_free(void* p);
+/* CPUs this process may really use: the visible CPUs capped by the cgroup's CPU-time quota (cpu.max); MAPAD_HOST_CPUS overrides.  What the library's own host
+ * thread pools (host tail, record strings, index preparation) size themselves by, and what a caller's pools beside them should (csrc/host_cpus.hpp). */
+unsigned mapad_host_cpus(void);
 
 /* Device-resident variant used by bench.py and the multi-GPU driver: inputs already in HBM (device pointers), results stay
  * in the context's device buffers until fetched.  Asynchronous on the context's stream. */

@@ -123,6 +123,7 @@ SYMBOLS = {
     "mapad_last_batch_counters": (_i32, [_vp, _vp]),
     "mapad_last_kernel_ms": (_i32, [_vp, _vp]),
     "mapad_last_launch_info": (_i32, [_vp, _vp]),
+    "mapad_host_cpus": (C.c_uint32, []),
     "mapad_ctx_set_tail_pops": (_i32, [_vp, C.c_uint32]),
     "mapad_last_tail_info": (_i32, [_vp, _vp]),
     "mapad_hits_to_records": (_i32, [_vp, _PP, C.POINTER(BatchResultC), _vp, _vp, _vp, _vp, _u64, C.POINTER(C.POINTER(RecordsC))]),
@@ -427,9 +428,10 @@ class Context:
 
     def tail_info(self):
         """{reads, gpu_pops, host_pops, host_us (wall), threads, budget, ..., host_thread_us (summed over the threads)} of the selected batch's host tail (after its collect / fetch)."""
-        out = np.zeros(10, np.uint64)
+        out = np.zeros(16, np.uint64)
         _check(lib().mapad_last_tail_info(self.h, _ptr(out)), "mapad_last_tail_info")
-        return dict(zip(("reads", "gpu_pops", "host_pops", "host_us", "threads", "budget", "host_e_search", "host_n_push", "host_n_node", "host_thread_us"), (int(x) for x in out)))
+        return dict(zip(("reads", "gpu_pops", "host_pops", "host_us", "threads", "budget", "host_e_search", "host_n_push", "host_n_node", "host_thread_us",
+                         "seen_live", "reads_dry_class", "reads_full_limit", "min_class"), (int(x) for x in out)))
 
     def launch_info(self):
         out = np.zeros(8, np.uint32)

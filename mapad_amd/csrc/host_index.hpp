@@ -5,6 +5,7 @@
 // OriginalSymbols).  Instead of rust-bio's Occ (u64 checkpoints every 128 rows, byte BWT) the rank structure is the
 // 128-byte-block layout of fmd_device.hpp, shared by host (SA walks) and device.
 #pragma once
+#include "host_cpus.hpp"
 #include <algorithm>
 #include <cstdint>
 #include <cstdlib>
@@ -203,7 +204,7 @@ inline void build_blocks(Index& ix) {
     ix.x_counts.clear();
     static const int CODE[6] = {0, 4, 5, 6, 7, 1};  // rank -> device symbol code
     // pass 1 (threads over block ranges): bit planes + the block's own symbol counts, parked in the count words
-    const unsigned T = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(std::min<unsigned>(std::thread::hardware_concurrency(), 32u), n_blocks / 4096 + 1));
+    const unsigned T = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(std::min<unsigned>(cpu_share(), 32u), n_blocks / 4096 + 1));
     std::vector<uint64_t> xs(n_blocks, 0);
     std::vector<std::vector<uint64_t>> sent(T);
     std::vector<int> bad(T, 0);
@@ -330,7 +331,7 @@ inline std::vector<uint8_t> prepare_text(const std::vector<std::string>& names, 
     uint64_t end = 0;
     for (size_t c = 0; c < names.size(); ++c) end += lens[c];
     text.resize(end);
-    const unsigned T = (unsigned)std::max<size_t>(1, std::min<size_t>(std::min<unsigned>(std::thread::hardware_concurrency(), 32u), text.size() / (1u << 22) + 1));
+    const unsigned T = (unsigned)std::max<size_t>(1, std::min<size_t>(std::min<unsigned>(cpu_share(), 32u), text.size() / (1u << 22) + 1));
     auto parallel = [&](const std::function<void(size_t, size_t, unsigned)>& fn, size_t total) {
         if (T == 1) { fn(0, total, 0); return; }
         std::vector<std::thread> pool;

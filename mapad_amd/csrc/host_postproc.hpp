@@ -16,6 +16,8 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+
+#include "host_cpus.hpp"
 #include <vector>
 
 #include "../../include/mapad_amd.h"
@@ -181,7 +183,7 @@ inline mapad_records_t* hits_to_records(const Index& ix, const mapad_params_t& p
     // each with its own text blob; blobs are concatenated in read order afterwards, so the output does not depend on the thread count.
     unsigned n_threads = 1;
     if (const char* e = std::getenv("MAPAD_POSTPROC_THREADS")) n_threads = (unsigned)std::max(1, std::atoi(e));
-    else n_threads = std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 64u);
+    else n_threads = std::min<unsigned>(cpu_share(), 64u);
     n_threads = (unsigned)std::min<uint64_t>(n_threads, std::max<uint64_t>(1, res.n_reads / 2048));
     std::vector<std::string> texts(n_threads);
     std::vector<std::exception_ptr> errors(n_threads);
@@ -287,7 +289,7 @@ inline mapad_records_t* records_from_coords(const Index& ix, const mapad_params_
     own->recs.resize(res.n_reads);
     unsigned n_threads = 1;
     if (const char* e = std::getenv("MAPAD_POSTPROC_THREADS")) n_threads = (unsigned)std::max(1, std::atoi(e));
-    else n_threads = std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 64u);
+    else n_threads = std::min<unsigned>(cpu_share(), 64u);
     n_threads = (unsigned)std::min<uint64_t>(n_threads, std::max<uint64_t>(1, res.n_reads / 2048));
     std::vector<std::string> texts(n_threads);
     std::vector<std::exception_ptr> errors(n_threads);
@@ -392,7 +394,7 @@ inline mapad_records_t* records_from_device_text(const mapad_params_t& prm, uint
     auto own = std::unique_ptr<RecordsOwner>(new RecordsOwner());
     own->recs.resize(n_reads);
     own->text.assign(text, text_len);
-    unsigned n_threads = (unsigned)std::min<uint64_t>(std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 16u), std::max<uint64_t>(1, n_reads / 16384));
+    unsigned n_threads = (unsigned)std::min<uint64_t>(std::min<unsigned>(cpu_share(), 16u), std::max<uint64_t>(1, n_reads / 16384));
     std::vector<int> bad(n_threads, 0);
     auto work = [&](unsigned t) {
         for (uint64_t r = n_reads * t / n_threads; r < n_reads * (t + 1) / n_threads; ++r) {

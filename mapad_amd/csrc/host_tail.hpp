@@ -17,6 +17,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <deque>
+#include <queue>
 #include <functional>
 #include <memory>
 #include <mutex>
@@ -29,6 +30,7 @@
 #include <map>
 #include <string>
 
+#include "host_cpus.hpp"
 #include "host_models.hpp"
 #include "search_core.hpp"
 
@@ -96,15 +98,18 @@ inline void tail_read_prefetch_env() {
 }
 
 // Worker threads shared by every context of the process (a read at the reference's limits keeps a thread busy for seconds and its arena is 336 MB, so
-// there is one pool, as wide as the machine — or as this process's CPU share of it: MAPAD_TAIL_THREADS overrides).  Started with the first task.
+// there is one pool, as wide as this process's CPU share of the machine: MAPAD_TAIL_THREADS overrides).  Started with the first task.
+// Tasks carry a weight — the pops the GPU had made when it gave the read up — and the heaviest waiting task is served first: the search cost of these reads is
+// heavy-tailed, so the pops so far predict the pops to come, and the batch's finish time is set by its longest read.
 class TailWorkers {
 public:
     static TailWorkers& instance() { static TailWorkers* w = new TailWorkers(); return *w; }  // never destroyed: workers may outlive static destructors
-    void submit(std::function<void()> f) {
+    void submit(std::function<void()> f, uint64_t weight = 0) {
         {
             std::lock_guard<std::mutex> g(mu_);
             if (threads_.empty()) start();
-            q_.push_back(std::move(f));
+            q_.emplace(std::make_pair(weight, ~seq_++), std::move(f));  // equal weights: first come, first served
+            pending_.fetch_add(1, std::memory_order_relaxed);
         }
         cv_.notify_one();
     }
@@ -112,60 +117,53 @@ public:
         std::lock_guard<std::mutex> g(mu_);
         return threads_.empty() ? wanted() : (unsigned)threads_.size();
     }
+    // tasks waiting or running: what a launch's dispatcher publishes to the kernel, which hands a read over on a dry arena class only while this is small
+    uint32_t pending() const { return pending_.load(std::memory_order_relaxed); }
+    // One process per GPU (bench.py --gpus N, `mapad-amd worker`): the ranks of a node share its CPUs, so each takes its part of the share and pins its
+    // workers to its own cache domains (LOCAL_WORLD_SIZE / LOCAL_RANK as torchrun sets them; MAPAD_LOCAL_WORLD_SIZE / MAPAD_LOCAL_RANK override).
+    static unsigned local_world() { return env_uint("MAPAD_LOCAL_WORLD_SIZE", env_uint("LOCAL_WORLD_SIZE", 1)); }
+    static unsigned local_rank() { return env_uint("MAPAD_LOCAL_RANK", env_uint("LOCAL_RANK", 0)); }
 private:
-    // CPUs this process may really use: a container often shows every CPU of the machine and limits the CPU TIME of its cgroup (the round-4 GPU box:
-    // 256 CPUs visible, cpu.max = 16 CPUs' worth) — threads beyond that share are throttled together and thrash each other's caches (measured: 256 threads
-    // 1.5 x slower than 16 there).
-    static unsigned cpu_share() {
-        unsigned n = std::thread::hardware_concurrency();
-        if (!n) n = 8;
-        auto read2 = [](const char* path, double& a, double& b) -> bool {
-            FILE* f = std::fopen(path, "r");
-            if (!f) return false;
-            char q[64] = {0}, per[64] = {0};
-            const int k = std::fscanf(f, "%63s %63s", q, per);
-            std::fclose(f);
-            if (k < 1 || q[0] == 'm' /* "max" */) return false;
-            a = std::atof(q); b = k == 2 ? std::atof(per) : 0.0;
-            return a > 0;
-        };
-        double quota = 0, period = 0;
-        if (read2("/sys/fs/cgroup/cpu.max", quota, period) && period > 0) n = std::min<unsigned>(n, (unsigned)std::max(1.0, quota / period + 0.5));
-        else {
-            double q1 = 0, p1 = 0, dummy = 0;
-            if (read2("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", q1, dummy) && read2("/sys/fs/cgroup/cpu/cpu.cfs_period_us", p1, dummy) && p1 > 0)
-                n = std::min<unsigned>(n, (unsigned)std::max(1.0, q1 / p1 + 0.5));
-        }
-        return n;
+    static unsigned env_uint(const char* name, unsigned dflt) {
+        const char* e = std::getenv(name);
+        if (!e || !e[0]) return dflt;
+        const unsigned long v = std::strtoul(e, nullptr, 10);
+        return v > 0 || e[0] == '0' ? (unsigned)v : dflt;
     }
     static unsigned wanted() {
         const char* e = std::getenv("MAPAD_TAIL_THREADS");
-        const unsigned n = e && e[0] ? (unsigned)std::strtoul(e, nullptr, 10) : cpu_share();
-        return n ? n : 8;
+        if (e && e[0]) { const unsigned n = (unsigned)std::strtoul(e, nullptr, 10); return n ? n : 8; }
+        const unsigned lw = std::max(1u, local_world());
+        return std::max(1u, (cpu_share() + lw - 1) / lw);  // this rank's part of the node's share
     }
     void start() {
-        const unsigned n = wanted();
+        const unsigned n = wanted(), first = local_rank() * n;  // pinning: this rank's workers take the domains behind those of the ranks before it
         tail_read_prefetch_env();
         for (unsigned i = 0; i < n; ++i) {
-            threads_.emplace_back([this, i] {
-                tail_pin_worker(i);
+            threads_.emplace_back([this, i, first] {
+                tail_pin_worker(first + i);
                 for (;;) {
                     std::function<void()> f;
                     {
                         std::unique_lock<std::mutex> l(mu_);
                         cv_.wait(l, [&] { return !q_.empty(); });
-                        f = std::move(q_.front());
-                        q_.pop_front();
+                        f = std::move(const_cast<Task&>(q_.top()).second);
+                        q_.pop();
                     }
                     f();
+                    pending_.fetch_sub(1, std::memory_order_relaxed);
                 }
             });
             threads_.back().detach();
         }
     }
+    using Task = std::pair<std::pair<uint64_t, uint64_t>, std::function<void()>>;
+    struct Lighter { bool operator()(const Task& a, const Task& b) const { return a.first < b.first; } };
     std::mutex mu_;
     std::condition_variable cv_;
-    std::deque<std::function<void()>> q_;
+    std::priority_queue<Task, std::vector<Task>, Lighter> q_;
+    uint64_t seq_ = 0;
+    std::atomic<uint32_t> pending_{0};
     std::vector<std::thread> threads_;
 };
 
@@ -213,8 +211,11 @@ struct TailBatch {
     DevIndex ix{};          // host view of the index (blocks in host memory)
     DevParams P{};          // points into *tables
     std::shared_ptr<const HostTables> tables;
-    const uint8_t* ring = nullptr;  // page-locked records
+    const uint8_t* ring = nullptr;  // records in host-coherent page-locked memory
     uint32_t stride = 0, cap = 0, lmax = 0;
+    uint32_t* ctl = nullptr;        // word the kernel reads before a hand-over it could do without (dry arena class): tasks the workers have waiting or running
+    std::function<bool()> launch_done;  // has the launch that writes this ring ended? (set by the library; counts the hand-overs that arrive while it runs)
+    uint32_t seen_live = 0;         // records the dispatcher saw while the launch was still running
 
     std::mutex mu;
     std::condition_variable cv;
@@ -307,19 +308,23 @@ inline void tail_start(const std::shared_ptr<TailBatch>& tb) {
             if (next < tb->cap) {
                 const TailRecord* rec = reinterpret_cast<const TailRecord*>(tb->ring + (size_t)next * tb->stride);
                 if (__atomic_load_n(&rec->ready, __ATOMIC_ACQUIRE) == 1u) {
+                    const bool live = tb->launch_done && !tb->launch_done();
                     {
                         std::lock_guard<std::mutex> g(tb->mu);
                         if (tb->dispatched == 0) tb->t_first = TailBatch::now_s();
                         tb->dispatched += 1;
                         tb->gpu_pops += rec->pops;
+                        tb->seen_live += live ? 1u : 0u;
                     }
-                    TailWorkers::instance().submit([tb, rec] { tail_map_read(tb, rec); });
+                    TailWorkers::instance().submit([tb, rec] { tail_map_read(tb, rec); }, rec->pops);
+                    if (tb->ctl) __atomic_store_n(tb->ctl, TailWorkers::instance().pending(), __ATOMIC_RELAXED);
                     next += 1;
                     idle = 0;
                     continue;
                 }
             }
             // nothing new: back off up to a millisecond (a hand-over is rare, and a read that needs one runs for seconds)
+            if (tb->ctl) __atomic_store_n(tb->ctl, TailWorkers::instance().pending(), __ATOMIC_RELAXED);
             idle = idle < 10 ? idle + 1 : 10;
             std::this_thread::sleep_for(std::chrono::microseconds(100 * idle));
         }

@@ -73,7 +73,8 @@ constexpr int kKeyBins = kMaxReadLen + 2;
 // handed on.  The two pool cursors are 64-bit (words 0-1 and 2-3): a batch may ask for more than 2^32 op words, which must show up as a pool
 // overflow, not wrap around.
 enum { CUR_HITS = 0, CUR_OPS = 2, CUR_POOL_OVF = 4, CUR_ERR = 5, CUR_WORK = 6, CUR_OVF = 7, CUR_GROWN = 6 + 2 * kStages, CUR_HEAVY_N = CUR_GROWN + 4 /* per quad stage */, CUR_HEAVY_WORK = CUR_GROWN + 6 /* per heavy stage */,
-       CUR_HEAVY_POPS = CUR_GROWN + 8 /* 64-bit */, CUR_HPROF = CUR_GROWN + 10 /* 8 x 64-bit, -DMAPAD_HEAVY_PROF */, CUR_TAIL = CUR_GROWN + 26 /* reads handed to the host tail */, CUR_COUNT = CUR_GROWN + 28 };
+       CUR_HEAVY_POPS = CUR_GROWN + 8 /* 64-bit */, CUR_HPROF = CUR_GROWN + 10 /* 8 x 64-bit, -DMAPAD_HEAVY_PROF */, CUR_TAIL = CUR_GROWN + 26 /* reads handed to the host tail */, CUR_TAIL_DRY = CUR_GROWN + 27 /* ... of them because an arena class was dry */,
+       CUR_TAIL_F = CUR_GROWN + 28 /* ... instead of going to the full-limit stage */, CUR_COUNT = CUR_GROWN + 30 };
 inline uint64_t cur64(const uint32_t* cur, int k) { return (uint64_t)cur[k] | ((uint64_t)cur[k + 1] << 32); }
 
 struct BatchDev {
@@ -102,6 +103,10 @@ struct BatchDev {
     uint8_t* tail_ring;
     uint32_t tail_stride, tail_cap, tail_lmax;
     uint32_t tail_pops;       // 0xFFFFFFFF: never
+    // ... or that needs an arena of class >= tail_min_class while all of them are taken (DeviceGrow::acquire), as long as the host has fewer than tail_backlog_max
+    // reads waiting or running (*tail_ctl, host-coherent, kept current by the launch's dispatcher thread); kClasses: never
+    const uint32_t* tail_ctl;
+    uint32_t tail_backlog_max, tail_min_class;
 };
 
 // A read that has outgrown its base arena, as the quad stage leaves it: everything else (heap, nodes, hit staging) is in the grown arena.
@@ -125,12 +130,17 @@ struct ArenaPool {
 // Size-class pools of grown arenas (heap + nodes only; hit staging stays in the slot's base arena).  A read that outgrows its
 // arena acquires a free arena of the next class (CAS on its owner word), migrates its heap and nodes, and gives the arena back when
 // the read is finished.  The descriptor lives in HBM (only the rare grow path reads it).
+// Entry kClasses of every array is the SET class (round 5): a free set of base arenas — the 16 read slots' worth of HBM a wavefront claims when it starts and
+// gives back when it exits (ArenaPool::set_owner) — taken whole as ONE grown arena (16 x 2.7 MB = 1 M nodes on a 3 Gbp index).  Once a launch's bulk is done its
+// wavefronts have exited and thousands of sets lie idle, exactly when the launch's heavy reads queue for the few hundred arenas of the big classes (C5 mix on
+// 3 Gbp, round 4: 128 arenas of 1 M nodes for 3 000 reads).  Same owner words, same per-XCD partition, same hand-off fences as the classes proper.
 struct GrowPools {
-    uint8_t* base[kClasses];
-    uint32_t* owner[kClasses];  // [count] 0 = free
-    uint64_t stride[kClasses], off_nodes[kClasses];
-    uint64_t off_hits[kClasses], off_hit_ops[kClasses], off_scratch[kClasses];  // hit staging of a suspended (heavy) read: it leaves its slot's base arena behind
-    uint32_t heap_cap[kClasses], node_cap[kClasses], count[kClasses];
+    uint8_t* base[kClasses + 1];
+    uint32_t* owner[kClasses + 1];  // [count] 0 = free
+    uint64_t stride[kClasses + 1], off_nodes[kClasses + 1];
+    uint64_t off_hits[kClasses + 1], off_hit_ops[kClasses + 1], off_scratch[kClasses + 1];  // hit staging of a suspended (heavy) read: it leaves its slot's base arena behind
+    uint32_t heap_cap[kClasses + 1], node_cap[kClasses + 1], count[kClasses + 1];
+    uint32_t set_next_class;  // the smallest class proper that is bigger than a set: where a read that outgrows a set arena goes
     uint32_t hit_ops_cap;
     uint32_t max_waits;  // fruitless requests (x 64 steps sat out each) after which a read of the first stages gives up and is restarted later
     uint32_t heavy_min_class;  // a read that grows into this class or beyond is handed to heavy_kernel (kClasses: never)
@@ -469,6 +479,7 @@ __device__ __forceinline__ void copy_units(MAPAD_GLOBAL uint4* dst, const MAPAD_
     for (; i < end; i += LPR) dst[i] = src[i];
 }
 
+constexpr uint32_t kAskTail = 0x80000000u;  // in ArenaT::n_waits: the read's last request found its arena class dry and the class is one the host tail takes reads of
 template <int LPR, bool NL, int TOP = kTop, bool HITS = false>
 struct DeviceGrow {
     const GrowPools* gp;
@@ -477,38 +488,53 @@ struct DeviceGrow {
     int w;
     bool may_give_up;
     mutable bool foreign = false;  // HITS: the arena the read is in now was taken by a wavefront on another XCD (release_grown)
+    uint32_t tail_min_class = kClasses;  // a read that finds every arena of the class it needs taken, class >= this, asks for the host tail (kAskTail in A.n_waits; search_kernel decides)
     // takes an arena of a size class that holds the read: GROW_OK (cls, idx), GROW_WAIT (all suitable arenas are busy: sit out), GROW_NEVER (no class can hold it)
     __device__ __forceinline__ int acquire(ArenaT<NL, TOP>& A, const SearchState& st, uint32_t& cls, uint32_t& idx) const {
         if (A.wait) { A.wait -= 1; return GROW_WAIT; }
-        const uint32_t first = A.grown >> kGrownShift;  // first class to try (0 = from the base arena); a dry class falls through to the next
-        cls = first;
+        const uint32_t cur = A.grown >> kGrownShift;  // class + 1 of the arena the read is in (0: its slot's base arena)
+        const uint32_t first = cur == (uint32_t)kClasses + 1 ? gp->set_next_class : cur;  // first class to try; a dry class falls through to the next
         idx = ~0u;
         bool exists = false;
-        for (; cls < (uint32_t)kClasses; ++cls) {
-            const uint32_t n = gp->count[cls];
-            if (n == 0 || gp->node_cap[cls] < st.tree_len + kStepNodes || gp->heap_cap[cls] < st.heap_len + kStepNodes) continue;
-            exists = true;
+        uint32_t need = (uint32_t)kClasses;  // the smallest class that can hold the read
+        auto probe = [&](uint32_t k) {  // an arena of class k, if one of this XCD's part is free
+            const uint32_t n = gp->count[k];
             if (w == 0) {
                 const bool part = n >= kPartitionMin;
                 const uint32_t m = part ? n / 8 : n, lo = part ? xcc_id() * m : 0;  // this XCD's part of the pool
                 uint32_t i = (uint32_t)(((uint64_t)(slot + st.tree_len) * 2654435761u) % m);
                 const uint32_t tries = m < 64u ? m : 64u;
-                uint32_t* own = gp->owner[cls] + lo;
+                uint32_t* own = gp->owner[k] + lo;
                 for (uint32_t t = 0; t < tries; ++t) {
                     if (atomicCAS(&own[i], 0u, 1u) == 0u) { idx = lo + i; break; }
                     if (++i == m) i = 0;
                 }
-                if (idx == ~0u) atomicOr(grown_counter + 1, 1u << cls);  // debugging aid: classes that ran dry
+                if (idx == ~0u) atomicOr(grown_counter + 1, 1u << k);  // debugging aid: classes that ran dry
             }
             idx = group_bcast<LPR>(idx);
+        };
+        auto holds = [&](uint32_t k) { return gp->count[k] != 0 && gp->node_cap[k] >= st.tree_len + kStepNodes && gp->heap_cap[k] >= st.heap_len + kStepNodes; };
+        for (cls = first; cls < (uint32_t)kClasses; ++cls) {
+            if (!holds(cls)) continue;
+            need = exists ? need : cls;
+            exists = true;
+            probe(cls);
             if (idx != ~0u) break;
+        }
+        if (!HITS && idx == ~0u && cur != (uint32_t)kClasses + 1 && holds(kClasses) && gp->node_cap[kClasses] > A.node_cap) {  // an idle set of base arenas as one arena
+            exists = true;
+            cls = kClasses;
+            probe(cls);
         }
         if (idx == ~0u) {
             if (!exists) return GROW_NEVER;  // no class can hold this read: it goes to the full-limit pass
             // only reads that are still small give up (cheap to restart, and it is the many mid-size reads that clog the big pools);
             // a read that already fills a large arena keeps waiting for the few larger ones.  With the heavy path every waiting read may give up:
             // the arenas it waits for can be held by SUSPENDED reads, which only move again in the next launch (heavy_kernel.hpp).
-            if (may_give_up && (first < 4 || gp->heavy_min_class < (uint32_t)kClasses) && ++A.n_waits > gp->max_waits) return GROW_NEVER;
+            if (may_give_up && (first < 4 || gp->heavy_min_class < (uint32_t)kClasses) && (++A.n_waits & ~kAskTail) > gp->max_waits) return GROW_NEVER;
+            // The big classes are few and held for seconds; a read that queues for one makes no pops and so never reaches the pop budget (round 4: 1 M reads of the
+            // C5 mix on 3 Gbp handed reads over until second 372 while the host threads idled).  It asks for the host instead — granted while the host keeps up.
+            if (tail_min_class < (uint32_t)kClasses && need >= tail_min_class) A.n_waits |= kAskTail;
             A.wait = 64;                     // every suitable arena is taken: its owners finish and give it back
             if (w == 0) atomicAdd(grown_counter + 2, 1u);
             return GROW_WAIT;
@@ -606,22 +632,28 @@ __device__ __forceinline__ void suspend_heavy(const BatchDev& B, const GrowPools
     }
 }
 
-// A quad gives its read to the host tail (host_tail.hpp): position data and D array -> record k of the batch's page-locked ring, visible to the host
-// while the kernel runs (fine-grained host memory; the `ready` word follows everything else behind a system-scope fence).
+// A quad gives its read to the host tail (host_tail.hpp): position data and D array -> record k of the batch's ring in host-coherent page-locked memory
+// (hipHostMallocCoherent), visible to the host while the kernel runs.  Every word goes out as a system-scope store — written through to the host, never
+// left dirty in an L2 — so that the order "payload, then `ready`" needs only the completion of the payload's stores (vmcnt), not the write-back of the XCD's
+// whole L2 that a system-scope release fence costs (round 4 used one per hand-over, and ordinary page-locked memory, whose visibility during a launch is not
+// guaranteed: ADVICE r4).  tests/test_gpu_tail.py checks that records arrive while the launch is still running (tail.seen_live).
+template <class T>
+__device__ __forceinline__ void store_through(T* p, T v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
 template <int LPR, bool NL>
 __device__ __forceinline__ void hand_to_host(const BatchDev& B, const ReadInT<NL>& rd, const SearchState& st, uint32_t read, uint32_t k, int w) {
     uint8_t* rec = B.tail_ring + (size_t)k * B.tail_stride;
     uint32_t* rq = (uint32_t*)(rec + 16);
-    float* rdd = (float*)(rec + 16 + ((2u * B.tail_lmax + 15u) & ~15u));
+    uint32_t* rdd = (uint32_t*)(rec + 16 + ((2u * B.tail_lmax + 15u) & ~15u));
     const typename near_ptr<const uint32_t, NL>::type qc4 = (typename near_ptr<const uint32_t, NL>::type)rd.qc;  // 16-byte aligned (near layout)
     const uint32_t nq = (2u * (uint32_t)rd.L + 3u) / 4u;
-    for (uint32_t i = w; i < nq; i += LPR) rq[i] = qc4[i];
-    for (uint32_t i = w; i < (uint32_t)rd.L; i += LPR) rdd[i] = rd.d[i];
+    for (uint32_t i = w; i < nq; i += LPR) store_through(&rq[i], (uint32_t)qc4[i]);
+    for (uint32_t i = w; i < (uint32_t)rd.L; i += LPR) store_through(&rdd[i], __float_as_uint(rd.d[i]));
     host::TailRecord* h = (host::TailRecord*)rec;
-    if (w == 0) { h->read = read; h->L = (uint32_t)rd.L; h->pops = st.c_pop; }
-    __threadfence_system();
+    if (w == 0) { store_through(&h->read, read); store_through(&h->L, (uint32_t)rd.L); store_through(&h->pops, st.c_pop); }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every lane's payload stores have completed ...
+    __builtin_amdgcn_wave_barrier();
     if (w == 0) {
-        __hip_atomic_store(&h->ready, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        store_through(&h->ready, 1u);  // ... before the word the host polls
         B.status[read] = ST_TAIL; B.hit_count[read] = 0; B.hit_first[read] = 0;
     }
 }
@@ -688,7 +720,7 @@ __global__ void __launch_bounds__(64, (LPR == 1 && NL) ? 1 : LPR == 2 ? 2 : MAPA
     uint32_t* work = &cursors[CUR_WORK + 2 * tier];
     // reads of the first stages give up after kMaxWaits fruitless waits for an arena and are restarted by the next stage, when the
     // pools are quiet; the last growable stage waits as long as it takes
-    const DeviceGrow<LPR, NL, TOPK> grow{GP, &cursors[CUR_GROWN], slot, w, stage + 2 < kStages || HEAVY};
+    const DeviceGrow<LPR, NL, TOPK> grow{GP, &cursors[CUR_GROWN], slot, w, stage + 2 < kStages || HEAVY, false, B0.tail_min_class};
     const uint32_t wide_copy_nodes = GP->wide_copy_nodes;
     const uint32_t tail_pops = B0.tail_pops;
     bool tail_denied = false;  // the ring was full when this read asked: it stays on the GPU
@@ -745,31 +777,49 @@ __global__ void __launch_bounds__(64, (LPR == 1 && NL) ? 1 : LPR == 2 ? 2 : MAPA
             if constexpr (PASS != 1) cont = search_step<LPR, CONT, NL>(ix, P, rd, A, st, w, grow);
             else cont = search_step<LPR, CONT, NL>(ix, P, rd, A, st, w, NoGrow());
             MAPAD_MARK(PROF_TAIL);
-            if (!cont) {
-                finalize_read<LPR>(kernarg_reload(kArgOffB, B0), rd, A, st, read, w, tier);
-                if (PASS != 1 && A.grown) {  // give the grown arena back; the next read starts in the base arena again
+            // the read leaves this quad for a host thread (host_tail.hpp), which maps it from scratch: a record of the batch's ring, if one is left
+            auto give_to_host = [&](int why) -> bool {
+                const BatchDev B = kernarg_reload(kArgOffB, B0);
+                if (B.tail_cap == 0) return false;
+                uint32_t k = 0;
+                if (w == 0) k = atomicAdd(&cursors[CUR_TAIL], 1u);
+                k = group_bcast<LPR>(k);
+                if (k >= B.tail_cap) return false;
+                hand_to_host<LPR, NL>(B, rd, st, read, k, w);
+                if (w == 0 && why) atomicAdd(&cursors[why], 1u);
+                return true;
+            };
+            auto back_to_base = [&]() {  // give the grown arena back; the next read starts in the base arena again
+                if (PASS != 1 && A.grown) {
                     release_grown<LPR>(GP, A.grown, w);
                     const ArenaT<NL, TOPK> base = carve<NL, TOPK>(kernarg_reload(kArgOffAP, AP0), slot);
                     A.heap = base.heap; A.nodes = base.nodes; A.heap_cap = base.heap_cap; A.node_cap = base.node_cap; A.grown = 0;
                 }
+            };
+            if (!cont) {
+                // A read the last growable stage cannot hold would start again in the full-limit stage — wavefront-per-read arenas of 336 MB, 5.7 us per pop, for
+                // tens of millions of pops (mapping.rs:1358-1380).  With the host tail on it goes to a host thread instead (0.34 us per pop), like the reads past the
+                // pop budget; only a full ring leaves it to the GPU's last stage.
+                bool handed = false;
+                if (PASS != 1 && tier + 2 == kStages) { if (MAPAD_UNLIKELY(st.status == ST_ARENA_OVERFLOW)) handed = give_to_host(CUR_TAIL_F); }
+                if (!handed) finalize_read<LPR>(kernarg_reload(kArgOffB, B0), rd, A, st, read, w, tier);
+                back_to_base();
                 have = false;
                 drain_memory();
                 MAPAD_MARK(PROF_FINALIZE);
-            } else if (MAPAD_UNLIKELY((st.c_pop >= tail_pops) & !tail_denied)) {
-                // past the pop budget: a host thread maps this read from scratch (host_tail.hpp), the quad takes its next read
-                const BatchDev B = kernarg_reload(kArgOffB, B0);
-                uint32_t k = 0;
-                if (w == 0) k = atomicAdd(&cursors[CUR_TAIL], 1u);
-                k = group_bcast<LPR>(k);
-                if (k < B.tail_cap) {
-                    hand_to_host<LPR, NL>(B, rd, st, read, k, w);
-                    if (PASS != 1 && A.grown) {
-                        release_grown<LPR>(GP, A.grown, w);
-                        const ArenaT<NL, TOPK> base = carve<NL, TOPK>(kernarg_reload(kArgOffAP, AP0), slot);
-                        A.heap = base.heap; A.nodes = base.nodes; A.heap_cap = base.heap_cap; A.node_cap = base.node_cap; A.grown = 0;
-                    }
-                    have = false;
-                } else tail_denied = true;
+            } else if (MAPAD_UNLIKELY(((st.c_pop >= tail_pops) | (A.n_waits >= kAskTail)) & !tail_denied)) {
+                // past the pop budget, or queuing for an arena class that is dry (DeviceGrow::acquire): a host thread maps this read from scratch, the quad takes its next read
+                const bool asked = st.c_pop < tail_pops;  // only the dry class speaks for it: granted while the host's workers keep up with what they have
+                bool take = true;
+                if (asked) {
+                    const BatchDev B = kernarg_reload(kArgOffB, B0);
+                    take = B.tail_cap != 0 && __hip_atomic_load(B.tail_ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < B.tail_backlog_max;
+                    A.n_waits &= ~kAskTail;  // (it asks again when its wait is over and the class is still dry)
+                }
+                if (take) {
+                    if (give_to_host(asked ? CUR_TAIL_DRY : 0)) { back_to_base(); have = false; }
+                    else tail_denied = true;  // the ring is full: this read stays on the GPU
+                }
                 drain_memory();
             } else if constexpr (HEAVY) { if (MAPAD_UNLIKELY(A.grown != 0)) {
                 // The read has outgrown its base arena: it is heavy.  Its state goes into the grown arena (heap top from the near array, hit staging
@@ -1015,6 +1065,28 @@ struct PinnedBuf {
     ~PinnedBuf() { PinnedPool::instance().give(p, cap_bytes); }
 };
 
+// Host memory the GPU and the host both see while a kernel runs (the host tail's hand-over ring and its control word): page-locked AND coherent — fine-grained,
+// not cached in the GPU's L2 —, which plain hipHostMalloc memory is not unless HIP_HOST_COHERENT=1.  Not pooled: one per batch slot, grown when needed.
+struct CoherentBuf {
+    uint8_t* p = nullptr;
+    size_t cap = 0;
+    CoherentBuf() = default;
+    CoherentBuf(const CoherentBuf&) = delete;
+    CoherentBuf& operator=(const CoherentBuf&) = delete;
+    bool ensure(size_t bytes) {
+        if (bytes <= cap) return true;
+        if (p) (void)hipHostFree(p);
+        p = nullptr; cap = 0;
+        size_t want = 1 << 16;
+        while (want < bytes) want <<= 1;
+        void* q = nullptr;
+        if (hipHostMalloc(&q, want, hipHostMallocPortable | hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) return false;
+        p = (uint8_t*)q; cap = want;
+        return true;
+    }
+    ~CoherentBuf() { if (p) (void)hipHostFree(p); }
+};
+
 }  // namespace
 
 namespace {
@@ -1067,7 +1139,9 @@ struct BatchSlot {
     bool ev_valid = false, timed = true;  // timed: its event times are already in the context's history
     uint64_t gen = 0;                     // process-wide serial number of this slot's latest launch: a fetched result knows whether the slot still holds it
     // host tail of the slot's latest launch (host_tail.hpp)
-    PinnedBuf<uint8_t> tail_ring;
+    CoherentBuf tail_ring;  // [64-byte header: control word][records]
+    std::shared_ptr<std::atomic<bool>> tail_launched;  // set once the launch's end event has been recorded (TailBatch::launch_done)
+    bool tail_failed = false;  // the host tail of this slot's batch could not be merged: the batch's collect keeps failing (reads handed over would otherwise come back unmapped)
     std::shared_ptr<host::TailBatch> tail;  // set while the launch's handed-over reads have not been merged into its pools
     DevBuf<uint8_t> d_tail_up;
     // Page-locked landing place of this slot's small device-to-host copies (cursors, a batch's base count).  A copy into pageable memory is staged by a copy
@@ -1080,7 +1154,8 @@ struct BatchSlot {
     DevBuf<DevRecord> d_rec_out;
     DevBuf<char> d_rec_text;
     DevBuf<float> d_rec_pairs;
-    uint64_t tail_info[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // reads, pops on the GPU before the hand-over, pops on the host, host wall microseconds, threads, budget, host E_search, N_push, N_node, host thread microseconds
+    uint64_t tail_info[16] = {};  // reads, pops on the GPU before the hand-over, pops on the host, host wall microseconds, threads, budget, host E_search, N_push, N_node, host thread microseconds,
+                                  // [10] records seen while the launch was running, [11] reads handed over on a dry arena class, [12] ... instead of the full-limit stage, [13] smallest class that hands over
 
     void release() {
         d_seqs.release(); d_quals.release(); d_offsets.release(); d_darr.release(); d_dscratch.release(); d_counters.release(); d_status.release(); d_hit_count.release();
@@ -1268,7 +1343,9 @@ int ensure_arenas(mapad_ctx* c, BatchSlot& S, uint32_t lmax, uint64_t n_reads) {
     const uint32_t rs = (uint32_t)std::min<uint64_t>((uint64_t)c->resident_waves * rpw, need_waves * rpw);  // read slots that can be busy at once
     // The big classes are held for seconds by the few heaviest reads of every batch in flight (C5 read mix: 0.5 % of the reads need class 4
     // or more; with 1024 / 256 / 64 arenas a 1 M-read launch spent a third of its time waiting for them): HBM is there to be used.
-    uint32_t counts[kClasses] = {rs / 2, rs / 4, rs / 8, rs / 16, 4096, 1024, 256, 128, 64, 64};
+    // (round 5: generous — the fit below trims the classes that hold the most bytes until the pools fit the HBM that is free, so the classes end up with equal shares
+    // of it instead of these numbers' proportions; round 4: rs / 16, 4096, 1024, 256, 128 for classes 3-7)
+    uint32_t counts[kClasses] = {rs / 2, rs / 4, rs / 8, rs / 8, 8192, 4096, 1024, 256, 64, 64};
     // ... in proportion to the reads in flight (1 in 64 may need class 4, ..., 1 in 16384 the full limits; a read at the reference's limits
     // holds a 400 MB arena for a minute, and only as many of those run at once as the last class has arenas), never fewer than 16
     const uint64_t in_flight = n_reads * (uint64_t)std::min(c->depth, 4);
@@ -1294,8 +1371,19 @@ int ensure_arenas(mapad_ctx* c, BatchSlot& S, uint32_t lmax, uint64_t n_reads) {
         g.off_scratch[k] = heavy_possible ? align(g.off_hit_ops[k] + (uint64_t)hit_ops_cap * 4) : g.off_hits[k];
         g.stride[k] = heavy_possible ? align(g.off_scratch[k] + 2ull * (lm + 1) * 2) : g.off_hits[k];
         // a class that is no bigger than the previous one (tiny semantic limits) is pointless: give it no arenas
-        const bool useful = g.node_cap[k] > (k ? g.node_cap[k - 1] : c->pool[0].node_cap) || g.heap_cap[k] > (k ? g.heap_cap[k - 1] : c->pool[0].heap_cap);
+        // ... nor is a class the base arena already covers (round 5: the test used to compare with the previous CLASS only, and a 3 Gbp context kept 18 000 arenas
+        // of 32 Ki and 64 Ki nodes — 32 GB — that no read leaving a 64 Ki-node base arena can use)
+        const bool useful = (g.node_cap[k] > (k ? g.node_cap[k - 1] : 0u) || g.heap_cap[k] > (k ? g.heap_cap[k - 1] : 0u)) &&
+                            (g.node_cap[k] > c->pool[0].node_cap || g.heap_cap[k] > c->pool[0].heap_cap);
         g.count[k] = useful ? std::min<uint32_t>(counts[k], (1u << kGrownShift) - 1) : 0;
+    }
+    // With the host tail on, a read leaves the GPU at tail_pops pops (one to two nodes per pop): the classes beyond what such a read can fill would hold
+    // HBM for nothing — they keep a handful of arenas (a read that does get there finds its class dry and asks for the host: DeviceGrow::acquire), and the fit
+    // below gives their room to the classes in which the reads short of the budget queue (round 4, budget 2^19: 128 arenas of 1 M nodes for 3 000 reads).
+    if (c->tail_pops && !std::getenv("MAPAD_CLASS_COUNTS")) {
+        int k_budget = kClasses - 1;
+        for (int k = 0; k < kClasses; ++k) if (g.node_cap[k] >= 2ull * c->tail_pops) { k_budget = k; break; }
+        for (int k = k_budget + 1; k < kClasses; ++k) g.count[k] = std::min<uint32_t>(g.count[k], env_u32("MAPAD_BEYOND_BUDGET_ARENAS", 4));
     }
     {   // fit the pools into the HBM that is free (index, tables and base arenas are already there; keep room for the batch buffers)
         for (auto& a : c->d_class) a.release();
@@ -1304,13 +1392,16 @@ int ensure_arenas(mapad_ctx* c, BatchSlot& S, uint32_t lmax, uint64_t n_reads) {
         const uint64_t reserve = std::min<uint64_t>(16ull << 30, free_b / 4) + other_slots_bytes;  // batch buffers + the base arenas of the other batches in flight
         uint64_t budget = free_b > reserve ? free_b - reserve : 0;
         if (const uint32_t gb = env_u32("MAPAD_POOL_BUDGET_GB", 0)) budget = std::min<uint64_t>(budget, (uint64_t)gb << 30);
-        for (;;) {
+        for (;;) {  // halve the class that holds the most bytes until the pools fit: the classes end up with about the same share of HBM each, i.e. arena counts in
+                    // inverse proportion to arena size — the shape of the reads' heavy tail (P(nodes > x) ~ 1 / x) — instead of all classes losing half at every turn
             uint64_t need = 0;
-            for (int k = 0; k < kClasses; ++k) need += (uint64_t)g.count[k] * g.stride[k];
-            if (need <= budget) break;
-            bool shrunk = false;
-            for (int k = 0; k < kClasses; ++k) if (g.count[k] > 4) { g.count[k] /= 2; shrunk = true; }
-            if (!shrunk) break;  // back-pressure copes with small pools; the allocation below reports a real shortage
+            int big = -1;
+            for (int k = 0; k < kClasses; ++k) {
+                need += (uint64_t)g.count[k] * g.stride[k];
+                if (g.count[k] > 4 && (big < 0 || (uint64_t)g.count[k] * g.stride[k] > (uint64_t)g.count[big] * g.stride[big])) big = k;
+            }
+            if (need <= budget || big < 0) break;  // back-pressure copes with small pools; the allocation below reports a real shortage
+            g.count[big] /= 2;
         }
     }
     for (int k = 0; k < kClasses; ++k) {
@@ -1319,6 +1410,26 @@ int ensure_arenas(mapad_ctx* c, BatchSlot& S, uint32_t lmax, uint64_t n_reads) {
         HIP_TRY(hipMemsetAsync(c->d_owner[k].p, 0, std::max<size_t>(g.count[k], 1) * 4, S.stream));
         g.base[k] = c->d_class[k].p;
         g.owner[k] = c->d_owner[k].p;
+    }
+    {   // the set class (GrowPools): one wavefront's set of base arenas as a single grown arena — heap in front, nodes behind it, as in make_pool_layout
+        const int k = kClasses;
+        const uint64_t set_bytes = (uint64_t)rpw * c->pool[0].stride;
+        auto align = [](uint64_t x) { return (x + 127) & ~127ull; };
+        uint64_t nodes = (set_bytes - 4096) / (sizeof(HeapEntry) + sizeof(Node));
+        nodes = std::min<uint64_t>(nodes & ~63ull, tree_cap);
+        g.heap_cap[k] = (uint32_t)std::min<uint64_t>(nodes, stack_cap);
+        g.node_cap[k] = (uint32_t)nodes;
+        g.off_nodes[k] = align(((uint64_t)g.heap_cap[k] + 16) * sizeof(HeapEntry));
+        g.off_hits[k] = g.off_hit_ops[k] = g.off_scratch[k] = 0;
+        g.stride[k] = set_bytes;
+        g.base[k] = c->pool[0].base;
+        g.owner[k] = c->pool[0].set_owner;
+        // not with reads suspended to heavy wavefronts (their hit staging travels in the grown arena), not for sets smaller than the base arena's next class, and
+        // MAPAD_SET_ARENAS=0 switches it off (A/B)
+        const bool on = env_u32("MAPAD_SET_ARENAS", 1) != 0 && !heavy_possible && g.off_nodes[k] + (uint64_t)g.node_cap[k] * sizeof(Node) <= set_bytes && g.node_cap[k] >= 2 * c->pool[0].node_cap;
+        g.count[k] = on ? c->pool[0].n_sets : 0;
+        g.set_next_class = kClasses;
+        for (int j = kClasses - 1; j >= 0; --j) if (g.node_cap[j] > g.node_cap[k] || g.heap_cap[j] > g.heap_cap[k]) g.set_next_class = (uint32_t)j;
     }
     g.max_waits = env_u32("MAPAD_MAX_WAITS", 64);
     g.hit_ops_cap = hit_ops_cap;
@@ -1439,24 +1550,42 @@ int launch_batch(mapad_ctx* c, BatchSlot& S, const uint8_t* d_seqs, const uint8_
     B.prof = c->d_prof.p;
 #endif
     B.tail_ring = nullptr; B.tail_stride = 0; B.tail_cap = 0; B.tail_lmax = 0; B.tail_pops = 0xFFFFFFFFu;
+    B.tail_ctl = nullptr; B.tail_backlog_max = 0; B.tail_min_class = (uint32_t)kClasses;
     if (S.tail) { host::tail_cancel(S.tail); S.tail.reset(); }
     for (auto& x : S.tail_info) x = 0;
+    S.tail_failed = false;
     if (c->tail_pops && !warm && n_reads) {
         const uint32_t tl = std::max<uint32_t>(lmax, 1);
         // (records of long reads are big — 6 bytes per base: the ring never takes more than 1 GB of page-locked memory; reads that find it full stay on the GPU)
         const uint32_t stride = host::tail_record_stride(tl);
         const uint32_t cap = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(std::min<uint64_t>(n_reads, env_u32("MAPAD_TAIL_RING", 65536)), (1ull << 30) / stride));
-        if (!S.tail_ring.resize((size_t)cap * stride)) return MAPAD_ERR_NOMEM;
-        for (uint32_t k = 0; k < cap; ++k) reinterpret_cast<host::TailRecord*>(S.tail_ring.data() + (size_t)k * stride)->ready = 0;
+        constexpr size_t kRingHeader = 64;  // the control word has a cache line of its own in front of the records
+        if (!S.tail_ring.ensure(kRingHeader + (size_t)cap * stride)) return MAPAD_ERR_NOMEM;
+        uint8_t* ring = S.tail_ring.p + kRingHeader;
+        uint32_t* ctl = reinterpret_cast<uint32_t*>(S.tail_ring.p);
+        *ctl = host::TailWorkers::instance().pending();
+        for (uint32_t k = 0; k < cap; ++k) reinterpret_cast<host::TailRecord*>(ring + (size_t)k * stride)->ready = 0;
         auto tb = std::make_shared<host::TailBatch>();
         tb->ix = c->index->ix.view();
         tb->tables = c->tables_snap;
         tb->P = c->dprm;
         tb->P.sdm_table = tb->tables->sdm.data(); tb->P.table_base = tb->tables->table_base.data(); tb->P.reject_thr = tb->tables->reject_thr.data();
-        tb->ring = S.tail_ring.data(); tb->stride = stride; tb->cap = cap; tb->lmax = tl;
+        tb->ring = ring; tb->stride = stride; tb->cap = cap; tb->lmax = tl; tb->ctl = ctl;
+        {   // "has this launch ended?" for the dispatcher's count of hand-overs that arrive during the launch: the event is recorded at the end of this function
+            auto launched = std::make_shared<std::atomic<bool>>(false);
+            S.tail_launched = launched;
+            hipEvent_t* evp = &S.ev[3];
+            tb->launch_done = [launched, evp]() { return launched->load(std::memory_order_acquire) && hipEventQuery(*evp) != hipErrorNotReady; };
+        }
         host::tail_start(tb);
         S.tail = tb;
-        B.tail_ring = S.tail_ring.data(); B.tail_stride = stride; B.tail_cap = cap; B.tail_lmax = tl; B.tail_pops = c->tail_pops;
+        B.tail_ring = ring; B.tail_stride = stride; B.tail_cap = cap; B.tail_lmax = tl; B.tail_pops = c->tail_pops;
+        // Hand-over on a dry arena class (DeviceGrow::acquire): classes from MAPAD_TAIL_MIN_CLASS up (default 4: the classes whose arena counts are absolute numbers,
+        // not a share of the resident read slots), while the host has fewer than MAPAD_TAIL_BACKLOG reads waiting or running (default: two per worker thread — the
+        // host is never idle while reads queue on the GPU, and never holds more than it can finish in the time the GPU frees an arena).
+        B.tail_ctl = ctl;
+        B.tail_min_class = env_u32("MAPAD_TAIL_MIN_CLASS", 4);
+        B.tail_backlog_max = env_u32("MAPAD_TAIL_BACKLOG", 2 * host::TailWorkers::instance().size());
     }
     S.last = B; S.last_total_bases = total_bases; S.last_lmax = lmax; S.compacted = false;
     // A process-wide launch number, not a per-slot count: a result of a destroyed context must not pass for the batch of a new context that happens to sit at
@@ -1561,6 +1690,7 @@ int launch_batch(mapad_ctx* c, BatchSlot& S, const uint8_t* d_seqs, const uint8_
 #undef MAPAD_LAUNCH
     if (warm) return MAPAD_OK;
     HIP_TRY(hipEventRecord(S.ev[3], S.stream));
+    if (S.tail_launched) S.tail_launched->store(true, std::memory_order_release);
     S.ev_valid = true; S.timed = false;
     S.launch_info[0] = grid_d; S.launch_info[1] = 64; S.launch_info[2] = (uint32_t)lds_bytes;
     S.launch_info[3] = grid_s; S.launch_info[4] = 64; S.launch_info[5] = c->slots[1];
@@ -1573,6 +1703,7 @@ int launch_batch(mapad_ctx* c, BatchSlot& S, const uint8_t* d_seqs, const uint8_
 int merge_tail(mapad_ctx* c, BatchSlot& S, uint32_t* cur) {
     std::shared_ptr<host::TailBatch> tb = S.tail;
     S.tail.reset();
+    S.tail_failed = true;  // until the results are on the device: a failure below leaves reads marked ST_TAIL, and the batch's collect must go on failing (compact_last)
     const bool ok = host::tail_finish(tb, cur[CUR_TAIL]);
     if (!ok) { std::fprintf(stderr, "mapad_amd: a read of the host tail could not be mapped (out of host memory?)\n"); return MAPAD_ERR_NOMEM; }
     std::vector<host::TailResult>& res = tb->results;
@@ -1580,7 +1711,8 @@ int merge_tail(mapad_ctx* c, BatchSlot& S, uint32_t* cur) {
     S.tail_info[3] = res.empty() ? 0 : (uint64_t)(std::max(tb->t_last - tb->t_first, 0.0) * 1e6); S.tail_info[4] = host::TailWorkers::instance().size(); S.tail_info[5] = c->tail_pops;
     for (const auto& r : res) { S.tail_info[6] += r.e_search; S.tail_info[7] += r.n_push; S.tail_info[8] += r.n_node; }
     S.tail_info[9] = (uint64_t)(tb->host_thread_s * 1e6);
-    if (res.empty()) return MAPAD_OK;
+    S.tail_info[10] = tb->seen_live; S.tail_info[11] = cur[CUR_TAIL_DRY]; S.tail_info[12] = cur[CUR_TAIL_F]; S.tail_info[13] = S.last.tail_min_class;
+    if (res.empty()) { S.tail_failed = false; return MAPAD_OK; }
     std::sort(res.begin(), res.end(), [](const host::TailResult& a, const host::TailResult& b) { return a.read < b.read; });
     const BatchDev& B = S.last;
     uint64_t n_hits = 0, n_ops = 0;
@@ -1593,7 +1725,7 @@ int merge_tail(mapad_ctx* c, BatchSlot& S, uint32_t* cur) {
     if (!S.h_small.resize(CUR_COUNT + 8)) return MAPAD_ERR_NOMEM;
     std::memcpy(S.h_small.data(), cur, (CUR_POOL_OVF + 1) * 4);
     HIP_TRY(hipMemcpyAsync(B.cursors, S.h_small.data(), (CUR_POOL_OVF + 1) * 4, hipMemcpyHostToDevice, S.stream));
-    if (!fits) { HIP_TRY(hipStreamSynchronize(S.stream)); return MAPAD_OK; }
+    if (!fits) { HIP_TRY(hipStreamSynchronize(S.stream)); S.tail_failed = false; return MAPAD_OK; }  // (the pool overflow is reported by the cursors; the batch is re-run)
     // staged in page-locked memory: [TailUp x reads][HitRec x n_hits][u32 x n_ops]
     const size_t off_hits = (res.size() * sizeof(TailUp) + 63) & ~(size_t)63, off_ops = (off_hits + n_hits * sizeof(HitRec) + 63) & ~(size_t)63;
     if (!S.h_tail_stage.resize(off_ops + n_ops * 4 + 64)) return MAPAD_ERR_NOMEM;
@@ -1615,6 +1747,7 @@ int merge_tail(mapad_ctx* c, BatchSlot& S, uint32_t* cur) {
     hipLaunchKernelGGL(tail_scatter_kernel, dim3((uint32_t)((res.size() + 63) / 64)), dim3(64), 0, S.stream, B, (const TailUp*)S.d_tail_up.p, (uint32_t)res.size());
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(S.stream));
+    S.tail_failed = false;
     return MAPAD_OK;
 }
 
@@ -1622,6 +1755,7 @@ int merge_tail(mapad_ctx* c, BatchSlot& S, uint32_t* cur) {
 int compact_last(mapad_ctx* c) {
     BatchSlot& S = c->bs[c->view];
     if (S.compacted) return MAPAD_OK;
+    if (S.tail_failed) { std::fprintf(stderr, "mapad_amd: the host tail of this batch failed earlier; its results are incomplete\n"); return MAPAD_ERR_NOMEM; }
     HIP_TRY(hipStreamSynchronize(S.stream));
     const BatchDev& B = S.last;
     const uint64_t n = B.n_reads;
@@ -1846,7 +1980,7 @@ int mapad_ctx_set_tail_pops(mapad_ctx_t* ctx, uint32_t pops) {
     ctx->tail_pops = pops;
     return MAPAD_OK;
 }
-int mapad_last_tail_info(mapad_ctx_t* ctx, uint64_t out[10]) {
+int mapad_last_tail_info(mapad_ctx_t* ctx, uint64_t out[16]) {
     if (!ctx || !out) return MAPAD_ERR_INVALID;
     std::memcpy(out, ctx->bs[ctx->view].tail_info, sizeof ctx->bs[ctx->view].tail_info);
     return MAPAD_OK;
@@ -1927,8 +2061,13 @@ int mapad_fetch_result(mapad_ctx_t* ctx, mapad_batch_result_t** out) {
     r->pub.hit_begin = r->hit_begin.data(); r->pub.hits = r->hits.data(); r->pub.ops = r->ops.data();
     r->pub.status = r->status.data(); r->pub.counters = r->counters.data(); r->pub.d_arrays = ctx->fetch_d ? r->d_arrays.data() : nullptr;
     r->pub.n_second_pass = cur[CUR_GROWN];  // arena migrations in pass 0
+    if (std::getenv("MAPAD_DEBUG")) {
+        std::fprintf(stderr, "mapad_amd: arena classes (nodes x count):");
+        for (int k = 0; k <= kClasses; ++k) std::fprintf(stderr, " %u x %u%s", ctx->grow.node_cap[k], ctx->grow.count[k], k == kClasses ? " (sets)" : "");
+        std::fprintf(stderr, "; base arenas %u nodes x %u slots; host tail: %u reads, %u on a dry class, %u instead of the full-limit stage\n", ctx->pool[0].node_cap, ctx->slots[0], cur[CUR_TAIL], cur[CUR_TAIL_DRY], cur[CUR_TAIL_F]);
+    }
     if (cur[CUR_GROWN + 1] && std::getenv("MAPAD_DEBUG")) std::fprintf(stderr, "mapad_amd: size-class pools that ran dry (bit per class): 0x%x, waits: %u, reads restarted: %u, re-run with full limits: %u\n", cur[CUR_GROWN + 1], cur[CUR_GROWN + 2], cur[CUR_OVF], cur[CUR_OVF + 2 * (kStages - 2)]);
-    r->pub.n_third_pass = cur[CUR_OVF + 2 * (kStages - 2)];  // reads re-run by the full-limit pass
+    r->pub.n_third_pass = cur[CUR_OVF + 2 * (kStages - 2)] + cur[CUR_TAIL_F];  // reads no growable arena could hold: re-run with the reference's full limits, by the last GPU stage or (host tail on) by a host thread
     if (std::getenv("MAPAD_DEBUG")) {
         std::fprintf(stderr, "mapad_amd: heavy reads %u + %u, pops by heavy wavefronts %llu\n", cur[CUR_HEAVY_N], cur[CUR_HEAVY_N + 1], (unsigned long long)cur64(cur, CUR_HEAVY_POPS));
 #if defined(MAPAD_HEAVY_PROF)
@@ -2095,6 +2234,7 @@ extern "C++" HostBlockCache& host_blocks() { static HostBlockCache* c = new Host
 }  // namespace
 void* mapad_host_alloc(size_t bytes) { return host_blocks().alloc(bytes ? bytes : 1); }
 void mapad_host_free(void* p) { if (p) host_blocks().release(p); }
+unsigned mapad_host_cpus(void) { return host::cpu_share(); }
 
 int mapad_device_result_ptrs(mapad_ctx_t* ctx, void** d_hit_count, void** d_hit_first, void** d_hits, void** d_ops, void** d_cursors) {
     if (!ctx) return MAPAD_ERR_INVALID;

@@ -138,6 +138,19 @@ def records_digest(recs, text, pairs):
     return h.hexdigest()
 
 
+def rebase_record_offsets(r, mapped, text_base, pair_base, text_bytes, n_pairs):
+    """Adds a shard's bases to the text_off / mq_off words of its mapped records, in place, and returns the bases of the next shard.  The two offsets are u32
+    fields of the int32 record array: the add happens on a uint32 view (as int32 it overflows once the concatenated text passes 2^31 bytes — 8 ranks x 1.1 GB
+    at C4), and the merged pools must stay addressable by them."""
+    text_end, pair_end = text_base + text_bytes, pair_base + n_pairs
+    if text_end > 0xFFFFFFFF or pair_end > 0xFFFFFFFF:
+        raise OverflowError(f"merged record pools exceed the records' 32-bit offsets ({text_end} text bytes, {pair_end} pairs): merge fewer ranks' steps at a time")
+    u = r.view(np.uint32)
+    u[mapped, _REC_TEXT_OFF] += np.uint32(text_base)
+    u[mapped, _REC_MQ_OFF] += np.uint32(pair_base)
+    return text_end, pair_end
+
+
 def merge_gathered_records(parts):
     """rank-ordered (records int32[n_r * 22], text as int32 (bytes padded to a multiple of 4), pairs as int32 views of f32[2 * n_pairs_r]) of read-ordered
     shards -> the chunk's records (n x 22 int32, text_off / mq_off rebased into the concatenated pools), text bytes, pairs (float32) and the
@@ -151,10 +164,8 @@ def merge_gathered_records(parts):
         digests.append(records_digest(r, t, p))
         r = r.copy()
         mapped = r[:, 3] != 0
-        r[mapped, _REC_TEXT_OFF] += text_base
-        r[mapped, _REC_MQ_OFF] += pair_base
-        text_base += int(t.size) * 4
-        pair_base += int(p.size) // 2
+        text_end, pair_end = rebase_record_offsets(r, mapped, text_base, pair_base, int(t.size) * 4, int(p.size) // 2)
+        text_base, pair_base = text_end, pair_end
         recs.append(r)
         texts.append(t.view(np.uint8))
         pairs.append(p.view(np.float32))

@@ -36,8 +36,6 @@ def main():
     index = mapad_amd.Index.build([("chr1", genome)], seed=1234, device=0)
     print(f"genome + index {time.time() - t0:.1f} s", flush=True)
     seqs, quals, offsets = synth.reads(genome, args.reads, 50, seed=4321 + 5, qual_range=(20, 40), damage=dict(f=0.5, t=0.5, d=0.02, s=1.0), len_range=(35, 100), indel_frac=0.05)
-    ctx = mapad_amd.Context(index, mapad_amd.make_params(resolve(DAMAGE)), 0)
-    ctx.set_fetch_d_arrays(False)
     import hashlib
     for budget in ([int(b) for b in args.budgets.split(",")] if args.budgets else [None]):
         log_path = args.log + (f".{budget}" if budget is not None else "")
@@ -45,13 +43,16 @@ def main():
             os.remove(log_path)
         os.environ["MAPAD_TAIL_LOG"] = log_path
         if budget is not None:
-            ctx.set_tail_pops(budget)
+            os.environ["MAPAD_TAIL_POPS"] = str(budget)  # read when the context is created: the arena pools are sized for the budget
+        ctx = mapad_amd.Context(index, mapad_amd.make_params(resolve(DAMAGE)), 0)
+        ctx.set_fetch_d_arrays(False)
         print("memory before:", cg("memory.current"), "max", cg("memory.max"), flush=True)
         cpu0 = cg("cpu.stat")
         t1 = time.time()
         res = ctx.map_batch(seqs, quals, offsets)
         wall = time.time() - t1
         info = ctx.tail_info()
+        info["kernel_ms"] = [round(float(x), 1) for x in ctx.kernel_ms()]
         h = hashlib.sha256()
         for a in (res.hit_begin, res.hits_arr, res.ops, res.status, res.counters):
             h.update(np.ascontiguousarray(a).tobytes())
@@ -65,7 +66,7 @@ def main():
             h_, e_ = np.histogram(log[:, 3], bins=[0, 5, 10, 15, 20, 30, 45, 60, 90, 120, 180, 240, 300, 400, 1000])
             print("  hand-overs by start time:", {f"{e_[i]:.0f}-{e_[i + 1]:.0f}": int(h_[i]) for i in range(len(h_)) if h_[i]}, flush=True)
         del res
-    ctx.close()
+        ctx.close()
 
 
 if __name__ == "__main__":

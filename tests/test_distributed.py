@@ -206,3 +206,21 @@ def test_bench_two_ranks_on_one_gpu_over_gloo(scaling):
     assert g["bytes_per_read"] <= 128 and g["merged_mapped"] > 0.8 * g["merged_reads"]  # compact records on the links, not hit intervals + edit tracks
     assert g["index"]["built_by"].startswith("rank 0") and g["index"]["load_s_per_rank"][1] is not None
     assert len(g["per_rank"]) == 2 and sum(r["reads"] for r in g["per_rank"]) == g["merged_reads"]
+
+
+def test_merged_record_offsets_past_2_pow_31_do_not_overflow():
+    """text_off / mq_off are u32 fields of an int32 record array; rank 0's rebase must not overflow int32 once the concatenated text pool passes
+    2^31 bytes (8 ranks x 1.1 GB at C4), and must refuse pools the 32-bit offsets cannot address."""
+    from mapad_amd.distributed import rebase_record_offsets
+    recs, text, pairs = _fake_records(50, seed=1)
+    mapped = recs[:, 3] != 0
+    r = recs.copy()
+    text_base, pair_base = 2_200_000_000, 2_300_000_000
+    ends = rebase_record_offsets(r, mapped, text_base, pair_base, text.size * 4, pairs.size // 2)
+    assert ends == (text_base + text.size * 4, pair_base + pairs.size // 2)
+    u = r.view(np.uint32)
+    assert np.array_equal(u[mapped, 12].astype(np.int64), recs[mapped, 12].astype(np.int64) + text_base) and (u[mapped, 12] > 2 ** 31).all()
+    assert np.array_equal(u[mapped, 18].astype(np.int64), recs[mapped, 18].astype(np.int64) + pair_base)
+    assert np.array_equal(r[~mapped], recs[~mapped]) and np.array_equal(np.delete(r, [12, 18], axis=1), np.delete(recs, [12, 18], axis=1))
+    with pytest.raises(OverflowError):
+        rebase_record_offsets(recs.copy(), mapped, 0xFFFFFFF0, 0, 64, 0)

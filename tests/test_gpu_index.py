@@ -164,6 +164,7 @@ def test_index_beyond_2_pow_32_rows_maps_like_the_oracle(monkeypatch):
         seqs, quals, offsets = c5
         rp = dict(resolve_params(DAMAGE), **c5_limits)
         monkeypatch.setenv("MAPAD_CLASS_COUNTS", os.environ.get("MAPAD_TEST_C5_CLASS_COUNTS", "8192,4096,2048,1024,0,0,0,0,0,0"))
+        monkeypatch.setenv("MAPAD_SET_ARENAS", "0")  # (round 5: an idle set of base arenas would hold these reads whole — 1 M nodes — and nothing would reach the full-limit stage)
         ctx = mapad_amd.Context(pidx, mapad_amd.make_params(rp), 0)
         ctx.set_tail_pops(0)  # this case is about the GPU's own stages (growth through the size classes, the full-limit stage): nothing goes to the host tail
         t5 = time.time()
@@ -185,6 +186,7 @@ def test_index_beyond_2_pow_32_rows_maps_like_the_oracle(monkeypatch):
     n_heavy = int(os.environ.get("MAPAD_TEST_C5_HEAVY", 2_000))
     if n_pre and n > 2 ** 32:
         monkeypatch.delenv("MAPAD_CLASS_COUNTS", raising=False)
+        monkeypatch.delenv("MAPAD_SET_ARENAS", raising=False)
         seqs, quals, offsets = synth.reads(g, n_pre, 50, seed=4328, qual_range=(20, 40), damage=dict(f=0.5, t=0.5, d=0.02, s=1.0), len_range=(35, 100), indel_frac=0.05)
         rp = resolve_params(DAMAGE)
         ctx = mapad_amd.Context(pidx, mapad_amd.make_params(rp), 0)

@@ -92,7 +92,7 @@ def test_scheduling_and_memory_variants_do_not_change_results(env, monkeypatch):
 
 
 @pytest.mark.parametrize("heavy", ["0", "1"])
-@pytest.mark.parametrize("class_counts", ["512,512,512,512,512,512,512,512,512", "8,2"])
+@pytest.mark.parametrize("class_counts", ["512,512,512,512,512,512,512,512,512", "8,2", "8,2+sets"])
 def test_small_arena_growth_last_pass_and_limits(monkeypatch, class_counts, heavy):
     """Reads that outgrow their arena migrate into the size-class pools (owner-word acquire / release); when a pool is dry the
     read is re-run by the full-limit pass.  Tiny STACK/EDIT_TREE limits exercise the overflow recovery of mapping.rs:1358-1380."""
@@ -103,11 +103,17 @@ def test_small_arena_growth_last_pass_and_limits(monkeypatch, class_counts, heav
     oidx = ob.OracleIndex.from_bwt(pidx.bwt(), "$ACGTX", 128)
     monkeypatch.setenv("MAPAD_HEAVY", heavy)  # 1: a read that outgrows its base arena is continued by a wavefront of its own (heavy_kernel.hpp)
     monkeypatch.setenv("MAPAD_TIER0_NODES", "32")  # classes: 64, 128, 256, ..., 16384 nodes, full limits
-    monkeypatch.setenv("MAPAD_CLASS_COUNTS", class_counts)  # "8,2": reads wait for the few arenas; those that need > 128 nodes are re-run
+    # "8,2": reads wait for the few arenas; those that need > 128 nodes are re-run with the full limits.  "+sets" (round 5, the default): a read that finds the
+    # classes dry or too small takes an idle SET of base arenas as one arena (GrowPools: entry kClasses) — here 16 x 32-node slots' worth of HBM hold a few thousand
+    # nodes, and no read is left for the full-limit pass.
+    sets = class_counts.endswith("+sets")
+    class_counts = class_counts.split("+")[0]
+    monkeypatch.setenv("MAPAD_SET_ARENAS", "1" if sets else "0")
+    monkeypatch.setenv("MAPAD_CLASS_COUNTS", class_counts)
     rp = resolve_params(NO_DAMAGE)
     res = _gpu_map(pidx, mapad_amd.make_params(rp), seqs, quals, offsets)
     assert res.n_second_pass > 0  # migrations
-    assert (res.n_third_pass > 0) == (class_counts == "8,2")  # reads handed to the full-limit pass only when no class can hold them
+    assert (res.n_third_pass > 0) == (class_counts == "8,2" and not sets)  # reads re-run with the full limits (by a host thread, host tail on: tests/test_gpu_tail.py) only when no class can hold them
     ores = oidx.map_batch(ob.make_params(rp), reads, qs, n_threads=8, keep_d=True)
     assert_same_as_oracle(ores, res, offsets)
     for limits in ({"stack_limit": 40, "edit_tree_limit": 100000}, {"stack_limit": 100000, "edit_tree_limit": 120},

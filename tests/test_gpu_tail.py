@@ -139,3 +139,63 @@ def test_tail_with_batches_in_flight_and_an_uncollected_batch():
         assert_same_as_oracle(ores, got[i][0], b[2])
         assert got[i][1]["reads"] == int((ores.counters[:, 3] > 64).sum()) > 20
     _same(again, got[3][0])
+
+
+def test_a_dry_arena_class_sends_reads_to_the_host(monkeypatch):
+    """Round 5: a read that needs a grown arena of a scarce class while every one is taken asks for the host instead of queuing (DeviceGrow::acquire) — here every
+    class counts as scarce, each has two arenas, and the pop budget is out of reach, so whatever goes to the host goes for that reason (or because no class holds it)."""
+    monkeypatch.setenv("MAPAD_TIER0_NODES", "32")
+    monkeypatch.setenv("MAPAD_CLASS_COUNTS", "2,2,2,2,2,2,2,2,2,2")
+    monkeypatch.setenv("MAPAD_SET_ARENAS", "0")  # (idle sets of base arenas would take the reads the dry classes turn away: tests/test_gpu_parity.py covers those)
+    monkeypatch.setenv("MAPAD_TAIL_MIN_CLASS", "0")
+    monkeypatch.setenv("MAPAD_TAIL_BACKLOG", "100000")  # the host takes whatever comes
+    g = synth.genome(200_000, seed=21)
+    seqs, quals, offsets = synth.reads(g, 4000, 50, seed=6, qual_range=(20, 40), damage=dict(f=0.5, t=0.5, d=0.02, s=1.0))
+    rp = resolve_params(DAMAGE)
+    pidx = mapad_amd.Index.build([("chr1", g)])
+    oidx = ob.OracleIndex.from_bwt(pidx.bwt(), "$ACGTX", 128)
+    res, info = _map(pidx, mapad_amd.make_params(rp), seqs, quals, offsets, tail_pops=1 << 30)
+    reads, qs = split_reads(seqs, quals, offsets)
+    ores = oidx.map_batch(ob.make_params(rp), reads, qs, n_threads=8, keep_d=True)
+    assert_same_as_oracle(ores, res, offsets)
+    assert info["reads_dry_class"] > 50 and info["reads"] == info["reads_dry_class"] + info["reads_full_limit"]
+    assert (res.status & 16).sum() == 0
+    # a backlog limit of zero: the host is "busy" from the start, nobody is handed over for a dry class; the reads queue on the GPU as in round 4
+    monkeypatch.setenv("MAPAD_TAIL_BACKLOG", "0")
+    res0, info0 = _map(pidx, mapad_amd.make_params(rp), seqs, quals, offsets, tail_pops=1 << 30)
+    assert info0["reads_dry_class"] == 0
+    _same(res, res0)
+
+
+def test_reads_no_growable_arena_holds_go_to_the_host_instead_of_the_full_limit_stage(monkeypatch):
+    """The classes end at 128 nodes: a read that needs more would be re-run by the full-limit stage (heavy_kernel, 336 MB arenas); with the host tail on it goes to a
+    host thread.  n_third_pass counts such reads wherever they were finished; with the tail off the GPU's last stage takes them — same results."""
+    monkeypatch.setenv("MAPAD_TIER0_NODES", "32")
+    monkeypatch.setenv("MAPAD_CLASS_COUNTS", "512,512")
+    monkeypatch.setenv("MAPAD_SET_ARENAS", "0")
+    monkeypatch.setenv("MAPAD_TAIL_MIN_CLASS", "10")  # no hand-over for dry classes: only the reads no class can hold
+    g = synth.genome(100_000, seed=5)
+    seqs, quals, offsets = synth.reads(g, 1500, 50, seed=11)
+    rp = resolve_params(NO_DAMAGE)
+    pidx = mapad_amd.Index.build([("chr1", g)])
+    oidx = ob.OracleIndex.from_bwt(pidx.bwt(), "$ACGTX", 128)
+    reads, qs = split_reads(seqs, quals, offsets)
+    ores = oidx.map_batch(ob.make_params(rp), reads, qs, n_threads=8, keep_d=True)
+    res, info = _map(pidx, mapad_amd.make_params(rp), seqs, quals, offsets, tail_pops=1 << 30)
+    assert_same_as_oracle(ores, res, offsets)
+    assert info["reads_full_limit"] > 20 and info["reads"] == info["reads_full_limit"] == res.n_third_pass
+    off, info_off = _map(pidx, mapad_amd.make_params(rp), seqs, quals, offsets, tail_pops=0)
+    assert info_off["reads"] == 0 and off.n_third_pass == res.n_third_pass
+    _same(res, off)
+
+
+def test_hand_overs_reach_the_host_while_the_launch_is_running():
+    """The ring is host-coherent page-locked memory and every word of a record is written through (hand_to_host): the dispatcher thread sees records — and the
+    workers start on them — during the launch, not when it ends (with ordinary page-locked memory that was luck)."""
+    g = synth.genome(2_000_000, seed=41)
+    seqs, quals, offsets = synth.reads(g, 400_000, 50, seed=8, qual_range=(20, 40), damage=dict(f=0.5, t=0.5, d=0.02, s=1.0))
+    pidx = mapad_amd.Index.build([("chr1", g)], device=0)
+    res, info = _map(pidx, mapad_amd.make_params(resolve_params(DAMAGE)), seqs, quals, offsets, tail_pops=4096)
+    assert info["reads"] > 100, info
+    assert info["seen_live"] > info["reads"] // 2, info  # the launch runs for a good 100 ms; the first hand-overs come within the first few
+    assert (res.status & 16).sum() == 0
