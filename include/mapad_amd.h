@@ -122,6 +122,10 @@ void mapad_ctx_destroy(mapad_ctx_t* ctx);
 /* run every launch on this HIP stream (a hipStream_t; NULL = the default stream) */
 int mapad_ctx_set_stream(mapad_ctx_t* ctx, void* hip_stream);
 
+/* Leave the last `n_cus` compute units of the device free of this context's launches (its batch slots' streams get a CU mask; pipeline depth >= 2 only: depth 1
+ * runs on the caller's stream).  A search launch fills every CU it may use; RCCL's transfer kernels (248-256 VGPRs, 37.6 KB of LDS per block) only fit on CUs it
+ * does not use.  For one-process-per-GPU runs that gather results over xGMI beside the next search; before the first batch.  MAPAD_RESERVED_CUS sets the default. */
+int mapad_ctx_set_reserved_cus(mapad_ctx_t* ctx, int n_cus);
 /* The heavy tail.  The reference absorbs the reads that run into STACK_LIMIT / EDIT_TREE_LIMIT (src/map/mapping.rs:52-54,1358-1380) on its rayon threads; here a
  * read is handed — by the kernel, while it runs, through host-coherent page-locked memory — to the library's host threads when (a) it has made `pops` pops on the
  * GPU (default 2^19; MAPAD_TAIL_POPS; 0 = the host tail is off), (b) it needs a grown arena of a class the GPU has few of and every one is taken, while the host

@@ -124,6 +124,7 @@ SYMBOLS = {
     "mapad_last_kernel_ms": (_i32, [_vp, _vp]),
     "mapad_last_launch_info": (_i32, [_vp, _vp]),
     "mapad_host_cpus": (C.c_uint32, []),
+    "mapad_ctx_set_reserved_cus": (_i32, [_vp, C.c_int32]),
     "mapad_ctx_set_tail_pops": (_i32, [_vp, C.c_uint32]),
     "mapad_last_tail_info": (_i32, [_vp, _vp]),
     "mapad_hits_to_records": (_i32, [_vp, _PP, C.POINTER(BatchResultC), _vp, _vp, _vp, _vp, _u64, C.POINTER(C.POINTER(RecordsC))]),
@@ -421,6 +422,10 @@ class Context:
         out = np.zeros(3, np.float32)
         _check(lib().mapad_last_kernel_ms(self.h, _ptr(out)), "mapad_last_kernel_ms")
         return out
+
+    def set_reserved_cus(self, n):
+        """Leave the last n CUs free of this context's launches (room for RCCL's transfer kernels beside a search; before the first batch, depth >= 2)."""
+        _check(lib().mapad_ctx_set_reserved_cus(self.h, int(n)), "mapad_ctx_set_reserved_cus")
 
     def set_tail_pops(self, pops):
         """Pop budget of a read on the GPU before the library's host threads take it over (0 = never; csrc/host_tail.hpp)."""

@@ -14,6 +14,12 @@
 #define MAPAD_HD inline
 #endif
 
+// MAPAD_TOUCH(pointer, bytes, is_write): nothing in the product.  tests/emu defines it to feed a line-granular cache model with every arena and index access of
+// the host build of the step (tests/emu/emu.cpp: which lines a pop asks memory for — index, nodes, heap levels, hit staging; profiles/r05/request_attribution.json).
+#if !defined(MAPAD_TOUCH)
+#define MAPAD_TOUCH(p, bytes, wr) ((void)0)
+#endif
+
 namespace mapad {
 
 // ---- alphabet -------------------------------------------------------------------------------------------

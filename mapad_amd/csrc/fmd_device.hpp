@@ -88,6 +88,7 @@ MAPAD_HD void finish_ext4(const DevIndex& ix, uint64_t lower, uint64_t lower_rev
 // occ(r, A|C|G|T) by ONE lane: the whole 128-byte block, all four words, branch-free.
 MAPAD_HD void occ4_lane(const DevIndex& ix, uint64_t r, uint64_t out[4]) {
     const uint64_t* blk = ix.blocks + (r >> 8) * 16;
+    MAPAD_TOUCH(blk, 128, false);
     const int r_in = (int)(r & 255);
     uint32_t a = 0, c = 0, g = 0, t = 0;
 #pragma unroll

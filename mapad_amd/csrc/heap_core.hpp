@@ -209,6 +209,7 @@ MAPAD_HD HeapPair load_pair(const HeapEntry* p) {  // p is 16-byte aligned
     return r;
 #else
     HeapPair r;
+    MAPAD_TOUCH(p, sizeof r, false);
     std::memcpy(&r, p, sizeof r);
     return r;
 #endif
@@ -231,8 +232,8 @@ __device__ __forceinline__ HeapPair load_pair(const MAPAD_LDS HeapEntry* p) {
 // heap slot i of this read: the top levels sit in the near array (LDS), the rest in the HBM arena
 // Entries are moved field by field: copying the struct would bind the source to a reference in the generic address space, and after
 // the near/arena branches are merged the access would stay a flat_* instruction (vmcnt and lgkmcnt, no overlap with anything).
-template <class P> MAPAD_HD HeapEntry load_entry(P p) { HeapEntry e; e.score = p->score; e.node = p->node; return e; }
-template <class P> MAPAD_HD void store_entry(P p, const HeapEntry e) { p->score = e.score; p->node = e.node; }
+template <class P> MAPAD_HD HeapEntry load_entry(P p) { HeapEntry e; MAPAD_TOUCH(&*p, sizeof e, false); e.score = p->score; e.node = p->node; return e; }
+template <class P> MAPAD_HD void store_entry(P p, const HeapEntry e) { MAPAD_TOUCH(&*p, sizeof e, true); p->score = e.score; p->node = e.node; }
 template <bool NL, int TOP> MAPAD_HD HeapEntry hp_get(const ArenaT<NL, TOP>& A, uint32_t i) {
     if (i < (uint32_t)TOP) return load_entry(A.top + i);
     return load_entry(A.heap + i);

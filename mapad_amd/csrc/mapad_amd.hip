@@ -53,17 +53,14 @@ enum : uint32_t { ST_POOL_OVERFLOW = 4, ST_NO_TABLE = 8, ST_TAIL = 16 /* handed 
 //   Q1  search_kernel again over the reads that gave up waiting for an arena in Q0 (normally none: the launch exits at once), H1 its suspended reads.
 //   F   heavy_kernel from scratch, with arenas that hold the reference's full limits (STACK_LIMIT / EDIT_TREE_LIMIT, mapping.rs:52-54), for the reads
 //       that no size class could hold.
-// Pop budget of a read on the GPU before a host thread takes it over (host_tail.hpp); MAPAD_TAIL_POPS / mapad_ctx_set_tail_pops override, 0 = never.
-// 2^19 pops are ~3 s of one quad's time: no 50 bp read of C1-C4 gets there (heaviest C4 read: see DESIGN.md section 5), the heavy tail of the 35-100 bp mix does.
-// On a large index (>= 2^31 rows: the 3 Gbp genome) the budget is 2^17: there a read that is still going after 2^17 pops has grown into arena classes HBM holds few
-// of, and the launch then waits for such reads one after the other — measured on 1 M reads of the C5 mix at the real limits: with 2^19 the GPU handed reads over
-// for 370 s while the host threads (41 s of work for 16) sat idle; with 2^18 for > 250 s; with 2^17 the batch takes 125 s, bound by the 16 host CPUs.
-// No 50 bp read of C4 gets to 2^17 either (heaviest of 10 M: 76 272 pops).
+// Pop budget of a read on the GPU before a host thread takes it over (host_tail.hpp); MAPAD_TAIL_POPS / mapad_ctx_set_tail_pops override, 0 = the host tail is off.
+// 2^20 pops are ~6 s of one quad's time: no 50 bp read of C1-C4 gets near it (heaviest of 10 M C4 reads: 76 272 pops), the heavy tail of the 35-100 bp mix does.
+// Round 5, 1 M reads of the C5 mix on 3 Gbp at the real limits, one GPU + 16 CPUs (profiles/r05/c5_3gbp_1m_budgets.txt): 2^19 -> 51-57 s (the 16 CPUs busy
+// throughout), 2^20 -> 41.5 s (GPU 32 s, host 29 s of work), 2^21 -> 55 s (the GPU's own tail: 12 s per such read).  Round 4 needed 2^17 on a large index (125 s)
+// because reads that queued for an arena of a scarce class made no pops and never reached a larger budget; they now ask for the host when they queue
+// (DeviceGrow::acquire), so one budget serves every index size.
 #if !defined(MAPAD_DEFAULT_TAIL_POPS)
-#define MAPAD_DEFAULT_TAIL_POPS (1u << 19)
-#endif
-#if !defined(MAPAD_DEFAULT_TAIL_POPS_LARGE_INDEX)
-#define MAPAD_DEFAULT_TAIL_POPS_LARGE_INDEX (1u << 17)
+#define MAPAD_DEFAULT_TAIL_POPS (1u << 20)
 #endif
 constexpr int kTiers = 2;   // arena pools: growable base arenas, full-limit arenas
 constexpr int kStages = 3;  // hand-over lists: Q0 -> Q1 -> F
@@ -1227,6 +1224,7 @@ struct mapad_ctx {
     uint64_t last_locate_rows = 0;
     int lpr = 4;  // lanes per read in the search kernel (MAPAD_LANES_PER_READ = 4 | 1)
     int n_cu = 256;
+    int reserved_cus = 0;  // CUs the batch slots' streams leave free (create_slot_stream)
     uint64_t counter_sums[6] = {0, 0, 0, 0, 0, 0};
     DevBuf<unsigned long long> d_prof;  // -DMAPAD_PROFILE_SECTIONS builds
 
@@ -1318,7 +1316,8 @@ int ensure_arenas(mapad_ctx* c, BatchSlot& S, uint32_t lmax, uint64_t n_reads) {
                 while (nodes > 16384 && (uint64_t)c->n_cu * 16 * 64 / c->lpr * ((uint64_t)nodes * 40 + 16384) > free_b / 4 * 3) nodes /= 2;  // base arenas take at most three quarters of what is free
         }
         c->pool[0] = make_pool_layout((uint32_t)std::min<uint64_t>(nodes, stack_cap), (uint32_t)std::min<uint64_t>(nodes, tree_cap), hit_ops_cap, lm);
-        c->resident_waves = env_u32("MAPAD_TIER0_WAVES_PER_CU", c->lpr == 4 ? 4 * MAPAD_MIN_WAVES : 8) * (uint32_t)c->n_cu;  // lanes-per-read 2: eight blocks of 32 read slots per CU
+        const uint32_t cus_used = (uint32_t)(c->depth > 1 ? c->n_cu - c->reserved_cus : c->n_cu);  // (mapad_ctx_set_reserved_cus: the launches of a pipelined context leave CUs free)
+        c->resident_waves = env_u32("MAPAD_TIER0_WAVES_PER_CU", c->lpr == 4 ? 4 * MAPAD_MIN_WAVES : 8) * cus_used;  // lanes-per-read 2: eight blocks of 32 read slots per CU
         const uint64_t per_xcd_full = ((uint64_t)c->resident_waves * 4 / 3 + 7) / 8;
         const uint64_t per_xcd_need = (need_waves * (uint64_t)std::min(c->depth, 4) + 7) / 8 + 4;  // small batches (tests): no more than they can use
         n_sets[0] = 8 * (uint32_t)std::max<uint64_t>(std::min(per_xcd_full, per_xcd_need), kPartitionMin / 8);
@@ -1463,13 +1462,28 @@ int record_times(mapad_ctx* c, BatchSlot& S) {
     return MAPAD_OK;
 }
 
+// A batch slot's own stream.  With `reserved_cus` > 0 (mapad_ctx_set_reserved_cus; MAPAD_RESERVED_CUS) the stream carries a CU mask that leaves the last CUs of the
+// device to others: a search launch fills every CU it may use with persistent wavefronts — 11 blocks per CU leave one wave slot of <= 176 VGPRs and 13 KB of LDS —
+// and RCCL's transfer kernel (ncclDevKernel_Generic: 248-256 VGPRs, 37.6 KB of LDS, 256-512 threads per block) becomes resident only on a CU the search does not
+// use (measured with a stand-in of that shape: profiles/r05/rccl_standin.txt).  One process per GPU with a gather beside the search (bench.py --gpus N) sets it.
+int create_slot_stream(mapad_ctx* c, hipStream_t* out) {
+    if (c->reserved_cus > 0 && c->reserved_cus < c->n_cu) {
+        std::vector<uint32_t> mask((size_t)(c->n_cu + 31) / 32, 0u);
+        for (int cu = 0; cu < c->n_cu - c->reserved_cus; ++cu) mask[(size_t)cu / 32] |= 1u << (cu % 32);
+        HIP_TRY(hipExtStreamCreateWithCUMask(out, (uint32_t)mask.size(), mask.data()));
+        return MAPAD_OK;
+    }
+    HIP_TRY(hipStreamCreateWithFlags(out, hipStreamNonBlocking));
+    return MAPAD_OK;
+}
+
 // Makes slot `k` ready for a new batch: its previous batch has finished, its stream exists and waits for the caller's stream.
 int acquire_slot(mapad_ctx* c, int k) {
     BatchSlot& S = c->bs[k];
     if (S.ev_valid) { HIP_TRY(hipStreamSynchronize(S.stream)); int rc = record_times(c, S); if (rc) return rc; }
     if (S.tail) { host::tail_cancel(S.tail); S.tail.reset(); }  // the previous batch of this slot was never collected: its handed-over reads are dropped with it
     if (c->depth == 1) S.stream = c->stream;  // one batch at a time: everything runs on the caller's stream (own_stream stays false)
-    else if (!S.stream) { HIP_TRY(hipStreamCreateWithFlags(&S.stream, hipStreamNonBlocking)); S.own_stream = true; }
+    else if (!S.stream) { const int rc_s = create_slot_stream(c, &S.stream); if (rc_s) return rc_s; S.own_stream = true; }
     if (c->depth > 1) {  // the slot's stream is non-blocking: order it behind whatever the caller has queued on its own stream (async uploads of the inputs)
         if (!S.ev_in) HIP_TRY(hipEventCreateWithFlags(&S.ev_in, hipEventDisableTiming));
         HIP_TRY(hipEventRecord(S.ev_in, c->stream));
@@ -1662,7 +1676,7 @@ int launch_batch(mapad_ctx* c, BatchSlot& S, const uint8_t* d_seqs, const uint8_
         for (auto& o : c->bs) if (&o != &S && o.ev_valid) HIP_TRY(hipStreamWaitEvent(S.stream, o.ev[3], 0));
         others_running = false;  // this launch will have the chip to itself
     }
-    const uint32_t full_waves = c->resident_waves, shared_waves = std::max<uint32_t>(1, std::min<uint32_t>(full_waves, env_u32("MAPAD_SHARED_WAVES_PER_CU", 8) * (uint32_t)c->n_cu));
+    const uint32_t full_waves = c->resident_waves, shared_waves = std::max<uint32_t>(1, std::min<uint32_t>(full_waves, env_u32("MAPAD_SHARED_WAVES_PER_CU", 8) * (uint32_t)(c->depth > 1 ? c->n_cu - c->reserved_cus : c->n_cu)));
     const uint32_t grid_s = warm ? 1u : (uint32_t)std::min<uint64_t>((n_reads + rpw - 1) / rpw, others_running ? shared_waves : full_waves);
     // heavy wavefronts: as many as the chip holds (LDS: heap levels 0-9 + the read's position data); a wavefront that finds no work exits at once
     const uint32_t heavy_lds = heavy_lds_bytes(near_lmax);
@@ -1964,7 +1978,8 @@ int mapad_ctx_create(const mapad_index_t* idx, const mapad_params_t* params, int
     c->device = device_id; c->params = *params; c->index = idx; c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     c->tables = host::make_tables(*params);
     c->depth = (int)std::min<uint32_t>(std::max<uint32_t>(env_u32("MAPAD_PIPELINE_DEPTH", 1), 1), kMaxDepth);
-    c->tail_pops = env_u32("MAPAD_TAIL_POPS", idx->ix.n >= (1ull << 31) ? MAPAD_DEFAULT_TAIL_POPS_LARGE_INDEX : MAPAD_DEFAULT_TAIL_POPS);
+    c->tail_pops = env_u32("MAPAD_TAIL_POPS", MAPAD_DEFAULT_TAIL_POPS);
+    c->reserved_cus = (int)std::min<uint32_t>(env_u32("MAPAD_RESERVED_CUS", 0), (uint32_t)c->n_cu - 1);
     int rc;
     if ((rc = c->d_blocks.ensure(idx->ix.blocks.size()))) return rc;
     HIP_TRY(hipMemcpy(c->d_blocks.p, idx->ix.blocks.data(), idx->ix.blocks.size() * 8, hipMemcpyHostToDevice));
@@ -2272,6 +2287,12 @@ int mapad_last_launch_info(mapad_ctx_t* ctx, uint32_t out[8]) {
     return MAPAD_OK;
 }
 
+int mapad_ctx_set_reserved_cus(mapad_ctx_t* ctx, int n_cus) {
+    if (!ctx || n_cus < 0 || n_cus >= ctx->n_cu) return MAPAD_ERR_INVALID;
+    for (auto& b : ctx->bs) if (b.own_stream) return MAPAD_ERR_INVALID;  // the slots' streams exist already: set this before the first batch / mapad_ctx_reserve
+    ctx->reserved_cus = n_cus;
+    return MAPAD_OK;
+}
 int mapad_ctx_set_pipeline_depth(mapad_ctx_t* ctx, int depth) {
     if (!ctx || depth < 1 || depth > kMaxDepth) return MAPAD_ERR_INVALID;
     if (hipSetDevice(ctx->device) != hipSuccess) return MAPAD_ERR_NO_DEVICE;
@@ -2290,7 +2311,7 @@ int mapad_ctx_reserve(mapad_ctx_t* ctx, uint64_t n_reads, uint64_t total_bases, 
     for (int k = 0; k < ctx->depth; ++k) {
         BatchSlot& S = ctx->bs[k];
         if (ctx->depth == 1) S.stream = ctx->stream;
-        else if (!S.stream) { HIP_TRY(hipStreamCreateWithFlags(&S.stream, hipStreamNonBlocking)); S.own_stream = true; }
+        else if (!S.stream) { const int rc_s = create_slot_stream(ctx, &S.stream); if (rc_s) return rc_s; S.own_stream = true; }
         if ((rc = ensure_batch_buffers(ctx, S, n_reads, total_bases, max_read_len, host_inputs != 0))) return rc;
         // the collect's outputs: ~1 hit per read, one op per base + indels (grown on demand if a batch needs more)
         if ((rc = S.d_c_hit_begin.ensure(n_reads + 1))) return rc;

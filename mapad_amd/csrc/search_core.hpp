@@ -44,7 +44,8 @@ template <class NP>
 MAPAD_HD uint32_t tree_insert(NP nodes, SearchState& st, const Node& nd) {
     const uint32_t key = st.tree_next;
     if (key == st.tree_entries) { st.tree_entries += 1; st.tree_next = key + 1; }
-    else st.tree_next = node_parent(nodes[key]);  // vacant slot stores the next free key
+    else { MAPAD_TOUCH(&nodes[key], 8, false); st.tree_next = node_parent(nodes[key]); }  // vacant slot stores the next free key
+    MAPAD_TOUCH(&nodes[key], sizeof(Node), true);
     nodes[key] = nd;
     st.tree_len += 1;
     return key;
@@ -62,6 +63,7 @@ MAPAD_HD uint32_t free_list_next(NP nodes, uint32_t key) {
     asm volatile("global_load_dword %0, %1, off offset:4\n\ts_waitcnt vmcnt(0)" : "=v"(r) : "v"(p) : "memory");
     return r;
 #else
+    MAPAD_TOUCH(&nodes[key], 8, false);
     return node_parent(nodes[key]);
 #endif
 }
@@ -76,6 +78,7 @@ MAPAD_HD uint32_t tree_alloc(NP nodes, SearchState& st) {
 template <class NP>
 MAPAD_HD void tree_remove(NP nodes, SearchState& st, uint32_t key) {  // backtrack_tree.rs:50-54
     if (key == 0) return;
+    MAPAD_TOUCH(&nodes[key], sizeof(Node), true);
     Node nd = nodes[key];
     nd.w2 &= ~(1ull << 52);
     nd.w0 = (nd.w0 & 0xFFFFFFFFull) | ((uint64_t)st.tree_next << 32);
@@ -95,6 +98,7 @@ MAPAD_RARE uint32_t extract_ops_general(NP nodes, uint32_t end_node, int alignme
     for (int i = 0; i <= L; ++i) { cnt[i] = 0; fill[i] = 0; }
     uint32_t m = 0;
     for (uint32_t s = end_node; s != 0;) {
+        MAPAD_TOUCH(&nodes[s], sizeof(Node), false);
         const Node nd = nodes[s];
         if (!node_occupied(nd)) break;
         cnt[node_op(nd) & 0xFFFFu] += 1;
@@ -127,11 +131,12 @@ MAPAD_RARE uint32_t extract_ops(NP nodes, uint32_t end_node, int alignment_start
         uint32_t m = 0, prev = 0;
         bool in_order = true;
         for (uint32_t s = end_node; s != 0;) {
+            MAPAD_TOUCH(&nodes[s], 8, false);
             const uint64_t w0 = nodes[s].w0;
             const uint32_t op = (uint32_t)w0, p = op & 0xFFFFu;
             in_order = in_order && p >= prev && (int)p < alignment_start;
             prev = p;
-            if (m < out_cap) out[m] = op;
+            if (m < out_cap) { MAPAD_TOUCH(&out[m], 4, true); out[m] = op; }
             m += 1;
             s = (uint32_t)(w0 >> 32);
         }
@@ -148,11 +153,14 @@ MAPAD_HD void hits_push(HP hits, uint32_t& n, const HitRec& h) {
     n += 1;
     while (pos > 0) {
         const uint32_t parent = (pos - 1) >> 1;
+        MAPAD_TOUCH(&hits[parent], sizeof(HitRec), false);
         const HitRec pe = hits[parent];
         if (h.score <= pe.score) break;
+        MAPAD_TOUCH(&hits[pos], sizeof(HitRec), true);
         hits[pos] = pe;
         pos = parent;
     }
+    MAPAD_TOUCH(&hits[pos], sizeof(HitRec), true);
     hits[pos] = h;
 }
 
@@ -234,7 +242,7 @@ MAPAD_HD void commit_child(const DevParams& P, const ReadInT<NLR>& rd, ArenaT<NL
     const uint32_t pos = st.heap_len;
     Ancestors an{};
     if (pushes) an = load_ancestors(A, pos);
-    if (store) A.nodes[id] = nd;
+    if (store) { MAPAD_TOUCH(&A.nodes[id], sizeof(Node), true); A.nodes[id] = nd; }
     st.c_node += 1;
     if (MAPAD_UNLIKELY(len == rd.L)) {  // rare: the state takes a round trip through memory only here, so it can live in registers otherwise
         Node u = nd;
@@ -348,12 +356,14 @@ MAPAD_HD bool search_step(const DevIndex& ix, const DevParams& P, const ReadInT<
 #endif
         uint64_t g1 = 0, g2 = 0, g3 = 0;
         if (MAPAD_UNLIKELY(!hit)) {  // a miss takes the trip to the arena and waits for it here, so that the hit path carries no wait at all (drain_memory)
+            MAPAD_TOUCH(&A.nodes[top.node], sizeof(Node), false);
             const Node g = A.nodes[top.node];
             g1 = g.w1; g2 = g.w2; g3 = g.w3;
             drain_memory();
         }
         top_node.w0 = 0; top_node.w1 = hit ? c1 : g1; top_node.w2 = hit ? c2 : g2; top_node.w3 = hit ? c3 : g3;
     } else {
+        MAPAD_TOUCH(&A.nodes[top.node], sizeof(Node), false);
         top_node = A.nodes[top.node];
     }
     HeapEntry last;
@@ -412,6 +422,7 @@ MAPAD_HD bool search_step(const DevIndex& ix, const DevParams& P, const ReadInT<
 #if defined(MAPAD_PC_STATS) && !defined(__HIP_DEVICE_COMPILE__)
             g_pc_stats[3] += 1;  // nodes fetched ahead
 #endif
+            MAPAD_TOUCH(&A.nodes[id], sizeof(Node), false);
             const Node g = A.nodes[id]; pf1 = g.w1; pf2 = g.w2; pf3 = g.w3; pf_id = id; pf_valid = true;
         };
         if (top_idx < st.heap_len) mm_trickle_down<true>(A, st.heap_len, top_idx, last, fetch);
@@ -596,6 +607,7 @@ MAPAD_HD bool search_step(const DevIndex& ix, const DevParams& P, const ReadInT<
                     pos4[wv] = n0 + base + wv; elt4[wv] = HeapEntry{score, id0 + base + (uint32_t)wv};
                     an4[wv] = load_ancestors(A, pos4[wv]);
                     const uint64_t xl = e.lower[k], xr = e.lower_rev[k], xs = e.size[k];
+                    MAPAD_TOUCH(&A.nodes[elt4[wv].node], sizeof(Node), true);
                     A.nodes[elt4[wv].node] = make_child(t, k, xl, xr, xs);
                 }
                 for (int wv = 0; wv < 4 && base + wv < kids; ++wv) {  // all decisions against the heap as it was, stayers stored
@@ -643,6 +655,7 @@ MAPAD_HD bool search_step(const DevIndex& ix, const DevParams& P, const ReadInT<
                 const uint64_t xr = k == 0 ? e.lower_rev[0] : k == 1 ? e.lower_rev[1] : k == 2 ? e.lower_rev[2] : e.lower_rev[3];
                 const uint64_t xs = k == 0 ? e.size[0] : k == 1 ? e.size[1] : k == 2 ? e.size[2] : e.size[3];
                 made = make_child(t, k, xl, xr, xs);
+                MAPAD_TOUCH(&A.nodes[id], sizeof(Node), true);
                 A.nodes[id] = made;
             }
             const uint32_t fin = mm_bubble_up(A, pos, HeapEntry{score, id}, an);

@@ -10,6 +10,10 @@
 #include <vector>
 
 #define MAPAD_PC_STATS 1
+// Every arena and index access of the host build of the step goes through this hook (csrc/common.hpp: MAPAD_TOUCH): a line-granular model of what lies between a
+// read slot and HBM (emu_touch below) attributes the requests of a pop to the structures that cause them.  Off (one predictable branch) unless a caller asks.
+extern "C" void emu_touch(const void* p, unsigned long bytes, bool wr);
+#define MAPAD_TOUCH(p, bytes, wr) emu_touch((const void*)(p), (unsigned long)(bytes), (wr))
 #define MAPAD_PAR_COMMIT_EMU 1  // the lane-parallel commit of the quad kernel, emulated lane by lane (search_core.hpp); runs when the payload cache is off
 
 #include "../../include/mapad_amd.h"
@@ -18,6 +22,60 @@
 #include "../../mapad_amd/csrc/search_core.hpp"
 
 using namespace mapad;
+
+// ---- request attribution (round 5; the verdict's lever (c): which lines are the ~5 requests per pop that leave the L2?) --------------------------------------
+// A read slot's share of the caches is tiny — 4 MB of L2 per XCD over 5 632 resident read slots = 6 lines of 128 B, 256 MB of Infinity Cache over 45 056 slots = 45 —
+// so each read's ARENA traffic is modelled by a private fully-associative LRU of `cap` lines (write-back, write-allocate without fetch: the L2 keeps byte masks),
+// for several (line size, capacity) pairs at once.  Counted per structure: read misses (a request to the next level) and dirty evictions (a write-back).  Index
+// lines are shared by all reads of the chip and cannot be modelled per read: they are counted as touches (2 per extension) and as distinct lines per read.
+namespace {
+enum { K_INDEX = 0, K_HEAP = 1, K_NODE = 2, K_HITS = 3, K_OTHER = 4, K_N = 5 };
+struct LineCache {
+    uint32_t line_shift = 7, cap = 6;
+    std::vector<std::pair<uint64_t, uint32_t>> lines;  // (line address, kind | dirty << 8), most recently used last
+    uint64_t read_miss[K_N] = {}, writeback[K_N] = {}, access[K_N] = {};
+    void touch(uint64_t addr, uint32_t bytes, bool wr, int kind) {
+        for (uint64_t ln = addr >> line_shift; ln <= (addr + bytes - 1) >> line_shift; ++ln) {
+            access[kind] += 1;
+            size_t i = 0;
+            for (; i < lines.size(); ++i) if (lines[i].first == ln) break;
+            if (i < lines.size()) {
+                auto e = lines[i];
+                if (wr) e.second |= 0x100;
+                lines.erase(lines.begin() + (long)i);
+                lines.push_back(e);
+                continue;
+            }
+            if (!wr) read_miss[kind] += 1;
+            if (lines.size() >= cap) { if (lines.front().second & 0x100) writeback[lines.front().second & 0xFF] += 1; lines.erase(lines.begin()); }
+            lines.emplace_back(ln, (uint32_t)kind | (wr ? 0x100u : 0u));
+        }
+    }
+    void flush() { for (auto& e : lines) if (e.second & 0x100) writeback[e.second & 0xFF] += 1; lines.clear(); }
+};
+struct Attribution {
+    bool on = false;
+    uint64_t heap_lo = 0, heap_hi = 0, node_lo = 0, node_hi = 0, hits_lo = 0, hits_hi = 0, ops_lo = 0, ops_hi = 0, index_lo = 0, index_hi = 0, near_lo = 0, near_hi = 0;
+    std::vector<LineCache> caches;
+    uint64_t index_touches = 0, near_touches = 0, pops = 0;
+    uint64_t heap_level_reads[32] = {};  // arena heap reads by heap level (log2(slot + 1)): where a sift's trips go
+} g_attr;
+}  // namespace
+extern "C" void emu_touch(const void* p, unsigned long bytes, bool wr) {
+    if (!g_attr.on) return;
+    const uint64_t a = (uint64_t)p;
+    int kind = K_OTHER;
+    if (a >= g_attr.near_lo && a < g_attr.near_hi) { g_attr.near_touches += 1; return; }  // LDS on the device
+    if (a >= g_attr.index_lo && a < g_attr.index_hi) { g_attr.index_touches += 1; kind = K_INDEX; }
+    else if (a >= g_attr.heap_lo && a < g_attr.heap_hi) {
+        kind = K_HEAP;
+        if (!wr) { const uint64_t slot = (a - g_attr.heap_lo) / sizeof(HeapEntry); g_attr.heap_level_reads[63 - __builtin_clzll(slot + 1)] += 1; }
+    }
+    else if (a >= g_attr.node_lo && a < g_attr.node_hi) kind = K_NODE;
+    else if ((a >= g_attr.hits_lo && a < g_attr.hits_hi) || (a >= g_attr.ops_lo && a < g_attr.ops_hi)) kind = K_HITS;
+    if (kind == K_INDEX) return;  // shared by every read of the chip: not a per-read cache's business
+    for (auto& c : g_attr.caches) c.touch(a, (uint32_t)bytes, wr, kind);
+}
 
 namespace {
 struct EmuResult {
@@ -107,11 +165,20 @@ mapad_batch_result_t* emu_map_batch(const uint64_t* blocks, uint64_t n_blocks, u
             A.heap_cap = std::min<uint32_t>(hc, 1u << 22); A.node_cap = (uint32_t)nodes.size(); A.hit_ops_cap = (uint32_t)hit_ops.size();
             A.pc = use_pc ? pc_words : nullptr;
             ReadIn rd{qc.data(), dnear.data(), L, P.reject_thr[L], P.table_base[L]};
+            if (g_attr.on) {  // (the attribution run gives every read an arena it cannot outgrow: no migrations, one set of address ranges per read)
+                g_attr.heap_lo = (uint64_t)A.heap; g_attr.heap_hi = (uint64_t)(heap.data() + heap.size());
+                g_attr.node_lo = (uint64_t)nodes.data(); g_attr.node_hi = (uint64_t)(nodes.data() + nodes.size());
+                g_attr.hits_lo = (uint64_t)hits.data(); g_attr.hits_hi = (uint64_t)(hits.data() + hits.size());
+                g_attr.ops_lo = (uint64_t)hit_ops.data(); g_attr.ops_hi = (uint64_t)(hit_ops.data() + hit_ops.size());
+                g_attr.near_lo = (uint64_t)top.data(); g_attr.near_hi = (uint64_t)(top.data() + top.size());
+                g_attr.index_lo = (uint64_t)ix.blocks; g_attr.index_hi = (uint64_t)(ix.blocks + ix.n_blocks * 16);
+            }
             if (pass == 0) search_read(ix, P, rd, A, st, 0, grow);
             else search_read(ix, P, rd, A, st, 0);
             if (st.status != ST_ARENA_OVERFLOW) break;
             if (pass == 0) second += 1;
         }
+        if (g_attr.on) { for (auto& c : g_attr.caches) c.flush(); g_attr.pops += st.c_pop; }
         r->status[i] = st.status;
         ctr.e_search = st.c_esearch; ctr.n_push = st.c_push; ctr.n_pop = st.c_pop; ctr.n_node = st.c_node; ctr.n_hits = st.c_hits;
         std::memcpy(&r->counters[i], &ctr, sizeof ctr);
@@ -132,6 +199,21 @@ mapad_batch_result_t* emu_map_batch(const uint64_t* blocks, uint64_t n_blocks, u
     return &r->pub;
 }
 void emu_result_free(mapad_batch_result_t* r) { if (r) delete reinterpret_cast<EmuResult*>(r); }
+
+// Request attribution: emu_attr_begin(configs as (line_shift, capacity) pairs) ... emu_map_batch(...) ... emu_attr_end(out): per config and structure
+// {accesses, read misses, write-backs}, then the totals.  out: n_cfg x 5 kinds x 3 u64, then {pops, index touches, near touches}, then 32 heap-level read counts.
+void emu_attr_begin(const uint32_t* cfg, uint32_t n_cfg) {
+    g_attr = Attribution();
+    for (uint32_t i = 0; i < n_cfg; ++i) { LineCache c; c.line_shift = cfg[2 * i]; c.cap = cfg[2 * i + 1]; g_attr.caches.push_back(c); }
+    g_attr.on = true;
+}
+void emu_attr_end(uint64_t* out) {
+    g_attr.on = false;
+    size_t k = 0;
+    for (auto& c : g_attr.caches) for (int kind = 0; kind < K_N; ++kind) { out[k++] = c.access[kind]; out[k++] = c.read_miss[kind]; out[k++] = c.writeback[kind]; }
+    out[k++] = g_attr.pops; out[k++] = g_attr.index_touches; out[k++] = g_attr.near_touches;
+    for (int l = 0; l < 32; ++l) out[k++] = g_attr.heap_level_reads[l];
+}
 
 // Property check of the lane-parallel commit (search_core.hpp: MAPAD_PAR_COMMIT) on random heaps: `trials` times a min-max heap of n0 in [16, max_n] entries is
 // built by sequential pushes of scores drawn from `levels` distinct values (few levels = many ties, the common case of the no-damage model), then k in [1, 9]
