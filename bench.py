@@ -134,6 +134,7 @@ def main():
                     help="N > 1: weak = --reads per GPU (total work grows with N); strong = ONE chunk of --reads reads cut into N contiguous slices (SURVEY 8e)")
     ap.add_argument("--watchdog-s", type=float, default=600.0, help="N > 1: exit 3 if no step or gather completes for this long (a starved transfer must not hang the node)")
     ap.add_argument("--search-waves-per-cu", type=int, default=0, help="resident search wavefronts per CU (0 = the library's default, the same for every N)")
+    ap.add_argument("--reserved-cus", type=int, default=-1, help="CUs the search launches leave free for RCCL's transfer kernels (-1: 8 when N > 1 over nccl, else 0)")
     ap.add_argument("--own-index", action="store_true", help="N > 1: every rank builds its own index instead of loading the files rank 0 wrote")
     args = ap.parse_args()
     if args.depth is None:
@@ -274,6 +275,10 @@ def main():
     stream = torch.cuda.current_stream(dev)
     ctx = mapad_amd.Context(index, params, local_rank)
     ctx.set_stream(ctypes.c_void_p(stream.cuda_stream))
+    # N > 1 over RCCL: the search launches leave a few CUs to the transfer kernels (csrc: create_slot_stream; profiles/r05/rccl_standin.txt for the choice)
+    reserved_cus = args.reserved_cus if args.reserved_cus >= 0 else (8 if world > 1 and args.dist_backend == "nccl" and args.depth > 1 else 0)
+    if reserved_cus:
+        ctx.set_reserved_cus(reserved_cus)
     ctx.set_pipeline_depth(args.depth)
     lens = np.diff(offsets.astype(np.int64))
     max_len = int(lens.max())
@@ -296,6 +301,13 @@ def main():
         pairs = torch.as_tensor(DevArray(p_pairs, (max(n_pairs, 1) * 2,), "<i4"), device=dev)[:n_pairs * 2]
         return recs, text, pairs
 
+    # The gather runs on a stream of its own (round 5): RCCL's transfer kernels need whole CUs (248-256 VGPRs, 37.6 KB of LDS per block) and so start when the search
+    # beside them leaves some free — on the CUs mapad_ctx_set_reserved_cus keeps free, or when a launch thins out.  On the caller's stream a late gather would hold
+    # back everything submitted behind it; on its own stream it only has to be over before ITS batch slot is launched again (`depth` submissions later), which the
+    # step loop enforces with an event.  gather.issue_to_done_ms (per step, on the line) shows how late it ran.
+    gather_stream = torch.cuda.Stream(dev) if world > 1 and args.dist_backend == "nccl" else None
+    gather_events = []  # per gathered step: (issued, done) events on the gather stream
+
     def gather_hits():
         """The only exchange of the path: every rank's record fields in read order (<= 128 bytes per read once the SA lookup is on the device) go to rank 0."""
         if world == 1:
@@ -305,7 +317,15 @@ def main():
         if args.dist_backend == "gloo":
             torch.cuda.synchronize(dev)
             recs, text, pairs = recs.cpu(), text.cpu(), pairs.cpu()
-        return gather_hit_records(recs, text, pairs, rank, world, device=xdev, meta_group=meta_group)
+            return gather_hit_records(recs, text, pairs, rank, world, device=xdev, meta_group=meta_group)
+        gather_stream.wait_stream(torch.cuda.current_stream(dev))  # the record kernels of this batch have been queued on the caller's stream
+        with torch.cuda.stream(gather_stream):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(gather_stream)
+            out = gather_hit_records(recs, text, pairs, rank, world, device=xdev, meta_group=meta_group)
+            e1.record(gather_stream)
+        gather_events.append((e0, e1))
+        return out
 
     tail_steps = []  # per collected step: the host tail's figures (csrc/host_tail.hpp)
 
@@ -336,6 +356,8 @@ def main():
         last = None
         d = args.depth
         for i in range(k):
+            if gather_stream is not None and gather_events:  # the batch slot this submission reuses is the one whose records were gathered last (step i - depth): that transfer must be over
+                torch.cuda.current_stream(dev).wait_event(gather_events[-1][1])
             timed("submit", ctx.map_batch_device, d_seqs.data_ptr(), d_quals.data_ptr(), d_offsets.data_ptr(), n_reads, max_len)
             heartbeat(f"step {i} submitted")
             if i >= d - 1:  # `depth` batches are in flight: collect the oldest (the host waits for it — and for its host tail — while the others map)
@@ -354,6 +376,7 @@ def main():
     torch.cuda.synchronize(dev)
     ctx.kernel_history()  # drop the warm-up launches' time stamps
     tail_steps.clear()
+    gather_events.clear()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize(dev)
@@ -422,6 +445,10 @@ def main():
                             "merged_mapped": int((m_recs[:, 3] != 0).sum()), "merged_text_bytes": int(m_text.size), "merged_pairs": int(m_pairs.size // 2),
                             "payload": "per read an 88-byte record (position, contig, strand, AS / XS / NM / X0 / X1 / XT, text and pair offsets) + its CIGAR / MD / XA text + the (score, size) pairs of the mapping quality",
                             "bytes_per_read": round(sum(gather_bytes) / max(len(gather_bytes), 1) / max(n_reads, 1), 1), "per_rank": rank_rates,
+                            # rank 0, per timed step: from the gather's issue (behind the step's record kernels) to the arrival of the last peer's records; a transfer
+                            # that had to wait for CUs shows here as a step's length instead of a few tens of ms
+                            "issue_to_done_ms": [round(a.elapsed_time(b), 1) for a, b in gather_events[:args.steps]] if gather_events else None,
+                            "reserved_cus": reserved_cus,
                             "exchange": "RCCL point-to-point fan-in to rank 0 over xGMI, issued behind the next step's submission" if args.dist_backend == "nccl" else "gloo through host memory (test mode)",
                             "index": {"built_by": "rank 0, saved, loaded by the others" if shared is not None else "every rank", "save_s": None if t_index_save is None else round(t_index_save, 1), "load_s_per_rank": loads}}
             if not all(ok):

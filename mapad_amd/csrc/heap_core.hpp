@@ -355,8 +355,14 @@ struct HostPrefetch {
 inline HostPrefetch g_host_prefetch;
 #endif
 
-template <bool MAX, bool NL, int TOP, class Hook = NoOccupantHook>
-MAPAD_HD void mm_trickle_down(const ArenaT<NL, TOP>& A, uint32_t n, uint32_t pos, HeapEntry elt, Hook&& occupant = Hook()) {
+// SPEC (device quads, MAPAD_SPEC_SIFT): two strides per trip to the arena.  A sift through a deep heap is a chain of dependent trips — at C4 three or four of
+// them per pop for the read slots with 2^12 ... 2^14 frames, each as long as the slowest of the wavefront's 16 read slots takes (an HBM miss) — and is the
+// longest serial piece of a step; the rank-query loads (one such trip) hide behind it, not the other way round.  With the demand loads of a stride (the hole's
+// children and grandchildren, the same addresses in all four lanes) lane w also asks for the children and grandchildren of grandchild w: whichever grandchild
+// the hole moves to, the next stride's six candidates are then in that lane's registers (handed round by ds_bpermute), and the stride after next starts its
+// trip one trip earlier.  The speculative lines are the ones the next stride would have asked for anyway (8 + 16 contiguous entries), plus their siblings.
+template <bool MAX, bool NL, int TOP, class Hook = NoOccupantHook, bool SPEC = false>
+MAPAD_HD void mm_trickle_down(const ArenaT<NL, TOP>& A, uint32_t n, uint32_t pos, HeapEntry elt, Hook&& occupant = Hook(), int w = 0) {
     bool going = true;
     uint32_t placed_node = elt.node;  // node of the entry that was stored into the slot a stride started from (elt itself if the stride stored nothing there)
     const uint32_t start = pos;
@@ -417,6 +423,31 @@ MAPAD_HD void mm_trickle_down(const ArenaT<NL, TOP>& A, uint32_t n, uint32_t pos
             if (!g_near) { hga = load_pair(A.heap + g1); hgb = load_pair(A.heap + g1 + 2); }
             c = c_near ? nc : hc; ga = g_near ? nga : hga; gb = g_near ? ngb : hgb;
         }
+#if defined(__HIP_DEVICE_COMPILE__)
+        if constexpr (SPEC) {
+            // grandchild w of the hole: its children (one pair) and grandchildren (two pairs), if they exist and live in the arena; nothing this stride stores
+            // (the hole's slot, one of its children) is among them
+            const bool spec = (g1 >= (uint32_t)TOP) & (g1 < n);  // quad-uniform
+            const uint32_t G = g1 + (uint32_t)w, sc1 = 2 * G + 1, sg1 = 2 * sc1 + 1;
+            HeapPair sc = HeapPair{}, sga = HeapPair{}, sgb = HeapPair{};
+            if (spec & (sc1 < n)) sc = load_pair(A.heap + sc1);
+            if (spec & (sg1 < n)) { sga = load_pair(A.heap + sg1); sgb = load_pair(A.heap + sg1 + 2); }
+            going = stride(c, ga, gb, c1, g1, set_any);
+            if (spec & going & (2 * pos + 1 < n)) {  // the hole went to grandchild pos = g1 + k: lane k holds the next stride's candidates
+                const int src = (int)((threadIdx.x & ~3u) + (pos - g1)) << 2;
+                auto take = [&](const HeapPair& p) {
+                    HeapPair r;
+                    r.a.score = __uint_as_float((uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)__float_as_uint(p.a.score))); r.a.node = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)p.a.node);
+                    r.b.score = __uint_as_float((uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)__float_as_uint(p.b.score))); r.b.node = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)p.b.node);
+                    return r;
+                };
+                const HeapPair c2 = take(sc), ga2 = take(sga), gb2 = take(sgb);
+                const uint32_t c1b = 2 * pos + 1;
+                going = stride(c2, ga2, gb2, c1b, 2 * c1b + 1, set_any);
+            }
+            continue;
+        }
+#endif
         going = stride(c, ga, gb, c1, g1, set_any);
     }
     hp_set(A, pos, elt);

@@ -385,7 +385,7 @@ __device__ MAPAD_FINALIZE_ATTR void finalize_read(const BatchDev B, const ReadIn
     if (st.status == ST_ARENA_OVERFLOW && tier + 1 < kStages) {  // hand the read to the next stage
         if (w == 0) {
             const uint32_t k = atomicAdd(&B.cursors[CUR_OVF + 2 * tier], 1u);
-            B.overflow_list[(size_t)tier * B.n_reads + k] = read + 1u;  // consumed by the next launch
+            atomicExch(&B.overflow_list[(size_t)tier * B.n_reads + k], read + 1u);  // consumed by the next launch — or, tier 0, by a quad of this one that has run out of reads (search_kernel)
         }
         return;
     }
@@ -476,6 +476,7 @@ __device__ __forceinline__ void copy_units(MAPAD_GLOBAL uint4* dst, const MAPAD_
     for (; i < end; i += LPR) dst[i] = src[i];
 }
 
+constexpr uint32_t kRestarted = 0x40000000u;  // in ArenaT::n_waits: this read gave up waiting for an arena once already (taken from the restart list): it waits as long as it takes now
 constexpr uint32_t kAskTail = 0x80000000u;  // in ArenaT::n_waits: the read's last request found its arena class dry and the class is one the host tail takes reads of
 template <int LPR, bool NL, int TOP = kTop, bool HITS = false>
 struct DeviceGrow {
@@ -528,7 +529,7 @@ struct DeviceGrow {
             // only reads that are still small give up (cheap to restart, and it is the many mid-size reads that clog the big pools);
             // a read that already fills a large arena keeps waiting for the few larger ones.  With the heavy path every waiting read may give up:
             // the arenas it waits for can be held by SUSPENDED reads, which only move again in the next launch (heavy_kernel.hpp).
-            if (may_give_up && (first < 4 || gp->heavy_min_class < (uint32_t)kClasses) && (++A.n_waits & ~kAskTail) > gp->max_waits) return GROW_NEVER;
+            if (may_give_up && !(A.n_waits & kRestarted) && (first < 4 || gp->heavy_min_class < (uint32_t)kClasses) && (++A.n_waits & ~(kAskTail | kRestarted)) > gp->max_waits) return GROW_NEVER;
             // The big classes are few and held for seconds; a read that queues for one makes no pops and so never reaches the pop budget (round 4: 1 M reads of the
             // C5 mix on 3 Gbp handed reads over until second 372 while the host threads idled).  It asks for the host instead — granted while the host keeps up.
             if (tail_min_class < (uint32_t)kClasses && need >= tail_min_class) A.n_waits |= kAskTail;
@@ -721,6 +722,7 @@ __global__ void __launch_bounds__(64, (LPR == 1 && NL) ? 1 : LPR == 2 ? 2 : MAPA
     const uint32_t wide_copy_nodes = GP->wide_copy_nodes;
     const uint32_t tail_pops = B0.tail_pops;
     bool tail_denied = false;  // the ring was full when this read asked: it stays on the GPU
+    bool drained = false;      // the launch's own list of reads is exhausted (this quad has seen its end)
 #if defined(MAPAD_PROFILE_SECTIONS)
     if (lane < 2 * PROF_N + 2) g_prof_lds[lane] = 0;
     g_prof_hist[lane] = 0;
@@ -736,12 +738,36 @@ __global__ void __launch_bounds__(64, (LPR == 1 && NL) ? 1 : LPR == 2 ? 2 : MAPA
         MAPAD_MARK(PROF_LOOP);
         if (!have && !done) {
             uint32_t item = 0;
-            if (w == 0) item = atomicAdd(work, 1u);
+            if (w == 0 && !drained) item = atomicAdd(work, 1u);
             item = group_bcast<LPR>(item);
-            if (item >= n_items) done = true;
+            uint32_t again = ~0u;  // an entry of the restart list
+            if (PASS == 0 && !HEAVY && (drained | (item >= n_items))) {  // (not with reads suspended to heavy wavefronts: the arenas a waiting read needs may be held by suspended reads, which only move in the next launch — there every waiting read must be able to give up)
+                // Out of reads.  The reads of this launch that gave up waiting for an arena start again in the next launch — which begins when the LAST read of this
+                // one is done, although quads idle here from the moment the bulk is through (C5 mix, 1 M reads on 3 Gbp: 25 000-33 000 such reads; the second launch
+                // was a quarter of the batch's time).  A quad that has run out takes them over: it claims the next entry of the restart list (the next launch's
+                // work counter, by CAS, so that no entry is skipped) and starts that read from scratch, as the next launch would.  Entries appended later are the
+                // next launch's, as before.
+                drained = true;
+                if (w == 0) {
+                    const uint32_t cnt = __hip_atomic_load(&cursors[CUR_OVF], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    uint32_t cur = __hip_atomic_load(&cursors[CUR_WORK + 2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    while (cur < cnt) {
+                        const uint32_t old = atomicCAS(&cursors[CUR_WORK + 2], cur, cur + 1u);
+                        if (old == cur) { again = cur; break; }
+                        cur = old;
+                    }
+                }
+                again = group_bcast<LPR>(again);
+            }
+            if ((item >= n_items || drained) && again == ~0u) done = true;
             else {
                 const BatchDev B = kernarg_reload(kArgOffB, B0);
                 const uint32_t* items = B.overflow_list + (size_t)(tier > 0 ? tier - 1 : 0) * B.n_reads;
+                if (again != ~0u) {  // (the entry was reserved before it was written: wait for the writer, a few instructions away)
+                    uint32_t e = 0;
+                    if (w == 0) { while ((e = __hip_atomic_load(&B.overflow_list[again], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0u) __builtin_amdgcn_s_sleep(8); }
+                    read = group_bcast<LPR>(e) - 1u;
+                } else
                 read = tier == 0 ? (B.order ? B.order[item] : item) : items[item] - 1u;
                 const uint64_t off = B.offsets[read];
                 rd.L = (int)(B.offsets[read + 1] - off);
@@ -753,7 +779,7 @@ __global__ void __launch_bounds__(64, (LPR == 1 && NL) ? 1 : LPR == 2 ? 2 : MAPA
                 } else {
                     read_setup(B.seqs + off, B.quals + off, B.d_arrays + off, rd.L, near_qc, near_d, w, LPR);
                     SearchState tmp;
-                    A.n_waits = 0;
+                    A.n_waits = again != ~0u ? kRestarted : 0u;
                     search_init(kernarg_reload(0, ix).n, alignment_start_of(P, rd.L), rd, A, tmp);
                     st = tmp;
                     have = true;
@@ -798,8 +824,9 @@ __global__ void __launch_bounds__(64, (LPR == 1 && NL) ? 1 : LPR == 2 ? 2 : MAPA
                 // tens of millions of pops (mapping.rs:1358-1380).  With the host tail on it goes to a host thread instead (0.34 us per pop), like the reads past the
                 // pop budget; only a full ring leaves it to the GPU's last stage.
                 bool handed = false;
-                if (PASS != 1 && tier + 2 == kStages) { if (MAPAD_UNLIKELY(st.status == ST_ARENA_OVERFLOW)) handed = give_to_host(CUR_TAIL_F); }
-                if (!handed) finalize_read<LPR>(kernarg_reload(kArgOffB, B0), rd, A, st, read, w, tier);
+                const int tier_r = tier + ((A.n_waits & kRestarted) ? 1 : 0);  // a read taken from the restart list is a read of the next stage
+                if (PASS != 1 && tier_r + 2 == kStages) { if (MAPAD_UNLIKELY(st.status == ST_ARENA_OVERFLOW)) handed = give_to_host(CUR_TAIL_F); }
+                if (!handed) finalize_read<LPR>(kernarg_reload(kArgOffB, B0), rd, A, st, read, w, tier_r);
                 back_to_base();
                 have = false;
                 drain_memory();
@@ -1388,7 +1415,10 @@ int ensure_arenas(mapad_ctx* c, BatchSlot& S, uint32_t lmax, uint64_t n_reads) {
         for (auto& a : c->d_class) a.release();
         size_t free_b = 0, total_b = 0;
         HIP_TRY(hipMemGetInfo(&free_b, &total_b));
-        const uint64_t reserve = std::min<uint64_t>(16ull << 30, free_b / 4) + other_slots_bytes;  // batch buffers + the base arenas of the other batches in flight
+        // what the batch slots will ask for behind this: inputs, D arrays, per-read words, hit and edit-op pools and their read-ordered copies, record fields —
+        // about 1.5 KB per read and slot (C4: 10 M reads x 2 slots = 30 GB; the round-4 fit left that much free by accident, the round-5 fit fills what it is given)
+        const uint64_t slot_bytes = (uint64_t)std::min(c->depth, 4) * n_reads * 1536ull;
+        const uint64_t reserve = std::min<uint64_t>(std::max<uint64_t>(16ull << 30, (8ull << 30) + slot_bytes), free_b / 3) + other_slots_bytes;
         uint64_t budget = free_b > reserve ? free_b - reserve : 0;
         if (const uint32_t gb = env_u32("MAPAD_POOL_BUDGET_GB", 0)) budget = std::min<uint64_t>(budget, (uint64_t)gb << 30);
         for (;;) {  // halve the class that holds the most bytes until the pools fit: the classes end up with about the same share of HBM each, i.e. arena counts in
@@ -1468,8 +1498,20 @@ int record_times(mapad_ctx* c, BatchSlot& S) {
 // use (measured with a stand-in of that shape: profiles/r05/rccl_standin.txt).  One process per GPU with a gather beside the search (bench.py --gpus N) sets it.
 int create_slot_stream(mapad_ctx* c, hipStream_t* out) {
     if (c->reserved_cus > 0 && c->reserved_cus < c->n_cu) {
+        // Which CUs: workgroups are dealt to the eight XCDs in turn whatever the mask says, so the reserved CUs must be spread evenly over the XCDs — eight CUs
+        // taken from ONE XCD leave it with a quarter fewer slots than its share of the persistent wavefronts, and the launch ends with a second round on that
+        // XCD (measured: -12 % reads/s; profiles/r05/rccl_standin.txt).  MAPAD_RESERVED_CU_LAYOUT: "blocked" (default: bit i = CU i % 32 of XCD i / 32: the last
+        // CUs of every 32-bit word) or "striped" (bit i = a CU of XCD i % 8: the last bits of the mask).
         std::vector<uint32_t> mask((size_t)(c->n_cu + 31) / 32, 0u);
-        for (int cu = 0; cu < c->n_cu - c->reserved_cus; ++cu) mask[(size_t)cu / 32] |= 1u << (cu % 32);
+        for (int cu = 0; cu < c->n_cu; ++cu) mask[(size_t)cu / 32] |= 1u << (cu % 32);
+        const char* layout = std::getenv("MAPAD_RESERVED_CU_LAYOUT");
+        const bool striped = layout && layout[0] == 's';
+        const int n_xcd = 8, per_xcd = c->n_cu / n_xcd;
+        for (int k = 0; k < c->reserved_cus; ++k) {
+            const int xcd = k % n_xcd, nth = k / n_xcd;  // the nth-last CU of XCD xcd
+            const int bit = striped ? (c->n_cu - 1 - k) : (xcd * per_xcd + per_xcd - 1 - nth);
+            if (bit >= 0 && bit < c->n_cu) mask[(size_t)bit / 32] &= ~(1u << (bit % 32));
+        }
         HIP_TRY(hipExtStreamCreateWithCUMask(out, (uint32_t)mask.size(), mask.data()));
         return MAPAD_OK;
     }
@@ -1548,6 +1590,7 @@ int launch_batch(mapad_ctx* c, BatchSlot& S, const uint8_t* d_seqs, const uint8_
     if (ordered && (rc = zero_async(S.stream, S.d_key_hist.p, (size_t)n_chunks * kKeyBins * 4))) return rc;
     if ((rc = zero_async(S.stream, S.d_cursors.p, CUR_COUNT * 4))) return rc;
     if ((rc = zero_async(S.stream, S.d_status.p, nr * 4))) return rc;
+    if ((rc = zero_async(S.stream, S.d_overflow.p, nr * 4))) return rc;  // the restart list of the first stage: a quad of the same launch may look at an entry before it is written
     BatchDev B{};
     B.seqs = d_seqs; B.quals = d_quals; B.offsets = d_offsets; B.n_reads = (uint32_t)n_reads;
     B.d_arrays = S.d_darr.p; B.counters = S.d_counters.p; B.status = S.d_status.p;
@@ -1595,11 +1638,11 @@ int launch_batch(mapad_ctx* c, BatchSlot& S, const uint8_t* d_seqs, const uint8_
         S.tail = tb;
         B.tail_ring = ring; B.tail_stride = stride; B.tail_cap = cap; B.tail_lmax = tl; B.tail_pops = c->tail_pops;
         // Hand-over on a dry arena class (DeviceGrow::acquire): classes from MAPAD_TAIL_MIN_CLASS up (default 4: the classes whose arena counts are absolute numbers,
-        // not a share of the resident read slots), while the host has fewer than MAPAD_TAIL_BACKLOG reads waiting or running (default: two per worker thread — the
-        // host is never idle while reads queue on the GPU, and never holds more than it can finish in the time the GPU frees an arena).
+        // not a share of the resident read slots), while the host has fewer than MAPAD_TAIL_BACKLOG reads waiting or running (default: one per worker thread — a read is
+        // handed over when a thread is free to start on it; with two per thread the 16 CPUs of the box were the last to finish, 41.6 s against the GPU's 27.9 s).
         B.tail_ctl = ctl;
         B.tail_min_class = env_u32("MAPAD_TAIL_MIN_CLASS", 4);
-        B.tail_backlog_max = env_u32("MAPAD_TAIL_BACKLOG", 2 * host::TailWorkers::instance().size());
+        B.tail_backlog_max = env_u32("MAPAD_TAIL_BACKLOG", host::TailWorkers::instance().size());
     }
     S.last = B; S.last_total_bases = total_bases; S.last_lmax = lmax; S.compacted = false;
     // A process-wide launch number, not a per-slot count: a result of a destroyed context must not pass for the batch of a new context that happens to sit at

@@ -322,6 +322,10 @@ MAPAD_HD void pc_clear(const ArenaT<NL, TOP>& A) { A.pc[0] = 0; A.pc[4] = 0; }
 #if !defined(MAPAD_PAR_COMMIT)
 #define MAPAD_PAR_COMMIT 1
 #endif
+// MAPAD_SPEC_SIFT=1: the pop's sift fetches two strides per trip to the arena (heap_core.hpp: mm_trickle_down<.., SPEC>).  Quads with near data in LDS only.
+#if !defined(MAPAD_SPEC_SIFT)
+#define MAPAD_SPEC_SIFT 1
+#endif
 template <int LPR, bool CONT, bool NL, bool PC = false, class Grow = NoGrow, int TOP = kTop, bool NLR = NL>
 MAPAD_HD bool search_step(const DevIndex& ix, const DevParams& P, const ReadInT<NLR>& rd, ArenaT<NL, TOP>& A, SearchState& st, int w, const Grow& grow) {
     if (st.heap_len == 0 || st.status != ST_OK) return false;
@@ -427,6 +431,10 @@ MAPAD_HD bool search_step(const DevIndex& ix, const DevParams& P, const ReadInT<
         };
         if (top_idx < st.heap_len) mm_trickle_down<true>(A, st.heap_len, top_idx, last, fetch);
     } else {
+#if defined(__HIP_DEVICE_COMPILE__) && MAPAD_SPEC_SIFT
+        if constexpr (LPR == 4 && NL) { if (top_idx < st.heap_len) mm_trickle_down<true, NL, TOP, NoOccupantHook, true>(A, st.heap_len, top_idx, last, NoOccupantHook(), w); }
+        else
+#endif
         if (top_idx < st.heap_len) mm_trickle_down<true>(A, st.heap_len, top_idx, last);
     }
     MAPAD_MARK(PROF_POP);

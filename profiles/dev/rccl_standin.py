@@ -59,7 +59,10 @@ def main():
     print(json.dumps({"standin_alone_ms": round(solo_ms, 2), "bytes": args.bytes, "blocks": args.blocks, "GB/s": round(args.bytes / solo_ms / 1e6, 1)}), flush=True)
     for setting in args.settings.split(","):
         parts = setting.split(":")
-        per_cu, reserved, with_standin = int(parts[0]), int(parts[1]), len(parts) < 3
+        per_cu, reserved = int(parts[0]), int(parts[1])
+        with_standin = "nostandin" not in parts
+        layout = "striped" if "striped" in parts else "blocked"
+        os.environ["MAPAD_RESERVED_CU_LAYOUT"] = layout
         os.environ["MAPAD_SEARCH_BLOCKS_PER_CU"] = str(per_cu)
         stream = torch.cuda.current_stream(dev)
         ctx = mapad_amd.Context(index, mapad_amd.make_params(resolve(NO_DAMAGE)), 0)
@@ -95,7 +98,7 @@ def main():
         torch.cuda.synchronize(dev)
         dt = time.perf_counter() - t0
         hist = ctx.kernel_history().astype(np.float64)
-        out = {"search_blocks_per_cu": per_cu, "reserved_cus": reserved, "standin": with_standin, "reads_per_s": round(args.reads * args.steps / dt, 1), "ms_per_step": round(dt / args.steps * 1e3, 1),
+        out = {"search_blocks_per_cu": per_cu, "reserved_cus": reserved, "reserved_layout": layout if reserved else None, "standin": with_standin, "reads_per_s": round(args.reads * args.steps / dt, 1), "ms_per_step": round(dt / args.steps * 1e3, 1),
                "search_ms_per_launch": [round(float(x), 1) for x in (hist[:, 2] - hist[:, 1])],
                "standin_issue_to_done_ms": [round(a.elapsed_time(b), 1) for a, b in ev], "standin_alone_ms": round(solo_ms, 1)}
         print(json.dumps(out), flush=True)

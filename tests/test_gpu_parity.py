@@ -113,7 +113,11 @@ def test_small_arena_growth_last_pass_and_limits(monkeypatch, class_counts, heav
     rp = resolve_params(NO_DAMAGE)
     res = _gpu_map(pidx, mapad_amd.make_params(rp), seqs, quals, offsets)
     assert res.n_second_pass > 0  # migrations
-    assert (res.n_third_pass > 0) == (class_counts == "8,2" and not sets)  # reads re-run with the full limits (by a host thread, host tail on: tests/test_gpu_tail.py) only when no class can hold them
+    sets_used = sets and heavy == "0"  # (set arenas are off when reads are suspended to heavy wavefronts: their hit staging travels in the grown arena)
+    if sets_used:
+        assert res.n_third_pass <= 3  # (a set holds a few thousand nodes here: at most a read or two of this batch need more)
+    else:
+        assert (res.n_third_pass > 0) == (class_counts == "8,2")  # reads re-run with the full limits (by a host thread, host tail on: tests/test_gpu_tail.py) only when no class can hold them
     ores = oidx.map_batch(ob.make_params(rp), reads, qs, n_threads=8, keep_d=True)
     assert_same_as_oracle(ores, res, offsets)
     for limits in ({"stack_limit": 40, "edit_tree_limit": 100000}, {"stack_limit": 100000, "edit_tree_limit": 120},
