@@ -134,7 +134,7 @@ def main():
                     help="N > 1: weak = --reads per GPU (total work grows with N); strong = ONE chunk of --reads reads cut into N contiguous slices (SURVEY 8e)")
     ap.add_argument("--watchdog-s", type=float, default=600.0, help="N > 1: exit 3 if no step or gather completes for this long (a starved transfer must not hang the node)")
     ap.add_argument("--search-waves-per-cu", type=int, default=0, help="resident search wavefronts per CU (0 = the library's default, the same for every N)")
-    ap.add_argument("--reserved-cus", type=int, default=-1, help="CUs the search launches leave free for RCCL's transfer kernels (-1: 8 when N > 1 over nccl, else 0)")
+    ap.add_argument("--reserved-cus", type=int, default=-1, help="CUs the search launches leave free for RCCL's transfer kernels (default 0: see profiles/r05/rccl_standin.txt)")
     ap.add_argument("--own-index", action="store_true", help="N > 1: every rank builds its own index instead of loading the files rank 0 wrote")
     args = ap.parse_args()
     if args.depth is None:
@@ -276,7 +276,10 @@ def main():
     ctx = mapad_amd.Context(index, params, local_rank)
     ctx.set_stream(ctypes.c_void_p(stream.cuda_stream))
     # N > 1 over RCCL: the search launches leave a few CUs to the transfer kernels (csrc: create_slot_stream; profiles/r05/rccl_standin.txt for the choice)
-    reserved_cus = args.reserved_cus if args.reserved_cus >= 0 else (8 if world > 1 and args.dist_backend == "nccl" and args.depth > 1 else 0)
+    # Default 0 (profiles/r05/rccl_standin.txt): a kernel of RCCL's shape issued beside the pipelined C4 loop ran at the boundary between two search launches — one
+    # step late, at no cost to the search — while eight CUs kept free for it (one per XCD) made it run within 0.2 s but cost the search 6.7 %.  The gather has its
+    # own stream and only holds back the launch that reuses its batch slot (below), so a late transfer does not stall the pipeline.
+    reserved_cus = max(args.reserved_cus, 0)
     if reserved_cus:
         ctx.set_reserved_cus(reserved_cus)
     ctx.set_pipeline_depth(args.depth)

@@ -287,7 +287,7 @@ int cmd_map(const Args& a, uint64_t seed, const std::vector<int>& devices, const
     // in input order; on the way out a small pool of ENCODE threads turns a finished chunk each into BGZF blocks, written in input order.
     const unsigned cpus = std::max(1u, mapad_host_cpus());
     const unsigned parse_threads = (unsigned)std::max(1, std::min(std::atoi(a.get("parse_threads", "0").c_str()) ? std::atoi(a.get("parse_threads", "0").c_str()) : (int)std::max(1u, cpus / 5), 16));
-    const unsigned encode_threads = (unsigned)std::max(1, std::min(std::atoi(a.get("encode_threads", "0").c_str()) ? std::atoi(a.get("encode_threads", "0").c_str()) : (int)std::max(1u, cpus * 3 / 8), 32));
+    const unsigned encode_threads = (unsigned)std::max(1, std::min(std::atoi(a.get("encode_threads", "0").c_str()) ? std::atoi(a.get("encode_threads", "0").c_str()) : (int)std::max(1u, cpus / 2), 32));
     std::vector<std::unique_ptr<BoundedQueue<ChunkPtr>>> dev_q;
     for (size_t d = 0; d < n_dev; ++d) dev_q.emplace_back(new BoundedQueue<ChunkPtr>(2));  // read ahead; `in_flight` more are on the device
     BoundedQueue<ChunkPtr> rec_q(4), done_q(encode_threads + 2);
@@ -532,32 +532,45 @@ int cmd_map(const Args& a, uint64_t seed, const std::vector<int>& devices, const
     });
 
     // ---- writer: encode pool -> BGZF blocks in input order ----
+    // A finished chunk is cut into `pieces` contiguous record ranges; every piece is a task of the encode pool (BAM encoding + BGZF deflate of whole blocks) and
+    // the writer thread writes the pieces in (chunk, piece) order.  Pieces, not whole chunks, are the unit: deflate is the most expensive host stage (2.5 us per
+    // record on one thread — a 1 M-read chunk would sit in one thread for 2.5 s, and the chunks still in the pool when the GPU is done would be the run's tail).
     uint64_t n_total = 0, n_mapped = 0;
+    const unsigned pieces = encode_threads;
     struct Encoded { std::vector<uint8_t> comp; uint64_t n = 0, mapped = 0; };
+    struct EncodeTask { ChunkPtr c; uint64_t seq = 0; unsigned k = 0; std::shared_ptr<std::atomic<unsigned>> left; };
+    BoundedQueue<EncodeTask> task_q(4 * pieces);
     std::mutex out_mu;
     std::condition_variable out_cv;
-    std::map<uint64_t, std::shared_ptr<Encoded>> encoded;  // finished out of turn
+    std::map<uint64_t, std::shared_ptr<Encoded>> encoded;  // finished out of turn, keyed seq * pieces + k
     uint64_t write_next = 0;
     bool encoders_done = false;
     std::atomic<unsigned> encoders_left{encode_threads};
-    // The order of the output is the order of the chunks (mapping.rs:288); chunk numbers have no gaps except for blocks that held no record — those never reach
-    // this stage, so the writer goes by the sequence in which chunks ENTER the encode pool (done_q is fed in order by the records thread).
-    std::atomic<uint64_t> enter_seq{0};
-    std::mutex pop_mu;
+    std::thread splitter([&] {  // chunks arrive in input order (the records thread feeds done_q in order): number them and cut them into tasks
+        uint64_t seq = 0;
+        ChunkPtr c;
+        while (done_q.pop(c)) {
+            if (failed) continue;
+            auto left = std::make_shared<std::atomic<unsigned>>(pieces);
+            for (unsigned k = 0; k < pieces; ++k) task_q.push(EncodeTask{c, seq, k, left});
+            seq += 1;
+            c.reset();
+        }
+        task_q.close();
+    });
     auto encoder = [&] {
         try {
-            for (;;) {
-                ChunkPtr c;
-                uint64_t seq;
-                { std::lock_guard<std::mutex> l(pop_mu); if (!done_q.pop(c)) break; seq = enter_seq++; }  // pop and number under one lock: the numbers follow the queue's order
-                if (failed) continue;
+            EncodeTask t;
+            while (task_q.pop(t)) {
+                if (failed) { t = EncodeTask(); continue; }
                 const uint64_t t_w0 = now_us();
+                ChunkPtr& c = t.c;
                 auto e = std::make_shared<Encoded>();
-                const size_t n = c->in.size();
+                const size_t n = c->in.size(), lo = n * t.k / pieces, hi = n * (t.k + 1) / pieces;
                 std::vector<uint8_t> enc;
-                enc.reserve(n * 160);
+                enc.reserve((hi - lo) * 160);
                 size_t d = 0;
-                for (size_t i = 0; i < n; ++i) {
+                for (size_t i = lo; i < hi; ++i) {
                     OutFields f;
                     const int64_t r = c->read_of[i];
                     if (r < 0) f.flags = (uint16_t)((c->in[i].flags & ~(0x8 | 0x20 | 0x2 | 0x100 | 0x800 | 0x10)) | 0x4);  // unmapped (mapping.rs:748-776)
@@ -573,21 +586,18 @@ int cmd_map(const Args& a, uint64_t seed, const std::vector<int>& devices, const
                     f.xd = c->per_read_s;  // the reference stores the wall time of each read's search (mapping.rs:912-918); here: chunk time / reads
                     encode_bam_record(c->in[i], f, rg, enc);
                 }
-                BgzfWriter::compress_all(enc.data(), enc.size(), e->comp);  // whole BGZF blocks; written in order by whoever holds the next chunk
-                e->n = n;
-                for (auto& sl : c->slices) { mapad_records_free(sl.recs); mapad_batch_result_free(sl.res); sl.recs = nullptr; sl.res = nullptr; }
-                c.reset();
+                BgzfWriter::compress_all(enc.data(), enc.size(), e->comp);  // whole BGZF blocks; written in order by the writer thread
+                e->n = hi - lo;
+                if (--*t.left == 0)  // the chunk's last piece: its results go back to the library
+                    for (auto& sl : c->slices) { mapad_records_free(sl.recs); mapad_batch_result_free(sl.res); sl.recs = nullptr; sl.res = nullptr; }
+                const uint64_t key = t.seq * pieces + t.k;
+                t = EncodeTask();
                 us_encode += now_us() - t_w0;
-                {
-                    std::unique_lock<std::mutex> l(out_mu);
-                    encoded.emplace(seq, std::move(e));
-                    // a thread far ahead of the writer waits here, so that the encoded chunks in memory stay a handful
-                    out_cv.wait(l, [&] { return seq < write_next + 2 * encode_threads || failed.load(); });
-                }
+                { std::lock_guard<std::mutex> l(out_mu); encoded.emplace(key, std::move(e)); }
                 out_cv.notify_all();
             }
         } catch (const std::exception& e) { fail(e.what()); out_cv.notify_all(); }
-        { ChunkPtr c; std::lock_guard<std::mutex> l(pop_mu); while (done_q.pop(c)) {} }
+        { EncodeTask t; while (task_q.pop(t)) {} }
         if (--encoders_left == 0) { std::lock_guard<std::mutex> l(out_mu); encoders_done = true; }
         out_cv.notify_all();
     };
@@ -604,13 +614,12 @@ int cmd_map(const Args& a, uint64_t seed, const std::vector<int>& devices, const
                     if (it == encoded.end()) { if (encoders_done || failed) break; continue; }
                     e = std::move(it->second);
                     encoded.erase(it);
+                    write_next += 1;
                 }
                 const uint64_t t_w0 = now_us();
                 out.write_compressed(e->comp);
                 n_total += e->n; n_mapped += e->mapped;
                 us_writer += now_us() - t_w0;
-                { std::lock_guard<std::mutex> l(out_mu); write_next += 1; }
-                out_cv.notify_all();
             }
         } catch (const std::exception& e) { fail(e.what()); out_cv.notify_all(); }
     });
@@ -620,6 +629,7 @@ int cmd_map(const Args& a, uint64_t seed, const std::vector<int>& devices, const
     for (auto& w : workers) w.join();
     rec_q.close();
     recorder.join();
+    splitter.join();
     for (auto& t : encoders) t.join();
     writer.join();
     if (failed) die(fail_msg);

@@ -1420,6 +1420,9 @@ int ensure_arenas(mapad_ctx* c, BatchSlot& S, uint32_t lmax, uint64_t n_reads) {
         const uint64_t slot_bytes = (uint64_t)std::min(c->depth, 4) * n_reads * 1536ull;
         const uint64_t reserve = std::min<uint64_t>(std::max<uint64_t>(16ull << 30, (8ull << 30) + slot_bytes), free_b / 3) + other_slots_bytes;
         uint64_t budget = free_b > reserve ? free_b - reserve : 0;
+        // ... and no more than the reads in flight can make use of (128 KB of grown arenas per read in flight, at least 8 GB): a context for 250 000-read chunks or
+        // for a test's few thousand reads must not take the whole device — a second context on the same GPU (`--devices 0,0`, two ranks on one GPU) needs its share
+        budget = std::min<uint64_t>(budget, std::max<uint64_t>(8ull << 30, in_flight * (128ull << 10)));
         if (const uint32_t gb = env_u32("MAPAD_POOL_BUDGET_GB", 0)) budget = std::min<uint64_t>(budget, (uint64_t)gb << 30);
         for (;;) {  // halve the class that holds the most bytes until the pools fit: the classes end up with about the same share of HBM each, i.e. arena counts in
                     // inverse proportion to arena size — the shape of the reads' heavy tail (P(nodes > x) ~ 1 / x) — instead of all classes losing half at every turn
@@ -1638,11 +1641,12 @@ int launch_batch(mapad_ctx* c, BatchSlot& S, const uint8_t* d_seqs, const uint8_
         S.tail = tb;
         B.tail_ring = ring; B.tail_stride = stride; B.tail_cap = cap; B.tail_lmax = tl; B.tail_pops = c->tail_pops;
         // Hand-over on a dry arena class (DeviceGrow::acquire): classes from MAPAD_TAIL_MIN_CLASS up (default 4: the classes whose arena counts are absolute numbers,
-        // not a share of the resident read slots), while the host has fewer than MAPAD_TAIL_BACKLOG reads waiting or running (default: one per worker thread — a read is
-        // handed over when a thread is free to start on it; with two per thread the 16 CPUs of the box were the last to finish, 41.6 s against the GPU's 27.9 s).
+        // not a share of the resident read slots), while the host has fewer than MAPAD_TAIL_BACKLOG reads waiting or running (default: half the worker threads — such a
+        // read is handed over only when the reads past the pop budget leave threads idle.  1 M reads of the C5 mix on 3 Gbp, 16 threads: limit 32 / 16 / 8 ->
+        // 43.0 / 39.3 / 37.7 s, the host's threads the last to finish each time: profiles/r05/c5_3gbp_1m_budgets.txt).
         B.tail_ctl = ctl;
         B.tail_min_class = env_u32("MAPAD_TAIL_MIN_CLASS", 4);
-        B.tail_backlog_max = env_u32("MAPAD_TAIL_BACKLOG", host::TailWorkers::instance().size());
+        B.tail_backlog_max = env_u32("MAPAD_TAIL_BACKLOG", std::max(1u, host::TailWorkers::instance().size() / 2));
     }
     S.last = B; S.last_total_bases = total_bases; S.last_lmax = lmax; S.compacted = false;
     // A process-wide launch number, not a per-slot count: a result of a destroyed context must not pass for the batch of a new context that happens to sit at

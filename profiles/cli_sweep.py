@@ -1,12 +1,13 @@
-"""mapad-amd map on an 8 M-read FASTQ (C2 workload; CLI_GENOME_BP=3000000000 for C4's) for several --batch_size / --in_flight settings: reads/s and stage busy times."""
+"""mapad-amd map on an 8 M-read FASTQ (C2 workload; CLI_GENOME_BP=3000000000 for C4's; CLI_READS=24000000 for the size of bench.py's leg) for several
+--batch_size / --in_flight [/ --coalesce / pool sizes] settings: reads/s and stage busy times.  Cases: batch:in_flight[:coalesce=N][:parse_threads=N][:encode_threads=N][:ENV=VAL...]"""
 import os, re, subprocess, sys, tempfile, time
 sys.path.insert(0, ".")
 import numpy as np
 from mapad_amd import build as mbuild, synth
-n = 8_000_000
+n = int(float(os.environ.get("CLI_READS", "8000000")))
 genome_bp = int(float(os.environ.get("CLI_GENOME_BP", "48000000")))
 g = synth.genome(genome_bp, seed=1234)
-parts = [synth.reads(g, 2_000_000, 50, seed=4323 + 1000 * k, qual=40) for k in range(4)]
+parts = [synth.reads(g, n // 4, 50, seed=4323 + 1000 * k, qual=40) for k in range(4)]
 seqs = np.concatenate([p[0] for p in parts]); quals = np.concatenate([p[1] for p in parts])
 tmp = tempfile.mkdtemp(prefix="mapad_cli_")
 fa, fq, bam = os.path.join(tmp, "ref.fa"), os.path.join(tmp, "reads.fastq"), os.path.join(tmp, "out.bam")
@@ -37,11 +38,15 @@ if len(sys.argv) > 1:  # e.g. "250000:4:MAPAD_TIER0_WAVES_PER_CU=10"
         cases.append((int(f[0]), int(f[1]), dict(x.split("=") for x in f[2:])))
 for bs, fl, env in cases:
     cmd = base + ["--batch_size", str(bs), "--in_flight", str(fl)]
+    for opt in ("coalesce", "parse_threads", "encode_threads"):
+        if opt in env:
+            cmd += ["--" + opt, env.pop(opt)]
     if env.pop("ROCPROF", None):  # kernel statistics of the run: the summary lands in gpurun_out/prof_cli
         cmd = ["rocprofv3", "--kernel-trace", "--stats", "-d", os.path.join(os.getcwd(), "gpurun_out", "prof_cli"), "-o", "out", "--output-format", "csv", "--"] + cmd
     pr = subprocess.run(cmd, stderr=subprocess.PIPE, text=True, env=dict(os.environ, **env))
     m = re.search(r"mapping ([0-9.]+) s \((\d+) reads/s\)", pr.stderr)
     b = re.search(r"reader ([0-9.]+) s, device worker 0 ([0-9.]+) s, writer ([0-9.]+) s", pr.stderr)
     w = re.search(r"submit ([0-9.]+) s, fetch \(incl. waiting for the GPU\) ([0-9.]+) s, coordinates ([0-9.]+) s; records thread \(strings, MAPQ\) ([0-9.]+) s", pr.stderr)
-    print("   worker:", w.groups() if w else None)
+    hp = re.search(r"host pools.*", pr.stderr)
+    print("   worker:", w.groups() if w else None, "|", hp.group(0) if hp else "")
     print(bs, fl, env, m.group(1) if m else pr.stderr[-300:], m.group(2) if m else "", b.groups() if b else "", flush=True)

@@ -12,7 +12,7 @@ for spec in "$@"; do
   IFS=','; for e in $envs; do export "$e"; done; unset IFS
   for cfg in $CFGS; do
     steps=8; [ "$cfg" = c4 ] && steps=${AB_C4_STEPS:-3}
-    python bench.py --config $cfg --steps $steps --warmup 2 --no-cpu-baseline --no-extras 2> gpurun_out/ab/err_${v}_$cfg.txt | python -c "
+    python bench.py --config $cfg --steps $steps --warmup 2 --no-cpu-baseline --no-extras $AB_EXTRA 2> gpurun_out/ab/err_${v}_$cfg.txt | python -c "
 import json,sys
 try:
     d=json.load(sys.stdin); r=d['roofline']; print('$spec $cfg rep$rep reads/s', d['value'], 'kernel_ms', r['kernel_ms'], 'frac', r['frac'], 'solo', r['solo_launch']['search_ms'], flush=True)
