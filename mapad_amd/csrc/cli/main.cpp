@@ -361,7 +361,10 @@ int cmd_map(const Args& a, uint64_t seed, const std::vector<int>& devices, const
                 auto rb = std::make_shared<RawBlock>();
                 rb->no = block_no;
                 std::vector<std::pair<uint32_t, uint32_t>> lines;
-                const char* block = src.fastq_block(chunk_reads, lines);
+                // ramp-up: the first blocks are single --batch_size chunks, so that the stages behind the reader start after 250 000 reads, not after a coalesced
+                // launch's worth (the fill of the pipeline is dead time for a file of a few dozen launches); then two chunks, then --coalesce chunks per launch
+                const uint64_t block_reads = std::min<uint64_t>(chunk_reads, prm.chunk_size * (block_no < 2 ? 1 : block_no < 4 ? 2 : coalesce));
+                const char* block = src.fastq_block(block_reads, lines);
                 bool regular = block && !lines.empty() && lines.size() % 4 == 0;
                 if (regular) {  // what parse_fastq_record checks, without building the records: a block that passes is parsed by the pool, four lines per record
                     for (size_t i = 0; i < lines.size() && regular; i += 4)
@@ -370,7 +373,7 @@ int cmd_map(const Args& a, uint64_t seed, const std::vector<int>& devices, const
                 if (regular) {
                     const size_t end = (size_t)lines.back().first + lines.back().second;
                     rb->text.assign(block, block + end);
-                    more = lines.size() == 4 * chunk_reads;
+                    more = lines.size() == 4 * block_reads;
                     rb->lines = std::move(lines);
                 } else {
                     auto c = std::make_shared<Chunk>();
@@ -381,16 +384,16 @@ int cmd_map(const Args& a, uint64_t seed, const std::vector<int>& devices, const
                         size_t i = 0;
                         while (i < lines.size()) {
                             if (lines[i].second == 0) { ++i; continue; }
-                            if (i + 4 > lines.size()) { if (lines.size() == 4 * chunk_reads) src.fastq_unread_from(lines[i].first); break; }  // a cut record goes back
+                            if (i + 4 > lines.size()) { if (lines.size() == 4 * block_reads) src.fastq_unread_from(lines[i].first); break; }  // a cut record goes back
                             InRecord r;
                             if (ReadSource::parse_fastq_record(block, &lines[i], r)) admit(*c, bases, std::move(r), true);
                             else std::fprintf(stderr, "Skip record due to an error: malformed FASTQ record\n");
                             i += 4;
                         }
-                        more = lines.size() == 4 * chunk_reads;
+                        more = lines.size() == 4 * block_reads;
                     } else {
                         InRecord r;
-                        while (c->in.size() < chunk_reads && (more = src.next(r))) admit(*c, bases, std::move(r), true);
+                        while (c->in.size() < block_reads && (more = src.next(r))) admit(*c, bases, std::move(r), true);
                     }
                     if (c->in.empty()) { us_reader += now_us() - t_r0; if (more) continue; break; }  // a whole block of blank / malformed records: keep reading
                     finish_chunk(*c);

@@ -95,7 +95,14 @@ inline mapad_params_t decode_params(Cursor& c) {
         break;
     }
     case 2: p.model_kind = MAPAD_MODEL_TEST; p.deam_score = c.get<float>(); p.mm_score = c.get<float>(); p.match_score = c.get<float>(); break;
-    case 1: throw std::runtime_error("the VindijaPwm difference model is not available on the device");
+    case 1: {  // VindijaPwm { ppm_read_ends_symmetric_ct: [f32; 7], position_probability_ct_default, observed_substitution_probability_default } (:340-345): bincode
+        // writes a fixed-size array without a length.  The model has no parameters a caller can set — VindijaPwm::new() (:384-396) is its only constructor — and the
+        // library's tables are built from those constants (host_models.hpp: vindija_get); a message that carries other values is refused rather than mis-scored.
+        static const float want[9] = {0.4f, 0.25f, 0.1f, 0.06f, 0.05f, 0.04f, 0.03f, 0.02f, 0.0005f};
+        for (float w : want) if (c.get<float>() != w) throw std::runtime_error("VindijaPwm with values other than VindijaPwm::new()'s is not supported");
+        p.model_kind = MAPAD_MODEL_VINDIJA_PWM;
+        break;
+    }
     default: throw std::runtime_error("unknown SequenceDifferenceModelDispatch variant");
     }
     switch (c.get<uint32_t>()) {  // MismatchBoundDispatch

@@ -23,6 +23,10 @@ CONTINUOUS = {k: v for k, v in dict(DAMAGE, bound="continuous", cutoff=-0.2, exp
 DOUBLE_STRANDED = dict(DAMAGE, library="double_stranded")
 # `--ignore_base_quality`: one quality level (sequence_difference_models.rs:286-287)
 IGNORE_BQ = dict(DAMAGE, ignore_base_quality=1)
+# the VindijaPwm difference model (sequence_difference_models.rs:336-396; "only for testing purposes" in the reference, reachable through the worker's task sheet):
+# position-dependent C->T probabilities symmetric about the read's middle, alignment starting there (bidirectional search)
+VINDIJA = {"model": "vindija_pwm", "bound": "discrete", "poisson_threshold": 0.03, "base_error_rate": 0.02,
+           "penalty_gap_open": {"log2": 0.001}, "penalty_gap_extend": {"repr_mm_times": 1.0}, "gap_dist_ends": 5, "max_num_gaps_open": 2}
 
 
 def _log2f(x):

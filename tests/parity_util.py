@@ -5,7 +5,7 @@ from oracle import binding as ob
 
 import mapad_amd
 
-from mapad_amd.presets import CONTINUOUS, DAMAGE, DOUBLE_STRANDED, IGNORE_BQ, NO_DAMAGE  # noqa: F401  (benchmark parameter presets)
+from mapad_amd.presets import CONTINUOUS, DAMAGE, DOUBLE_STRANDED, IGNORE_BQ, NO_DAMAGE, VINDIJA  # noqa: F401  (benchmark parameter presets)
 
 
 def split_reads(seqs, quals, offsets):

@@ -7,7 +7,7 @@ from mapad_amd import synth
 from oracle import binding as ob
 
 from kat_util import load, quals_for, resolve_params
-from parity_util import CONTINUOUS, DAMAGE, DOUBLE_STRANDED, IGNORE_BQ, NO_DAMAGE, assert_same_as_oracle, split_reads
+from parity_util import CONTINUOUS, DAMAGE, DOUBLE_STRANDED, IGNORE_BQ, NO_DAMAGE, VINDIJA, assert_same_as_oracle, split_reads
 from test_oracle_kats import KATS, check_search_expectations, integration_reads
 
 pytestmark = pytest.mark.gpu
@@ -50,6 +50,8 @@ def test_search_kat_on_gpu(case):
     ("continuous_mixed_len", CONTINUOUS, dict(qual_range=(20, 40), len_range=(35, 70), indel_frac=0.05)),
     ("double_stranded", DOUBLE_STRANDED, dict(qual_range=(20, 40), damage=dict(f=0.5, t=0.5, d=0.02, s=1.0))),
     ("ignore_base_quality", IGNORE_BQ, dict(qual_range=(2, 40), damage=dict(f=0.5, t=0.5, d=0.02, s=1.0))),
+    # VindijaPwm (sequence_difference_models.rs:336-396): what a dispatcher's task sheet may name (worker.rs:57-75); bidirectional search from the read's middle
+    ("vindija_pwm", VINDIJA, dict(qual_range=(20, 40), damage=dict(f=0.5, t=0.5, d=0.02, s=1.0), len_range=(35, 70), indel_frac=0.05)),
 ])
 @pytest.mark.parametrize("lanes_per_read", ["4", "2", "1"])
 def test_synthetic_batch_matches_oracle(name, prm, kw, lanes_per_read, monkeypatch):

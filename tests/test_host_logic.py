@@ -15,7 +15,7 @@ from oracle import binding as ob
 
 import emu_util
 from kat_util import load, quals_for, resolve_params
-from parity_util import CONTINUOUS, DAMAGE, DOUBLE_STRANDED, IGNORE_BQ, NO_DAMAGE, assert_same_as_oracle, split_reads
+from parity_util import CONTINUOUS, DAMAGE, DOUBLE_STRANDED, IGNORE_BQ, NO_DAMAGE, VINDIJA, assert_same_as_oracle, split_reads
 from test_oracle_kats import KATS, SDM, check_search_expectations, integration_reads
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -218,6 +218,7 @@ def test_kernel_logic_search_kat(case):
     ("continuous_mixed_len", CONTINUOUS, dict(qual_range=(20, 40), len_range=(35, 70), indel_frac=0.05), 150),
     ("double_stranded", DOUBLE_STRANDED, dict(qual_range=(20, 40), damage=dict(f=0.5, t=0.5, d=0.02, s=1.0)), 300),
     ("ignore_base_quality", IGNORE_BQ, dict(qual_range=(2, 40), damage=dict(f=0.5, t=0.5, d=0.02, s=1.0)), 300),
+    ("vindija_pwm", VINDIJA, dict(qual_range=(20, 40), damage=dict(f=0.5, t=0.5, d=0.02, s=1.0), len_range=(35, 70), indel_frac=0.05), 200),
 ])
 @pytest.mark.parametrize("step", ["lane_parallel_commit", "payload_cache"])
 def test_kernel_logic_synthetic(name, prm, kw, n, step, monkeypatch):

@@ -45,6 +45,8 @@ def encode_params(p):
         use_default = b"\x01" + struct.pack("<f", 1e-3) if p.ignore_base_quality else b"\x00"
         model = struct.pack("<I", 0) + lib + struct.pack("<fff", p.ds_deamination_rate, p.ss_deamination_rate, p.divergence) + use_default
         model += struct.pack("<Q", 3) + struct.pack("<fff", 0.1, 0.2, 0.3) + b"\x01" + struct.pack("<h", 7)  # a cache and a flank offset to be skipped
+    elif p.model_kind == 1:  # VindijaPwm { [f32; 7], f32, f32 } (sequence_difference_models.rs:340-345,384-396): a fixed-size array has no length on the wire
+        model = struct.pack("<I9f", 1, 0.4, 0.25, 0.1, 0.06, 0.05, 0.04, 0.03, 0.02, 0.0005)
     else:
         model = struct.pack("<Ifff", 2, p.deam_score, p.mm_score, p.match_score)
     if p.bound_kind == 0:    # MAPAD_BOUND_DISCRETE = variant 1 of MismatchBoundDispatch
@@ -132,14 +134,16 @@ def test_worker_framing_and_record_echo_without_a_gpu():
                 (b"Xf", "f", 1.5), (b"Xd", "d", 2.25), (b"XZ", "Z", b"hello"), (b"XH", "H", b"1AE3"), (b"Ba", "Bc", [-1, 2]), (b"Bb", "BC", [1, 2, 3]),
                 (b"Bd", "Bs", [-300]), (b"Be", "BS", [60000, 1]), (b"Bg", "Bi", [-70000]), (b"Bh", "BI", [4000000000]), (b"Bj", "Bf", [0.5, 0.25])]
     recs = [encode_record(b"ACGTACGT", [30] * 8, b"read1", all_tags, 0x4D), encode_record(b"", [], None, (), 0), encode_record(b"GATTACA", [40] * 7, b"r3")]
+    vindija = mapad_amd.make_params(presets.resolve(presets.DAMAGE))
+    vindija.model_kind = 1  # round 5: the worker takes VindijaPwm (worker.rs:57-75 takes any model) — its values are VindijaPwm::new()'s constants, checked on arrival
     for chunk, (ref, prm) in enumerate([(b"/nonexistent/ref.fa", mapad_amd.make_params(presets.resolve(presets.DAMAGE))), (None, None),
-                                        (b"x", mapad_amd.make_params(presets.resolve(presets.CONTINUOUS)))]):
+                                        (b"x", mapad_amd.make_params(presets.resolve(presets.CONTINUOUS))), (b"y", vindija)]):
         conn.sendall(encode_task(100 + chunk, recs, ref, prm))
         chunk_id, hits, durations = read_result(conn, recs)
         assert chunk_id == 100 + chunk and hits == [[], [], []] and len(durations) == 3
     conn.close()
     assert proc.wait(timeout=60) == 0
-    assert b"3 task(s), 9 reads" in proc.stderr.read()
+    assert b"4 task(s), 12 reads" in proc.stderr.read()
     srv.close()
 
 
@@ -159,7 +163,7 @@ def test_worker_rejects_malformed_tasks(damage):
     elif damage == "trailing_bytes":
         body = good[8:] + b"xx"
         msg = struct.pack("<Q", len(body) + 8) + body
-    else:                            # VindijaPwm (variant 1) is not available on the device
+    else:                            # VindijaPwm (variant 1) with values other than VindijaPwm::new()'s
         body = struct.pack("<QQ", 1, 0) + b"\x00" + b"\x01" + struct.pack("<I", 1) + b"\x00" * 64
         msg = struct.pack("<Q", len(body) + 8) + body
     conn.sendall(msg)
