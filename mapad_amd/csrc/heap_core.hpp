@@ -320,6 +320,34 @@ MAPAD_HD uint32_t mm_bubble_up(const ArenaT<NL, TOP>& A, uint32_t pos, const Hea
 }
 template <bool NL, int TOP>
 MAPAD_HD uint32_t mm_bubble_up(const ArenaT<NL, TOP>& A, uint32_t pos, const HeapEntry elt) { return mm_bubble_up(A, pos, elt, load_ancestors(A, pos)); }
+// What a bubble-up of `elt` from the leaf `pos` will write ABOVE the leaf, judged from its three ancestors alone (the first two compares of mm_bubble_up): the
+// parent's slot if it swaps with the parent (w1), the grandparent's slot of wherever it then sits if it climbs there (w2), and whether it may climb on from there
+// (`climbs`: mm_bubble_up's rare third and further levels, which read and write slots four and more levels above the leaf).  kNoSlot where it writes nothing.
+// The lane-parallel commit lets several movers of a frame bubble up side by side when no later one's ancestors are among an earlier one's writes.
+constexpr uint32_t kNoSlot = 0xFFFFFFFFu;
+struct MoverPlan { uint32_t w1, w2; bool climbs; };
+MAPAD_HD MoverPlan mm_mover_plan(uint32_t pos, const HeapEntry elt, const Ancestors& an) {
+    const uint32_t i1 = pos > 0 ? (pos - 1) >> 1 : 0, i2 = pos > 2 ? (pos - 3) >> 2 : 0, i3 = i1 > 2 ? (i1 - 3) >> 2 : 0;
+    const bool min_level = mm_is_min_level(pos);
+    const uint32_t flip1 = min_level ? 0u : 0x80000000u;
+    const bool moved = (pos > 0) & (flip_sign(elt.score, flip1) > flip_sign(an.e1.score, flip1));
+    const bool greater = min_level == moved;
+    const uint32_t flip2 = greater ? 0u : 0x80000000u;
+    const uint32_t pos1 = moved ? i1 : pos, gp = moved ? i3 : i2;
+    const float ge = moved ? an.e3.score : an.e2.score;
+    const bool moved2 = (pos1 > 2) & (flip_sign(elt.score, flip2) > flip_sign(ge, flip2));
+    MoverPlan m;
+    m.w1 = moved ? i1 : kNoSlot; m.w2 = moved2 ? gp : kNoSlot; m.climbs = moved2 & (gp > 2);
+    return m;
+}
+// Does a mover whose ancestors sit in slots (i1, i2, i3 of `pos`) depend on what an EARLIER mover with plan `a` writes?  (Both may climb on: their further
+// levels can meet.)  A mover's own writes above its leaf are among its ancestors' slots, so two movers that do not depend on each other write disjoint slots.
+MAPAD_HD bool mm_mover_depends(uint32_t pos, bool climbs, const MoverPlan& a) {
+    const uint32_t i1 = pos > 0 ? (pos - 1) >> 1 : 0, i2 = pos > 2 ? (pos - 3) >> 2 : 0, i3 = i1 > 2 ? (i1 - 3) >> 2 : 0;
+    const bool hit1 = (a.w1 != kNoSlot) & ((a.w1 == i1) | (a.w1 == i2) | (a.w1 == i3));
+    const bool hit2 = (a.w2 != kNoSlot) & ((a.w2 == i1) | (a.w2 == i2) | (a.w2 == i3));
+    return hit1 | hit2 | (climbs & a.climbs);
+}
 // Would mm_bubble_up leave `elt` in slot pos (neither of its first two compares moves it)?  Such a push stores one entry and touches no other slot.
 MAPAD_HD bool mm_push_stays(uint32_t pos, const HeapEntry elt, const Ancestors& an) {
     const bool min_level = mm_is_min_level(pos);

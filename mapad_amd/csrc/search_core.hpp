@@ -302,6 +302,7 @@ MAPAD_RARE void search_init(uint64_t n_text, int alignment_start, const ReadInT<
 // the cache.  What leaves the step's dependent chain is one HBM round trip in six.
 #if defined(MAPAD_PC_STATS) && !defined(__HIP_DEVICE_COMPILE__)
 static unsigned long long g_pc_stats[5];
+static unsigned long long g_par_stats[4];  // commits with >= 2 movers in a round of four, their movers, the rounds of bubble-ups they take with the parallel prefix
 static unsigned long long g_commit_stats[8];  // steps with children, children, movers, steps without a mover, steps with >= 3 children, ... of those without a mover, movers in those
 #endif
 template <bool NL, int TOP>
@@ -621,6 +622,25 @@ MAPAD_HD bool search_step(const DevIndex& ix, const DevParams& P, const ReadInT<
                 for (int wv = 0; wv < 4 && base + wv < kids; ++wv) {  // all decisions against the heap as it was, stayers stored
                     if (mm_push_stays(pos4[wv], elt4[wv], an4[wv])) hp_set(A, pos4[wv], elt4[wv]); else movers |= 1u << wv;
                 }
+#if defined(MAPAD_PC_STATS)
+                {   // How many of these rounds of bubble-ups could run side by side?  (round 5: the movers of a round go one after the other, each behind the first with a
+                    // reload — at C3 that is 40 % of the wave time.)  Count the longest prefix of movers, in commit order, none of which depends on an earlier one's writes
+                    // (heap_core.hpp: mm_mover_plan / mm_mover_depends): measured 5 % fewer rounds at C3 (2.9 movers per multi-mover round, nearly all dependent: the four
+                    // leaves share two grandparents and the movers of the damage model climb to them) — not built.
+                    MoverPlan plan4[4];
+                    int n_par = 0, n_mov = 0;
+                    bool open = true;
+                    for (int wv = 0; wv < 4; ++wv) if ((movers >> wv) & 1u) {
+                        plan4[wv] = mm_mover_plan(pos4[wv], elt4[wv], an4[wv]);
+                        bool dep = false;
+                        for (int u = 0; u < wv; ++u) if ((movers >> u) & 1u) dep |= mm_mover_depends(pos4[wv], plan4[wv].climbs, plan4[u]);
+                        open = open && !dep;
+                        n_par += open ? 1 : 0;
+                        n_mov += 1;
+                    }
+                    if (n_mov >= 2) { g_par_stats[0] += 1; g_par_stats[1] += n_mov; g_par_stats[2] += 1 + (n_mov - n_par); }
+                }
+#endif
                 bool first = true;
                 for (int wv = 0; wv < 4; ++wv) if ((movers >> wv) & 1u) {
                     if (!first) an4[wv] = load_ancestors(A, pos4[wv]);

@@ -118,6 +118,7 @@ mapad_batch_result_t* emu_map_batch(const uint64_t* blocks, uint64_t n_blocks, u
     uint64_t pc_words[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     g_pc_stats[0] = g_pc_stats[1] = g_pc_stats[2] = g_pc_stats[3] = g_pc_stats[4] = 0;
     for (auto& x : g_commit_stats) x = 0;
+    for (auto& x : g_par_stats) x = 0;
     std::vector<uint8_t> qc(2 * (lmax + 1));
     std::vector<float> dnear(lmax + 1);
     std::vector<float> pen(lmax + 1), chain(lmax + 1);
@@ -192,6 +193,7 @@ mapad_batch_result_t* emu_map_batch(const uint64_t* blocks, uint64_t n_blocks, u
     }
     if (std::getenv("MAPAD_EMU_PC_STATS")) std::fprintf(stderr, "emu commit loop: %llu steps with children, %llu children, %llu movers, %llu steps without a mover; >= 3 children: %llu steps, %llu without a mover, %llu movers\n",
                                                        g_commit_stats[0], g_commit_stats[1], g_commit_stats[2], g_commit_stats[3], g_commit_stats[4], g_commit_stats[5], g_commit_stats[6]);
+    if (std::getenv("MAPAD_EMU_PC_STATS")) std::fprintf(stderr, "emu lane-parallel commit: %llu rounds with >= 2 movers, %llu movers in them = rounds of bubble-ups one after the other; %llu rounds with the parallel prefix\n", g_par_stats[0], g_par_stats[1], g_par_stats[2]);
     if (std::getenv("MAPAD_EMU_PC_STATS")) std::fprintf(stderr, "emu payload cache: %llu hits, %llu misses, %llu pops of a one-entry heap; %llu nodes fetched ahead, %llu steps with a child landing in slot 1 / 2\n", g_pc_stats[0], g_pc_stats[1], g_pc_stats[2], g_pc_stats[3], g_pc_stats[4]);
     r->pub.n_reads = n_reads; r->pub.n_hits = r->hits.size(); r->pub.n_ops = r->ops.size();
     r->pub.hit_begin = r->hit_begin.data(); r->pub.hits = r->hits.data(); r->pub.ops = r->ops.data(); r->pub.status = r->status.data();
