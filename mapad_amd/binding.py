@@ -154,7 +154,12 @@ def lib():
                 path = _build.build(heap_variant=hv)
         L = C.CDLL(path)
         for name, (res, args) in SYMBOLS.items():
-            fn = getattr(L, name)  # AttributeError = the library does not export what the header declares
+            try:
+                fn = getattr(L, name)  # AttributeError = the library does not export what the header declares
+            except AttributeError:
+                if os.environ.get("MAPAD_AMD_LIB") and os.environ.get("MAPAD_AMD_LIB_OLD_ABI"):  # an A/B run against an older build of the library (profiles/dev/ab3.sh)
+                    continue
+                raise
             fn.restype = res
             fn.argtypes = args
         _lib = L

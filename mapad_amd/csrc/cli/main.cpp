@@ -286,11 +286,18 @@ int cmd_map(const Args& a, uint64_t seed, const std::vector<int>& devices, const
     // lines, a small pool of PARSE threads turns a block each into a chunk (records, page-locked read buffers, slices), and chunks are handed to the device workers
     // in input order; on the way out a small pool of ENCODE threads turns a finished chunk each into BGZF blocks, written in input order.
     const unsigned cpus = std::max(1u, mapad_host_cpus());
-    const unsigned parse_threads = (unsigned)std::max(1, std::min(std::atoi(a.get("parse_threads", "0").c_str()) ? std::atoi(a.get("parse_threads", "0").c_str()) : (int)std::max(1u, cpus / 5), 16));
-    const unsigned encode_threads = (unsigned)std::max(1, std::min(std::atoi(a.get("encode_threads", "0").c_str()) ? std::atoi(a.get("encode_threads", "0").c_str()) : (int)std::max(1u, cpus / 2), 32));
+    // The pools add up to the CPU share: source 1 + parse cpus/8 + device worker(s) + record strings cpus/4 (the library's own pool: MAPAD_POSTPROC_THREADS) + encode
+    // cpus/2.  More runnable threads than the cgroup's quota get the whole process stopped for the rest of a scheduler period, the device worker with it (same-box
+    // against round 4's bursts of 32 threads per stage: profiles/r05/cli_sweep_c4.txt).
+    auto pool_size = [&](const char* opt, unsigned dflt, unsigned hi) { const int v = std::atoi(a.get(opt, "0").c_str()); return (unsigned)std::max(1, std::min(v > 0 ? v : (int)std::max(1u, dflt), (int)hi)); };
+    const unsigned parse_threads = pool_size("parse_threads", cpus / 8, 16), encode_threads = pool_size("encode_threads", cpus / 2, 32);
+    if (!std::getenv("MAPAD_POSTPROC_THREADS")) setenv("MAPAD_POSTPROC_THREADS", std::to_string(pool_size("record_threads", cpus / 4, 32)).c_str(), 1);
     std::vector<std::unique_ptr<BoundedQueue<ChunkPtr>>> dev_q;
     for (size_t d = 0; d < n_dev; ++d) dev_q.emplace_back(new BoundedQueue<ChunkPtr>(2));  // read ahead; `in_flight` more are on the device
-    BoundedQueue<ChunkPtr> rec_q(4), done_q(encode_threads + 2);
+    // (short queues behind the device stage: every chunk waiting there holds a fetched result — 250 MB of page-locked buffers per million reads — and the library
+    //  recycles only a handful of such blocks per size; with ten chunks queued in front of the encode pool every fetch pinned fresh memory and every free unpinned
+    //  it, which waits for the device: fetch + coordinates 9.9 s instead of 7.9 s per 24 M reads, profiles/r05/cli_sweep_c4.txt)
+    BoundedQueue<ChunkPtr> rec_q(2), done_q(2);
     std::atomic<bool> failed{false};
     std::atomic<uint64_t> us_reader{0}, us_parse{0}, us_device{0}, us_writer{0}, us_encode{0}, us_submit{0}, us_fetch{0}, us_records{0}, us_text{0};  // busy time of the stages (the slowest one sets the throughput)
     auto now_us = [] { return (uint64_t)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
@@ -542,7 +549,7 @@ int cmd_map(const Args& a, uint64_t seed, const std::vector<int>& devices, const
     const unsigned pieces = encode_threads;
     struct Encoded { std::vector<uint8_t> comp; uint64_t n = 0, mapped = 0; };
     struct EncodeTask { ChunkPtr c; uint64_t seq = 0; unsigned k = 0; std::shared_ptr<std::atomic<unsigned>> left; };
-    BoundedQueue<EncodeTask> task_q(4 * pieces);
+    BoundedQueue<EncodeTask> task_q(2 * pieces);
     std::mutex out_mu;
     std::condition_variable out_cv;
     std::map<uint64_t, std::shared_ptr<Encoded>> encoded;  // finished out of turn, keyed seq * pieces + k

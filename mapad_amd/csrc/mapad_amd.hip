@@ -765,10 +765,12 @@ __global__ void __launch_bounds__(64, (LPR == 1 && NL) ? 1 : LPR == 2 ? 2 : MAPA
                 const uint32_t* items = B.overflow_list + (size_t)(tier > 0 ? tier - 1 : 0) * B.n_reads;
                 if (again != ~0u) {  // (the entry was reserved before it was written: wait for the writer, a few instructions away)
                     uint32_t e = 0;
-                    if (w == 0) { while ((e = __hip_atomic_load(&B.overflow_list[again], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0u) __builtin_amdgcn_s_sleep(8); }
+                    if (w == 0) { while ((e = atomicExch(&B.overflow_list[again], 0u)) == 0u) __builtin_amdgcn_s_sleep(8); }  // (taken and cleared for the next batch in one go)
                     read = group_bcast<LPR>(e) - 1u;
-                } else
-                read = tier == 0 ? (B.order ? B.order[item] : item) : items[item] - 1u;
+                } else {
+                    read = tier == 0 ? (B.order ? B.order[item] : item) : items[item] - 1u;
+                    if (tier == 1 && w == 0) B.overflow_list[item] = 0u;  // the restart list is left as it was found: zeros
+                }
                 const uint64_t off = B.offsets[read];
                 rd.L = (int)(B.offsets[read + 1] - off);
                 const DevParams Pf = kernarg_reload(kArgOffP, P);  // the two table pointers are only used here
@@ -1164,6 +1166,8 @@ struct BatchSlot {
     uint64_t gen = 0;                     // process-wide serial number of this slot's latest launch: a fetched result knows whether the slot still holds it
     // host tail of the slot's latest launch (host_tail.hpp)
     CoherentBuf tail_ring;  // [64-byte header: control word][records]
+    uint32_t tail_ring_stride = 0, tail_ring_dirty = 0;  // records whose `ready` word the last launch may have set
+    const uint8_t* tail_ring_base = nullptr;
     std::shared_ptr<std::atomic<bool>> tail_launched;  // set once the launch's end event has been recorded (TailBatch::launch_done)
     bool tail_failed = false;  // the host tail of this slot's batch could not be merged: the batch's collect keeps failing (reads handed over would otherwise come back unmapped)
     std::shared_ptr<host::TailBatch> tail;  // set while the launch's handed-over reads have not been merged into its pools
@@ -1562,7 +1566,13 @@ int ensure_batch_buffers(mapad_ctx* c, BatchSlot& S, uint64_t n_reads, uint64_t 
     if ((rc = S.d_status.ensure(nr))) return rc;
     if ((rc = S.d_hit_count.ensure(nr))) return rc;
     if ((rc = S.d_hit_first.ensure(nr))) return rc;
-    if ((rc = S.d_overflow.ensure(nr * kStages))) return rc;
+    {   // the restart list of the first stage must read as zeros before an entry is written (a quad of the same launch may look at a reserved entry first): cleared when
+        // it is allocated, and every entry is cleared again by whoever consumes it — no clearing kernel per launch (one more kernel in front of every search cost
+        // mapad-amd map 5 % at C4: its thousands of one-wavefront blocks queue for wave slots behind the searches in flight)
+        const uint32_t* before = S.d_overflow.p;
+        if ((rc = S.d_overflow.ensure(nr * kStages))) return rc;
+        if (S.d_overflow.p != before) HIP_TRY(hipMemsetAsync(S.d_overflow.p, 0, S.d_overflow.cap * sizeof(uint32_t), S.stream));
+    }
     const uint32_t order_shift = order_shift_for(nr);
     const uint32_t n_chunks = (uint32_t)((nr + (1ull << order_shift) - 1) >> order_shift);
     if (env_u32("MAPAD_ORDER", 1) != 0) {
@@ -1593,7 +1603,6 @@ int launch_batch(mapad_ctx* c, BatchSlot& S, const uint8_t* d_seqs, const uint8_
     if (ordered && (rc = zero_async(S.stream, S.d_key_hist.p, (size_t)n_chunks * kKeyBins * 4))) return rc;
     if ((rc = zero_async(S.stream, S.d_cursors.p, CUR_COUNT * 4))) return rc;
     if ((rc = zero_async(S.stream, S.d_status.p, nr * 4))) return rc;
-    if ((rc = zero_async(S.stream, S.d_overflow.p, nr * 4))) return rc;  // the restart list of the first stage: a quad of the same launch may look at an entry before it is written
     BatchDev B{};
     B.seqs = d_seqs; B.quals = d_quals; B.offsets = d_offsets; B.n_reads = (uint32_t)n_reads;
     B.d_arrays = S.d_darr.p; B.counters = S.d_counters.p; B.status = S.d_status.p;
@@ -1624,7 +1633,11 @@ int launch_batch(mapad_ctx* c, BatchSlot& S, const uint8_t* d_seqs, const uint8_
         uint8_t* ring = S.tail_ring.p + kRingHeader;
         uint32_t* ctl = reinterpret_cast<uint32_t*>(S.tail_ring.p);
         *ctl = host::TailWorkers::instance().pending();
-        for (uint32_t k = 0; k < cap; ++k) reinterpret_cast<host::TailRecord*>(ring + (size_t)k * stride)->ready = 0;
+        // (`ready` words: all of them after a (re)allocation or a change of the record size, else those the slot's previous launch can have set — page-locked coherent
+        //  memory is slow to write from the host, and 65 536 stores in front of every launch were 10 ms of the submitting thread's time)
+        const uint32_t dirty = (S.tail_ring_stride == stride && S.tail_ring_base == S.tail_ring.p) ? std::min<uint32_t>(S.tail_ring_dirty, cap) : cap;
+        for (uint32_t k = 0; k < dirty; ++k) reinterpret_cast<host::TailRecord*>(ring + (size_t)k * stride)->ready = 0;
+        S.tail_ring_stride = stride; S.tail_ring_base = S.tail_ring.p; S.tail_ring_dirty = cap;  // until the launch's count of hand-overs is known (merge_tail)
         auto tb = std::make_shared<host::TailBatch>();
         tb->ix = c->index->ix.view();
         tb->tables = c->tables_snap;
@@ -1765,6 +1778,7 @@ int merge_tail(mapad_ctx* c, BatchSlot& S, uint32_t* cur) {
     std::shared_ptr<host::TailBatch> tb = S.tail;
     S.tail.reset();
     S.tail_failed = true;  // until the results are on the device: a failure below leaves reads marked ST_TAIL, and the batch's collect must go on failing (compact_last)
+    S.tail_ring_dirty = std::min<uint32_t>(cur[CUR_TAIL], tb->cap);  // the launch has ended: this many records were written
     const bool ok = host::tail_finish(tb, cur[CUR_TAIL]);
     if (!ok) { std::fprintf(stderr, "mapad_amd: a read of the host tail could not be mapped (out of host memory?)\n"); return MAPAD_ERR_NOMEM; }
     std::vector<host::TailResult>& res = tb->results;

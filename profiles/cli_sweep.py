@@ -38,6 +38,8 @@ if len(sys.argv) > 1:  # e.g. "250000:4:MAPAD_TIER0_WAVES_PER_CU=10"
         cases.append((int(f[0]), int(f[1]), dict(x.split("=") for x in f[2:])))
 for bs, fl, env in cases:
     cmd = base + ["--batch_size", str(bs), "--in_flight", str(fl)]
+    if env.get("exe"):  # another build of the command (e.g. exe=profiles/dev/r04_bin/mapad-amd: round 4's, with its own library beside it)
+        cmd[0] = os.path.abspath(env.pop("exe"))
     for opt in ("coalesce", "parse_threads", "encode_threads"):
         if opt in env:
             cmd += ["--" + opt, env.pop(opt)]
