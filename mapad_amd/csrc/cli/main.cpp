@@ -280,181 +280,116 @@ int cmd_map(const Args& a, uint64_t seed, const std::vector<int>& devices, const
         }
         out.write(h.data(), h.size());
     }
-    // Host threads.  The process may use mapad_host_cpus() CPUs (visible CPUs capped by the cgroup's CPU-time quota); pools wider than that do not map faster, they get
-    // the whole process throttled — the device worker's thread included.  Round 5: the reader and the writer were one thread each that fanned every chunk out to 32
-    // short-lived threads and did the rest of the chunk alone (bench, C4: busy 57 % and 53 % of the run).  Now a SOURCE thread cuts the input into blocks of whole
-    // lines, a small pool of PARSE threads turns a block each into a chunk (records, page-locked read buffers, slices), and chunks are handed to the device workers
-    // in input order; on the way out a small pool of ENCODE threads turns a finished chunk each into BGZF blocks, written in input order.
-    const unsigned cpus = std::max(1u, mapad_host_cpus());
-    // The pools add up to the CPU share: source 1 + parse cpus/8 + device worker(s) + record strings cpus/4 (the library's own pool: MAPAD_POSTPROC_THREADS) + encode
-    // cpus/2.  More runnable threads than the cgroup's quota get the whole process stopped for the rest of a scheduler period, the device worker with it (same-box
-    // against round 4's bursts of 32 threads per stage: profiles/r05/cli_sweep_c4.txt).
-    auto pool_size = [&](const char* opt, unsigned dflt, unsigned hi) { const int v = std::atoi(a.get(opt, "0").c_str()); return (unsigned)std::max(1, std::min(v > 0 ? v : (int)std::max(1u, dflt), (int)hi)); };
-    const unsigned parse_threads = pool_size("parse_threads", cpus / 8, 16), encode_threads = pool_size("encode_threads", cpus / 2, 32);
-    if (!std::getenv("MAPAD_POSTPROC_THREADS")) setenv("MAPAD_POSTPROC_THREADS", std::to_string(pool_size("record_threads", cpus / 4, 32)).c_str(), 1);
+    // Reader and writer fan every chunk out to short-lived bursts of up to 32 threads (parsing; BAM encoding + BGZF deflate) and do the rest of a chunk themselves.
+    // Round 5 replaced this by standing pools sized to the cgroup's CPU share (a source thread, a parse pool with ordered emit, an encode pool working on pieces of a
+    // chunk, an ordered writer: reader 1.5 s and writer 0.1 s busy instead of 5.5 s each) — and measured it 15-25 % SLOWER end to end on the same box with the same
+    // library (24 M reads at C4: 11.4-13.3 s against 9.7-9.8 s; profiles/r05/cli_sweep_c4.txt): the bursts finish a chunk's host work in a fifth of a second and leave
+    // the CPUs to the device worker in between, the pools keep 10 threads busy all the time.  The pools are in the history (commit d19f153), not in the tree.
+    const unsigned host_threads = std::max(1u, std::min(std::thread::hardware_concurrency(), 32u));
     std::vector<std::unique_ptr<BoundedQueue<ChunkPtr>>> dev_q;
     for (size_t d = 0; d < n_dev; ++d) dev_q.emplace_back(new BoundedQueue<ChunkPtr>(2));  // read ahead; `in_flight` more are on the device
-    // (short queues behind the device stage: every chunk waiting there holds a fetched result — 250 MB of page-locked buffers per million reads — and the library
-    //  recycles only a handful of such blocks per size; with ten chunks queued in front of the encode pool every fetch pinned fresh memory and every free unpinned
-    //  it, which waits for the device: fetch + coordinates 9.9 s instead of 7.9 s per 24 M reads, profiles/r05/cli_sweep_c4.txt)
-    BoundedQueue<ChunkPtr> rec_q(2), done_q(2);
+    BoundedQueue<ChunkPtr> rec_q(4), done_q(4);
     std::atomic<bool> failed{false};
-    std::atomic<uint64_t> us_reader{0}, us_parse{0}, us_device{0}, us_writer{0}, us_encode{0}, us_submit{0}, us_fetch{0}, us_records{0}, us_text{0};  // busy time of the stages (the slowest one sets the throughput)
+    std::atomic<uint64_t> us_reader{0}, us_device{0}, us_writer{0}, us_submit{0}, us_fetch{0}, us_records{0}, us_text{0};  // busy time of the three stages (the slowest one sets the throughput)
     auto now_us = [] { return (uint64_t)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     std::string fail_msg;
     std::mutex fail_mu;
     auto fail = [&](const std::string& m) { std::lock_guard<std::mutex> l(fail_mu); if (!failed.exchange(true)) fail_msg = m; };
 
-    // ---- reader: source -> parse pool -> chunks in input order ----
-    struct RawBlock {
-        uint64_t no = 0;
-        std::vector<char> text;                                // a block of whole lines (regular FASTQ: four per record), owned
-        std::vector<std::pair<uint32_t, uint32_t>> lines;      // (offset, length) into `text`
-        ChunkPtr built;                                        // everything else (BAM / CRAM records, irregular FASTQ text): parsed by the source thread itself
-    };
-    using RawPtr = std::shared_ptr<RawBlock>;
-    BoundedQueue<RawPtr> raw_q(parse_threads + 1);
-    // Reads the device cannot take (longer than MAPAD_MAX_READ_LEN; the reference's limit is i16::MAX, src/map/record.rs:144-150) and empty reads stay in the
-    // output as unmapped records, so that input and output hold the same number of records.
-    auto admit = [](Chunk& c, size_t& bases, InRecord&& r, bool copy) {
-        const bool mappable = !r.seq.empty() && r.seq.size() <= MAPAD_MAX_READ_LEN;
-        if (!mappable) std::fprintf(stderr, "mapad-amd: read \"%s\" (%zu bp) is %s; written as unmapped\n", r.name.c_str(), r.seq.size(), r.seq.empty() ? "empty" : "longer than the device limit");
-        c.read_of.push_back(mappable ? (int64_t)(c.offsets.size() - 1) : -1);
-        if (mappable) {
-            if (copy) { c.seqs.append(r.seq.data(), r.seq.size()); c.quals.append(r.qual.data(), r.seq.size()); }
-            bases += r.seq.size();
-            c.offsets.push_back(bases);
-            c.flags.push_back(r.flags);
-        }
-        c.in.push_back(std::move(r));
-    };
-    auto finish_chunk = [&](Chunk& c) {  // contiguous slices: concatenation in device order = input order
-        const uint64_t n_reads = c.offsets.size() - 1;
-        c.slices.resize(n_dev);
-        for (size_t d = 0; d < n_dev; ++d) {
-            Slice& sl = c.slices[d];
-            const uint64_t base = n_reads / n_dev, extra = n_reads % n_dev;
-            sl.lo = d * base + std::min<uint64_t>(d, extra); sl.hi = sl.lo + base + (d < extra ? 1 : 0);
-            sl.offsets.resize(sl.hi - sl.lo + 1);
-            for (uint64_t i = sl.lo; i <= sl.hi; ++i) sl.offsets[i - sl.lo] = c.offsets[i] - c.offsets[sl.lo];
-        }
-        c.pending = (int)n_dev;
-    };
-    // chunks leave in block order whatever order the parse threads finish them in; the run-wide read count (the records' seeds count in reads of the run) is
-    // assigned here, where the chunks before this one are known
-    std::mutex emit_mu;
-    std::map<uint64_t, ChunkPtr> parsed;  // finished out of turn (nullptr: the block held no record)
-    uint64_t emit_next = 0, reads_so_far = 0;
-    auto emit = [&](uint64_t no, ChunkPtr c) {
-        std::lock_guard<std::mutex> l(emit_mu);
-        parsed.emplace(no, std::move(c));
-        for (auto it = parsed.find(emit_next); it != parsed.end(); it = parsed.find(emit_next)) {
-            ChunkPtr ch = std::move(it->second);
-            parsed.erase(it);
-            emit_next += 1;
-            if (!ch) continue;
-            ch->first_read = reads_so_far;
-            reads_so_far += ch->offsets.size() - 1;
-            ch->t_submit = std::chrono::steady_clock::now();
-            for (size_t d = 0; d < n_dev; ++d) dev_q[d]->push(ch);
-        }
-    };
-    std::thread reader([&] {  // the source
+    // ---- reader ----
+    std::thread reader([&] {
         try {
-            uint64_t block_no = 0;
+            uint64_t chunk_no = 0, reads_so_far = 0;
             bool more = true;
             while (more && !failed) {
                 const uint64_t t_r0 = now_us();
-                auto rb = std::make_shared<RawBlock>();
-                rb->no = block_no;
+                auto c = std::make_shared<Chunk>();
+                c->no = chunk_no;
+                c->first_read = reads_so_far;
+                c->offsets.assign(1, 0);
+                size_t bases = 0;
+                auto admit = [&](InRecord&& r, bool copy) {
+                    // Reads the device cannot take (longer than MAPAD_MAX_READ_LEN; the reference's limit is i16::MAX, src/map/record.rs:144-150) and empty
+                    // reads stay in the output as unmapped records, so that input and output hold the same number of records.
+                    const bool mappable = !r.seq.empty() && r.seq.size() <= MAPAD_MAX_READ_LEN;
+                    if (!mappable) std::fprintf(stderr, "mapad-amd: read \"%s\" (%zu bp) is %s; written as unmapped\n", r.name.c_str(), r.seq.size(), r.seq.empty() ? "empty" : "longer than the device limit");
+                    c->read_of.push_back(mappable ? (int64_t)(c->offsets.size() - 1) : -1);
+                    if (mappable) {
+                        if (copy) { c->seqs.append(r.seq.data(), r.seq.size()); c->quals.append(r.qual.data(), r.seq.size()); }
+                        bases += r.seq.size();
+                        c->offsets.push_back(bases);
+                        c->flags.push_back(r.flags);
+                    }
+                    c->in.push_back(std::move(r));
+                };
                 std::vector<std::pair<uint32_t, uint32_t>> lines;
-                // ramp-up: the first blocks are single --batch_size chunks, so that the stages behind the reader start after 250 000 reads, not after a coalesced
-                // launch's worth (the fill of the pipeline is dead time for a file of a few dozen launches); then two chunks, then --coalesce chunks per launch
-                const uint64_t block_reads = std::min<uint64_t>(chunk_reads, prm.chunk_size * (block_no < 2 ? 1 : block_no < 4 ? 2 : coalesce));
-                const char* block = src.fastq_block(block_reads, lines);
-                bool regular = block && !lines.empty() && lines.size() % 4 == 0;
-                if (regular) {  // what parse_fastq_record checks, without building the records: a block that passes is parsed by the pool, four lines per record
-                    for (size_t i = 0; i < lines.size() && regular; i += 4)
-                        regular = lines[i].second != 0 && block[lines[i].first] == '@' && lines[i + 2].second != 0 && block[lines[i + 2].first] == '+' && lines[i + 1].second == lines[i + 3].second;
-                }
-                if (regular) {
-                    const size_t end = (size_t)lines.back().first + lines.back().second;
-                    rb->text.assign(block, block + end);
-                    more = lines.size() == 4 * block_reads;
-                    rb->lines = std::move(lines);
-                } else {
-                    auto c = std::make_shared<Chunk>();
-                    c->offsets.assign(1, 0);
-                    size_t bases = 0;
-                    if (block) {
-                        // irregular text (blank lines, a malformed record, a truncated tail): the same lines through the tolerant sequential rules
-                        size_t i = 0;
-                        while (i < lines.size()) {
-                            if (lines[i].second == 0) { ++i; continue; }
-                            if (i + 4 > lines.size()) { if (lines.size() == 4 * block_reads) src.fastq_unread_from(lines[i].first); break; }  // a cut record goes back
-                            InRecord r;
-                            if (ReadSource::parse_fastq_record(block, &lines[i], r)) admit(*c, bases, std::move(r), true);
-                            else std::fprintf(stderr, "Skip record due to an error: malformed FASTQ record\n");
-                            i += 4;
-                        }
-                        more = lines.size() == 4 * block_reads;
-                    } else {
-                        InRecord r;
-                        while (c->in.size() < block_reads && (more = src.next(r))) admit(*c, bases, std::move(r), true);
+                const char* block = src.fastq_block(chunk_reads, lines);
+                bool block_done = false;
+                if (block && !lines.empty() && lines.size() % 4 == 0) {
+                    // FASTQ fast path: the chunk's lines are cut sequentially (one memchr per line), the records are parsed by several threads
+                    const size_t n_rec = lines.size() / 4;
+                    std::vector<InRecord> recs(n_rec);
+                    std::vector<char> good(n_rec, 0);
+                    parallel_for(n_rec, host_threads, [&](size_t lo, size_t hi, unsigned) {
+                        for (size_t i = lo; i < hi; ++i) good[i] = ReadSource::parse_fastq_record(block, &lines[4 * i], recs[i]);
+                    });
+                    bool all_good = true;
+                    for (char g : good) all_good &= g != 0;
+                    if (all_good) {
+                        c->in.reserve(n_rec);
+                        for (auto& r : recs) admit(std::move(r), false);
+                        // bases of the mappable reads into the page-locked buffers, in parallel (offsets are known now)
+                        c->seqs.append(nullptr, 0); c->quals.append(nullptr, 0);
+                        c->seqs.resize_uninitialized(bases); c->quals.resize_uninitialized(bases);
+                        parallel_for(c->in.size(), host_threads, [&](size_t lo, size_t hi, unsigned) {
+                            for (size_t i = lo; i < hi; ++i) {
+                                const int64_t k = c->read_of[i];
+                                if (k < 0) continue;
+                                const InRecord& r = c->in[i];
+                                std::memcpy(c->seqs.p + c->offsets[(size_t)k], r.seq.data(), r.seq.size());
+                                std::memcpy(c->quals.p + c->offsets[(size_t)k], r.qual.data(), r.seq.size());
+                            }
+                        });
+                        more = lines.size() == 4 * chunk_reads;
+                        block_done = true;
                     }
-                    if (c->in.empty()) { us_reader += now_us() - t_r0; if (more) continue; break; }  // a whole block of blank / malformed records: keep reading
-                    finish_chunk(*c);
-                    rb->built = c;
                 }
+                if (block && !block_done) {
+                    // irregular text (blank lines, a malformed record, a truncated tail): the same lines through the tolerant sequential rules
+                    size_t i = 0;
+                    while (i < lines.size()) {
+                        if (lines[i].second == 0) { ++i; continue; }
+                        if (i + 4 > lines.size()) { if (lines.size() == 4 * chunk_reads) src.fastq_unread_from(lines[i].first); break; }  // a cut record goes back
+                        InRecord r;
+                        if (ReadSource::parse_fastq_record(block, &lines[i], r)) admit(std::move(r), true);
+                        else std::fprintf(stderr, "Skip record due to an error: malformed FASTQ record\n");
+                        i += 4;
+                    }
+                    more = lines.size() == 4 * chunk_reads;
+                } else if (!block) {
+                    InRecord r;
+                    while (c->in.size() < chunk_reads && (more = src.next(r))) admit(std::move(r), true);
+                }
+                if (c->in.empty()) { if (more) continue; break; }  // a whole block of blank / malformed records: keep reading
+                const uint64_t n_reads = c->offsets.size() - 1;
+                c->slices.resize(n_dev);
+                for (size_t d = 0; d < n_dev; ++d) {  // contiguous slices: concatenation in device order = input order
+                    Slice& sl = c->slices[d];
+                    const uint64_t base = n_reads / n_dev, extra = n_reads % n_dev;
+                    sl.lo = d * base + std::min<uint64_t>(d, extra); sl.hi = sl.lo + base + (d < extra ? 1 : 0);
+                    sl.offsets.resize(sl.hi - sl.lo + 1);
+                    for (uint64_t i = sl.lo; i <= sl.hi; ++i) sl.offsets[i - sl.lo] = c->offsets[i] - c->offsets[sl.lo];
+                }
+                c->pending = (int)n_dev;
                 us_reader += now_us() - t_r0;
-                raw_q.push(rb);
-                block_no += 1;
+                c->t_submit = std::chrono::steady_clock::now();
+                for (size_t d = 0; d < n_dev; ++d) dev_q[d]->push(c);
+                chunk_no += 1;
+                reads_so_far += n_reads;
             }
         } catch (const std::exception& e) { fail(e.what()); }
-        raw_q.close();
+        for (auto& q : dev_q) q->close();
     });
-    std::atomic<unsigned> parsers_left{parse_threads};
-    auto parser = [&] {
-        try {
-            RawPtr rb;
-            while (raw_q.pop(rb)) {
-                if (failed) continue;
-                const uint64_t t0 = now_us();
-                ChunkPtr c = rb->built;
-                if (!c) {
-                    c = std::make_shared<Chunk>();
-                    const size_t n_rec = rb->lines.size() / 4;
-                    c->offsets.assign(1, 0);
-                    c->in.reserve(n_rec); c->read_of.reserve(n_rec); c->offsets.reserve(n_rec + 1); c->flags.reserve(n_rec);
-                    size_t bases = 0;
-                    for (size_t i = 0; i < n_rec; ++i) {
-                        InRecord r;
-                        if (ReadSource::parse_fastq_record(rb->text.data(), &rb->lines[4 * i], r)) admit(*c, bases, std::move(r), false);
-                        else std::fprintf(stderr, "Skip record due to an error: malformed FASTQ record\n");  // (cannot happen: the source checked the block)
-                    }
-                    // bases of the mappable reads into the page-locked buffers (the offsets are known now)
-                    c->seqs.resize_uninitialized(bases); c->quals.resize_uninitialized(bases);
-                    for (size_t i = 0; i < c->in.size(); ++i) {
-                        const int64_t k = c->read_of[i];
-                        if (k < 0) continue;
-                        const InRecord& r = c->in[i];
-                        std::memcpy(c->seqs.p + c->offsets[(size_t)k], r.seq.data(), r.seq.size());
-                        std::memcpy(c->quals.p + c->offsets[(size_t)k], r.qual.data(), r.seq.size());
-                    }
-                    finish_chunk(*c);
-                }
-                c->no = rb->no;
-                const uint64_t no = rb->no;
-                rb.reset();
-                us_parse += now_us() - t0;
-                emit(no, c->in.empty() ? nullptr : c);
-            }
-        } catch (const std::exception& e) { fail(e.what()); }
-        { RawPtr rb; while (raw_q.pop(rb)) {} }
-        if (--parsers_left == 0) for (auto& q : dev_q) q->close();
-    };
-    std::vector<std::thread> parsers;
-    for (unsigned t = 0; t < parse_threads; ++t) parsers.emplace_back(parser);
 
     // ---- device workers ----
     auto worker = [&](size_t d) {
@@ -541,106 +476,50 @@ int cmd_map(const Args& a, uint64_t seed, const std::vector<int>& devices, const
         done_q.close();
     });
 
-    // ---- writer: encode pool -> BGZF blocks in input order ----
-    // A finished chunk is cut into `pieces` contiguous record ranges; every piece is a task of the encode pool (BAM encoding + BGZF deflate of whole blocks) and
-    // the writer thread writes the pieces in (chunk, piece) order.  Pieces, not whole chunks, are the unit: deflate is the most expensive host stage (2.5 us per
-    // record on one thread — a 1 M-read chunk would sit in one thread for 2.5 s, and the chunks still in the pool when the GPU is done would be the run's tail).
+    // ---- writer ----
     uint64_t n_total = 0, n_mapped = 0;
-    const unsigned pieces = encode_threads;
-    struct Encoded { std::vector<uint8_t> comp; uint64_t n = 0, mapped = 0; };
-    struct EncodeTask { ChunkPtr c; uint64_t seq = 0; unsigned k = 0; std::shared_ptr<std::atomic<unsigned>> left; };
-    BoundedQueue<EncodeTask> task_q(2 * pieces);
-    std::mutex out_mu;
-    std::condition_variable out_cv;
-    std::map<uint64_t, std::shared_ptr<Encoded>> encoded;  // finished out of turn, keyed seq * pieces + k
-    uint64_t write_next = 0;
-    bool encoders_done = false;
-    std::atomic<unsigned> encoders_left{encode_threads};
-    std::thread splitter([&] {  // chunks arrive in input order (the records thread feeds done_q in order): number them and cut them into tasks
-        uint64_t seq = 0;
-        ChunkPtr c;
-        while (done_q.pop(c)) {
-            if (failed) continue;
-            auto left = std::make_shared<std::atomic<unsigned>>(pieces);
-            for (unsigned k = 0; k < pieces; ++k) task_q.push(EncodeTask{c, seq, k, left});
-            seq += 1;
-            c.reset();
-        }
-        task_q.close();
-    });
-    auto encoder = [&] {
-        try {
-            EncodeTask t;
-            while (task_q.pop(t)) {
-                if (failed) { t = EncodeTask(); continue; }
-                const uint64_t t_w0 = now_us();
-                ChunkPtr& c = t.c;
-                auto e = std::make_shared<Encoded>();
-                const size_t n = c->in.size(), lo = n * t.k / pieces, hi = n * (t.k + 1) / pieces;
-                std::vector<uint8_t> enc;
-                enc.reserve((hi - lo) * 160);
-                size_t d = 0;
-                for (size_t i = lo; i < hi; ++i) {
-                    OutFields f;
-                    const int64_t r = c->read_of[i];
-                    if (r < 0) f.flags = (uint16_t)((c->in[i].flags & ~(0x8 | 0x20 | 0x2 | 0x100 | 0x800 | 0x10)) | 0x4);  // unmapped (mapping.rs:748-776)
-                    else {
-                        while ((uint64_t)r >= c->slices[d].hi) ++d;
-                        const mapad_records_t* recs = c->slices[d].recs;
-                        const mapad_record_t& m = recs->recs[(uint64_t)r - c->slices[d].lo];
-                        f.mapped = m.mapped; f.reverse = m.reverse; f.flags = m.flags; f.tid = m.tid; f.pos = m.pos; f.mapq = m.mapq;
-                        f.cigar.assign(recs->text + m.cigar_off, m.cigar_len); f.md.assign(recs->text + m.md_off, m.md_len); f.xa.assign(recs->text + m.xa_off, m.xa_len);
-                        f.as = m.as_score; f.xs = m.xs_score; f.nm = m.nm; f.x0 = m.x0; f.x1 = m.x1; f.has_xs = m.has_xs; f.has_alt = m.mapped; f.xt = m.xt;
-                        e->mapped += m.mapped;
-                    }
-                    f.xd = c->per_read_s;  // the reference stores the wall time of each read's search (mapping.rs:912-918); here: chunk time / reads
-                    encode_bam_record(c->in[i], f, rg, enc);
-                }
-                BgzfWriter::compress_all(enc.data(), enc.size(), e->comp);  // whole BGZF blocks; written in order by the writer thread
-                e->n = hi - lo;
-                if (--*t.left == 0)  // the chunk's last piece: its results go back to the library
-                    for (auto& sl : c->slices) { mapad_records_free(sl.recs); mapad_batch_result_free(sl.res); sl.recs = nullptr; sl.res = nullptr; }
-                const uint64_t key = t.seq * pieces + t.k;
-                t = EncodeTask();
-                us_encode += now_us() - t_w0;
-                { std::lock_guard<std::mutex> l(out_mu); encoded.emplace(key, std::move(e)); }
-                out_cv.notify_all();
-            }
-        } catch (const std::exception& e) { fail(e.what()); out_cv.notify_all(); }
-        { EncodeTask t; while (task_q.pop(t)) {} }
-        if (--encoders_left == 0) { std::lock_guard<std::mutex> l(out_mu); encoders_done = true; }
-        out_cv.notify_all();
-    };
-    std::vector<std::thread> encoders;
-    for (unsigned t = 0; t < encode_threads; ++t) encoders.emplace_back(encoder);
     std::thread writer([&] {
         try {
-            for (;;) {
-                std::shared_ptr<Encoded> e;
-                {
-                    std::unique_lock<std::mutex> l(out_mu);
-                    out_cv.wait(l, [&] { return encoded.count(write_next) || encoders_done || failed.load(); });
-                    auto it = encoded.find(write_next);
-                    if (it == encoded.end()) { if (encoders_done || failed) break; continue; }
-                    e = std::move(it->second);
-                    encoded.erase(it);
-                    write_next += 1;
-                }
+            ChunkPtr c;
+            while (done_q.pop(c)) {
+                if (failed) continue;
                 const uint64_t t_w0 = now_us();
-                out.write_compressed(e->comp);
-                n_total += e->n; n_mapped += e->mapped;
+                const size_t n = c->in.size();
+                std::vector<std::vector<uint8_t>> enc(host_threads), comp(host_threads);
+                std::vector<uint64_t> mapped(host_threads, 0);
+                parallel_for(n, host_threads, [&](size_t lo, size_t hi, unsigned t) {
+                    size_t d = 0;
+                    for (size_t i = lo; i < hi; ++i) {
+                        OutFields f;
+                        const int64_t r = c->read_of[i];
+                        if (r < 0) f.flags = (uint16_t)((c->in[i].flags & ~(0x8 | 0x20 | 0x2 | 0x100 | 0x800 | 0x10)) | 0x4);  // unmapped (mapping.rs:748-776)
+                        else {
+                            while ((uint64_t)r >= c->slices[d].hi) ++d;
+                            const mapad_records_t* recs = c->slices[d].recs;
+                            const mapad_record_t& m = recs->recs[(uint64_t)r - c->slices[d].lo];
+                            f.mapped = m.mapped; f.reverse = m.reverse; f.flags = m.flags; f.tid = m.tid; f.pos = m.pos; f.mapq = m.mapq;
+                            f.cigar.assign(recs->text + m.cigar_off, m.cigar_len); f.md.assign(recs->text + m.md_off, m.md_len); f.xa.assign(recs->text + m.xa_off, m.xa_len);
+                            f.as = m.as_score; f.xs = m.xs_score; f.nm = m.nm; f.x0 = m.x0; f.x1 = m.x1; f.has_xs = m.has_xs; f.has_alt = m.mapped; f.xt = m.xt;
+                            mapped[t] += m.mapped;
+                        }
+                        f.xd = c->per_read_s;  // the reference stores the wall time of each read's search (mapping.rs:912-918); here: chunk time / reads
+                        encode_bam_record(c->in[i], f, rg, enc[t]);
+                    }
+                    BgzfWriter::compress_all(enc[t].data(), enc[t].size(), comp[t]);  // every thread deflates what it encoded; the blocks are written in order below
+                });
+                for (unsigned t = 0; t < host_threads; ++t) { out.write_compressed(comp[t]); n_mapped += mapped[t]; }
+                n_total += n;
+                for (auto& sl : c->slices) { mapad_records_free(sl.recs); mapad_batch_result_free(sl.res); sl.recs = nullptr; sl.res = nullptr; }
                 us_writer += now_us() - t_w0;
             }
-        } catch (const std::exception& e) { fail(e.what()); out_cv.notify_all(); }
+        } catch (const std::exception& e) { fail(e.what()); }
+        { ChunkPtr c; while (done_q.pop(c)) {} }
     });
 
     reader.join();
-    for (auto& t : parsers) t.join();
     for (auto& w : workers) w.join();
     rec_q.close();
     recorder.join();
-    splitter.join();
-    for (auto& t : encoders) t.join();
     writer.join();
     if (failed) die(fail_msg);
     out.close();
@@ -648,7 +527,6 @@ int cmd_map(const Args& a, uint64_t seed, const std::vector<int>& devices, const
     std::fprintf(stderr, "mapad-amd: %llu reads, %llu mapped; %zu device(s); index + contexts %.2f s, mapping %.2f s (%.0f reads/s)\n", (unsigned long long)n_total,
                  (unsigned long long)n_mapped, n_dev, t_load, t_all - t_load, (double)n_total / std::max(t_all - t_load, 1e-9));
     std::fprintf(stderr, "mapad-amd: stage busy time: reader %.2f s, device worker 0 %.2f s, writer %.2f s\n", us_reader.load() * 1e-6, us_device.load() * 1e-6, us_writer.load() * 1e-6);
-    std::fprintf(stderr, "mapad-amd: host pools (%u CPUs): %u parse threads busy %.2f s in all, %u encode threads busy %.2f s in all\n", cpus, parse_threads, us_parse.load() * 1e-6, encode_threads, us_encode.load() * 1e-6);
     std::fprintf(stderr, "mapad-amd: device worker 0: submit %.2f s, fetch (incl. waiting for the GPU) %.2f s, coordinates %.2f s; records thread (strings, MAPQ) %.2f s\n",
                  us_submit.load() * 1e-6, us_fetch.load() * 1e-6, us_records.load() * 1e-6, us_text.load() * 1e-6);
     for (auto* c : ctxs) mapad_ctx_destroy(c);
