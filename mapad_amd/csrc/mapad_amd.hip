@@ -46,13 +46,13 @@ namespace {
 
 enum : uint32_t { ST_POOL_OVERFLOW = 4, ST_NO_TABLE = 8, ST_TAIL = 16 /* handed to the host tail (host_tail.hpp); replaced by the read's final status when its result comes back */ };
 // Launches over a batch (all on the batch's stream):
-//   Q0  search_kernel, every read: one quad per read, a per-slot base arena that GROWS on demand (size classes below).  A read that has outgrown
-//       its base arena is HEAVY: its state moves into the grown arena and the read is suspended (HeavyItem) — the quad takes its next read.
-//   H0  heavy_kernel: one WAVEFRONT per suspended read continues it where the quad stopped (heap levels 0-9 in LDS, the deep levels of a sift
-//       fetched speculatively across the lanes, all children of a frame scored lane-parallel; heavy_kernel.hpp).
-//   Q1  search_kernel again over the reads that gave up waiting for an arena in Q0 (normally none: the launch exits at once), H1 its suspended reads.
-//   F   heavy_kernel from scratch, with arenas that hold the reference's full limits (STACK_LIMIT / EDIT_TREE_LIMIT, mapping.rs:52-54), for the reads
-//       that no size class could hold.
+//   Q0  search_kernel, every read: one quad per read, a per-slot base arena that GROWS on demand (size classes and idle sets of base arenas, below).  A quad that
+//       has run out of reads takes over reads of this launch that gave up waiting for an arena (the restart list).  With the host tail on (the default) a read
+//       leaves for a host thread when it passes the pop budget, queues for a scarce arena class while the host has room, or fits no growable arena.
+//       (MAPAD_HEAVY=1 only: a read that has outgrown its base arena is suspended (HeavyItem) and H0 — heavy_kernel, one WAVEFRONT per read — continues it.)
+//   Q1  search_kernel again over what is left of the restart list (normally nothing: the launch exits at once); these reads wait for arenas as long as it takes.
+//   F   heavy_kernel from scratch, with arenas that hold the reference's full limits (STACK_LIMIT / EDIT_TREE_LIMIT, mapping.rs:52-54), for the reads that no
+//       growable arena could hold — only when the host tail is off or its ring full; otherwise those reads went to the host from Q0 / Q1.
 // Pop budget of a read on the GPU before a host thread takes it over (host_tail.hpp); MAPAD_TAIL_POPS / mapad_ctx_set_tail_pops override, 0 = the host tail is off.
 // 2^20 pops are ~6 s of one quad's time: no 50 bp read of C1-C4 gets near it (heaviest of 10 M C4 reads: 76 272 pops), the heavy tail of the 35-100 bp mix does.
 // Round 5, 1 M reads of the C5 mix on 3 Gbp at the real limits, one GPU + 16 CPUs (profiles/r05/c5_3gbp_1m_budgets.txt): 2^19 -> 51-57 s (the 16 CPUs busy

@@ -26,6 +26,8 @@ def main():
     ap.add_argument("--genome-bp", type=int, default=3_000_000_000)
     ap.add_argument("--chunk", type=int, default=500_000)
     ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r04", "c4_full_parity.json"))
+    ap.add_argument("--against", default=None, help="a committed audit of the same batch (e.g. profiles/r04/c4_full_parity.json): map on the GPU only and compare the digest of the "
+                                                    "results with that audit's ORACLE digest (same arrays, same chunking) — a minute instead of the oracle's 25")
     args = ap.parse_args()
 
     import mapad_amd
@@ -49,6 +51,29 @@ def main():
     ctx.close()
     print(f"index {t_index:.1f} s, GPU mapped {args.reads} reads in {t_gpu:.1f} s ({res.n_hits} hits)", file=sys.stderr, flush=True)
 
+    if args.against:
+        prior = json.load(open(args.against))
+        assert prior["reads_checked"] == args.reads and prior.get("digests_equal"), "the audit to compare with must be a complete one of the same batch"
+        h = hashlib.sha256()
+        hb_all = res.hit_begin.astype(np.int64)
+        c = res.counters
+        for lo in range(0, args.reads, args.chunk):
+            hi = min(lo + args.chunk, args.reads)
+            h0, h1 = int(hb_all[lo]), int(hb_all[hi])
+            g_hits = res.hits_arr[h0:h1]
+            o0 = int(g_hits["ops_offset"][0]) if h1 > h0 else 0
+            n_ops = int(g_hits["n_ops"].astype(np.int64).sum())
+            g_ctr = np.stack([c[k][lo:hi] for k in ("e_search", "e_darray", "n_push", "n_pop", "n_node", "n_hits")], axis=1).astype(np.uint64)
+            for a in ((hb_all[lo:hi + 1] - h0).astype(np.uint64), g_hits["lower"], g_hits["lower_rev"], g_hits["size"], g_hits["score"].view(np.uint32), g_hits["n_ops"].astype(np.uint64), res.ops[o0:o0 + n_ops], g_ctr):
+                h.update(np.ascontiguousarray(a).tobytes())
+        out = {"config": prior["config"], "reads_checked": args.reads, "hits": int(res.n_hits), "sha256_gpu": h.hexdigest(), "sha256_oracle_of": args.against, "sha256_oracle": prior["sha256_oracle"],
+               "digests_equal": h.hexdigest() == prior["sha256_oracle"], "gpu_map_batch_s": round(t_gpu, 1), "index_s": round(t_index, 1), "host_tail_reads": tail["reads"],
+               "what": "this build's GPU results for all reads of the bench's C4 batch, digested like the audit named in sha256_oracle_of (hit offsets, intervals, score bits, edit-track lengths, "
+                       "edit tracks, six event counters per 500 000-read chunk) and compared with the ORACLE digest committed there: equal digests = every read bit-identical to the oracle"}
+        os.makedirs(os.path.dirname(args.out), exist_ok=True)
+        json.dump(out, open(args.out, "w"), indent=1)
+        print(json.dumps(out))
+        return 0 if out["digests_equal"] else 1
     oidx = ob.OracleIndex.from_bwt(index.bwt(), "$ACGTX", 128)
     op = ob.make_params(rp)
     cores = bench.host_cpus()
