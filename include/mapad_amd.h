@@ -137,7 +137,9 @@ int mapad_ctx_set_tail_pops(mapad_ctx_t* ctx, uint32_t pops);
 /* the batch selected by mapad_ctx_select_batch, after its collect / fetch: {reads finished on the host, pops the GPU had spent on them, pops on the host,
  * host wall-clock microseconds from the first hand-over to the last result, host threads, pop budget, and the host reads' E_search, N_push, N_node sums
  * (SURVEY 8d events the kernel did not execute), microseconds the host threads spent inside these reads, summed over the threads,
- * [10] hand-overs the host saw while the launch was still running, [11] reads handed over for reason (b), [12] for reason (c), [13] smallest class of (b), [14-15] 0} */
+ * [10] hand-overs the host saw while the launch was still running, [11] reads handed over for reason (b), [12] for reason (c), [13] smallest class of (b),
+ * [14] reads a host thread CONTINUED from the GPU's state (heap and nodes copied out of the read's grown arena) instead of mapping them from scratch, [15] reads
+ * the kernel handed over with their state.  For continued reads the pop / event figures above count the host's share only.} */
 int mapad_last_tail_info(mapad_ctx_t* ctx, uint64_t out[16]);
 /* whether mapad_fetch_result()/mapad_map_batch() also copy the D arrays back (default on; bench.py turns it off) */
 int mapad_ctx_set_fetch_d_arrays(mapad_ctx_t* ctx, int on);

@@ -441,7 +441,7 @@ class Context:
         out = np.zeros(16, np.uint64)
         _check(lib().mapad_last_tail_info(self.h, _ptr(out)), "mapad_last_tail_info")
         return dict(zip(("reads", "gpu_pops", "host_pops", "host_us", "threads", "budget", "host_e_search", "host_n_push", "host_n_node", "host_thread_us",
-                         "seen_live", "reads_dry_class", "reads_full_limit", "min_class"), (int(x) for x in out)))
+                         "seen_live", "reads_dry_class", "reads_full_limit", "min_class", "continued", "handed_over_with_state"), (int(x) for x in out)))
 
     def launch_info(self):
         out = np.zeros(8, np.uint32)

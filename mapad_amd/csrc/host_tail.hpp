@@ -45,11 +45,23 @@ struct TailRecord {
     uint32_t L;
     uint32_t pops;   // pops the GPU had made when it gave the read up
 };
-inline uint32_t tail_record_stride(uint32_t lmax) { return (16u + ((2u * lmax + 15u) & ~15u) + 4u * lmax + 63u) & ~63u; }
+// Round 5: the record may carry the search itself.  A read that sits in a grown arena when it is handed over (and has found no hit yet) leaves that arena to the
+// host instead of giving it back: heap top written out of LDS into the arena, the SearchState into this block at the end of the record.  A worker copies heap and
+// nodes over PCIe, releases the arena and CONTINUES the search where the GPU stopped — a third of the host tail's pops used to be repeats of the GPU's
+// (1 M reads of the C5 mix: 0.73 G of 1.68 G).  `grown` == 0: no state, the read is mapped from scratch as before.
+struct TailState {
+    uint32_t grown;     // (class + 1) << 27 | arena index (mapad_amd.hip: kGrownShift), 0 = none
+    uint32_t reserved[3];
+    SearchState st;
+};
+static_assert(sizeof(SearchState) == 64 && sizeof(TailState) == 80, "hand-over state block");
+MAPAD_HD uint32_t tail_state_offset(uint32_t lmax) { return (16u + ((2u * lmax + 15u) & ~15u) + 4u * lmax + 15u) & ~15u; }
+MAPAD_HD uint32_t tail_record_stride(uint32_t lmax) { return (tail_state_offset(lmax) + (uint32_t)sizeof(TailState) + 63u) & ~63u; }
 
 struct TailResult {
     uint32_t read = 0, status = 0;
     uint32_t e_search = 0, n_push = 0, n_pop = 0, n_node = 0, n_hits = 0;
+    uint32_t gpu_e_search = 0, gpu_n_push = 0, gpu_n_pop = 0, gpu_n_node = 0;  // of these, what the GPU had done when a continued read changed hands (0: mapped from scratch)
     std::vector<HitRec> hits;   // BinaryHeap array order; ops_off relative to `ops`
     std::vector<uint32_t> ops;
 };
@@ -216,6 +228,11 @@ struct TailBatch {
     uint32_t* ctl = nullptr;        // word the kernel reads before a hand-over it could do without (dry arena class): tasks the workers have waiting or running
     std::function<bool()> launch_done;  // has the launch that writes this ring ended? (set by the library; counts the hand-overs that arrive while it runs)
     uint32_t seen_live = 0;         // records the dispatcher saw while the launch was still running
+    // continuation (TailState): copies heap slots [0, heap_len] (physical, shifted by one) and nodes [0, tree_entries) of the grown arena into the worker's arena and
+    // releases the arena on the device; false = could not (the read is then mapped from scratch and the arena released all the same).  Set by the library.
+    std::function<bool(uint32_t grown, uint32_t heap_len, uint32_t tree_entries, HeapEntry* heap_phys, Node* nodes)> fetch_state;
+    std::vector<uint8_t> fetched;   // per record: its arena has been taken care of (a cancelled batch releases the others: mapad_amd.hip)
+    uint32_t continued = 0;         // reads continued from the GPU's state
 
     std::mutex mu;
     std::condition_variable cv;
@@ -269,7 +286,27 @@ inline void tail_map_read(const std::shared_ptr<TailBatch>& tb, const TailRecord
         A.pc = sc.pc;
         const ReadIn rd{qc, d, L, tb->P.reject_thr[L], tb->P.table_base[L]};
         SearchState st;
-        tail_search(tb->ix, tb->P, rd, A, st, 0, &tb->cancel);
+        const TailState* ts = reinterpret_cast<const TailState*>(reinterpret_cast<const uint8_t*>(rec) + tail_state_offset(tb->lmax));
+        bool resumed = false;
+        if (ts->grown != 0 && tb->fetch_state) {
+            const size_t k = (size_t)((reinterpret_cast<const uint8_t*>(rec) - tb->ring) / tb->stride);
+            const SearchState s0 = ts->st;
+            resumed = s0.n_hits == 0 && s0.heap_len + kStepNodes <= sc.heap_cap && s0.tree_entries + kStepNodes <= sc.node_cap &&
+                      tb->fetch_state(ts->grown, s0.heap_len, s0.tree_entries, sc.heap, sc.nodes);
+            if (k < tb->fetched.size()) tb->fetched[k] = 1;  // (fetch_state releases the arena whether or not the copy worked)
+            if (resumed) {
+                const uint32_t n_top = s0.heap_len < (uint32_t)kTop ? s0.heap_len : (uint32_t)kTop;
+                for (uint32_t i = 0; i < n_top; ++i) A.top[i] = A.heap[i];  // heap levels 0-5: the kernel had them in LDS and wrote them into the arena's unused slots
+                st = s0;
+                r.gpu_e_search = s0.c_esearch; r.gpu_n_push = s0.c_push; r.gpu_n_pop = s0.c_pop; r.gpu_n_node = s0.c_node;
+                pc_clear(A);
+#if !defined(__HIP_DEVICE_COMPILE__)
+                if (tb->P.bound_kind == BOUND_CONTINUOUS) { while (!tb->cancel.load(std::memory_order_relaxed) && search_step<1, true, false, true>(tb->ix, tb->P, rd, A, st, 0, NoGrow())) {} }
+                else { while (!tb->cancel.load(std::memory_order_relaxed) && search_step<1, false, false, true>(tb->ix, tb->P, rd, A, st, 0, NoGrow())) {} }
+#endif
+            }
+        }
+        if (!resumed) tail_search(tb->ix, tb->P, rd, A, st, 0, &tb->cancel);
         r.status = st.status;
         r.e_search = st.c_esearch; r.n_push = st.c_push; r.n_pop = st.c_pop; r.n_node = st.c_node; r.n_hits = st.c_hits;
         pops = st.c_pop;
@@ -282,10 +319,12 @@ inline void tail_map_read(const std::shared_ptr<TailBatch>& tb, const TailRecord
         if (!ok) tb->failed = true;
         if (const char* log = std::getenv("MAPAD_TAIL_LOG")) {  // diagnostics: one line per read the host finished (read, length, pops, start relative to the first hand-over, seconds, cpu)
             if (FILE* f = std::fopen(log, "a")) {
-                std::fprintf(f, "%u %d %llu %.3f %.3f %d\n", r.read, L, (unsigned long long)pops, t_begin - tb->t_first, TailBatch::now_s() - t_begin, sched_getcpu());
+                std::fprintf(f, "%u %d %llu %.3f %.3f %d\n", r.read, L, (unsigned long long)(pops - r.gpu_n_pop), t_begin - tb->t_first, TailBatch::now_s() - t_begin, sched_getcpu());  // pops = the host's own
                 std::fclose(f);
             }
         }
+        tb->continued += r.gpu_n_pop ? 1u : 0u;
+        pops -= r.gpu_n_pop;  // what the host did itself
         tb->results.push_back(std::move(r));
         tb->done += 1;
         tb->host_pops += pops;

@@ -71,7 +71,7 @@ constexpr int kKeyBins = kMaxReadLen + 2;
 // overflow, not wrap around.
 enum { CUR_HITS = 0, CUR_OPS = 2, CUR_POOL_OVF = 4, CUR_ERR = 5, CUR_WORK = 6, CUR_OVF = 7, CUR_GROWN = 6 + 2 * kStages, CUR_HEAVY_N = CUR_GROWN + 4 /* per quad stage */, CUR_HEAVY_WORK = CUR_GROWN + 6 /* per heavy stage */,
        CUR_HEAVY_POPS = CUR_GROWN + 8 /* 64-bit */, CUR_HPROF = CUR_GROWN + 10 /* 8 x 64-bit, -DMAPAD_HEAVY_PROF */, CUR_TAIL = CUR_GROWN + 26 /* reads handed to the host tail */, CUR_TAIL_DRY = CUR_GROWN + 27 /* ... of them because an arena class was dry */,
-       CUR_TAIL_F = CUR_GROWN + 28 /* ... instead of going to the full-limit stage */, CUR_COUNT = CUR_GROWN + 30 };
+       CUR_TAIL_F = CUR_GROWN + 28 /* ... instead of going to the full-limit stage */, CUR_TAIL_STATE = CUR_GROWN + 29 /* ... handed over with their state */, CUR_COUNT = CUR_GROWN + 31 };
 inline uint64_t cur64(const uint32_t* cur, int k) { return (uint64_t)cur[k] | ((uint64_t)cur[k + 1] << 32); }
 
 struct BatchDev {
@@ -104,6 +104,7 @@ struct BatchDev {
     // reads waiting or running (*tail_ctl, host-coherent, kept current by the launch's dispatcher thread); kClasses: never
     const uint32_t* tail_ctl;
     uint32_t tail_backlog_max, tail_min_class;
+    uint32_t tail_continue;   // 1: a read in a grown arena is handed over WITH its state (host_tail.hpp: TailState), the arena stays the read's until a host thread has copied it
 };
 
 // A read that has outgrown its base arena, as the quad stage leaves it: everything else (heap, nodes, hit staging) is in the grown arena.
@@ -603,8 +604,10 @@ struct DeviceGrow {
             const MAPAD_GLOBAL uint4* ns = (const MAPAD_GLOBAL uint4*)bcast64((uint64_t)A.nodes);
             const uint32_t heap_len = (uint32_t)__builtin_amdgcn_readlane((int)st.heap_len, leader), entries = (uint32_t)__builtin_amdgcn_readlane((int)st.tree_entries, leader);
             uint8_t* b = gp->base[cls] + (uint64_t)idx * gp->stride[cls];
-            copy_units<64>((MAPAD_GLOBAL uint4*)b, hs, (TOP + 1) >> 1, (heap_len + 2) >> 1, lane);
-            copy_units<64>((MAPAD_GLOBAL uint4*)(b + gp->off_nodes[cls]), ns, 0, 2 * entries, lane);
+            int lane_o = lane;
+            asm volatile("" : "+v"(lane_o));  // (opaque: see hand_to_host)
+            copy_units<64>((MAPAD_GLOBAL uint4*)b, hs, (TOP + 1) >> 1, (heap_len + 2) >> 1, lane_o);
+            copy_units<64>((MAPAD_GLOBAL uint4*)(b + gp->off_nodes[cls]), ns, 0, 2 * entries, lane_o);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the copy has landed before the quad works in the new arena (and before its old one changes owners)
             if (mine) adopt(A, cls, idx);
         }
@@ -637,8 +640,8 @@ __device__ __forceinline__ void suspend_heavy(const BatchDev& B, const GrowPools
 // guaranteed: ADVICE r4).  tests/test_gpu_tail.py checks that records arrive while the launch is still running (tail.seen_live).
 template <class T>
 __device__ __forceinline__ void store_through(T* p, T v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
-template <int LPR, bool NL>
-__device__ __forceinline__ void hand_to_host(const BatchDev& B, const ReadInT<NL>& rd, const SearchState& st, uint32_t read, uint32_t k, int w) {
+template <int LPR, bool NL, class AR>
+__device__ __forceinline__ void hand_to_host(const BatchDev& B, const ReadInT<NL>& rd, const AR& A, const SearchState& st, uint32_t read, uint32_t k, int w, bool with_state) {
     uint8_t* rec = B.tail_ring + (size_t)k * B.tail_stride;
     uint32_t* rq = (uint32_t*)(rec + 16);
     uint32_t* rdd = (uint32_t*)(rec + 16 + ((2u * B.tail_lmax + 15u) & ~15u));
@@ -648,6 +651,26 @@ __device__ __forceinline__ void hand_to_host(const BatchDev& B, const ReadInT<NL
     for (uint32_t i = w; i < (uint32_t)rd.L; i += LPR) store_through(&rdd[i], __float_as_uint(rd.d[i]));
     host::TailRecord* h = (host::TailRecord*)rec;
     if (w == 0) { store_through(&h->read, read); store_through(&h->L, (uint32_t)rd.L); store_through(&h->pops, st.c_pop); }
+    {   // the search itself, if the read leaves its grown arena to the host (TailState): heap levels 0-5 out of the near array into the arena's unused slots,
+        // the state into the record; the arena's lines must then leave this XCD's L2 — a copy engine reads them, not a CU (the one place a hand-over pays for a
+        // write-back of the L2's dirty lines)
+        uint32_t* ts = (uint32_t*)(rec + host::tail_state_offset(B.tail_lmax));
+        if (with_state) {
+            const uint32_t n_top = st.heap_len < (uint32_t)AR::kTopN ? st.heap_len : (uint32_t)AR::kTopN;
+            uint32_t i0 = (uint32_t)w;
+            asm volatile("" : "+v"(i0));  // (opaque: lane-derived loop bounds of this rare path were hoisted to the kernel's start and then spilled to scratch)
+#pragma unroll 1
+            for (uint32_t i = i0; i < n_top; i += LPR) store_entry(A.heap + i, load_entry(A.top + i));
+            if (w == 0) {  // (field by field: taking the state's address would put it — the hottest registers of the loop — into scratch memory)
+                store_through(&ts[0], A.grown);
+                store_through(&ts[4], st.c_esearch); store_through(&ts[5], st.c_push); store_through(&ts[6], st.c_pop); store_through(&ts[7], st.c_node); store_through(&ts[8], st.c_hits);
+                store_through(&ts[9], st.heap_len); store_through(&ts[10], st.tree_entries); store_through(&ts[11], st.tree_next); store_through(&ts[12], st.tree_len);
+                store_through(&ts[13], st.n_hits); store_through(&ts[14], st.hit_ops_used); store_through(&ts[15], st.status); store_through(&ts[16], __float_as_uint(st.best_score));
+                store_through(&ts[17], 0u); store_through(&ts[18], (uint32_t)st.best_size); store_through(&ts[19], (uint32_t)(st.best_size >> 32));
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");  // system scope: write back
+        } else if (w == 0) store_through(&ts[0], 0u);
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every lane's payload stores have completed ...
     __builtin_amdgcn_wave_barrier();
     if (w == 0) {
@@ -810,8 +833,16 @@ __global__ void __launch_bounds__(64, (LPR == 1 && NL) ? 1 : LPR == 2 ? 2 : MAPA
                 if (w == 0) k = atomicAdd(&cursors[CUR_TAIL], 1u);
                 k = group_bcast<LPR>(k);
                 if (k >= B.tail_cap) return false;
-                hand_to_host<LPR, NL>(B, rd, st, read, k, w);
+                // with its state if it sits in a grown arena and has found nothing yet (hit staging stays in the slot's base arena): the arena then belongs to the
+                // read until a host thread has copied it and releases it (TailBatch::fetch_state) — this quad just lets go of it
+                const bool with_state = PASS != 1 && B.tail_continue != 0 && A.grown != 0 && st.n_hits == 0 && st.status == ST_OK;
+                hand_to_host<LPR, NL>(B, rd, A, st, read, k, w, with_state);
                 if (w == 0 && why) atomicAdd(&cursors[why], 1u);
+                if (with_state) {
+                    if (w == 0) atomicAdd(&cursors[CUR_TAIL_STATE], 1u);
+                    const ArenaT<NL, TOPK> base = carve<NL, TOPK>(kernarg_reload(kArgOffAP, AP0), slot);
+                    A.heap = base.heap; A.nodes = base.nodes; A.heap_cap = base.heap_cap; A.node_cap = base.node_cap; A.grown = 0;
+                }
                 return true;
             };
             auto back_to_base = [&]() {  // give the grown arena back; the next read starts in the base arena again
@@ -1256,12 +1287,15 @@ struct mapad_ctx {
     int lpr = 4;  // lanes per read in the search kernel (MAPAD_LANES_PER_READ = 4 | 1)
     int n_cu = 256;
     int reserved_cus = 0;  // CUs the batch slots' streams leave free (create_slot_stream)
+    hipStream_t tail_stream = nullptr;  // the host tail's workers copy handed-over searches out of grown arenas on it (fetch_tail_state)
+    std::mutex tail_mu;
     uint64_t counter_sums[6] = {0, 0, 0, 0, 0, 0};
     DevBuf<unsigned long long> d_prof;  // -DMAPAD_PROFILE_SECTIONS builds
 
     ~mapad_ctx() {
         (void)hipSetDevice(device);
-        for (auto& b : bs) { if (b.stream) (void)hipStreamSynchronize(b.stream); b.release(); }
+        for (auto& b : bs) { if (b.stream) (void)hipStreamSynchronize(b.stream); b.release(); }  // (release() waits for the host tail's workers of the slot's batch)
+        if (tail_stream) { (void)hipStreamDestroy(tail_stream); tail_stream = nullptr; }
         d_blocks.release(); d_sdm.release(); d_thr.release(); d_base.release();
         for (auto& a : d_class) a.release();
         for (auto& a : d_owner) a.release();
@@ -1526,11 +1560,12 @@ int create_slot_stream(mapad_ctx* c, hipStream_t* out) {
     return MAPAD_OK;
 }
 
+void drop_tail(mapad_ctx* c, BatchSlot& S);  // (below, beside the host tail's other library-side pieces)
 // Makes slot `k` ready for a new batch: its previous batch has finished, its stream exists and waits for the caller's stream.
 int acquire_slot(mapad_ctx* c, int k) {
     BatchSlot& S = c->bs[k];
     if (S.ev_valid) { HIP_TRY(hipStreamSynchronize(S.stream)); int rc = record_times(c, S); if (rc) return rc; }
-    if (S.tail) { host::tail_cancel(S.tail); S.tail.reset(); }  // the previous batch of this slot was never collected: its handed-over reads are dropped with it
+    drop_tail(c, S);  // the previous batch of this slot was never collected: its handed-over reads are dropped with it
     if (c->depth == 1) S.stream = c->stream;  // one batch at a time: everything runs on the caller's stream (own_stream stays false)
     else if (!S.stream) { const int rc_s = create_slot_stream(c, &S.stream); if (rc_s) return rc_s; S.own_stream = true; }
     if (c->depth > 1) {  // the slot's stream is non-blocking: order it behind whatever the caller has queued on its own stream (async uploads of the inputs)
@@ -1590,6 +1625,51 @@ int ensure_batch_buffers(mapad_ctx* c, BatchSlot& S, uint64_t n_reads, uint64_t 
     return MAPAD_OK;
 }
 
+// A worker of the host tail takes over a read WITH its search (host_tail.hpp: TailState): heap slots [0, heap_len] (physical: logical i lives in slot i + 1; the
+// kernel has written levels 0-5 out of LDS) and nodes [0, tree_entries) of the grown arena `grown` come over PCIe into the worker's arena, then the arena is
+// released on the device (its owner word cleared by a one-wavefront kernel: fits beside the searches).  Called from worker threads, several at a time: one copy
+// stream per context, every caller waits for its own event.  The arena is released whether or not the copies worked; false = map the read from scratch.
+bool release_tail_arena(mapad_ctx* c, uint32_t grown) {
+    const uint32_t cls = (grown >> kGrownShift) - 1, idx = grown & ((1u << kGrownShift) - 1);
+    if (cls > (uint32_t)kClasses || idx >= c->grow.count[cls]) return false;
+    hipLaunchKernelGGL(zero_words_kernel, dim3(1), dim3(64), 0, c->tail_stream, c->grow.owner[cls] + idx, (uint64_t)1);
+    return hipGetLastError() == hipSuccess;
+}
+bool fetch_tail_state(mapad_ctx* c, uint32_t grown, uint32_t heap_len, uint32_t tree_entries, HeapEntry* heap_phys, Node* nodes) {
+    if (hipSetDevice(c->device) != hipSuccess) return false;
+    const uint32_t cls = (grown >> kGrownShift) - 1, idx = grown & ((1u << kGrownShift) - 1);
+    if (cls > (uint32_t)kClasses || idx >= c->grow.count[cls]) return false;
+    std::lock_guard<std::mutex> g(c->tail_mu);  // (one stream: the copies of two workers would queue behind each other anyway)
+    if (!c->tail_stream && hipStreamCreateWithFlags(&c->tail_stream, hipStreamNonBlocking) != hipSuccess) return false;
+    const uint8_t* b = c->grow.base[cls] + (uint64_t)idx * c->grow.stride[cls];
+    bool ok = heap_len < c->grow.heap_cap[cls] + 8 && tree_entries <= c->grow.node_cap[cls];
+    ok = ok && hipMemcpyAsync(heap_phys, b, ((size_t)heap_len + 2) * sizeof(HeapEntry), hipMemcpyDeviceToHost, c->tail_stream) == hipSuccess;
+    ok = ok && hipMemcpyAsync(nodes, b + c->grow.off_nodes[cls], (size_t)tree_entries * sizeof(Node), hipMemcpyDeviceToHost, c->tail_stream) == hipSuccess;
+    const bool released = release_tail_arena(c, grown);
+    ok = (hipStreamSynchronize(c->tail_stream) == hipSuccess) && ok && released;
+    return ok;
+}
+
+// The batch of slot S is abandoned (its slot is reused, the pipeline depth changes, the context goes away) with its launch over: its handed-over reads are dropped,
+// and the grown arenas that reads handed over WITH their state still hold — no worker has come for them — are released.
+void drop_tail(mapad_ctx* c, BatchSlot& S) {
+    if (!S.tail) return;
+    std::shared_ptr<host::TailBatch> tb = S.tail;
+    S.tail.reset();
+    host::tail_cancel(tb);
+    if (!tb->fetch_state || hipSetDevice(c->device) != hipSuccess) return;
+    std::lock_guard<std::mutex> g(c->tail_mu);
+    if (!c->tail_stream && hipStreamCreateWithFlags(&c->tail_stream, hipStreamNonBlocking) != hipSuccess) return;
+    bool any = false;
+    for (uint32_t k = 0; k < tb->cap; ++k) {
+        const uint8_t* rec = tb->ring + (size_t)k * tb->stride;
+        if (reinterpret_cast<const host::TailRecord*>(rec)->ready != 1u || tb->fetched[k]) continue;
+        const host::TailState* ts = reinterpret_cast<const host::TailState*>(rec + host::tail_state_offset(tb->lmax));
+        if (ts->grown) any = release_tail_arena(c, ts->grown) || any;
+    }
+    if (any) (void)hipStreamSynchronize(c->tail_stream);
+}
+
 // warm: an empty launch of the search kernels only (mapad_ctx_reserve): the first dispatch on a stream that needs scratch memory sets up the
 // queue's scratch ring, which waits for kernels running on other queues — better paid before the pipeline starts.
 int launch_batch(mapad_ctx* c, BatchSlot& S, const uint8_t* d_seqs, const uint8_t* d_quals, const uint64_t* d_offsets, uint64_t n_reads, uint64_t total_bases,
@@ -1619,8 +1699,8 @@ int launch_batch(mapad_ctx* c, BatchSlot& S, const uint8_t* d_seqs, const uint8_
     B.prof = c->d_prof.p;
 #endif
     B.tail_ring = nullptr; B.tail_stride = 0; B.tail_cap = 0; B.tail_lmax = 0; B.tail_pops = 0xFFFFFFFFu;
-    B.tail_ctl = nullptr; B.tail_backlog_max = 0; B.tail_min_class = (uint32_t)kClasses;
-    if (S.tail) { host::tail_cancel(S.tail); S.tail.reset(); }
+    B.tail_ctl = nullptr; B.tail_backlog_max = 0; B.tail_min_class = (uint32_t)kClasses; B.tail_continue = 0;
+    drop_tail(c, S);
     for (auto& x : S.tail_info) x = 0;
     S.tail_failed = false;
     if (c->tail_pops && !warm && n_reads) {
@@ -1650,6 +1730,10 @@ int launch_batch(mapad_ctx* c, BatchSlot& S, const uint8_t* d_seqs, const uint8_
             hipEvent_t* evp = &S.ev[3];
             tb->launch_done = [launched, evp]() { return launched->load(std::memory_order_acquire) && hipEventQuery(*evp) != hipErrorNotReady; };
         }
+        // continuation: a read handed over with its state (TailState) — a worker copies its heap and nodes out of the grown arena and releases the arena
+        B.tail_continue = env_u32("MAPAD_TAIL_CONTINUE", 1) && c->grow.heavy_min_class >= (uint32_t)kClasses ? 1u : 0u;
+        tb->fetched.assign(cap, 0);
+        if (B.tail_continue) tb->fetch_state = [c](uint32_t grown, uint32_t heap_len, uint32_t tree_entries, HeapEntry* heap_phys, Node* nodes) { return fetch_tail_state(c, grown, heap_len, tree_entries, heap_phys, nodes); };
         host::tail_start(tb);
         S.tail = tb;
         B.tail_ring = ring; B.tail_stride = stride; B.tail_cap = cap; B.tail_lmax = tl; B.tail_pops = c->tail_pops;
@@ -1784,9 +1868,10 @@ int merge_tail(mapad_ctx* c, BatchSlot& S, uint32_t* cur) {
     std::vector<host::TailResult>& res = tb->results;
     S.tail_info[0] = res.size(); S.tail_info[1] = tb->gpu_pops; S.tail_info[2] = tb->host_pops;
     S.tail_info[3] = res.empty() ? 0 : (uint64_t)(std::max(tb->t_last - tb->t_first, 0.0) * 1e6); S.tail_info[4] = host::TailWorkers::instance().size(); S.tail_info[5] = c->tail_pops;
-    for (const auto& r : res) { S.tail_info[6] += r.e_search; S.tail_info[7] += r.n_push; S.tail_info[8] += r.n_node; }
+    for (const auto& r : res) { S.tail_info[6] += r.e_search - r.gpu_e_search; S.tail_info[7] += r.n_push - r.gpu_n_push; S.tail_info[8] += r.n_node - r.gpu_n_node; }  // what the host threads did themselves
     S.tail_info[9] = (uint64_t)(tb->host_thread_s * 1e6);
     S.tail_info[10] = tb->seen_live; S.tail_info[11] = cur[CUR_TAIL_DRY]; S.tail_info[12] = cur[CUR_TAIL_F]; S.tail_info[13] = S.last.tail_min_class;
+    S.tail_info[14] = tb->continued; S.tail_info[15] = cur[CUR_TAIL_STATE];
     if (res.empty()) { S.tail_failed = false; return MAPAD_OK; }
     std::sort(res.begin(), res.end(), [](const host::TailResult& a, const host::TailResult& b) { return a.read < b.read; });
     const BatchDev& B = S.last;
@@ -2359,7 +2444,7 @@ int mapad_ctx_set_pipeline_depth(mapad_ctx_t* ctx, int depth) {
     if (hipSetDevice(ctx->device) != hipSuccess) return MAPAD_ERR_NO_DEVICE;
     int rc;
     if ((rc = sync_all_slots(ctx))) return rc;
-    for (auto& b : ctx->bs) { if ((rc = record_times(ctx, b))) return rc; b.release(); b.ev_valid = false; b.compacted = false; }
+    for (auto& b : ctx->bs) { if ((rc = record_times(ctx, b))) return rc; drop_tail(ctx, b); b.release(); b.ev_valid = false; b.compacted = false; }
     ctx->depth = depth; ctx->cur = 0; ctx->view = 0;
     ctx->arena_reads = 0; ctx->arena_lmax = 0; ctx->pool[0].stride = 0;  // pools are re-sized around the base arenas of `depth` batches
     return MAPAD_OK;

@@ -199,3 +199,66 @@ def test_hand_overs_reach_the_host_while_the_launch_is_running():
     assert info["reads"] > 100, info
     assert info["seen_live"] > info["reads"] // 2, info  # the launch runs for a good 100 ms; the first hand-overs come within the first few
     assert (res.status & 16).sum() == 0
+
+
+@pytest.mark.parametrize("name,prm,kw,n", [
+    ("damage", DAMAGE, dict(qual_range=(20, 40), damage=dict(f=0.5, t=0.5, d=0.02, s=1.0)), 3000),
+    ("mixed_len_indels", DAMAGE, dict(qual_range=(20, 40), len_range=(35, 100), indel_frac=0.05), 800),
+    ("continuous_bound", CONTINUOUS, dict(qual_range=(20, 40), damage=dict(f=0.5, t=0.5, d=0.02, s=1.0)), 2000),
+])
+def test_reads_handed_over_with_their_search_are_continued_on_the_host(name, prm, kw, n, monkeypatch):
+    """Round 5: a read that sits in a grown arena when it is handed over leaves the arena to the host (heap top written out of LDS, SearchState in the record); a
+    worker copies heap and nodes over PCIe, releases the arena and goes on where the GPU stopped (host_tail.hpp: TailState).  32-node base arenas make every read
+    of consequence grow before the 150-pop budget; the results — event counters included, which now add GPU pops and host pops of one read — equal the oracle's
+    and those of the same batch mapped from scratch on the host (MAPAD_TAIL_CONTINUE=0) and entirely on the GPU."""
+    monkeypatch.setenv("MAPAD_TIER0_NODES", "32")
+    g = synth.genome(300_000, seed=77)
+    seqs, quals, offsets = synth.reads(g, n, 50, seed=3 + len(name), **kw)
+    rp = resolve_params(prm)
+    pidx = mapad_amd.Index.build([("chr1", g)])
+    oidx = ob.OracleIndex.from_bwt(pidx.bwt(), "$ACGTX", 128)
+    params = mapad_amd.make_params(rp)
+    res, info = _map(pidx, params, seqs, quals, offsets, tail_pops=150)
+    reads, qs = split_reads(seqs, quals, offsets)
+    ores = oidx.map_batch(ob.make_params(rp), reads, qs, n_threads=8, keep_d=True)
+    assert_same_as_oracle(ores, res, offsets)
+    pops = ores.counters[:, 3]
+    assert info["reads"] == int((pops > 150).sum()) > n // 50
+    assert info["continued"] > info["reads"] // 2 and info["handed_over_with_state"] >= info["continued"], info  # (reads with a hit already found go from scratch)
+    assert info["host_pops"] < int(pops[pops > 150].sum()) - 100 * info["continued"]  # the host did not repeat the GPU's pops of the continued reads
+    assert (res.status & 16).sum() == 0
+    monkeypatch.setenv("MAPAD_TAIL_CONTINUE", "0")
+    scratch, info0 = _map(pidx, params, seqs, quals, offsets, tail_pops=150)
+    assert info0["continued"] == 0 and info0["reads"] == info["reads"]
+    _same(res, scratch)
+    off, _ = _map(pidx, params, seqs, quals, offsets, tail_pops=0)
+    _same(res, off)
+
+
+def test_arenas_of_reads_nobody_came_for_are_released(monkeypatch):
+    """Batches with reads handed over WITH their state are submitted and never collected; their slots are reused.  The grown arenas those reads still hold must go
+    back to the pools (drop_tail): with two arenas per class a leak would leave later batches without any — they would still finish (dry classes send reads to
+    the host) but with every class dry from the start, which the migration count shows."""
+    monkeypatch.setenv("MAPAD_TIER0_NODES", "32")
+    monkeypatch.setenv("MAPAD_CLASS_COUNTS", "8,8,8,8,8,8,8,8,8,8")
+    monkeypatch.setenv("MAPAD_SET_ARENAS", "0")
+    g = synth.genome(200_000, seed=31)
+    rp = resolve_params(DAMAGE)
+    pidx = mapad_amd.Index.build([("chr1", g)])
+    oidx = ob.OracleIndex.from_bwt(pidx.bwt(), "$ACGTX", 128)
+    b = synth.reads(g, 1500, 50, seed=44, qual_range=(20, 40), damage=dict(f=0.5, t=0.5, d=0.02, s=1.0))
+    ctx = mapad_amd.Context(pidx, mapad_amd.make_params(rp), 0)
+    try:
+        ctx.set_pipeline_depth(2)
+        ctx.set_tail_pops(150)
+        for _ in range(12):  # each submission reuses a slot whose batch nobody collected
+            ctx.submit_batch(*b)
+        ctx.select_batch(0)
+        res = ctx.fetch()
+        info = ctx.tail_info()
+    finally:
+        ctx.close()
+    reads, qs = split_reads(*b)
+    ores = oidx.map_batch(ob.make_params(rp), reads, qs, n_threads=8, keep_d=True)
+    assert_same_as_oracle(ores, res, b[2])
+    assert info["handed_over_with_state"] > 0 and res.n_second_pass > 500  # reads still find grown arenas: nothing leaked
