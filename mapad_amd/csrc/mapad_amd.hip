@@ -1287,7 +1287,7 @@ struct mapad_ctx {
     int lpr = 4;  // lanes per read in the search kernel (MAPAD_LANES_PER_READ = 4 | 1)
     int n_cu = 256;
     int reserved_cus = 0;  // CUs the batch slots' streams leave free (create_slot_stream)
-    hipStream_t tail_stream = nullptr;  // the host tail's workers copy handed-over searches out of grown arenas on it (fetch_tail_state)
+    hipStream_t tail_stream = nullptr;  // drop_tail releases the grown arenas of abandoned hand-overs on it (the workers fetch on streams of their own)
     std::mutex tail_mu;
     uint64_t counter_sums[6] = {0, 0, 0, 0, 0, 0};
     DevBuf<unsigned long long> d_prof;  // -DMAPAD_PROFILE_SECTIONS builds
@@ -1627,26 +1627,34 @@ int ensure_batch_buffers(mapad_ctx* c, BatchSlot& S, uint64_t n_reads, uint64_t 
 
 // A worker of the host tail takes over a read WITH its search (host_tail.hpp: TailState): heap slots [0, heap_len] (physical: logical i lives in slot i + 1; the
 // kernel has written levels 0-5 out of LDS) and nodes [0, tree_entries) of the grown arena `grown` come over PCIe into the worker's arena, then the arena is
-// released on the device (its owner word cleared by a one-wavefront kernel: fits beside the searches).  Called from worker threads, several at a time: one copy
-// stream per context, every caller waits for its own event.  The arena is released whether or not the copies worked; false = map the read from scratch.
-bool release_tail_arena(mapad_ctx* c, uint32_t grown) {
+// released on the device (its owner word cleared by a one-wavefront kernel: fits beside the searches).  Called from worker threads, several at a time, each on
+// a stream of its own.  The arena is released whether or not the copies worked; false = map the read from scratch.
+bool release_tail_arena(mapad_ctx* c, uint32_t grown, hipStream_t st) {
     const uint32_t cls = (grown >> kGrownShift) - 1, idx = grown & ((1u << kGrownShift) - 1);
     if (cls > (uint32_t)kClasses || idx >= c->grow.count[cls]) return false;
-    hipLaunchKernelGGL(zero_words_kernel, dim3(1), dim3(64), 0, c->tail_stream, c->grow.owner[cls] + idx, (uint64_t)1);
+    hipLaunchKernelGGL(zero_words_kernel, dim3(1), dim3(64), 0, st, c->grow.owner[cls] + idx, (uint64_t)1);
     return hipGetLastError() == hipSuccess;
+}
+// a stream of the calling thread's own on device `dev` (the host tail's workers live as long as the process: never destroyed), so that the copies of several
+// workers travel side by side instead of queuing behind one another's synchronisation
+hipStream_t thread_stream(int dev) {
+    static thread_local hipStream_t streams[16] = {};
+    if (dev < 0 || dev >= 16) return nullptr;
+    if (!streams[dev] && hipStreamCreateWithFlags(&streams[dev], hipStreamNonBlocking) != hipSuccess) streams[dev] = nullptr;
+    return streams[dev];
 }
 bool fetch_tail_state(mapad_ctx* c, uint32_t grown, uint32_t heap_len, uint32_t tree_entries, HeapEntry* heap_phys, Node* nodes) {
     if (hipSetDevice(c->device) != hipSuccess) return false;
     const uint32_t cls = (grown >> kGrownShift) - 1, idx = grown & ((1u << kGrownShift) - 1);
     if (cls > (uint32_t)kClasses || idx >= c->grow.count[cls]) return false;
-    std::lock_guard<std::mutex> g(c->tail_mu);  // (one stream: the copies of two workers would queue behind each other anyway)
-    if (!c->tail_stream && hipStreamCreateWithFlags(&c->tail_stream, hipStreamNonBlocking) != hipSuccess) return false;
+    hipStream_t st = thread_stream(c->device);
+    if (!st) return false;
     const uint8_t* b = c->grow.base[cls] + (uint64_t)idx * c->grow.stride[cls];
     bool ok = heap_len < c->grow.heap_cap[cls] + 8 && tree_entries <= c->grow.node_cap[cls];
-    ok = ok && hipMemcpyAsync(heap_phys, b, ((size_t)heap_len + 2) * sizeof(HeapEntry), hipMemcpyDeviceToHost, c->tail_stream) == hipSuccess;
-    ok = ok && hipMemcpyAsync(nodes, b + c->grow.off_nodes[cls], (size_t)tree_entries * sizeof(Node), hipMemcpyDeviceToHost, c->tail_stream) == hipSuccess;
-    const bool released = release_tail_arena(c, grown);
-    ok = (hipStreamSynchronize(c->tail_stream) == hipSuccess) && ok && released;
+    ok = ok && hipMemcpyAsync(heap_phys, b, ((size_t)heap_len + 2) * sizeof(HeapEntry), hipMemcpyDeviceToHost, st) == hipSuccess;
+    ok = ok && hipMemcpyAsync(nodes, b + c->grow.off_nodes[cls], (size_t)tree_entries * sizeof(Node), hipMemcpyDeviceToHost, st) == hipSuccess;
+    const bool released = release_tail_arena(c, grown, st);
+    ok = (hipStreamSynchronize(st) == hipSuccess) && ok && released;
     return ok;
 }
 
@@ -1665,7 +1673,7 @@ void drop_tail(mapad_ctx* c, BatchSlot& S) {
         const uint8_t* rec = tb->ring + (size_t)k * tb->stride;
         if (reinterpret_cast<const host::TailRecord*>(rec)->ready != 1u || tb->fetched[k]) continue;
         const host::TailState* ts = reinterpret_cast<const host::TailState*>(rec + host::tail_state_offset(tb->lmax));
-        if (ts->grown) any = release_tail_arena(c, ts->grown) || any;
+        if (ts->grown) any = release_tail_arena(c, ts->grown, c->tail_stream) || any;
     }
     if (any) (void)hipStreamSynchronize(c->tail_stream);
 }
