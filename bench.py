@@ -789,7 +789,7 @@ def main():
                      # why reads went to the host: past the pop budget; their arena class was dry while the host had room (round 5); no growable arena could hold them
                      "reads_dry_class": int(sum(t.get("reads_dry_class", 0) for t in tail_timed)), "reads_full_limit": int(sum(t.get("reads_full_limit", 0) for t in tail_timed)),
                      "seen_while_launch_ran": int(sum(t.get("seen_live", 0) for t in tail_timed)),
-                     "where": f"{tail_last['threads']} host threads, search_core.hpp compiled for the host (the kernel's source; from scratch), overlapped with the GPU's bulk" if tail_last["budget"] else "off"},
+                     "where": f"{tail_last['threads']} host threads, search_core.hpp compiled for the host (the kernel's source; reads handed over from a grown arena continue from the GPU's state, others start over), overlapped with the GPU's bulk" if tail_last["budget"] else "off"},
             "secondary": secondary, "e2e": e2e, "cli": cli, "sa_locate": locate, "post_search": post,
         }
         if gather_check is not None:

@@ -106,7 +106,7 @@ uint64_t mapad_index_sa_sample_len(const mapad_index_t* idx);
 uint64_t mapad_index_sa_extra_len(const mapad_index_t* idx);
 int mapad_index_copy_sa(const mapad_index_t* idx, uint64_t* sample, uint64_t* extra_rows, uint64_t* extra_vals);
 
-/* the rank structure as the GPU sees it: 128-byte blocks (16 x u64 per 256 BWT rows; layout in mapad_amd/csrc/fmd_device.hpp),
+/* the rank structure as the GPU sees it: 64-byte blocks (8 x u64 per 96 BWT rows; layout in mapad_amd/csrc/fmd_device.hpp),
  * less[8] (reference ranks) and the two sentinel rows */
 int mapad_index_device_view(const mapad_index_t* idx, const uint64_t** blocks, uint64_t* n_blocks, uint64_t less[8], uint64_t sentinel[2]);
 /* SampledSuffixArray::get (src/index/mod.rs:160-187) */

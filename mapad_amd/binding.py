@@ -324,9 +324,9 @@ class Index:
         return blocks.value, nb.value, less, sent
 
     def blocks(self):
-        """the rank blocks (16 x u64 per 256 rows) as a numpy view of the index's host copy"""
+        """the rank blocks (8 x u64 per 96 rows) as a numpy view of the index's host copy"""
         ptr, nb, _, _ = self.device_view()
-        return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint64)), shape=(int(nb) * 16,))
+        return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint64)), shape=(int(nb) * 8,))
 
 
 class Context:

@@ -19,14 +19,25 @@
 #if !defined(MAPAD_TOUCH)
 #define MAPAD_TOUCH(p, bytes, wr) ((void)0)
 #endif
+// MAPAD_PRIO=1 (experiment): a wavefront raises its issue priority from the pop until its loads for the step are out (node, index blocks, sift), and around the
+// loads of the commit's ancestors — with under three wavefronts per SIMD a ready wavefront otherwise queues behind an older one's arithmetic.
+#if defined(MAPAD_PRIO) && MAPAD_PRIO && defined(__HIP_DEVICE_COMPILE__)
+#define MAPAD_PRIO_HIGH() __builtin_amdgcn_s_setprio(3)
+#define MAPAD_PRIO_LOW() __builtin_amdgcn_s_setprio(0)
+#else
+#define MAPAD_PRIO_HIGH() ((void)0)
+#define MAPAD_PRIO_LOW() ((void)0)
+#endif
 
 namespace mapad {
 
 // ---- alphabet -------------------------------------------------------------------------------------------
 // Reference ranks (src/index/indexing.rs:146-148): $=0 A=1 C=2 G=3 T=4 X=5.
 // Device symbol codes (3 bit-planes): $=0 X=1 A=4 C=5 G=6 T=7 — plane 2 marks "is ACGT", planes 1..0 the base index.
-constexpr int kBlockRows = 256;   // BWT rows per 128-byte block
-constexpr int kBlockBytes = 128;  // 4 sub-blocks x {u64 count[base w]; u64 plane0, plane1, plane2}
+constexpr int kBlockRows = 96;   // BWT rows per 64-byte block
+constexpr int kBlockBytes = 64;  // 4 sub-blocks x 16 bytes {40-bit count[base w], 3 planes x 24 rows} (fmd_device.hpp)
+constexpr int kBlockWords = kBlockBytes / 8;
+constexpr int kSubRows = kBlockRows / 4;
 
 MAPAD_HD int base_index(uint8_t c) {  // ASCII -> 0..3 for ACGT, 4 otherwise
     return c == 'A' ? 0 : c == 'C' ? 1 : c == 'G' ? 2 : c == 'T' ? 3 : 4;
@@ -42,7 +53,7 @@ MAPAD_HD uint32_t pack_op(uint32_t kind, uint32_t pos, uint32_t base) { return (
 
 // ---- device view of the FMD index ---------------------------------------------------------------------------
 struct DevIndex {
-    const uint64_t* blocks;  // n_blocks * 16 u64
+    const uint64_t* blocks;  // n_blocks * kBlockWords u64
     uint64_t n;              // BWT length = 2*|G| + 2
     uint64_t n_blocks;
     uint64_t less[8];        // less[rank], rank 0..6

@@ -1,16 +1,19 @@
-// fmd_device.hpp — rank queries and FMD extension on the 128-byte-block device layout.
+// fmd_device.hpp — rank queries and FMD extension on the 64-byte-block device layout.
 //
 // Replaces, on the device: FmdExtIterator (src/map/fmd_index.rs:109-182) + Occ::get_small_k / Less / BWT of the
 // rust-bio fork (byte BWT + u64 checkpoints every 128 rows).  occ(r, c) is a mathematically unique number, so the
-// layout is free: here one 128-byte line answers occ(r, A|C|G|T) for 256 rows.
+// layout is free: here one 64-byte request answers occ(r, A|C|G|T) for 96 rows (rounds 1-5a: 128 bytes per 256 rows —
+// two requests between L1 and L2 per rank query; the index was 4 of the 5.7 read requests of a pop).
 //
-//   block b (rows 256b .. 256b+255), 16 x u64:
-//     sub-block w = words [4w .. 4w+3] = { count of base w in rows [0, 256b) ; plane0 ; plane1 ; plane2 }  (rows 256b+64w ..+63)
+//   block b (rows 96b .. 96b+95), 8 x u64:
+//     sub-block w = words [2w, 2w+1], rows 96b+24w .. +23:
+//       word 0 = count of base w in rows [0, 96b) (bits 0..39) | plane0 << 40 (24 bits)
+//       word 1 = plane1 (bits 0..23) | plane2 << 24 (bits 24..47); bits 48..63 zero
 //   symbol codes: $=0 X=1 A=4 C=5 G=6 T=7  -> "is base k" = plane2 & (plane1 == k>>1) & (plane0 == k&1)
 //
-// One quad (4 adjacent lanes) serves one rank query pair: lane w loads sub-block w (32 contiguous bytes, so the quad
-// reads the whole 128-byte line coalesced), popcounts its 64 rows for all four bases, and a 2-step DPP butterfly
-// inside the quad sums the partial counts.  Lane w ends up with occ(r, base w).
+// One quad (4 adjacent lanes) serves one rank query: lane w loads sub-block w (16 contiguous bytes, so the quad
+// reads the whole 64-byte block coalesced), popcounts its 24 rows for all four bases into the four bytes of one word, and a
+// 2-step DPP butterfly inside the quad sums the partial counts.  Lane w ends up with occ(r, base w).
 #pragma once
 #include "common.hpp"
 
@@ -32,32 +35,71 @@ MAPAD_HD int popc32(uint32_t x) {
 #endif
 }
 
-// rows of sub-block w that are <= r_in (r_in = row index inside the block, 0..255), as a bit mask
-MAPAD_HD uint64_t row_mask(int w, int r_in) {
-    int t = r_in + 1 - 64 * w;  // rows of this sub-block that count: <= 0 none, >= 64 all
-    t = t < 0 ? 0 : (t > 64 ? 64 : t);
-    const uint64_t m = ~0ull >> ((64 - t) & 63);  // one 64-bit shift instead of two clamped 32-bit halves (17 -> 7 instructions per rank query)
-    return t == 0 ? 0ull : m;
+constexpr uint64_t kCountMask = (1ull << 40) - 1;
+
+// block and row inside the block of BWT row r (r < 2^51): r / 96 without a 64-bit division — with x = r / 32 = 65536 xh + xl and 65536 = 3 * 21845 + 1,
+// x / 3 = 21845 xh + (xh + xl) / 3 exactly, and x % 3 = (xh + xl) % 3.
+struct BlockPos {
+    uint64_t b;
+    int r_in;  // 0..95
+};
+MAPAD_HD BlockPos block_pos(uint64_t r) {
+    const uint64_t x = r >> 5;
+    const uint32_t xh = (uint32_t)(x >> 16), y = xh + (uint32_t)(x & 0xFFFFu);
+    const uint32_t q = y / 3u;
+    BlockPos p;
+    p.b = (uint64_t)xh * 21845u + q;
+    p.r_in = (int)((uint32_t)r & 31u) + 32 * (int)(y - 3u * q);
+    return p;
 }
+MAPAD_HD const uint64_t* block_ptr(const DevIndex& ix, uint64_t r) { return ix.blocks + block_pos(r).b * kBlockWords; }
+
+// rows of sub-block w that are <= r_in (r_in = row index inside the block), as a bit mask over its 24 rows
+MAPAD_HD uint32_t sub_mask(int w, int r_in) {
+    int t = r_in + 1 - kSubRows * w;  // rows of this sub-block that count: <= 0 none, >= 24 all
+    t = t < 0 ? 0 : (t > kSubRows ? kSubRows : t);
+    return (1u << t) - 1u;
+}
+// the planes of a sub-block, out of its two words (plane 2 carries bits 24.. of word 1 above it: always used under a sub_mask)
+MAPAD_HD uint32_t sub_p0(uint64_t w0) { return (uint32_t)(w0 >> 40); }
+MAPAD_HD uint32_t sub_p1(uint64_t w1) { return (uint32_t)w1; }
+MAPAD_HD uint32_t sub_p2(uint64_t w1) { return (uint32_t)(w1 >> 24); }
+MAPAD_HD uint64_t pack_sub0(uint64_t count, uint32_t p0) { return (count & kCountMask) | ((uint64_t)p0 << 40); }
+MAPAD_HD uint64_t pack_sub1(uint32_t p1, uint32_t p2) { return (uint64_t)p1 | ((uint64_t)p2 << 24); }
+// rows of the sub-block holding base k (0..3), under mask m
+MAPAD_HD uint32_t sub_is_base(uint64_t w0, uint64_t w1, int k, uint32_t m) {
+    const uint32_t inv1 = (k & 2) ? 0u : ~0u, inv0 = (k & 1) ? 0u : ~0u;
+    return sub_p2(w1) & (sub_p1(w1) ^ inv1) & (sub_p0(w0) ^ inv0) & m;
+}
+MAPAD_HD uint32_t sub_is_x(uint64_t w0, uint64_t w1, uint32_t m) { return sub_p0(w0) & ~sub_p1(w1) & ~sub_p2(w1) & m; }  // 'X' (code 1): plane 0 only
 
 // ---- scalar reference of the same layout (host emulation + device single-lane paths such as SA walks) -------------
 // occurrences of base k (0..3 = ACGT) in bwt[0..=r]
 MAPAD_HD uint64_t occ_scalar(const DevIndex& ix, uint64_t r, int k) {
-    const uint64_t* blk = ix.blocks + (r >> 8) * 16;
-    const int r_in = (int)(r & 255);
-    uint64_t c = blk[4 * k];
-    const uint64_t inv1 = (k & 2) ? 0ull : ~0ull, inv0 = (k & 1) ? 0ull : ~0ull;
-    for (int w = 0; w <= (r_in >> 6); ++w) {
-        const uint64_t p0 = blk[4 * w + 1], p1 = blk[4 * w + 2], p2 = blk[4 * w + 3];
-        c += popc64(p2 & (p1 ^ inv1) & (p0 ^ inv0) & row_mask(w, r_in));
-    }
+    const BlockPos bp = block_pos(r);
+    const uint64_t* blk = ix.blocks + bp.b * kBlockWords;
+    uint64_t c = blk[2 * k] & kCountMask;
+    for (int w = 0; w * kSubRows <= bp.r_in; ++w) c += (uint64_t)popc32(sub_is_base(blk[2 * w], blk[2 * w + 1], k, sub_mask(w, bp.r_in)));
     return c;
+}
+// occurrences of 'X' in bwt[0..=r]; x_counts[b] = 'X' rows in [0, 96b) (null: the text has none)
+MAPAD_HD uint64_t occ_x_scalar(const DevIndex& ix, const uint64_t* x_counts, uint64_t r) {
+    const BlockPos bp = block_pos(r);
+    const uint64_t* blk = ix.blocks + bp.b * kBlockWords;
+    uint64_t c = x_counts ? x_counts[bp.b] : 0;
+    for (int w = 0; w * kSubRows <= bp.r_in; ++w) c += (uint64_t)popc32(sub_is_x(blk[2 * w], blk[2 * w + 1], sub_mask(w, bp.r_in)));
+    return c;
+}
+// device symbol code of the row `bit` (0..23) of a sub-block
+MAPAD_HD int sub_code(uint64_t w0, uint64_t w1, int bit) {
+    return (int)((sub_p0(w0) >> bit) & 1u) | (int)(((sub_p1(w1) >> bit) & 1u) << 1) | (int)(((sub_p2(w1) >> bit) & 1u) << 2);
 }
 // device symbol code of bwt[r] (0 '$', 1 'X', 4..7 ACGT)
 MAPAD_HD int bwt_code(const DevIndex& ix, uint64_t r) {
-    const uint64_t* blk = ix.blocks + (r >> 8) * 16;
-    const int w = (int)((r >> 6) & 3), bit = (int)(r & 63);
-    return (int)((blk[4 * w + 1] >> bit) & 1) | (int)(((blk[4 * w + 2] >> bit) & 1) << 1) | (int)(((blk[4 * w + 3] >> bit) & 1) << 2);
+    const BlockPos bp = block_pos(r);
+    const int w = bp.r_in / kSubRows;
+    const uint64_t* sb = ix.blocks + bp.b * kBlockWords + 2 * w;
+    return sub_code(sb[0], sb[1], bp.r_in - kSubRows * w);
 }
 // number of '$' rows in [0, pos]  -> sentinel_occ() of fmd_index.rs:140-146 is "count of sentinel rows <= pos"
 MAPAD_HD uint64_t sentinel_le(const DevIndex& ix, uint64_t pos) {
@@ -85,20 +127,23 @@ MAPAD_HD void finish_ext4(const DevIndex& ix, uint64_t lower, uint64_t lower_rev
     }
 }
 
-// occ(r, A|C|G|T) by ONE lane: the whole 128-byte block, all four words, branch-free.
+// the four base counts of a sub-block's rows under mask m, one per byte (A in bits 0..7, ... T in bits 24..31; each <= 24, a block's sum <= 96)
+MAPAD_HD uint32_t sub_counts4(uint64_t w0, uint64_t w1, uint32_t m) {
+    const uint32_t p0 = sub_p0(w0), p1 = sub_p1(w1), p2 = sub_p2(w1) & m;
+    const uint32_t hi1 = p2 & p1, lo1 = p2 & ~p1;  // {G,T} / {A,C}
+    return (uint32_t)popc32(lo1 & ~p0) | ((uint32_t)popc32(lo1 & p0) << 8) | ((uint32_t)popc32(hi1 & ~p0) << 16) | ((uint32_t)popc32(hi1 & p0) << 24);
+}
+
+// occ(r, A|C|G|T) by ONE lane: the whole 64-byte block, all four sub-blocks, branch-free.
 MAPAD_HD void occ4_lane(const DevIndex& ix, uint64_t r, uint64_t out[4]) {
-    const uint64_t* blk = ix.blocks + (r >> 8) * 16;
-    MAPAD_TOUCH(blk, 128, false);
-    const int r_in = (int)(r & 255);
-    uint32_t a = 0, c = 0, g = 0, t = 0;
+    const BlockPos bp = block_pos(r);
+    const uint64_t* blk = ix.blocks + bp.b * kBlockWords;
+    MAPAD_TOUCH(blk, kBlockBytes, false);
+    uint32_t c4 = 0;
 #pragma unroll
-    for (int w = 0; w < 4; ++w) {
-        const uint64_t p0 = blk[4 * w + 1], p1 = blk[4 * w + 2], p2 = blk[4 * w + 3] & row_mask(w, r_in);
-        const uint64_t hi1 = p2 & p1, lo1 = p2 & ~p1;
-        a += (uint32_t)popc64(lo1 & ~p0); c += (uint32_t)popc64(lo1 & p0);
-        g += (uint32_t)popc64(hi1 & ~p0); t += (uint32_t)popc64(hi1 & p0);
-    }
-    out[0] = blk[0] + a; out[1] = blk[4] + c; out[2] = blk[8] + g; out[3] = blk[12] + t;
+    for (int w = 0; w < 4; ++w) c4 += sub_counts4(blk[2 * w], blk[2 * w + 1], sub_mask(w, bp.r_in));
+#pragma unroll
+    for (int k = 0; k < 4; ++k) out[k] = (blk[2 * k] & kCountMask) + ((c4 >> (8 * k)) & 0xFFu);
 }
 
 MAPAD_HD void ext4_scalar(const DevIndex& ix, uint64_t lower, uint64_t lower_rev, uint64_t size, Ext4& out) {
@@ -129,24 +174,20 @@ __device__ __forceinline__ uint32_t quad_sum32(uint32_t v) {
 // lane w (= threadIdx & 3) returns occ(r, base w) for the quad-uniform row r.  Split into the loads and the arithmetic so that a
 // caller with two queries has all four loads in flight before the first popcount (the DPP moves are scheduling barriers for the
 // compiler, it does not hoist the second query's loads over them by itself).
-struct OccLoads { ulonglong2 v0, v1; };
+struct OccLoads {
+    ulonglong2 v;  // the lane's sub-block
+    int r_in;      // row inside the block
+};
 __device__ __forceinline__ OccLoads quad_occ_issue(const DevIndex& ix, uint64_t r, int w) {
-    const uint64_t* sb = ix.blocks + (r >> 8) * 16 + 4 * w;
+    const BlockPos bp = block_pos(r);
     OccLoads l;
-    l.v0 = *reinterpret_cast<const ulonglong2*>(sb);      // count_w, plane0
-    l.v1 = *reinterpret_cast<const ulonglong2*>(sb + 2);  // plane1, plane2
+    l.v = *reinterpret_cast<const ulonglong2*>(ix.blocks + bp.b * kBlockWords + 2 * w);
+    l.r_in = bp.r_in;
     return l;
 }
-__device__ __forceinline__ uint64_t quad_occ_finish(const OccLoads& l, uint64_t r, int w) {
-    const uint64_t m = row_mask(w, (int)(r & 255));
-    const uint64_t p0 = l.v0.y, p1 = l.v1.x, p2 = l.v1.y & m;
-    const uint64_t hi1 = p2 & p1, lo1 = p2 & ~p1;  // {G,T} / {A,C}
-    uint32_t ac = (uint32_t)popc64(lo1 & ~p0) | ((uint32_t)popc64(lo1 & p0) << 16);
-    uint32_t gt = (uint32_t)popc64(hi1 & ~p0) | ((uint32_t)popc64(hi1 & p0) << 16);
-    ac = quad_sum32(ac);
-    gt = quad_sum32(gt);
-    const uint32_t pair = (w & 2) ? gt : ac;
-    return l.v0.x + ((w & 1) ? (pair >> 16) : (pair & 0xFFFFu));
+__device__ __forceinline__ uint64_t quad_occ_finish(const OccLoads& l, uint64_t, int w) {
+    const uint32_t c4 = quad_sum32(sub_counts4(l.v.x, l.v.y, sub_mask(w, l.r_in)));
+    return (l.v.x & kCountMask) + ((c4 >> (8 * w)) & 0xFFu);
 }
 __device__ __forceinline__ uint64_t quad_occ(const DevIndex& ix, uint64_t r, int w) { return quad_occ_finish(quad_occ_issue(ix, r, w), r, w); }
 
@@ -227,37 +268,28 @@ __device__ __forceinline__ void ext4_quad_lane(const DevIndex& ix, uint64_t lowe
 }
 
 // ---- pair-cooperative versions: two adjacent lanes per read (lanes-per-read 2) ----------------------------------------------------------------
-// Lane h (= lane & 1) loads sub-blocks 2h and 2h + 1 of a block — 64 contiguous bytes, the pair reads the 128-byte line — and ends up with
+// Lane h (= lane & 1) loads sub-blocks 2h and 2h + 1 of a block — 32 contiguous bytes, the pair reads the 64-byte block — and ends up with
 // occ(r, base 2h) and occ(r, base 2h + 1): the count words of its two sub-blocks are the running counts of exactly these two bases.  Twice the
 // loads and popcounts of a quad lane per instruction stream, but a wavefront then serves 32 reads instead of 16.
-struct OccLoads2 { ulonglong2 a0, a1, b0, b1; };
+struct OccLoads2 {
+    ulonglong2 a, b;
+    int r_in;
+};
 __device__ __forceinline__ OccLoads2 pair_occ_issue(const DevIndex& ix, uint64_t r, int h) {
-    const uint64_t* sb = ix.blocks + (r >> 8) * 16 + 8 * h;
+    const BlockPos bp = block_pos(r);
+    const uint64_t* sb = ix.blocks + bp.b * kBlockWords + 4 * h;
     OccLoads2 l;
-    l.a0 = *reinterpret_cast<const ulonglong2*>(sb);      l.a1 = *reinterpret_cast<const ulonglong2*>(sb + 2);
-    l.b0 = *reinterpret_cast<const ulonglong2*>(sb + 4);  l.b1 = *reinterpret_cast<const ulonglong2*>(sb + 6);
+    l.a = *reinterpret_cast<const ulonglong2*>(sb);
+    l.b = *reinterpret_cast<const ulonglong2*>(sb + 2);
+    l.r_in = bp.r_in;
     return l;
 }
-__device__ __forceinline__ void pair_occ_finish(const OccLoads2& l, uint64_t r, int h, uint64_t& o0, uint64_t& o1) {
-    const int r_in = (int)(r & 255);
-    uint32_t ac = 0, gt = 0;
-    {
-        const uint64_t p0 = l.a0.y, p1 = l.a1.x, p2 = l.a1.y & row_mask(2 * h, r_in);
-        const uint64_t hi1 = p2 & p1, lo1 = p2 & ~p1;
-        ac += (uint32_t)popc64(lo1 & ~p0) | ((uint32_t)popc64(lo1 & p0) << 16);
-        gt += (uint32_t)popc64(hi1 & ~p0) | ((uint32_t)popc64(hi1 & p0) << 16);
-    }
-    {
-        const uint64_t p0 = l.b0.y, p1 = l.b1.x, p2 = l.b1.y & row_mask(2 * h + 1, r_in);
-        const uint64_t hi1 = p2 & p1, lo1 = p2 & ~p1;
-        ac += (uint32_t)popc64(lo1 & ~p0) | ((uint32_t)popc64(lo1 & p0) << 16);
-        gt += (uint32_t)popc64(hi1 & ~p0) | ((uint32_t)popc64(hi1 & p0) << 16);
-    }
-    ac += dpp_quad<0xB1>(ac);  // the other lane of the pair
-    gt += dpp_quad<0xB1>(gt);
-    const uint32_t pr = h ? gt : ac;
-    o0 = l.a0.x + (pr & 0xFFFFu);
-    o1 = l.b0.x + (pr >> 16);
+__device__ __forceinline__ void pair_occ_finish(const OccLoads2& l, uint64_t, int h, uint64_t& o0, uint64_t& o1) {
+    uint32_t c4 = sub_counts4(l.a.x, l.a.y, sub_mask(2 * h, l.r_in)) + sub_counts4(l.b.x, l.b.y, sub_mask(2 * h + 1, l.r_in));
+    c4 += dpp_quad<0xB1>(c4);  // the other lane of the pair
+    const uint32_t pr = h ? (c4 >> 16) : c4;
+    o0 = (l.a.x & kCountMask) + (pr & 0xFFu);
+    o1 = (l.b.x & kCountMask) + ((pr >> 8) & 0xFFu);
 }
 __device__ __forceinline__ uint64_t pair_other64(uint64_t v) {  // the value the other lane of the pair holds
     const uint32_t lo = dpp_quad<0xB1>((uint32_t)v), hi = dpp_quad<0xB1>((uint32_t)(v >> 32));
@@ -307,15 +339,14 @@ __device__ __forceinline__ void ext4_pair_lane_finish(const DevIndex& ix, const 
 // Lane w counts base k in its own sub-block only (one popcount instead of four) and every lane reads the block's count word of base k.
 __device__ __forceinline__ void ext1_quad(const DevIndex& ix, uint64_t lower, uint64_t size, int k, int w, uint64_t& new_lower, uint64_t& new_size) {
     const uint64_t r_lo = lower == 0 ? 0 : lower - 1, r_hi = lower + size - 1;
-    const uint64_t* b_lo = ix.blocks + (r_lo >> 8) * 16;
-    const uint64_t* b_hi = ix.blocks + (r_hi >> 8) * 16;
-    const ulonglong2 a0 = *reinterpret_cast<const ulonglong2*>(b_lo + 4 * w), a1 = *reinterpret_cast<const ulonglong2*>(b_lo + 4 * w + 2);
-    const ulonglong2 h0 = *reinterpret_cast<const ulonglong2*>(b_hi + 4 * w), h1 = *reinterpret_cast<const ulonglong2*>(b_hi + 4 * w + 2);
-    const uint64_t c_lo = b_lo[4 * k], c_hi = b_hi[4 * k];
-    const uint64_t inv1 = (k & 2) ? 0ull : ~0ull, inv0 = (k & 1) ? 0ull : ~0ull;
-    uint32_t n_lo = (uint32_t)popc64(a1.y & (a1.x ^ inv1) & (a0.y ^ inv0) & row_mask(w, (int)(r_lo & 255)));
-    uint32_t n_hi = (uint32_t)popc64(h1.y & (h1.x ^ inv1) & (h0.y ^ inv0) & row_mask(w, (int)(r_hi & 255)));
-    const uint32_t both = quad_sum32(n_lo | (n_hi << 16));  // each count <= 256
+    const BlockPos p_lo = block_pos(r_lo), p_hi = block_pos(r_hi);
+    const uint64_t* b_lo = ix.blocks + p_lo.b * kBlockWords;
+    const uint64_t* b_hi = ix.blocks + p_hi.b * kBlockWords;
+    const ulonglong2 a = *reinterpret_cast<const ulonglong2*>(b_lo + 2 * w), h = *reinterpret_cast<const ulonglong2*>(b_hi + 2 * w);
+    const uint64_t c_lo = b_lo[2 * k] & kCountMask, c_hi = b_hi[2 * k] & kCountMask;
+    const uint32_t n_lo = (uint32_t)popc32(sub_is_base(a.x, a.y, k, sub_mask(w, p_lo.r_in)));
+    const uint32_t n_hi = (uint32_t)popc32(sub_is_base(h.x, h.y, k, sub_mask(w, p_hi.r_in)));
+    const uint32_t both = quad_sum32(n_lo | (n_hi << 16));  // each count <= 96
     const uint64_t lo = lower == 0 ? 0 : c_lo + (both & 0xFFFFu);
     const uint64_t hi = c_hi + (both >> 16);
     new_lower = (k == 0 ? ix.less[1] : k == 1 ? ix.less[2] : k == 2 ? ix.less[3] : ix.less[4]) + lo;

@@ -35,7 +35,7 @@ static_assert(MAPAD_HEAP_VARIANT >= 0 && MAPAD_HEAP_VARIANT <= 3, "MAPAD_HEAP_VA
 // -DMAPAD_PROFILE_SECTIONS: wave time and lane time per section of the search loop (s_memtime deltas accumulated in LDS, dumped by the kernel).
 // A diagnostic build: the marks cost a few percent and the numbers are relative.
 #if defined(MAPAD_PROFILE_SECTIONS) && defined(__HIPCC__)
-enum { PROF_POP = 0, PROF_NODE = 1, PROF_EXT = 2, PROF_GATES = 3, PROF_COMMIT = 4, PROF_TAIL = 5, PROF_SETUP = 6, PROF_FINALIZE = 7, PROF_GROW = 8, PROF_HIT = 9, PROF_LOOP = 10, PROF_C_PRE = 11, PROF_C_LOAD = 12, PROF_N = 14 };
+enum { PROF_POP = 0, PROF_NODE = 1, PROF_EXT = 2, PROF_GATES = 3, PROF_COMMIT = 4, PROF_TAIL = 5, PROF_SETUP = 6, PROF_FINALIZE = 7, PROF_GROW = 8, PROF_HIT = 9, PROF_LOOP = 10, PROF_C_PRE = 11, PROF_C_LOAD = 12, PROF_C_ANC = 13, PROF_N = 14 };
 __shared__ unsigned long long g_prof_lds[2 * PROF_N + 2];  // [k] wave cycles, [PROF_N + k] lane cycles, [2 PROF_N] last stamp
 __shared__ unsigned int g_prof_hist[64];  // [0..23] log2(heap_len) at pop, [24..35] children committed by a pop, [36..47] commit-loop trips of a wave step, [48..63] trickle levels
 __device__ __forceinline__ void prof_mark(int k) {

@@ -3,7 +3,7 @@
 // Follows src/index/indexing.rs:43-212 (FASTA -> uppercase -> IUPAC replacement -> text$revcomp$ -> rank transform ->
 // suffix array -> BWT -> SA sample 1/32 + extra rows -> Less) and src/index/mod.rs (SampledSuffixArray, FastaIdPositions,
 // OriginalSymbols).  Instead of rust-bio's Occ (u64 checkpoints every 128 rows, byte BWT) the rank structure is the
-// 128-byte-block layout of fmd_device.hpp, shared by host (SA walks) and device.
+// 64-byte-block layout of fmd_device.hpp, shared by host (SA walks) and device.
 #pragma once
 #include "host_cpus.hpp"
 #include <algorithm>
@@ -28,8 +28,8 @@ struct Index {
     std::vector<uint8_t> bwt;        // reference ranks $=0 A=1 C=2 G=3 T=4 X=5
     uint64_t less[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     uint64_t sentinel[2] = {0, 0};
-    std::vector<uint64_t> blocks;    // device layout, 16 u64 per 256 rows
-    std::vector<uint64_t> x_counts;  // per block: X symbols in rows [0, 256b) (only needed for LF steps through 'X')
+    std::vector<uint64_t> blocks;    // device layout (fmd_device.hpp): kBlockWords u64 per kBlockRows rows
+    std::vector<uint64_t> x_counts;  // per block b: X symbols in rows [0, kBlockRows b) (only needed for LF steps through 'X')
     std::vector<uint64_t> sa_sample;
     uint64_t sa_rate = 32;
     std::map<uint64_t, uint64_t> extra_rows;
@@ -38,7 +38,7 @@ struct Index {
 
     DevIndex view() const {
         DevIndex v;
-        v.blocks = blocks.data(); v.n = n; v.n_blocks = blocks.size() / 16;
+        v.blocks = blocks.data(); v.n = n; v.n_blocks = blocks.size() / kBlockWords;
         for (int i = 0; i < 8; ++i) v.less[i] = less[i];
         v.sentinel[0] = sentinel[0]; v.sentinel[1] = sentinel[1];
         return v;
@@ -47,13 +47,7 @@ struct Index {
     uint64_t occ_rank(uint64_t r, int a) const {
         if (a >= 1 && a <= 4) return occ_scalar(view(), r, a - 1);
         if (a == 0) return (uint64_t)(r >= sentinel[0]) + (uint64_t)(r >= sentinel[1]);
-        // 'X': code 1 = plane0 only
-        const uint64_t* blk = blocks.data() + (r >> 8) * 16;
-        const int r_in = (int)(r & 255);
-        uint64_t c = x_counts.empty() ? 0 : x_counts[r >> 8];
-        for (int w = 0; w <= (r_in >> 6); ++w)
-            c += popc64(blk[4 * w + 1] & ~blk[4 * w + 2] & ~blk[4 * w + 3] & row_mask(w, r_in));
-        return c;
+        return occ_x_scalar(view(), x_counts.empty() ? nullptr : x_counts.data(), r);  // 'X'
     }
     // SampledSuffixArray::get (src/index/mod.rs:160-187)
     bool sa_get(uint64_t index, uint64_t& out) const {
@@ -200,7 +194,7 @@ void sais(const S* s, I* SA, I n, I K) {
 inline void build_blocks(Index& ix) {
     const uint64_t n = ix.n;
     const uint64_t n_blocks = (n + kBlockRows - 1) / kBlockRows + 1;  // one spare block keeps hi-row prefetches in bounds
-    ix.blocks.assign(n_blocks * 16, 0);
+    ix.blocks.assign(n_blocks * kBlockWords, 0);
     ix.x_counts.clear();
     static const int CODE[6] = {0, 4, 5, 6, 7, 1};  // rank -> device symbol code
     // pass 1 (threads over block ranges): bit planes + the block's own symbol counts, parked in the count words
@@ -211,22 +205,21 @@ inline void build_blocks(Index& ix) {
     auto work = [&](unsigned t) {
         const uint64_t b0 = n_blocks * t / T, b1 = n_blocks * (t + 1) / T;
         for (uint64_t b = b0; b < b1; ++b) {
-            uint64_t* blk = ix.blocks.data() + b * 16;
+            uint64_t* blk = ix.blocks.data() + b * kBlockWords;
             uint64_t cnt[4] = {0, 0, 0, 0}, xcnt = 0;
+            uint32_t pl[4][3] = {};
             const uint64_t r0 = b * kBlockRows;
             for (uint64_t r = r0; r < std::min(n, r0 + kBlockRows); ++r) {
                 const uint8_t a = ix.bwt[r];
                 if (a > 5) { bad[t] = 1; continue; }
                 const int code = CODE[a];
-                const int w = (int)((r - r0) >> 6), bit = (int)((r - r0) & 63);
-                if (code & 1) blk[4 * w + 1] |= 1ull << bit;
-                if (code & 2) blk[4 * w + 2] |= 1ull << bit;
-                if (code & 4) blk[4 * w + 3] |= 1ull << bit;
+                const int w = (int)(r - r0) / kSubRows, bit = (int)(r - r0) % kSubRows;
+                for (int k = 0; k < 3; ++k) if (code & (1 << k)) pl[w][k] |= 1u << bit;
                 if (a >= 1 && a <= 4) cnt[a - 1] += 1;
                 else if (a == 5) xcnt += 1;
                 else if (sent[t].size() < 4) sent[t].push_back(r);
             }
-            for (int w = 0; w < 4; ++w) blk[4 * w] = cnt[w];
+            for (int w = 0; w < 4; ++w) { blk[2 * w] = pack_sub0(cnt[w], pl[w][0]); blk[2 * w + 1] = pack_sub1(pl[w][1], pl[w][2]); }
             xs[b] = xcnt;
         }
     };
@@ -236,8 +229,8 @@ inline void build_blocks(Index& ix) {
     // pass 2: exclusive prefix sums over the blocks
     uint64_t cnt[4] = {0, 0, 0, 0}, xcnt = 0;
     for (uint64_t b = 0; b < n_blocks; ++b) {
-        uint64_t* blk = ix.blocks.data() + b * 16;
-        for (int w = 0; w < 4; ++w) { const uint64_t c = blk[4 * w]; blk[4 * w] = cnt[w]; cnt[w] += c; }
+        uint64_t* blk = ix.blocks.data() + b * kBlockWords;
+        for (int w = 0; w < 4; ++w) { const uint64_t c = blk[2 * w] & kCountMask; blk[2 * w] = pack_sub0(cnt[w], sub_p0(blk[2 * w])); cnt[w] += c; }
         const uint64_t x = xs[b]; xs[b] = xcnt; xcnt += x;
     }
     std::vector<uint64_t> all_sent;

@@ -6,7 +6,7 @@
 // other million were done.  A read that has made `tail_pops` pops (default 2^19: none of the 50 bp workloads gets there) is therefore given up by its
 // quad — the read's position data and D array go into a record in page-locked host memory, written by the kernel while it runs — and a host thread
 // maps it FROM SCRATCH with the product's own search step (search_core.hpp compiled for the host: the same source as the kernel, scalar rank queries
-// on the same 128-byte blocks; never the test oracle), beside the GPU's bulk of this and the next batches.  Results go back into the batch's device
+// on the same 64-byte blocks; never the test oracle), beside the GPU's bulk of this and the next batches.  Results go back into the batch's device
 // pools before the order-preserving collect, so everything downstream (collect, gather, post-search) is unchanged; hits, edit tracks and event counters
 // are bit-identical to what the GPU stages produce for the same read (tests/test_gpu_tail.py runs both ways against the oracle).
 // This is a stage of the GPU path, not a fallback: without a gfx950 device there is no context and nothing runs (mapad_ctx_create).
@@ -146,7 +146,10 @@ private:
         const char* e = std::getenv("MAPAD_TAIL_THREADS");
         if (e && e[0]) { const unsigned n = (unsigned)std::strtoul(e, nullptr, 10); return n ? n : 8; }
         const unsigned lw = std::max(1u, local_world());
-        return std::max(1u, (cpu_share() + lw - 1) / lw);  // this rank's part of the node's share
+        // this rank's part of the node's share, less an eighth: the launch's dispatcher thread, the HIP runtime's helpers and the caller run beside the workers, and a
+        // cgroup pushed over its quota is throttled as a whole (16 CPUs: 14 workers gave the wall time of 16 with 6 throttled periods instead of 300, same box)
+        const unsigned share = std::max(1u, (cpu_share() + lw - 1) / lw);
+        return share >= 4 ? share - std::max(1u, share / 8) : share;
     }
     void start() {
         const unsigned n = wanted(), first = local_rank() * n;  // pinning: this rank's workers take the domains behind those of the ranks before it

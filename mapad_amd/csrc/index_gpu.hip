@@ -12,7 +12,7 @@
 //      sort by group: no per-group launches, so one huge group — a run of N's — costs the same per element as millions of pairs), split it
 //      where the keys differ, double h.  Ranks are always monotone in the true suffix order, so refining some groups deeper than others is
 //      harmless.  i.i.d. genomes leave ~n^2 / 4^25 suffixes for step 3 (a few thousand at n = 6e9); repeats cost log(repeat length) rounds.
-//   4. BWT, SA sample and the 128-byte rank blocks (fmd_device.hpp layout) are produced on the device from the finished SA.
+//   4. BWT, SA sample and the 64-byte rank blocks (fmd_device.hpp layout) are produced on the device from the finished SA.
 // HBM traffic is dominated by the radix passes of step 2 (8 passes x 32 B per suffix) and three random 8-byte accesses per suffix.
 #include <hip/hip_runtime.h>
 
@@ -233,39 +233,39 @@ __global__ void __launch_bounds__(256) bwt_kernel(const uint8_t* __restrict__ t,
         if (c == 0) { const unsigned long long k = atomicAdd(&extra[16], 1ull); if (k < 4) extra[17 + k] = r; }  // '$' rows of the BWT
     }
 }
-// one thread per 256-row block: bit planes + symbol counts of the block
+// one thread per 96-row block: bit planes + symbol counts of the block
 __global__ void __launch_bounds__(256) block_planes_kernel(const uint8_t* __restrict__ bwt, uint64_t n, uint64_t n_blocks, uint64_t* __restrict__ blocks, uint32_t* __restrict__ counts /* [5][n_blocks] */) {
     const uint64_t b = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     if (b >= n_blocks) return;
     uint32_t c[6] = {0, 0, 0, 0, 0, 0};
-    uint64_t* blk = blocks + b * 16;
+    uint64_t* blk = blocks + b * kBlockWords;
     for (int w = 0; w < 4; ++w) {
-        uint64_t p0 = 0, p1 = 0, p2 = 0;
-        const uint64_t r0 = b * 256 + 64 * w;
+        uint32_t p0 = 0, p1 = 0, p2 = 0;
+        const uint64_t r0 = b * kBlockRows + (uint64_t)kSubRows * w;
         if (r0 < n) {
-            const uint4* src = reinterpret_cast<const uint4*>(bwt + r0);  // the BWT buffer is padded to a multiple of 256 rows
-            for (int q = 0; q < 4; ++q) {
-                const uint4 v = src[q];
-                const uint32_t ws[4] = {v.x, v.y, v.z, v.w};
-                for (int d = 0; d < 4; ++d)
+            const uint2* src = reinterpret_cast<const uint2*>(bwt + r0);  // the BWT buffer is padded to a multiple of 96 rows; 24 rows = 3 x 8 bytes
+            for (int q = 0; q < 3; ++q) {
+                const uint2 v = src[q];
+                const uint32_t ws[2] = {v.x, v.y};
+                for (int d = 0; d < 2; ++d)
                     for (int e = 0; e < 4; ++e) {
-                        const int bit = q * 16 + d * 4 + e;
+                        const int bit = q * 8 + d * 4 + e;
                         if (r0 + bit >= n) continue;
                         const uint32_t a = (ws[d] >> (8 * e)) & 0xFF;  // rank: $=0 A=1 C=2 G=3 T=4 X=5 -> code 0,4,5,6,7,1
                         const uint32_t code = a == 0 ? 0u : a == 5 ? 1u : a + 3u;
-                        p0 |= (uint64_t)(code & 1) << bit; p1 |= (uint64_t)((code >> 1) & 1) << bit; p2 |= (uint64_t)(code >> 2) << bit;
+                        p0 |= (code & 1) << bit; p1 |= ((code >> 1) & 1) << bit; p2 |= (code >> 2) << bit;
                         c[a] += 1;
                     }
             }
         }
-        blk[4 * w + 1] = p0; blk[4 * w + 2] = p1; blk[4 * w + 3] = p2;
+        blk[2 * w] = pack_sub0(0, p0); blk[2 * w + 1] = pack_sub1(p1, p2);
     }
     for (int k = 0; k < 5; ++k) counts[(uint64_t)k * n_blocks + b] = c[k + 1];
 }
 __global__ void __launch_bounds__(256) block_counts_kernel(const uint64_t* __restrict__ prefix /* [5][n_blocks] */, uint64_t n_blocks, uint64_t* __restrict__ blocks, uint64_t* __restrict__ x_counts) {
     const uint64_t b = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     if (b >= n_blocks) return;
-    for (int w = 0; w < 4; ++w) blocks[b * 16 + 4 * w] = prefix[(uint64_t)w * n_blocks + b];
+    for (int w = 0; w < 4; ++w) blocks[b * kBlockWords + 2 * w] |= prefix[(uint64_t)w * n_blocks + b] & kCountMask;
     x_counts[b] = prefix[4 * n_blocks + b];
 }
 
@@ -520,7 +520,7 @@ void suffix_products(const uint8_t* t_host, host::Index& ix, int device, bool ve
     for (unsigned long long k = 0; k < extra[0] && k < 4; ++k) ix.extra_rows[extra[1 + 2 * k]] = extra[2 + 2 * k];
     lap("BWT + SA sample");
 
-    Buf<uint64_t> d_blocks(n_blocks * 16), d_prefix(5 * n_blocks), d_xc(n_blocks);
+    Buf<uint64_t> d_blocks(n_blocks * kBlockWords), d_prefix(5 * n_blocks), d_xc(n_blocks);
     Buf<uint32_t> d_counts(5 * n_blocks);
     hipLaunchKernelGGL(block_planes_kernel, dim3(grid_for(n_blocks, 256)), dim3(256), 0, s, d_bwt.p, n, n_blocks, d_blocks.p, d_counts.p);
     GI_TRY(hipGetLastError());
@@ -542,8 +542,8 @@ void suffix_products(const uint8_t* t_host, host::Index& ix, int device, bool ve
     GI_TRY(hipMemcpy(ix.bwt.data(), d_bwt.p, n, hipMemcpyDeviceToHost));
     ix.sa_sample.resize(n_samples);
     GI_TRY(hipMemcpy(ix.sa_sample.data(), d_sample.p, n_samples * 8, hipMemcpyDeviceToHost));
-    ix.blocks.resize(n_blocks * 16);
-    GI_TRY(hipMemcpy(ix.blocks.data(), d_blocks.p, n_blocks * 16 * 8, hipMemcpyDeviceToHost));
+    ix.blocks.resize(n_blocks * kBlockWords);
+    GI_TRY(hipMemcpy(ix.blocks.data(), d_blocks.p, n_blocks * kBlockBytes, hipMemcpyDeviceToHost));
     ix.x_counts.clear();
     if (totals[4]) { ix.x_counts.resize(n_blocks); GI_TRY(hipMemcpy(ix.x_counts.data(), d_xc.p, n_blocks * 8, hipMemcpyDeviceToHost)); }
     const uint64_t per[6] = {2, totals[0], totals[1], totals[2], totals[3], totals[4]};  // Less

@@ -287,30 +287,28 @@ __global__ void __launch_bounds__(64) locate_kernel(DevIndex ix, LocateDev Q) {
         if (!done) {
             if ((pos & rate_mask) == 0) { result = Q.sa_sample[pos >> Q.sa_shift] + offset; done = true; }
             else {
-                const uint64_t blk = pos >> 8;
-                const uint64_t* sb = ix.blocks + blk * 16 + 4 * w;
-                const ulonglong2 v0 = *reinterpret_cast<const ulonglong2*>(sb), v1 = *reinterpret_cast<const ulonglong2*>(sb + 2);
-                const int sub = (int)((pos >> 6) & 3), bit = (int)(pos & 63);
-                uint32_t code = (uint32_t)((v0.y >> bit) & 1) | ((uint32_t)((v1.x >> bit) & 1) << 1) | ((uint32_t)((v1.y >> bit) & 1) << 2);
-                code = quad_or32(w == sub ? code : 0u);  // bwt[pos]: 0 '$', 1 'X', 4..7 ACGT
+                const BlockPos bp = block_pos(pos);
+                const uint64_t* blk = ix.blocks + bp.b * kBlockWords;
+                const ulonglong2 v = *reinterpret_cast<const ulonglong2*>(blk + 2 * w);
+                const int sub = bp.r_in / kSubRows, bit = bp.r_in - kSubRows * sub;
+                const uint32_t code = quad_or32(w == sub ? (uint32_t)sub_code(v.x, v.y, bit) : 0u);  // bwt[pos]: 0 '$', 1 'X', 4..7 ACGT
                 if (code == 0) { result = (pos == Q.extra_row[0] ? Q.extra_val[0] : Q.extra_val[1]) + offset; done = true; }
                 else {
-                    // occ(pos - 1, c): pos is not a multiple of 32 here, so pos - 1 lies in the same block
-                    const int r_in = (int)((pos - 1) & 255);
-                    const uint64_t m = row_mask(w, r_in);
-                    uint64_t sel, base_count, less;
+                    // occ(pos - 1, c) from the block of pos: when pos is the block's first row the mask is empty and the block's count words are the answer
+                    const uint32_t m = sub_mask(w, bp.r_in - 1);
+                    uint32_t sel;
+                    uint64_t base_count, less;
                     if (code >= 4) {
                         const int k = (int)code - 4;
-                        const uint64_t inv1 = (k & 2) ? 0ull : ~0ull, inv0 = (k & 1) ? 0ull : ~0ull;
-                        sel = v1.y & (v1.x ^ inv1) & (v0.y ^ inv0) & m;
-                        base_count = ix.blocks[blk * 16 + 4 * k];
+                        sel = sub_is_base(v.x, v.y, k, m);
+                        base_count = blk[2 * k] & kCountMask;
                         less = k == 0 ? ix.less[1] : k == 1 ? ix.less[2] : k == 2 ? ix.less[3] : ix.less[4];
-                    } else {  // 'X' (rank 5): plane0 only
-                        sel = v0.y & ~v1.x & ~v1.y & m;
-                        base_count = Q.x_counts ? Q.x_counts[blk] : 0;
+                    } else {  // 'X' (rank 5)
+                        sel = sub_is_x(v.x, v.y, m);
+                        base_count = Q.x_counts ? Q.x_counts[bp.b] : 0;
                         less = ix.less[5];
                     }
-                    pos = less + base_count + quad_sum32((uint32_t)popc64(sel));
+                    pos = less + base_count + quad_sum32((uint32_t)popc32(sel));
                     offset += 1;
                     n_steps += 1;
                 }
@@ -1287,7 +1285,7 @@ struct mapad_ctx {
     int lpr = 4;  // lanes per read in the search kernel (MAPAD_LANES_PER_READ = 4 | 1)
     int n_cu = 256;
     int reserved_cus = 0;  // CUs the batch slots' streams leave free (create_slot_stream)
-    hipStream_t tail_stream = nullptr;  // drop_tail releases the grown arenas of abandoned hand-overs on it (the workers fetch on streams of their own)
+    hipStream_t tail_stream = nullptr;  // the host tail's workers copy handed-over searches out of grown arenas on it (fetch_tail_state, one at a time); drop_tail releases abandoned arenas on it
     std::mutex tail_mu;
     uint64_t counter_sums[6] = {0, 0, 0, 0, 0, 0};
     DevBuf<unsigned long long> d_prof;  // -DMAPAD_PROFILE_SECTIONS builds
@@ -1627,8 +1625,7 @@ int ensure_batch_buffers(mapad_ctx* c, BatchSlot& S, uint64_t n_reads, uint64_t 
 
 // A worker of the host tail takes over a read WITH its search (host_tail.hpp: TailState): heap slots [0, heap_len] (physical: logical i lives in slot i + 1; the
 // kernel has written levels 0-5 out of LDS) and nodes [0, tree_entries) of the grown arena `grown` come over PCIe into the worker's arena, then the arena is
-// released on the device (its owner word cleared by a one-wavefront kernel: fits beside the searches).  Called from worker threads, several at a time, each on
-// a stream of its own.  The arena is released whether or not the copies worked; false = map the read from scratch.
+// released on the device (its owner word cleared by a one-wavefront kernel: fits beside the searches).  Called from worker threads, several at a time.  The arena is released whether or not the copies worked; false = map the read from scratch.
 bool release_tail_arena(mapad_ctx* c, uint32_t grown, hipStream_t st) {
     const uint32_t cls = (grown >> kGrownShift) - 1, idx = grown & ((1u << kGrownShift) - 1);
     if (cls > (uint32_t)kClasses || idx >= c->grow.count[cls]) return false;
@@ -1647,7 +1644,17 @@ bool fetch_tail_state(mapad_ctx* c, uint32_t grown, uint32_t heap_len, uint32_t 
     if (hipSetDevice(c->device) != hipSuccess) return false;
     const uint32_t cls = (grown >> kGrownShift) - 1, idx = grown & ((1u << kGrownShift) - 1);
     if (cls > (uint32_t)kClasses || idx >= c->grow.count[cls]) return false;
-    hipStream_t st = thread_stream(c->device);
+    // All workers share the context's one copy stream, one fetch at a time.  MAPAD_TAIL_THREAD_STREAMS=1: a stream per worker, copies side by side — measured
+    // slower on the same box (1 M reads of the C5 mix: 33.9-37.7 s against 32.8 s, profiles/r05/ab_tail_streams.txt): sixteen more streams share the process's few
+    // hardware queues with the launches.
+    std::unique_lock<std::mutex> g(c->tail_mu, std::defer_lock);
+    hipStream_t st = nullptr;
+    if (env_u32("MAPAD_TAIL_THREAD_STREAMS", 0) != 0) st = thread_stream(c->device);
+    else {
+        g.lock();
+        if (!c->tail_stream && hipStreamCreateWithFlags(&c->tail_stream, hipStreamNonBlocking) != hipSuccess) return false;
+        st = c->tail_stream;
+    }
     if (!st) return false;
     const uint8_t* b = c->grow.base[cls] + (uint64_t)idx * c->grow.stride[cls];
     bool ok = heap_len < c->grow.heap_cap[cls] + 8 && tree_entries <= c->grow.node_cap[cls];
@@ -2095,7 +2102,7 @@ int mapad_index_copy_sa(const mapad_index_t* idx, uint64_t* sample, uint64_t* ex
 int mapad_index_device_view(const mapad_index_t* idx, const uint64_t** blocks, uint64_t* n_blocks, uint64_t less[8], uint64_t sentinel[2]) {
     if (!idx) return MAPAD_ERR_INVALID;
     if (blocks) *blocks = idx->ix.blocks.data();
-    if (n_blocks) *n_blocks = idx->ix.blocks.size() / 16;
+    if (n_blocks) *n_blocks = idx->ix.blocks.size() / kBlockWords;
     if (less) std::memcpy(less, idx->ix.less, sizeof idx->ix.less);
     if (sentinel) { sentinel[0] = idx->ix.sentinel[0]; sentinel[1] = idx->ix.sentinel[1]; }
     return MAPAD_OK;
@@ -2258,11 +2265,11 @@ int mapad_fetch_result(mapad_ctx_t* ctx, mapad_batch_result_t** out) {
             std::fprintf(stderr, "\n");
         };
         row("log2(heap_len) at pop", 0, 24); row("children committed per pop", 24, 12); row("commit-loop trips per wave step", 36, 12);
-        static const char* names[PROF_N] = {"pop+sift", "node/row/D", "rank ext", "gates+kids", "commit loop", "step tail", "read setup", "finalize", "grow", "record hit", "loop head", "commit: pre", "commit: wait", "-"};
+        static const char* names[PROF_N] = {"pop+sift", "node/row/D", "rank ext", "gates+kids", "commit loop", "step tail", "read setup", "finalize", "grow", "record hit", "loop head", "commit: pre", "commit: wait", "commit: anc"};
         double tw = 0, tl = 0;
         for (int k = 0; k < PROF_N; ++k) { tw += (double)pv[k]; tl += (double)pv[PROF_N + k]; }
         std::fprintf(stderr, "[sections] wave-cycles %.3e, lane-cycles %.3e (mean active lanes %.1f)\n", tw, tl, tl / std::max(tw, 1.0));
-        for (int k = 0; k < PROF_N - 1; ++k)
+        for (int k = 0; k < PROF_N; ++k)
             std::fprintf(stderr, "[sections] %-12s wave %5.1f %%   lanes %5.1f %%   active lanes %4.1f\n", names[k], 100.0 * pv[k] / std::max(tw, 1.0), 100.0 * pv[PROF_N + k] / std::max(tl, 1.0),
                          (double)pv[PROF_N + k] / std::max<double>((double)pv[k], 1.0));
     }

@@ -115,14 +115,7 @@ MAPAD_HD bool sa_get_hd(const PostIndex& Q, uint64_t row, uint64_t& out) {
         const int code = bwt_code(Q.ix, pos);
         if (code == 0) { out = (pos == Q.extra_row[0] ? Q.extra_val[0] : Q.extra_val[1]) + offset; return true; }
         if (code >= 4) pos = Q.ix.less[code - 3] + occ_scalar(Q.ix, pos - 1, code - 4);
-        else {  // 'X' (rank 5): plane 0 only
-            const uint64_t r = pos - 1;
-            const uint64_t* blk = Q.ix.blocks + (r >> 8) * 16;
-            const int r_in = (int)(r & 255);
-            uint64_t c = Q.x_counts ? Q.x_counts[r >> 8] : 0;
-            for (int w = 0; w <= (r_in >> 6); ++w) c += (uint64_t)popc64(blk[4 * w + 1] & ~blk[4 * w + 2] & ~blk[4 * w + 3] & row_mask(w, r_in));
-            pos = Q.ix.less[5] + c;
-        }
+        else pos = Q.ix.less[5] + occ_x_scalar(Q.ix, Q.x_counts, pos - 1);  // 'X' (rank 5)
         offset += 1;
     }
 }

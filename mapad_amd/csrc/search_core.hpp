@@ -6,7 +6,7 @@
 //     (a frame and the tree node created for it are 1:1, mapping.rs:969-971, so the node id doubles as the frame id),
 //   * the hit list = Rust std BinaryHeap array order,
 // living in the read slot's arena in HBM, except for the top 31 heap entries, the read's position data and its D array, which are
-// "near" data (LDS on the device).  One pop costs: heap sift + one 32-byte node + one 16-byte score-table row + two 128-byte index
+// "near" data (LDS on the device).  One pop costs: heap sift + one 32-byte node + one 16-byte score-table row + two 64-byte index
 // blocks.  The four lanes of the quad execute the control flow on quad-uniform values; they split the work in the rank queries
 // (fmd_device.hpp: lane w counts sub-block w and keeps the extension by base w) and in building the children of a frame (lane w packs
 // the deletion and match/mismatch nodes of base w; search_step / commit_child).
@@ -26,7 +26,7 @@ struct SearchState {
     uint64_t best_size;
 };
 
-// LPR = lanes per read: 4 = the quad splits every rank query (one coalesced 128-byte line per query);
+// LPR = lanes per read: 4 = the quad splits every rank query (one coalesced 64-byte block per query);
 //                      1 = every lane owns a read and answers its own rank queries (more reads per instruction issued).
 template <int LPR>
 MAPAD_HD void ext4_any(const DevIndex& ix, uint64_t lower, uint64_t lower_rev, uint64_t size, int w, Ext4& out) {
@@ -350,6 +350,7 @@ MAPAD_HD bool search_step(const DevIndex& ix, const DevParams& P, const ReadInT<
     //   1. {popped frame's node, the heap's last entry}      2. {score row, four index loads} issued as soon as the frame is known, and behind
     //   them the repair of the heap (its round trips through the arena levels run while the index loads are in flight) and the window of
     //   ancestors for this step's pushes      3. nothing: counts, gates, children and pushes work on what has arrived.
+    MAPAD_PRIO_HIGH();
     const HeapEntry top = mm_find_max(A, st.heap_len, top_idx);
     Node top_node;
     if constexpr (PC) {
@@ -438,6 +439,7 @@ MAPAD_HD bool search_step(const DevIndex& ix, const DevParams& P, const ReadInT<
 #endif
         if (top_idx < st.heap_len) mm_trickle_down<true>(A, st.heap_len, top_idx, last);
     }
+    MAPAD_PRIO_LOW();
     MAPAD_MARK(PROF_POP);
     Ext4 e;
     uint64_t my_lower[kBases] = {}, my_lower_rev[kBases] = {}, my_size[kBases] = {};  // kLaneKids: extension by this lane's base(s)
@@ -579,8 +581,14 @@ MAPAD_HD bool search_step(const DevIndex& ix, const DevParams& P, const ReadInT<
                     score = is_del ? deletion_score : score; score = is_ins ? insertion_score : score;
                     const uint32_t pos = n0 + (act ? r : 0u);
                     const HeapEntry elt{score, id0 + r};
+                    MAPAD_MARK(PROF_C_PRE);  // (section profile) gates .. here: instructions only
+                    MAPAD_PRIO_HIGH();
                     const Ancestors an = load_ancestors(A, pos);
+                    MAPAD_PRIO_LOW();
                     const bool stays = mm_push_stays(pos, elt, an);
+#if defined(MAPAD_PROFILE_SECTIONS)
+                    if (__ballot(stays) != 0x0123456789ABCDEFull) MAPAD_MARK(PROF_C_ANC);  // ... the one trip of the commit: the ancestors have arrived
+#endif
                     if (act & stays) hp_set(A, pos, elt);
                     // the movers of this round, in commit order, each by its own lane
                     uint32_t movers = (uint32_t)(__ballot(act & !stays) >> (threadIdx.x & 60u)) & 15u;  // this quad's four lanes
@@ -776,9 +784,7 @@ MAPAD_HD bool search_step(const DevIndex& ix, const DevParams& P, const ReadInT<
             const HeapEntry nt = mm_find_max(A, tmp.heap_len, ni);
             const Frame nf = unpack_frame(A.nodes[nt.node]);
             const uint64_t nx = (nf.start <= L - nf.start - nf.len) ? nf.lower_rev : nf.lower;
-            const char* b0 = (const char*)(ix.blocks + ((nx ? nx - 1 : 0) >> 8) * 16);
-            const char* b1 = (const char*)(ix.blocks + ((nx + nf.size - 1) >> 8) * 16);
-            __builtin_prefetch(b0); __builtin_prefetch(b0 + 64); __builtin_prefetch(b1); __builtin_prefetch(b1 + 64);
+            __builtin_prefetch(block_ptr(ix, nx ? nx - 1 : 0)); __builtin_prefetch(block_ptr(ix, nx + nf.size - 1));
             evict_worst(A, tmp, (a > b ? a : b) - 1);
         } else
 #endif

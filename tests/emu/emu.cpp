@@ -172,7 +172,7 @@ mapad_batch_result_t* emu_map_batch(const uint64_t* blocks, uint64_t n_blocks, u
                 g_attr.hits_lo = (uint64_t)hits.data(); g_attr.hits_hi = (uint64_t)(hits.data() + hits.size());
                 g_attr.ops_lo = (uint64_t)hit_ops.data(); g_attr.ops_hi = (uint64_t)(hit_ops.data() + hit_ops.size());
                 g_attr.near_lo = (uint64_t)top.data(); g_attr.near_hi = (uint64_t)(top.data() + top.size());
-                g_attr.index_lo = (uint64_t)ix.blocks; g_attr.index_hi = (uint64_t)(ix.blocks + ix.n_blocks * 16);
+                g_attr.index_lo = (uint64_t)ix.blocks; g_attr.index_hi = (uint64_t)(ix.blocks + ix.n_blocks * mapad::kBlockWords);
             }
             if (pass == 0) search_read(ix, P, rd, A, st, 0, grow);
             else search_read(ix, P, rd, A, st, 0);
@@ -215,6 +215,22 @@ void emu_attr_end(uint64_t* out) {
     for (auto& c : g_attr.caches) for (int kind = 0; kind < K_N; ++kind) { out[k++] = c.access[kind]; out[k++] = c.read_miss[kind]; out[k++] = c.writeback[kind]; }
     out[k++] = g_attr.pops; out[k++] = g_attr.index_touches; out[k++] = g_attr.near_touches;
     for (int l = 0; l < 32; ++l) out[k++] = g_attr.heap_level_reads[l];
+}
+
+// Property check of fmd_device.hpp's row -> (block, row in block) split (a division by 96 written as 32-bit arithmetic): `trials` random rows below 2^bits plus
+// the rows around every power of two and around multiples of 96 * 65536.  Returns the number of rows it gets wrong (must be 0).
+uint64_t emu_block_pos_selftest(uint64_t seed, uint32_t trials, uint32_t bits) {
+    uint64_t x = seed * 0x9E3779B97F4A7C15ull + 1, bad = 0;
+    auto rnd = [&]() { x ^= x << 13; x ^= x >> 7; x ^= x << 17; return x; };
+    auto check = [&](uint64_t r) {
+        if (r >> bits) return;
+        const BlockPos p = block_pos(r);
+        bad += (p.b != r / (uint64_t)kBlockRows) || (p.r_in != (int)(r % (uint64_t)kBlockRows));
+    };
+    for (uint32_t t = 0; t < trials; ++t) check(rnd() >> (64 - bits));
+    for (uint32_t k = 0; k < bits; ++k) for (int64_t d = -200; d <= 200; ++d) if ((int64_t)(1ull << k) + d >= 0) check((1ull << k) + (uint64_t)d);
+    for (uint64_t m = 0; m < 4096; ++m) for (int64_t d = -3; d <= 3; ++d) if (m || d >= 0) check(m * 96u * 65536u + (uint64_t)d);
+    return bad;
 }
 
 // Property check of the lane-parallel commit (search_core.hpp: MAPAD_PAR_COMMIT) on random heaps: `trials` times a min-max heap of n0 in [16, max_n] entries is

@@ -31,6 +31,8 @@ def lib(heap_variant=0):
                                     C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32]
         L.emu_result_free.restype = None
         L.emu_result_free.argtypes = [C.POINTER(mb.BatchResultC)]
+        L.emu_block_pos_selftest.restype = C.c_uint64
+        L.emu_block_pos_selftest.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32]
         L.emu_par_commit_selftest.restype = C.c_uint64
         L.emu_par_commit_selftest.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32]
         _libs[heap_variant] = _lib = L

@@ -352,6 +352,13 @@ def test_lane_parallel_commit_equals_sequential_pushes_on_random_heaps(max_n, le
         assert emu_util.lib().emu_par_commit_selftest(seed + 17 * levels, 4000, max_n, levels) == 0
 
 
+@pytest.mark.parametrize("bits", [20, 33, 40, 47])
+def test_row_to_block_split_is_exact(bits):
+    """fmd_device.hpp: block_pos — BWT row -> (64-byte block of 96 rows, row inside it) by 32-bit arithmetic instead of a 64-bit division: exact on random rows, around
+    every power of two and around the multiples of 96 * 2^16 where the split of the quotient carries."""
+    assert emu_util.lib().emu_block_pos_selftest(7 + bits, 2_000_000, bits) == 0
+
+
 # ---- post-search ----------------------------------------------------------------------------------------------------------
 def check_integration_records(k, recs):
     """shared_expectation of tests/integration_tests.rs:464-868 on decoded record fields."""
