@@ -19,15 +19,7 @@
 #if !defined(MAPAD_TOUCH)
 #define MAPAD_TOUCH(p, bytes, wr) ((void)0)
 #endif
-// MAPAD_PRIO=1 (experiment): a wavefront raises its issue priority from the pop until its loads for the step are out (node, index blocks, sift), and around the
-// loads of the commit's ancestors — with under three wavefronts per SIMD a ready wavefront otherwise queues behind an older one's arithmetic.
-#if defined(MAPAD_PRIO) && MAPAD_PRIO && defined(__HIP_DEVICE_COMPILE__)
-#define MAPAD_PRIO_HIGH() __builtin_amdgcn_s_setprio(3)
-#define MAPAD_PRIO_LOW() __builtin_amdgcn_s_setprio(0)
-#else
-#define MAPAD_PRIO_HIGH() ((void)0)
-#define MAPAD_PRIO_LOW() ((void)0)
-#endif
+
 
 namespace mapad {
 

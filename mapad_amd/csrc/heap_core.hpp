@@ -417,8 +417,8 @@ MAPAD_HD void mm_trickle_down(const ArenaT<NL, TOP>& A, uint32_t n, uint32_t pos
     };
     auto set_near = [&](uint32_t i, const HeapEntry e) { store_entry(A.top + i, e); };
     auto set_any = [&](uint32_t i, const HeapEntry e) { hp_set(A, i, e); };
-    if constexpr (TOP >= 63) {
-        constexpr int kNearStrides = TOP >= 1023 ? 4 : TOP >= 255 ? 3 : 2;  // strides that stay inside the near levels when the sift starts at slot 1 or 2
+    if constexpr (TOP >= 31) {
+        constexpr int kNearStrides = TOP >= 1023 ? 4 : TOP >= 255 ? 3 : TOP >= 63 ? 2 : 1;  // strides that stay inside the near levels when the sift starts at slot 1 or 2
 #pragma unroll
         for (int k = 0; k < kNearStrides; ++k) {
             const uint32_t c1 = 2 * pos + 1, g1 = 2 * c1 + 1;

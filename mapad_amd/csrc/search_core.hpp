@@ -350,7 +350,6 @@ MAPAD_HD bool search_step(const DevIndex& ix, const DevParams& P, const ReadInT<
     //   1. {popped frame's node, the heap's last entry}      2. {score row, four index loads} issued as soon as the frame is known, and behind
     //   them the repair of the heap (its round trips through the arena levels run while the index loads are in flight) and the window of
     //   ancestors for this step's pushes      3. nothing: counts, gates, children and pushes work on what has arrived.
-    MAPAD_PRIO_HIGH();
     const HeapEntry top = mm_find_max(A, st.heap_len, top_idx);
     Node top_node;
     if constexpr (PC) {
@@ -439,7 +438,6 @@ MAPAD_HD bool search_step(const DevIndex& ix, const DevParams& P, const ReadInT<
 #endif
         if (top_idx < st.heap_len) mm_trickle_down<true>(A, st.heap_len, top_idx, last);
     }
-    MAPAD_PRIO_LOW();
     MAPAD_MARK(PROF_POP);
     Ext4 e;
     uint64_t my_lower[kBases] = {}, my_lower_rev[kBases] = {}, my_size[kBases] = {};  // kLaneKids: extension by this lane's base(s)
@@ -582,9 +580,7 @@ MAPAD_HD bool search_step(const DevIndex& ix, const DevParams& P, const ReadInT<
                     const uint32_t pos = n0 + (act ? r : 0u);
                     const HeapEntry elt{score, id0 + r};
                     MAPAD_MARK(PROF_C_PRE);  // (section profile) gates .. here: instructions only
-                    MAPAD_PRIO_HIGH();
                     const Ancestors an = load_ancestors(A, pos);
-                    MAPAD_PRIO_LOW();
                     const bool stays = mm_push_stays(pos, elt, an);
 #if defined(MAPAD_PROFILE_SECTIONS)
                     if (__ballot(stays) != 0x0123456789ABCDEFull) MAPAD_MARK(PROF_C_ANC);  // ... the one trip of the commit: the ancestors have arrived
