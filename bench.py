@@ -43,6 +43,7 @@ sys.path.insert(0, ROOT)
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")  # one hardware queue per batch in flight; must be set before torch or the library touch the GPU
 
 HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s
+RANDOM_ACCESS_CEILING_G = 45.0  # G requests/s: independent random 64-128-byte reads from an 8 GiB table, measured (profiles/calib/fetch_calib.hip: 42.8-48.5)
 
 CONFIGS = {  # genome bp, reads per GPU
     "c1": (5_386, 1_000), "c2": (48_000_000, 1_000_000), "c3": (48_000_000, 1_000_000), "c4": (3_000_000_000, 10_000_000), "c5": (48_000_000, 1_000_000),
@@ -476,7 +477,7 @@ def main():
     dom_bytes, dom_ms = (bytes_search, ms_search) if dominant == "search_kernel" else (bytes_darray, ms_darray)
     achieved = dom_bytes / (dom_ms * 1e-3) / 1e9
     # HBM traffic of the PMC passes (profiles/collect.sh) — reported only while the library's gfx950 machine code is the code those passes ran
-    traffic, traffic_stale, traffic_darray = None, None, None
+    traffic, traffic_stale, traffic_darray, hbm_requests = None, None, None, None
     tp = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tp):
         try:
@@ -489,6 +490,7 @@ def main():
                     traffic_stale = entry.get("kernel_source_sha16") != mbuild_.source_hash()
                 traffic = None if traffic_stale else entry.get(dominant)
                 traffic_darray = None if traffic_stale else entry.get("darray_kernel")
+                hbm_requests = None if traffic_stale else entry.get(dominant + "_hbm_requests")
         except Exception:
             traffic = None
     roofline = {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
@@ -508,7 +510,15 @@ def main():
                                                   "bound": "L2 / instruction issue (the index blocks of the first extensions are shared by all reads)"},
                                 "search_kernel": {"ms": round(float(ms_search), 4), "bytes": bytes_search, "GB/s": round(bytes_search / (ms_search * 1e-3) / 1e9, 2)},
                                 "search_kernel_last_pass": {"ms": round(float(ms_pass2), 4), "arena_migrations": res.n_second_pass, "reads": res.n_third_pass}},
-                # secondary bound of SURVEY 8(d): dependent random 128-byte index lines per second (2 per extension)
+                # the bound this path actually runs against (SURVEY 8(d)'s "random-access line rate"): requests the L2 sends to memory per second — the PMC passes'
+                # FETCH_SIZE + WRITE_SIZE in 64-byte request units (profiles/traffic.json) over a launch alone on the chip — against the rate at which independent
+                # random 64 / 128-byte reads of an 8 GiB table complete on this chip (profiles/calib/fetch_calib.hip, profiles/r05/calib_random_access.txt: 48.5 /
+                # 42.8 G/s; 32-byte records gathered per lane 40.3 G/s): a rate of accesses, whatever their size
+                "random_access": None if not hbm_requests or dominant != "search_kernel" else {
+                    "hbm_requests_per_launch": hbm_requests, "achieved": round(hbm_requests / (solo_ms[1] * 1e-3) / 1e9, 2), "ceiling": RANDOM_ACCESS_CEILING_G, "unit": "G requests/s",
+                    "frac": round(hbm_requests / (solo_ms[1] * 1e-3) / 1e9 / RANDOM_ACCESS_CEILING_G, 4),
+                    "what": "read + write requests behind the L2 per launch (PMC) / solo launch duration; ceiling = measured read-only random-access rate of this chip"},
+                # secondary bound of SURVEY 8(d): dependent random index blocks per second (2 per extension)
                 "index_lines_per_s": {"search_kernel": round(2 * e_search / (ms_search * 1e-3), 1), "darray_kernel": round(2 * e_darray / (ms_darray * 1e-3), 1)},
                 "events": {"E_search": e_search, "E_darray": e_darray, "N_push": n_push, "N_pop": n_pop, "N_node": n_node}}
 

@@ -90,6 +90,9 @@ for k, c in counters.items():
     summary["per_batch"][k] = per
     if "FETCH_SIZE" in per and "WRITE_SIZE" in per:
         traffic[k] = int((2 * per["FETCH_SIZE"] + per["WRITE_SIZE"]) * 1024)
+        # requests the L2 sent to memory (FETCH_SIZE and WRITE_SIZE are request counts x 64 B on gfx950, whatever a request's size): the path's accesses are
+        # random, and what such a path saturates is the rate of requests, not bytes (profiles/calib/fetch_calib.hip; bench.py: roofline.random_access)
+        traffic[k + "_hbm_requests"] = int((per["FETCH_SIZE"] + per["WRITE_SIZE"]) * 1024 / 64)
 summary["traffic_bytes_per_batch"] = traffic
 json.dump(summary, open(os.path.join(ROOT, "profiles", f"{tag}_pmc_summary.json"), "w"), indent=1)
 tp = os.path.join(ROOT, "profiles", "traffic.json")
