@@ -711,7 +711,7 @@ def main():
                 d = json.loads(pr.stdout.strip().splitlines()[-1])
                 r = d["roofline"]
                 secondary[cfg] = {"reads_per_s": d["value"], "ms_per_step": d["ms_per_step"], "steps": d["steps"], "workload": d["config"]["workload"], "batches_in_flight": d["config"]["batches_in_flight"],
-                                  "roofline": {k: r[k] for k in ("kernel", "achieved", "frac", "traffic", "traffic_stale", "kernel_ms", "algorithmic_bytes_per_launch")},
+                                  "roofline": {k: r.get(k) for k in ("kernel", "achieved", "frac", "traffic", "traffic_stale", "kernel_ms", "algorithmic_bytes_per_launch", "random_access")},
                                   "solo_launch": r["solo_launch"], "cpu_baseline": d["cpu_baseline"], "parity": d["parity"], "tail": d["tail"], "wall_s": round(time.perf_counter() - t, 1)}
             except Exception as e:
                 secondary[cfg] = {"skipped": f"{type(e).__name__}: {e}"}
