@@ -32,6 +32,19 @@ __global__ void gather_quads64(const ulonglong2* t, uint64_t n_blocks, uint64_t 
     }
     if (acc == 0x1234567) sink[0] = acc;
 }
+// the same with eight independent blocks in flight per quad and iteration: is the rate above the memory system's, or the loop's?
+__global__ void gather_quads64_x8(const ulonglong2* t, uint64_t n_blocks, uint64_t per_quad, uint64_t* sink) {
+    const uint64_t tid = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x, quad = tid >> 2, w = tid & 3;
+    uint64_t acc = 0;
+    for (uint64_t i = 0; i < per_quad; i += 8) {
+        ulonglong2 v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = t[(mix(quad * per_quad + i + k + 5) % n_blocks) * 4 + w];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc += v[k].x ^ v[k].y;
+    }
+    if (acc == 0x1234567) sink[0] = acc;
+}
 __global__ void gather_lanes(const ulonglong2* t, uint64_t n_recs, uint64_t per_lane, uint64_t* sink) {
     const uint64_t tid = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
     uint64_t acc = 0;
@@ -52,6 +65,7 @@ int main() {
     const uint64_t per = 512;
     hipLaunchKernelGGL(gather_quads, dim3(grid), dim3(block), 0, 0, (const ulonglong2*)t, bytes / 128, per, sink);
     hipLaunchKernelGGL(gather_lanes, dim3(grid), dim3(block), 0, 0, (const ulonglong2*)t, bytes / 32, per, sink);
+    hipLaunchKernelGGL(gather_quads64_x8, dim3(grid), dim3(block), 0, 0, (const ulonglong2*)t, bytes / 64, per, sink);
     hipLaunchKernelGGL(gather_quads64, dim3(grid), dim3(block), 0, 0, (const ulonglong2*)t, bytes / 64, per, sink);
     hipDeviceSynchronize();
     std::printf("gather_quads64 known_bytes %llu (x2 if the L2 fills whole 128-byte lines)\n", (unsigned long long)((uint64_t)grid * block / 4 * per * 64));
