@@ -21,7 +21,8 @@ its own shard (weak scaling) and, inside every step, lays its hits out in read o
 CIGAR / MD / XA text, MAPQ inputs: <= 128 bytes per read) and sends those to rank 0 (RCCL point-to-point over xGMI); after the timed region rank 0 merges
 the shards and checks them against every rank's own copy.
 
-Also on the line: `roofline` (dominant kernel: algorithmic bytes from the kernels' event counters / HIP-event time), `cpu_baseline`
+Also on the line: `roofline` (dominant kernel: algorithmic bytes from the kernels' event counters / HIP-event time; `random_access` = the requests the L2 sent to
+memory per second, from the committed PMC passes, against this chip's measured rate of independent random reads — the bound the path actually runs against), `cpu_baseline`
 (the C++ oracle on the host cores over a bounded sample, N = 1 only; its hits must equal the GPU's), `e2e` (host buffers in, host
 results out: H2D + kernels + device-side collect + D2H), `sa_locate` and `post_search` (the next rows of the path), `tail` (reads finished by host threads),
 `secondary` (C4 only: short C2 / C3 runs as processes of their own, and C5's read mix — 200 000 reads at the reference's real limits — on this run's 3 Gbp index).
