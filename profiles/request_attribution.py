@@ -30,7 +30,10 @@ def main():
     ap.add_argument("--genome-bp", type=int, default=48_000_000)
     ap.add_argument("--reads", type=int, default=20_000)
     ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r05", "request_attribution.json"))
+    ap.add_argument("--heap-layout", type=int, default=0, help="1: the model sees the arena's heap levels in the subtree-contiguous candidate layout (tests/emu/emu.cpp: "
+                                                               "subtree_slot) — what would a re-laid heap save?  The mapping itself is unchanged")
     args = ap.parse_args()
+    os.environ["MAPAD_ATTR_HEAP_LAYOUT"] = str(args.heap_layout)
     os.environ["MAPAD_EMU_PAYLOAD_CACHE"] = "0"
     import emu_util
     import mapad_amd
@@ -46,7 +49,7 @@ def main():
     L.emu_attr_end.argtypes = [C.c_void_p]
     cfgs = [(6, 12), (6, 90), (6, 720), (7, 6), (7, 45), (7, 360)]  # (log2 line bytes, lines): L2 share, Infinity-Cache share, generous
     out = {"what": "per pop: arena accesses / read misses / write-backs of a private LRU line cache per read, by structure; host build of the kernel's step",
-           "genome_bp": args.genome_bp, "reads": args.reads, "mixes": {}}
+           "genome_bp": args.genome_bp, "reads": args.reads, "heap_layout_seen_by_the_model": "subtree-contiguous blocks (candidate)" if args.heap_layout else "implicit array (as built)", "mixes": {}}
     mixes = {"c2_like": (NO_DAMAGE, dict(qual=40)), "c3_like": (DAMAGE, dict(qual_range=(20, 40), damage=dict(f=0.5, t=0.5, d=0.02, s=1.0)))}
     for name, (prm, kw) in mixes.items():
         seqs, quals, offsets = synth.reads(g, args.reads, 50, seed=4321 + len(name), **kw)

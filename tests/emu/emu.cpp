@@ -59,7 +59,21 @@ struct Attribution {
     std::vector<LineCache> caches;
     uint64_t index_touches = 0, near_touches = 0, pops = 0;
     uint64_t heap_level_reads[32] = {};  // arena heap reads by heap level (log2(slot + 1)): where a sift's trips go
+    uint32_t heap_layout = 0;            // 1: the model sees the arena's heap levels in the subtree-contiguous layout below instead of the implicit array
 } g_attr;
+// A candidate layout of the arena's heap levels (>= 6), evaluated through this model only: every odd-level (max-level) entry p owns a 64-byte block holding its two
+// children (slots 0-1) and four grandchildren (slots 2-5) — exactly what one stride of a pop's sift reads — so that a stride is one line instead of two.  Entries of
+// even levels live in their parent's block, entries of odd levels in their grandparent's; blocks are numbered level by level (odd levels 5, 7, 9, ...).
+uint64_t subtree_slot(uint64_t i) {  // logical heap slot (>= 63) -> physical 8-byte entry index
+    const uint64_t x = i + 1;
+    const int level = 63 - __builtin_clzll(x);
+    const bool even = (level & 1) == 0;
+    const uint64_t xp = even ? x >> 1 : x >> 2;          // the owner, 1-based
+    const uint64_t slot = even ? (x & 1) : 2 + (x & 3);
+    const int lp = even ? level - 1 : level - 2;          // the owner's level: odd, >= 5
+    const uint64_t block = (0xAAAAAAAAAAAAAAAAull & ((1ull << (lp - 1)) - 1)) + (xp - (1ull << lp)) - 10;  // (2^lp - 2) / 3 blocks belong to lower odd levels, 10 of them to levels 1 and 3 (near data)
+    return 64 + 8 * block + slot;
+}
 }  // namespace
 extern "C" void emu_touch(const void* p, unsigned long bytes, bool wr) {
     if (!g_attr.on) return;
@@ -74,6 +88,14 @@ extern "C" void emu_touch(const void* p, unsigned long bytes, bool wr) {
     else if (a >= g_attr.node_lo && a < g_attr.node_hi) kind = K_NODE;
     else if ((a >= g_attr.hits_lo && a < g_attr.hits_hi) || (a >= g_attr.ops_lo && a < g_attr.ops_hi)) kind = K_HITS;
     if (kind == K_INDEX) return;  // shared by every read of the chip: not a per-read cache's business
+    if (kind == K_HEAP && g_attr.heap_layout == 1) {
+        for (uint64_t off = 0; off < bytes; off += sizeof(HeapEntry)) {
+            const uint64_t slot = (a + off - g_attr.heap_lo) / sizeof(HeapEntry);  // logical slot (A.heap points one entry into the allocation)
+            const uint64_t phys = slot >= 63 ? subtree_slot(slot) : slot;
+            for (auto& c : g_attr.caches) c.touch(g_attr.heap_lo - sizeof(HeapEntry) + phys * sizeof(HeapEntry), (uint32_t)sizeof(HeapEntry), wr, kind);  // blocks 64-byte aligned
+        }
+        return;
+    }
     for (auto& c : g_attr.caches) c.touch(a, (uint32_t)bytes, wr, kind);
 }
 
@@ -206,6 +228,7 @@ void emu_result_free(mapad_batch_result_t* r) { if (r) delete reinterpret_cast<E
 // {accesses, read misses, write-backs}, then the totals.  out: n_cfg x 5 kinds x 3 u64, then {pops, index touches, near touches}, then 32 heap-level read counts.
 void emu_attr_begin(const uint32_t* cfg, uint32_t n_cfg) {
     g_attr = Attribution();
+    if (const char* e = std::getenv("MAPAD_ATTR_HEAP_LAYOUT")) g_attr.heap_layout = (uint32_t)std::atoi(e);
     for (uint32_t i = 0; i < n_cfg; ++i) { LineCache c; c.line_shift = cfg[2 * i]; c.cap = cfg[2 * i + 1]; g_attr.caches.push_back(c); }
     g_attr.on = true;
 }
