@@ -2,8 +2,8 @@
 //
 // Replaces, on the device: FmdExtIterator (src/map/fmd_index.rs:109-182) + Occ::get_small_k / Less / BWT of the
 // rust-bio fork (byte BWT + u64 checkpoints every 128 rows).  occ(r, c) is a mathematically unique number, so the
-// layout is free: here one 64-byte request answers occ(r, A|C|G|T) for 96 rows (rounds 1-5a: 128 bytes per 256 rows —
-// two requests between L1 and L2 per rank query; the index was 4 of the 5.7 read requests of a pop).
+// layout is free: here one 64-byte block answers occ(r, A|C|G|T) for 96 rows (until late round 5: 128 bytes per 256 rows; either is one
+// request to the L2 and one 128-byte line behind it — the smaller block halves the bytes between L1 and L2 and the registers a query holds: DESIGN.md section 4).
 //
 //   block b (rows 96b .. 96b+95), 8 x u64:
 //     sub-block w = words [2w, 2w+1], rows 96b+24w .. +23:

@@ -261,7 +261,7 @@ __global__ void MAPAD_SLIM order_scatter_kernel(BatchDev B) {
 
 // ---- SA locate: SampledSuffixArray::get (src/index/mod.rs:160-187) on the device, one quad per row ------------------------
 // Walk LF steps (pos = less[c] + occ(pos - 1, c), c = bwt[pos]) until a sampled row (pos % 32 == 0) or a '$' row (extra_rows).
-// Every step reads the 128-byte block of `pos`: lane w of the quad holds sub-block w, the lane that owns the row extracts the
+// Every step reads the 64-byte block of `pos`: lane w of the quad holds sub-block w, the lane that owns the row extracts the
 // symbol, all four count it up to row pos - 1.  <= 31 dependent steps per row: latency-bound, hidden by 16 rows per wavefront.
 struct LocateDev {
     const uint64_t* rows;
