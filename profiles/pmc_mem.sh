@@ -10,6 +10,7 @@ cd /tmp; export TMPDIR=/tmp
 BENCH_ARGS="$*"
 pass() {
   name=$1; shift
+  if [ -n "$PMC_MEM_PASSES" ] && ! echo " $PMC_MEM_PASSES " | grep -q " $name "; then return; fi  # PMC_MEM_PASSES="e f g h": only these (the GRBM / TA / TCC groups time out on this pool)
   timeout 280 rocprofv3 --pmc "$@" --kernel-trace -d "$OUT/$name" -o out --output-format csv -- python3 "$ROOT/bench.py" --steps 1 --warmup 0 --depth 1 --no-cpu-baseline --no-extras $BENCH_ARGS > "$OUT/$name.log" 2>&1; echo "$name rc=$?"
 }
 pass a GRBM_GUI_ACTIVE GRBM_TA_BUSY GRBM_TC_BUSY GRBM_EA_BUSY GRBM_UTCL2_BUSY
