@@ -134,6 +134,11 @@ int mapad_ctx_set_reserved_cus(mapad_ctx_t* ctx, int n_cus);
  * process's share of the CPUs, divided by LOCAL_WORLD_SIZE when several ranks share a node).  Their results join the batch before its order-preserving collect:
  * nothing a caller sees depends on where a read was finished. */
 int mapad_ctx_set_tail_pops(mapad_ctx_t* ctx, uint32_t pops);
+/* "This process is one rank of `local_world` on its node": the host tail's worker threads that take reads from now on are this rank's part of the node's CPU share
+ * (what LOCAL_WORLD_SIZE / MAPAD_LOCAL_WORLD_SIZE set at start; 0 = back to those).  Process-wide like the worker pool itself; returns the number of workers.
+ * The reference's workers each own a whole machine (src/distributed/worker.rs:80-198); eight ranks on one node share its CPUs, and bench.py measures C5 as such a
+ * rank on a one-GPU box with this call (`secondary.c5_rank_of_8`). */
+uint32_t mapad_tail_set_local_world(uint32_t local_world);
 /* the batch selected by mapad_ctx_select_batch, after its collect / fetch: {reads finished on the host, pops the GPU had spent on them, pops on the host,
  * host wall-clock microseconds from the first hand-over to the last result, host threads, pop budget, and the host reads' E_search, N_push, N_node sums
  * (SURVEY 8d events the kernel did not execute), microseconds the host threads spent inside these reads, summed over the threads,

@@ -126,6 +126,7 @@ SYMBOLS = {
     "mapad_host_cpus": (C.c_uint32, []),
     "mapad_ctx_set_reserved_cus": (_i32, [_vp, C.c_int32]),
     "mapad_ctx_set_tail_pops": (_i32, [_vp, C.c_uint32]),
+    "mapad_tail_set_local_world": (C.c_uint32, [C.c_uint32]),
     "mapad_last_tail_info": (_i32, [_vp, _vp]),
     "mapad_hits_to_records": (_i32, [_vp, _PP, C.POINTER(BatchResultC), _vp, _vp, _vp, _vp, _u64, C.POINTER(C.POINTER(RecordsC))]),
     "mapad_records_free": (None, [C.POINTER(RecordsC)]),
@@ -460,8 +461,9 @@ class Context:
         _check(lib().mapad_last_locate_info(self.h, C.byref(ms), C.byref(rows), C.byref(steps)), "mapad_last_locate_info")
         return float(ms.value), int(rows.value), int(steps.value)
 
-    def hits_to_records(self, result_cptr_owner, seqs, quals, offsets, in_flags=None, seed=0):
-        """mapad_hits_to_records_gpu -> list of dicts, same as hits_to_records() with the SA lookups done on the device."""
+    def hits_to_records(self, result_cptr_owner, seqs, quals, offsets, in_flags=None, seed=0, as_arrays=False):
+        """mapad_hits_to_records_gpu -> list of dicts, same as hits_to_records() with the SA lookups done on the device.  as_arrays: (records as a numpy structured
+        array with RecordC's fields, text bytes) instead — for millions of reads."""
         seqs = np.ascontiguousarray(seqs, dtype=np.uint8)
         quals = np.ascontiguousarray(quals, dtype=np.uint8)
         offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
@@ -469,11 +471,21 @@ class Context:
         out = C.POINTER(RecordsC)()
         _check(lib().mapad_hits_to_records_gpu(self.h, result_cptr_owner._cptr, _ptr(seqs), _ptr(quals), _ptr(offsets),
                                                _ptr(fl) if fl is not None else None, seed, C.byref(out)), "mapad_hits_to_records_gpu")
-        return _decode_records(out)
+        return _records_arrays(out) if as_arrays else _decode_records(out)
 
 
-def hits_to_records(index, params, result_cptr_owner, seqs, quals, offsets, in_flags=None, seed=0):
-    """mapad_hits_to_records -> list of dicts (decoded record fields)."""
+def _records_arrays(out):
+    """mapad_records_t -> (records as a numpy structured array with RecordC's fields, text bytes as uint8), copied; frees the C object"""
+    r = out.contents
+    n = int(r.n)
+    recs = np.frombuffer(C.string_at(C.addressof(r.recs.contents), n * C.sizeof(RecordC)), np.dtype(RecordC)).copy() if n else np.zeros(0, np.dtype(RecordC))
+    text = np.frombuffer(C.string_at(r.text, r.text_len), np.uint8).copy() if r.text_len else np.zeros(0, np.uint8)
+    lib().mapad_records_free(out)
+    return recs, text
+
+
+def hits_to_records(index, params, result_cptr_owner, seqs, quals, offsets, in_flags=None, seed=0, as_arrays=False):
+    """mapad_hits_to_records -> list of dicts (decoded record fields); as_arrays: (records structured array, text bytes)."""
     seqs = np.ascontiguousarray(seqs, dtype=np.uint8)
     quals = np.ascontiguousarray(quals, dtype=np.uint8)
     offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
@@ -481,7 +493,7 @@ def hits_to_records(index, params, result_cptr_owner, seqs, quals, offsets, in_f
     out = C.POINTER(RecordsC)()
     _check(lib().mapad_hits_to_records(index.h, C.byref(params), result_cptr_owner._cptr, _ptr(seqs), _ptr(quals), _ptr(offsets),
                                        _ptr(fl) if fl is not None else None, seed, C.byref(out)), "mapad_hits_to_records")
-    return _decode_records(out)
+    return _records_arrays(out) if as_arrays else _decode_records(out)
 
 
 def _decode_records(out):

@@ -104,9 +104,25 @@ def kernel_code_hash(lib=None):
     return h.hexdigest()[:16] if n else None
 
 
-def lib_path(heap_variant=0):
-    """The library of one reading of the frontier heap's tie rules (csrc/heap_core.hpp: MAPAD_HEAP_VARIANT); 0 = the default library."""
-    return LIB if not heap_variant else os.path.join(HERE, f"libmapad_amd.hv{int(heap_variant)}.so")
+# build flavours beside the default library: name -> (file, extra -D flags)
+#   hv1..hv3: the other readings of the frontier heap's tie rules (csrc/heap_core.hpp: MAPAD_HEAP_VARIANT)        tests/test_gpu_heap_variants.py
+#   heavy   : heavy_kernel.hpp compiled in (one wavefront per read, MAPAD_HEAVY=1; off the default path since round 5)  tests/test_gpu_parity.py (child processes)
+#   sub     : the arena's heap levels in subtree-contiguous 64-byte blocks (csrc/heap_core.hpp: MAPAD_SUBTREE_HEAP=1; measured slower, kept as an option) tests/test_gpu_heap_variants.py
+FLAVOURS = {"hv1": ["-DMAPAD_HEAP_VARIANT=1"], "hv2": ["-DMAPAD_HEAP_VARIANT=2"], "hv3": ["-DMAPAD_HEAP_VARIANT=3"], "heavy": ["-DMAPAD_HEAVY_KERNEL"], "sub": ["-DMAPAD_SUBTREE_HEAP=1"]}
+
+
+def _flavour(heap_variant=0, heavy=False, flavour=None):
+    if flavour:
+        return flavour
+    if heavy:
+        return "heavy"
+    return f"hv{int(heap_variant)}" if heap_variant else None
+
+
+def lib_path(heap_variant=0, heavy=False, flavour=None):
+    """The library of one build flavour (FLAVOURS); no arguments = the default library."""
+    f = _flavour(heap_variant, heavy, flavour)
+    return LIB if not f else os.path.join(HERE, f"libmapad_amd.{f}.so")
 
 
 def selected_variant():
@@ -117,19 +133,20 @@ def selected_variant():
     return v
 
 
-def needs_build(heap_variant=0):
-    lib = lib_path(heap_variant)
+def needs_build(heap_variant=0, heavy=False, flavour=None):
+    lib = lib_path(heap_variant, heavy, flavour)
     if not os.path.exists(lib):
         return True
     t = os.path.getmtime(lib)
     return any(os.path.getmtime(p) > t for p in _deps())
 
 
-def build(force=False, verbose=False, heap_variant=0):
-    lib = lib_path(heap_variant)
-    if not force and not needs_build(heap_variant):
+def build(force=False, verbose=False, heap_variant=0, heavy=False, flavour=None):
+    f = _flavour(heap_variant, heavy, flavour)
+    lib = lib_path(flavour=f)
+    if not force and not needs_build(flavour=f):
         return lib
-    extra = [f"-DMAPAD_HEAP_VARIANT={int(heap_variant)}"] if heap_variant else []
+    extra = FLAVOURS[f] if f else []
     tmp = lib + f".tmp{os.getpid()}"
     cmd = [HIPCC] + FLAGS + extra + os.environ.get("MAPAD_EXTRA_FLAGS", "").split() + ["-o", tmp] + [os.path.join(CSRC, s) for s in SOURCES]
     if verbose:
@@ -139,11 +156,11 @@ def build(force=False, verbose=False, heap_variant=0):
     return lib
 
 
-def build_all(force=False, verbose=False, variants=(0, 1, 2, 3)):
-    """The default library and the three other readings of the heap's tie rules, side by side (one hipcc each; they share nothing but the sources)."""
+def build_all(force=False, verbose=False, flavours=(None,) + tuple(FLAVOURS)):
+    """The default library and every flavour, side by side (one hipcc each; they share nothing but the sources)."""
     from concurrent.futures import ThreadPoolExecutor
-    with ThreadPoolExecutor(max_workers=4) as ex:
-        return list(ex.map(lambda v: build(force=force, verbose=verbose, heap_variant=v), variants))
+    with ThreadPoolExecutor(max_workers=6) as ex:
+        return list(ex.map(lambda f: build(force=force, verbose=verbose, flavour=f), flavours))
 
 
 if __name__ == "__main__":

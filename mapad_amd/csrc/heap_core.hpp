@@ -229,6 +229,79 @@ __device__ __forceinline__ HeapPair load_pair(const MAPAD_LDS HeapEntry* p) {
 }
 #endif
 
+// ---- where a logical heap slot of the arena levels lives (round 6) ---------------------------------------------------------------------------------------
+// MAPAD_SUBTREE_HEAP=0 (default): the implicit array, logical slot i at A.heap + i.
+// MAPAD_SUBTREE_HEAP=1 (libmapad_amd.sub.so, mapad_amd/build.py): the arena's heap levels in subtree-contiguous 64-byte blocks.  Every entry p of an ODD level (a
+// max level: the levels a pop_max's sift steps through) owns one block of eight 8-byte slots: its two children in slots 0-1, its four grandchildren in slots 2-5 —
+// exactly what one stride of the sift reads — so a stride is ONE 128-byte line instead of two (children pair + grandchildren quad of the implicit array lie in
+// different lines from level 8 on), and a push's leaf shares its block with its parent (odd leaf level) or its parent and grandparent share theirs (even).
+// Entries of even levels live in their parent's block, entries of odd levels in their grandparent's; blocks are numbered level by level (key levels K0,
+// K0 + 2, ...; K0 = the last odd level whose grandchildren are arena levels).  The first TOP + 1 physical entries stay what they were: the unused shadow of the
+// near levels (a hand-over writes the near levels there).  Purely a logical -> physical slot change: the heap, entry for entry, is the same min-max heap
+// (tests/emu/heap_selftest.cpp; the GPU parity suite runs on both builds).
+// Measured, same box (profiles/r06/ab_layout.txt, ab_pmc_layout.txt): the blocks take 15-21 % of the READ requests behind the L2 away (C3 7.79 -> 6.12 per pop,
+// C2 5.42 -> 4.58; writes unchanged) — and the kernel is 4-6 % SLOWER (C3 2.60 -> 2.47 M reads/s, C2 6.04 -> 5.75 M, C4 3.10 -> 2.97 M).  MAPAD_SUBTREE_HEAP=2
+// separates the two effects: the blocks' address arithmetic computed and kept alive, the implicit array addressed — C3 2.42 M, C2 5.78 M: the arithmetic (a dozen
+// dependent VALU instructions in front of every arena access of the sift and the pushes, +28 % static VALU in the kernel) costs 4-7 %, and a fifth fewer read
+// requests buy back 0-2 %.  The step is a chain of dependent round trips whose length, not the request rate behind the L2, sets its time; the implicit array stays.
+#if !defined(MAPAD_SUBTREE_HEAP)
+#define MAPAD_SUBTREE_HEAP 0
+#endif
+#if defined(MAPAD_HEAVY_KERNEL) && MAPAD_SUBTREE_HEAP != 0
+#error "heavy_kernel's wavefront-wide strides address the implicit heap array"
+#endif
+template <int TOP>
+struct HeapLayout {
+    static constexpr int kT = TOP >= 1023 ? 10 : TOP >= 511 ? 9 : TOP >= 255 ? 8 : TOP >= 127 ? 7 : TOP >= 63 ? 6 : TOP >= 31 ? 5 : TOP >= 15 ? 4 : 3;  // first arena level
+    static_assert(TOP == (1 << kT) - 1, "the near levels are whole levels");
+    static constexpr int kK0 = (kT & 1) ? kT - 2 : kT - 1;       // first key level (odd)
+    static constexpr uint32_t kC0 = ((1u << kK0) + 1u) / 3u;
+    // logical slot i >= TOP -> offset from A.heap (which points one entry into the 16-byte aligned allocation)
+    static MAPAD_HD uint32_t slot(uint32_t i) {
+#if MAPAD_SUBTREE_HEAP
+        const uint32_t x = i + 1u;
+#if defined(__HIP_DEVICE_COMPILE__)
+        const uint32_t level = 31u - (uint32_t)__clz((int)x);
+#else
+        const uint32_t level = 31u - (uint32_t)__builtin_clz(x);
+#endif
+        const bool even = (level & 1u) == 0u;
+        const uint32_t owner = even ? x >> 1 : x >> 2;                  // 1-based index of the odd-level entry whose block holds i
+        const uint32_t s = even ? (x & 1u) : 2u + (x & 3u);
+        const uint32_t m = (even ? 1u << level : 1u << (level - 1u));  // 2^(owner's level + 1), a power of four: (m - 1) / 3 = (m - 1) & 0x5555...
+        const uint32_t block = owner - ((m - 1u) & 0x55555555u) - kC0;
+#if MAPAD_SUBTREE_HEAP == 2
+        // experiment (profiles/r06/ab_layout.txt): the subtree layout's address arithmetic is computed and kept alive, the implicit array is addressed — separates what the
+        // layout's instructions cost from what its memory behaviour gives
+        uint32_t keep = (uint32_t)TOP + 8u * block + s;
+#if defined(__HIP_DEVICE_COMPILE__)
+        asm volatile("" : "+v"(keep));
+#endif
+        return i + (keep & 0u);
+#endif
+        return (uint32_t)TOP + 8u * block + s;
+#else
+        return i;
+#endif
+    }
+    // physical entries (counted from the allocation's start, A.heap - 1) that hold logical slots [0, n), the shadow of the near levels included; monotone in n
+    static MAPAD_HD uint32_t phys_end(uint32_t n) {
+#if MAPAD_SUBTREE_HEAP
+        if (n <= (uint32_t)TOP) return (uint32_t)TOP + 1u;
+        const uint32_t i = n - 1u;
+#if defined(__HIP_DEVICE_COMPILE__)
+        const uint32_t level = 31u - (uint32_t)__clz((int)n);
+#else
+        const uint32_t level = 31u - (uint32_t)__builtin_clz(n);
+#endif
+        if (level & 1u) return (uint32_t)TOP + 1u + 8u * (((1u << level) - (1u << kK0)) / 3u);  // the even level above is full: every block of key level `level - 2` is in use
+        return ((slot(i) + 1u) & ~7u) + 8u;                                                       // blocks of key level `level - 1` up to the parent's (blocks start at physical multiples of 8)
+#else
+        return n + 1u;
+#endif
+    }
+};
+
 // heap slot i of this read: the top levels sit in the near array (LDS), the rest in the HBM arena
 // Entries are moved field by field: copying the struct would bind the source to a reference in the generic address space, and after
 // the near/arena branches are merged the access would stay a flat_* instruction (vmcnt and lgkmcnt, no overlap with anything).
@@ -236,13 +309,12 @@ template <class P> MAPAD_HD HeapEntry load_entry(P p) { HeapEntry e; MAPAD_TOUCH
 template <class P> MAPAD_HD void store_entry(P p, const HeapEntry e) { MAPAD_TOUCH(&*p, sizeof e, true); p->score = e.score; p->node = e.node; }
 template <bool NL, int TOP> MAPAD_HD HeapEntry hp_get(const ArenaT<NL, TOP>& A, uint32_t i) {
     if (i < (uint32_t)TOP) return load_entry(A.top + i);
-    return load_entry(A.heap + i);
+    return load_entry(A.heap + HeapLayout<TOP>::slot(i));
 }
 template <bool NL, int TOP> MAPAD_HD void hp_set(const ArenaT<NL, TOP>& A, uint32_t i, const HeapEntry e) {
     if (i < (uint32_t)TOP) store_entry(A.top + i, e);
-    else store_entry(A.heap + i, e);
+    else store_entry(A.heap + HeapLayout<TOP>::slot(i), e);
 }
-template <bool NL, int TOP> MAPAD_HD HeapPair hp_pair(const ArenaT<NL, TOP>& A, uint32_t i) { if (i < (uint32_t)TOP) return load_pair(A.top + i); return load_pair(A.heap + i); }
 
 // ---- min-max heap (index 0 = min; even levels are min levels) ----------------------------------------------------
 MAPAD_HD bool mm_is_min_level(uint32_t pos) {
@@ -272,9 +344,9 @@ MAPAD_HD Ancestors load_ancestors(const ArenaT<NL, TOP>& A, uint32_t pos) {
     const uint32_t k1 = i1 < (uint32_t)TOP ? i1 : 0, k2 = i2 < (uint32_t)TOP ? i2 : 0, k3 = i3 < (uint32_t)TOP ? i3 : 0;
     const HeapEntry n1 = load_entry(A.top + k1), n2 = load_entry(A.top + k2), n3 = load_entry(A.top + k3);
     HeapEntry g1 = HeapEntry{0.0f, 0u}, g2 = HeapEntry{0.0f, 0u}, g3 = HeapEntry{0.0f, 0u};
-    if (i1 >= (uint32_t)TOP) g1 = load_entry(A.heap + i1);
-    if (i2 >= (uint32_t)TOP) g2 = load_entry(A.heap + i2);
-    if (i3 >= (uint32_t)TOP) g3 = load_entry(A.heap + i3);
+    if (i1 >= (uint32_t)TOP) g1 = load_entry(A.heap + HeapLayout<TOP>::slot(i1));
+    if (i2 >= (uint32_t)TOP) g2 = load_entry(A.heap + HeapLayout<TOP>::slot(i2));
+    if (i3 >= (uint32_t)TOP) g3 = load_entry(A.heap + HeapLayout<TOP>::slot(i3));
     a.e1 = i1 < (uint32_t)TOP ? n1 : g1; a.e2 = i2 < (uint32_t)TOP ? n2 : g2; a.e3 = i3 < (uint32_t)TOP ? n3 : g3;
     return a;
 }
@@ -358,9 +430,10 @@ MAPAD_HD bool mm_push_stays(uint32_t pos, const HeapEntry elt, const Ancestors& 
     return !moved & !moved2;
 }
 
-// The heap array is stored shifted by one entry (logical index i lives in physical slot i + 1; `v` points at logical 0), so the
-// two children of a node (logical 2p+1, 2p+2) form one 16-byte aligned pair and its four grandchildren (4p+3 .. 4p+6) one
-// 32-byte aligned group: a trickle-down level is three 16-byte loads instead of six 8-byte ones and touches at most 2 lines.
+// The near levels (and, with MAPAD_SUBTREE_HEAP=0, the arena levels) are stored shifted by one entry (logical index i lives in physical slot i + 1; `v` points
+// at logical 0), so the two children of a node (logical 2p+1, 2p+2) form one 16-byte aligned pair and its four grandchildren (4p+3 .. 4p+6) one
+// 32-byte aligned group: a trickle-down level is three 16-byte loads instead of six 8-byte ones.  The arena levels' subtree blocks (HeapLayout) keep those
+// pairs aligned too: children in slots 0-1, grandchildren in slots 2-5 of a 64-byte block.
 // candidates scanned in ascending index order (child1, child2, grandchildren) — or in family order, MAPAD_HEAP_VARIANT bit 0 —; a later one wins only if strictly better.
 // `elt` is the element being placed, starting at the hole `pos`.  Entries at or beyond n are stale memory: they are loaded
 // (the arena has slack) but neutralised by an index test.
@@ -435,10 +508,18 @@ MAPAD_HD void mm_trickle_down(const ArenaT<NL, TOP>& A, uint32_t n, uint32_t pos
         // 4 g + 3 ... 4 g + 6 for g in [g1, g1 + 3] — two short contiguous runs; asked for now, they arrive while this stride is decided (a sift is otherwise a
         // chain of ten cache misses, each waiting for the one before)
         if (g1 >= (uint32_t)TOP && g_host_prefetch.sift_lookahead >= 1) {
+#if MAPAD_SUBTREE_HEAP == 1
+            // subtree blocks: a pop_max sift (hole on an odd level) next looks at the blocks of g1 .. g1 + 3 — four adjacent 64-byte blocks; a pop_min sift (even
+            // level) at the children of g1 .. g1 + 3, which share the two blocks this stride reads anyway, and at their grandchildren: eight adjacent blocks
+            const HeapEntry* nb = A.heap + HeapLayout<TOP>::slot(MAX ? 2 * g1 + 1 : 4 * g1 + 3);
+            __builtin_prefetch(nb); __builtin_prefetch(nb + 8); __builtin_prefetch(nb + 16); __builtin_prefetch(nb + 24);
+            if (!MAX) { __builtin_prefetch(nb + 32); __builtin_prefetch(nb + 40); __builtin_prefetch(nb + 48); __builtin_prefetch(nb + 56); }
+#else
             const HeapEntry* nc = A.heap + (2 * g1 + 1);  // 8 entries
             const HeapEntry* ng = A.heap + (4 * g1 + 3);  // 16 entries
             __builtin_prefetch(nc); __builtin_prefetch(nc + 7);
             __builtin_prefetch(ng); __builtin_prefetch(ng + 8); __builtin_prefetch(ng + 15);
+#endif
         }
 #endif
         HeapPair c, ga, gb;  // a level is entirely near or entirely in the arena
@@ -447,8 +528,21 @@ MAPAD_HD void mm_trickle_down(const ArenaT<NL, TOP>& A, uint32_t n, uint32_t pos
             const uint32_t kc = c_near ? c1 : 1u, kg = g_near ? g1 : 3u;  // clamped indices keep the 16-byte alignment of a pair (odd logical index)
             const HeapPair nc = load_pair(A.top + kc), nga = load_pair(A.top + kg), ngb = load_pair(A.top + kg + 2);
             HeapPair hc = HeapPair{}, hga = HeapPair{}, hgb = HeapPair{};
+#if MAPAD_SUBTREE_HEAP == 2
+            const uint32_t sa = HeapLayout<TOP>::slot(g1), sc = MAX ? c1 : HeapLayout<TOP>::slot(c1), sb = sa + 2u;
+            if (!c_near) hc = load_pair(A.heap + sc);
+            if (!g_near) { hga = load_pair(A.heap + sa); hgb = load_pair(A.heap + sb); }
+#elif MAPAD_SUBTREE_HEAP
+            // pop_max sift (hole on an odd level): the six candidates are the hole's own block.  pop_min sift (even level): the children sit in their grandparent's
+            // block, the grandchildren in slots 0-1 of the two children's blocks, which are adjacent; a block whose first entry is beyond the heap is not loaded
+            // (its arena may end before it — the implicit array reads such slots and ignores them).
+            const uint32_t sa = HeapLayout<TOP>::slot(g1), sc = MAX ? sa - 2u : HeapLayout<TOP>::slot(c1), sb = MAX ? sa + 2u : sa + 8u;
+            if (!c_near) hc = load_pair(A.heap + sc);
+            if (!g_near) { if (MAX || g1 < n) hga = load_pair(A.heap + sa); if (MAX || g1 + 2 < n) hgb = load_pair(A.heap + sb); }
+#else
             if (!c_near) hc = load_pair(A.heap + c1);
             if (!g_near) { hga = load_pair(A.heap + g1); hgb = load_pair(A.heap + g1 + 2); }
+#endif
             c = c_near ? nc : hc; ga = g_near ? nga : hga; gb = g_near ? ngb : hgb;
         }
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -458,8 +552,15 @@ MAPAD_HD void mm_trickle_down(const ArenaT<NL, TOP>& A, uint32_t n, uint32_t pos
             const bool spec = (g1 >= (uint32_t)TOP) & (g1 < n);  // quad-uniform
             const uint32_t G = g1 + (uint32_t)w, sc1 = 2 * G + 1, sg1 = 2 * sc1 + 1;
             HeapPair sc = HeapPair{}, sga = HeapPair{}, sgb = HeapPair{};
-            if (spec & (sc1 < n)) sc = load_pair(A.heap + sc1);
+            const uint32_t ss = HeapLayout<TOP>::slot(sc1);  // subtree blocks: grandchild w's own block (the four lanes' blocks are adjacent: two lines)
+#if MAPAD_SUBTREE_HEAP == 1
+            static_assert(MAX, "the speculative stride is a pop_max sift's");
+            if (spec & (sc1 < n)) sc = load_pair(A.heap + ss);
+            if (spec & (sg1 < n)) { sga = load_pair(A.heap + ss + 2); sgb = load_pair(A.heap + ss + 4); }
+#else
+            if (spec & (sc1 < n)) sc = load_pair(A.heap + ss);
             if (spec & (sg1 < n)) { sga = load_pair(A.heap + sg1); sgb = load_pair(A.heap + sg1 + 2); }
+#endif
             going = stride(c, ga, gb, c1, g1, set_any);
             if (spec & going & (2 * pos + 1 < n)) {  // the hole went to grandchild pos = g1 + k: lane k holds the next stride's candidates
                 const int src = (int)((threadIdx.x & ~3u) + (pos - g1)) << 2;

@@ -16,6 +16,7 @@
 // through both paths.
 #pragma once
 
+static_assert(MAPAD_SUBTREE_HEAP == 0, "heavy_kernel's wavefront-wide strides address the implicit heap array (heap_core.hpp: HeapLayout)");
 constexpr int kHeavyTop = 1023;  // heap levels 0-9
 using HeavyArena = ArenaT<true, kHeavyTop>;
 using HeavyRead = ReadInT<true>;
@@ -397,6 +398,7 @@ __global__ void __launch_bounds__(64) heavy_kernel(DevIndex ix, DevParams P, Bat
             foreign = n_cls >= kPartitionMin && idx / (n_cls / 8) != xcc_id();
         } else {
             read = items[item] - 1u;
+            if (lane == 0) B.overflow_list[(size_t)(tier > 0 ? tier - 1 : 0) * B.n_reads + item] = 0u;  // the list is left as it was found: zeros (search_kernel)
             const ArenaT<false> a = carve<false>(AP, slot);
             A.heap = a.heap; A.nodes = a.nodes; A.hits = a.hits; A.hit_ops = a.hit_ops; A.scratch = a.scratch;
             A.heap_cap = a.heap_cap; A.node_cap = a.node_cap; A.hit_ops_cap = a.hit_ops_cap; A.grown = 0;

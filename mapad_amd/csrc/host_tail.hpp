@@ -40,7 +40,7 @@ namespace host {
 // Header of a hand-over record (page-locked host memory, written by the quad that gives the read up; mapad_amd.hip: hand_to_host).  It is followed by
 // qc[2 * L] (base class, quality per position: ReadIn::qc) at byte 16 and d[L] (the read's D array) at byte 16 + ((2 * lmax + 15) & ~15).
 struct TailRecord {
-    uint32_t ready;  // 1 once the rest of the record is visible (system-scope release store)
+    uint32_t ready;  // == the launch's number in this ring (TailBatch::gen, never 0) once the rest of the record is visible (system-scope store behind the payload's)
     uint32_t read;   // read number inside the batch
     uint32_t L;
     uint32_t pops;   // pops the GPU had made when it gave the read up
@@ -123,19 +123,32 @@ public:
             q_.emplace(std::make_pair(weight, ~seq_++), std::move(f));  // equal weights: first come, first served
             pending_.fetch_add(1, std::memory_order_relaxed);
         }
-        cv_.notify_one();
+        cv_.notify_all();  // (not notify_one: the thread it wakes may be one beyond limit_, which goes back to sleep without the task)
     }
     unsigned size() {
         std::lock_guard<std::mutex> g(mu_);
-        return threads_.empty() ? wanted() : (unsigned)threads_.size();
+        return threads_.empty() ? wanted() : limit_;
+    }
+    // "This process is one rank of `lw` on its node" (0: back to LOCAL_WORLD_SIZE / MAPAD_LOCAL_WORLD_SIZE): the workers that take tasks from now on are this rank's
+    // part of the node's CPU share (wanted()); threads beyond it sleep, missing ones are started.  Returns the count.  (mapad_tail_set_local_world: bench.py measures
+    // C5 as one rank of eight on a one-GPU box with it.)
+    unsigned set_local_world(unsigned lw) {
+        std::lock_guard<std::mutex> g(mu_);
+        lw_override().store(lw, std::memory_order_relaxed);
+        const unsigned n = wanted();
+        limit_ = n;
+        if (!threads_.empty()) start();  // (adds the missing threads, if any)
+        cv_.notify_all();
+        return n;
     }
     // tasks waiting or running: what a launch's dispatcher publishes to the kernel, which hands a read over on a dry arena class only while this is small
     uint32_t pending() const { return pending_.load(std::memory_order_relaxed); }
     // One process per GPU (bench.py --gpus N, `mapad-amd worker`): the ranks of a node share its CPUs, so each takes its part of the share and pins its
     // workers to its own cache domains (LOCAL_WORLD_SIZE / LOCAL_RANK as torchrun sets them; MAPAD_LOCAL_WORLD_SIZE / MAPAD_LOCAL_RANK override).
-    static unsigned local_world() { return env_uint("MAPAD_LOCAL_WORLD_SIZE", env_uint("LOCAL_WORLD_SIZE", 1)); }
+    static unsigned local_world() { const unsigned o = lw_override().load(std::memory_order_relaxed); return o ? o : env_uint("MAPAD_LOCAL_WORLD_SIZE", env_uint("LOCAL_WORLD_SIZE", 1)); }
     static unsigned local_rank() { return env_uint("MAPAD_LOCAL_RANK", env_uint("LOCAL_RANK", 0)); }
 private:
+    static std::atomic<unsigned>& lw_override() { static std::atomic<unsigned> v{0}; return v; }
     static unsigned env_uint(const char* name, unsigned dflt) {
         const char* e = std::getenv(name);
         if (!e || !e[0]) return dflt;
@@ -151,17 +164,18 @@ private:
         const unsigned share = std::max(1u, (cpu_share() + lw - 1) / lw);
         return share >= 4 ? share - std::max(1u, share / 8) : share;
     }
-    void start() {
+    void start() {  // (mu_ held) threads 0 .. wanted() - 1 exist afterwards; worker i takes tasks while i < limit_
         const unsigned n = wanted(), first = local_rank() * n;  // pinning: this rank's workers take the domains behind those of the ranks before it
         tail_read_prefetch_env();
-        for (unsigned i = 0; i < n; ++i) {
+        limit_ = n;
+        for (unsigned i = (unsigned)threads_.size(); i < n; ++i) {
             threads_.emplace_back([this, i, first] {
                 tail_pin_worker(first + i);
                 for (;;) {
                     std::function<void()> f;
                     {
                         std::unique_lock<std::mutex> l(mu_);
-                        cv_.wait(l, [&] { return !q_.empty(); });
+                        cv_.wait(l, [&] { return !q_.empty() && i < limit_; });
                         f = std::move(const_cast<Task&>(q_.top()).second);
                         q_.pop();
                     }
@@ -179,6 +193,7 @@ private:
     std::priority_queue<Task, std::vector<Task>, Lighter> q_;
     uint64_t seq_ = 0;
     std::atomic<uint32_t> pending_{0};
+    unsigned limit_ = 0;  // workers that take tasks (<= threads_.size())
     std::vector<std::thread> threads_;
 };
 
@@ -205,7 +220,7 @@ struct TailScratch {
 #endif
             return p;
         };
-        if (hc > heap_cap) { std::free(heap); heap = (HeapEntry*)big((2 * (size_t)hc + 64) * sizeof(HeapEntry)); heap_cap = heap ? hc : 0; }
+        if (hc > heap_cap) { std::free(heap); heap = (HeapEntry*)big((std::max<size_t>(2 * (size_t)hc, HeapLayout<kTop>::phys_end(hc)) + 64) * sizeof(HeapEntry)); heap_cap = heap ? hc : 0; }
         if (nc > node_cap) { std::free(nodes); nodes = (Node*)big(((size_t)nc + 1) * sizeof(Node)); node_cap = nodes ? nc : 0; }
         if (!heap || !nodes) return false;
         if (lm > lmax || top.empty()) {
@@ -228,11 +243,13 @@ struct TailBatch {
     std::shared_ptr<const HostTables> tables;
     const uint8_t* ring = nullptr;  // records in host-coherent page-locked memory
     uint32_t stride = 0, cap = 0, lmax = 0;
+    uint32_t gen = 1;               // a record of this launch is ready when its `ready` word holds this number
     uint32_t* ctl = nullptr;        // word the kernel reads before a hand-over it could do without (dry arena class): tasks the workers have waiting or running
     std::function<bool()> launch_done;  // has the launch that writes this ring ended? (set by the library; counts the hand-overs that arrive while it runs)
     uint32_t seen_live = 0;         // records the dispatcher saw while the launch was still running
     // continuation (TailState): copies heap slots [0, heap_len] (physical, shifted by one) and nodes [0, tree_entries) of the grown arena into the worker's arena and
-    // releases the arena on the device; false = could not (the read is then mapped from scratch and the arena released all the same).  Set by the library.
+    // releases the arena on the device; false = could not (the read is then mapped from scratch and the arena released all the same); null pointers = release
+    // only (the worker has no room for the state).  Set by the library.
     std::function<bool(uint32_t grown, uint32_t heap_len, uint32_t tree_entries, HeapEntry* heap_phys, Node* nodes)> fetch_state;
     std::vector<uint8_t> fetched;   // per record: its arena has been taken care of (a cancelled batch releases the others: mapad_amd.hip)
     uint32_t continued = 0;         // reads continued from the GPU's state
@@ -280,6 +297,11 @@ inline void tail_map_read(const std::shared_ptr<TailBatch>& tb, const TailRecord
     const int L = (int)rec->L;
     bool ok = sc.ensure(tb->P.stack_limit + 10, tb->P.edit_tree_limit + 10, std::max<uint32_t>(tb->lmax, (uint32_t)L));
     uint64_t pops = 0;
+    if (!ok && !tb->cancel.load(std::memory_order_relaxed)) {  // no arena for this worker: the read fails (tb->failed below), but a grown arena it came with goes back to its pool
+        const TailState* ts0 = reinterpret_cast<const TailState*>(reinterpret_cast<const uint8_t*>(rec) + tail_state_offset(tb->lmax));
+        const size_t k0 = (size_t)((reinterpret_cast<const uint8_t*>(rec) - tb->ring) / tb->stride);
+        if (ts0->grown != 0 && tb->fetch_state) { (void)tb->fetch_state(ts0->grown, 0, 0, nullptr, nullptr); if (k0 < tb->fetched.size()) tb->fetched[k0] = 1; }
+    }
     if (ok && !tb->cancel.load(std::memory_order_relaxed)) {
         const uint8_t* qc = reinterpret_cast<const uint8_t*>(rec) + 16;
         const float* d = reinterpret_cast<const float*>(reinterpret_cast<const uint8_t*>(rec) + 16 + ((2u * tb->lmax + 15u) & ~15u));
@@ -294,9 +316,10 @@ inline void tail_map_read(const std::shared_ptr<TailBatch>& tb, const TailRecord
         if (ts->grown != 0 && tb->fetch_state) {
             const size_t k = (size_t)((reinterpret_cast<const uint8_t*>(rec) - tb->ring) / tb->stride);
             const SearchState s0 = ts->st;
-            resumed = s0.n_hits == 0 && s0.heap_len + kStepNodes <= sc.heap_cap && s0.tree_entries + kStepNodes <= sc.node_cap &&
-                      tb->fetch_state(ts->grown, s0.heap_len, s0.tree_entries, sc.heap, sc.nodes);
-            if (k < tb->fetched.size()) tb->fetched[k] = 1;  // (fetch_state releases the arena whether or not the copy worked)
+            const bool fits = s0.n_hits == 0 && s0.heap_len + kStepNodes <= sc.heap_cap && s0.tree_entries + kStepNodes <= sc.node_cap;
+            // fetch_state releases the arena whether or not the copy worked; a state this worker cannot take (null pointers) is a release only
+            resumed = tb->fetch_state(ts->grown, s0.heap_len, s0.tree_entries, fits ? sc.heap : nullptr, fits ? sc.nodes : nullptr) && fits;
+            if (k < tb->fetched.size()) tb->fetched[k] = 1;
             if (resumed) {
                 const uint32_t n_top = s0.heap_len < (uint32_t)kTop ? s0.heap_len : (uint32_t)kTop;
                 for (uint32_t i = 0; i < n_top; ++i) A.top[i] = A.heap[i];  // heap levels 0-5: the kernel had them in LDS and wrote them into the arena's unused slots
@@ -349,7 +372,7 @@ inline void tail_start(const std::shared_ptr<TailBatch>& tb) {
             if (fin >= 0 && (int64_t)next >= fin) break;
             if (next < tb->cap) {
                 const TailRecord* rec = reinterpret_cast<const TailRecord*>(tb->ring + (size_t)next * tb->stride);
-                if (__atomic_load_n(&rec->ready, __ATOMIC_ACQUIRE) == 1u) {
+                if (__atomic_load_n(&rec->ready, __ATOMIC_ACQUIRE) == tb->gen) {
                     const bool live = tb->launch_done && !tb->launch_done();
                     {
                         std::lock_guard<std::mutex> g(tb->mu);

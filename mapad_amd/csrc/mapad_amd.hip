@@ -104,7 +104,11 @@ struct BatchDev {
     // reads waiting or running (*tail_ctl, host-coherent, kept current by the launch's dispatcher thread); kClasses: never
     const uint32_t* tail_ctl;
     uint32_t tail_backlog_max, tail_min_class;
+    // ... and (round 6) a read past the pop budget leaves only while the host has fewer than tail_backlog_budget reads waiting or running; refused, it goes on on the GPU
+    // and asks again every tail_ask_mask + 1 pops (a power of two)
+    uint32_t tail_backlog_budget, tail_ask_mask;
     uint32_t tail_continue;   // 1: a read in a grown arena is handed over WITH its state (host_tail.hpp: TailState), the arena stays the read's until a host thread has copied it
+    uint32_t tail_gen;        // what the kernel writes into a record's `ready` word: this launch's number in its ring (never 0) — words left by earlier launches do not match it
 };
 
 // A read that has outgrown its base arena, as the quad stage leaves it: everything else (heap, nodes, hit staging) is in the grown arena.
@@ -562,7 +566,7 @@ struct DeviceGrow {
         {
             const MAPAD_GLOBAL uint4* hs = (const MAPAD_GLOBAL uint4*)(A.heap - 1);  // physical slot 0 is 16-byte aligned
             MAPAD_GLOBAL uint4* hd = (MAPAD_GLOBAL uint4*)(nheap - 1);
-            const uint32_t h_end = (st.heap_len + 2) >> 1;  // pairs covering physical slots [TOP + 1, heap_len + 1)
+            const uint32_t h_end = (HeapLayout<TOP>::phys_end(st.heap_len) + 1) >> 1;  // pairs covering the physical slots of logical [TOP, heap_len) (heap_core.hpp: HeapLayout)
             copy_units<LPR>(hd, hs, (TOP + 1) >> 1, h_end, w);
             copy_units<LPR>((MAPAD_GLOBAL uint4*)nnodes, (const MAPAD_GLOBAL uint4*)A.nodes, 0, 2 * st.tree_entries, w);
         }
@@ -604,7 +608,7 @@ struct DeviceGrow {
             uint8_t* b = gp->base[cls] + (uint64_t)idx * gp->stride[cls];
             int lane_o = lane;
             asm volatile("" : "+v"(lane_o));  // (opaque: see hand_to_host)
-            copy_units<64>((MAPAD_GLOBAL uint4*)b, hs, (TOP + 1) >> 1, (heap_len + 2) >> 1, lane_o);
+            copy_units<64>((MAPAD_GLOBAL uint4*)b, hs, (TOP + 1) >> 1, (HeapLayout<TOP>::phys_end(heap_len) + 1) >> 1, lane_o);
             copy_units<64>((MAPAD_GLOBAL uint4*)(b + gp->off_nodes[cls]), ns, 0, 2 * entries, lane_o);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the copy has landed before the quad works in the new arena (and before its old one changes owners)
             if (mine) adopt(A, cls, idx);
@@ -672,7 +676,7 @@ __device__ __forceinline__ void hand_to_host(const BatchDev& B, const ReadInT<NL
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every lane's payload stores have completed ...
     __builtin_amdgcn_wave_barrier();
     if (w == 0) {
-        store_through(&h->ready, 1u);  // ... before the word the host polls
+        store_through(&h->ready, B.tail_gen);  // ... before the word the host polls
         B.status[read] = ST_TAIL; B.hit_count[read] = 0; B.hit_first[read] = 0;
     }
 }
@@ -741,7 +745,7 @@ __global__ void __launch_bounds__(64, (LPR == 1 && NL) ? 1 : LPR == 2 ? 2 : MAPA
     // pools are quiet; the last growable stage waits as long as it takes
     const DeviceGrow<LPR, NL, TOPK> grow{GP, &cursors[CUR_GROWN], slot, w, stage + 2 < kStages || HEAVY, false, B0.tail_min_class};
     const uint32_t wide_copy_nodes = GP->wide_copy_nodes;
-    const uint32_t tail_pops = B0.tail_pops;
+    const uint32_t tail_pops = B0.tail_pops, tail_ask_mask = B0.tail_ask_mask;
     bool tail_denied = false;  // the ring was full when this read asked: it stays on the GPU
     bool drained = false;      // the launch's own list of reads is exhausted (this quad has seen its end)
 #if defined(MAPAD_PROFILE_SECTIONS)
@@ -790,7 +794,7 @@ __global__ void __launch_bounds__(64, (LPR == 1 && NL) ? 1 : LPR == 2 ? 2 : MAPA
                     read = group_bcast<LPR>(e) - 1u;
                 } else {
                     read = tier == 0 ? (B.order ? B.order[item] : item) : items[item] - 1u;
-                    if (tier == 1 && w == 0) B.overflow_list[item] = 0u;  // the restart list is left as it was found: zeros
+                    if (tier >= 1 && w == 0) B.overflow_list[(size_t)(tier - 1) * B.n_reads + item] = 0u;  // the lists are left as they were found: zeros (a later batch of the slot with more reads lays its restart list over this range)
                 }
                 const uint64_t off = B.offsets[read];
                 rd.L = (int)(B.offsets[read + 1] - off);
@@ -833,7 +837,8 @@ __global__ void __launch_bounds__(64, (LPR == 1 && NL) ? 1 : LPR == 2 ? 2 : MAPA
                 if (k >= B.tail_cap) return false;
                 // with its state if it sits in a grown arena and has found nothing yet (hit staging stays in the slot's base arena): the arena then belongs to the
                 // read until a host thread has copied it and releases it (TailBatch::fetch_state) — this quad just lets go of it
-                const bool with_state = PASS != 1 && B.tail_continue != 0 && A.grown != 0 && st.n_hits == 0 && st.status == ST_OK;
+                // (quads only: the host's step reads the arena's heap levels in kTop's layout — heap_core.hpp: HeapLayout —, a pair kernel's blocks start one level earlier)
+                const bool with_state = PASS != 1 && TOPK == kTop && B.tail_continue != 0 && A.grown != 0 && st.n_hits == 0 && st.status == ST_OK;
                 hand_to_host<LPR, NL>(B, rd, A, st, read, k, w, with_state);
                 if (w == 0 && why) atomicAdd(&cursors[why], 1u);
                 if (with_state) {
@@ -862,15 +867,20 @@ __global__ void __launch_bounds__(64, (LPR == 1 && NL) ? 1 : LPR == 2 ? 2 : MAPA
                 have = false;
                 drain_memory();
                 MAPAD_MARK(PROF_FINALIZE);
-            } else if (MAPAD_UNLIKELY(((st.c_pop >= tail_pops) | (A.n_waits >= kAskTail)) & !tail_denied)) {
-                // past the pop budget, or queuing for an arena class that is dry (DeviceGrow::acquire): a host thread maps this read from scratch, the quad takes its next read
-                const bool asked = st.c_pop < tail_pops;  // only the dry class speaks for it: granted while the host's workers keep up with what they have
-                bool take = true;
-                if (asked) {
+            } else if (MAPAD_UNLIKELY((((st.c_pop >= tail_pops) & (((st.c_pop - tail_pops) & tail_ask_mask) == 0u)) | (A.n_waits >= kAskTail)) & !tail_denied)) {
+                // past the pop budget, or queuing for an arena class that is dry (DeviceGrow::acquire): a host thread takes this read over, the quad takes its next read —
+                // while the host's workers keep up with what they have.  Round 5 handed a read past the budget over whatever the host's backlog (only the dry-class
+                // trigger looked at it): a rank of eight on a 16-CPU box has two workers, and the reads the GPU gave up queued behind them for minutes while its quads
+                // idled.  Every trigger looks at the backlog word now; a read that is refused goes on on the GPU (a quad's pop is 15 x a worker's, but thousands of quads
+                // run side by side) and asks again tail_ask_mask + 1 pops later.
+                const bool over = st.c_pop >= tail_pops;
+                bool take;
+                {
                     const BatchDev B = kernarg_reload(kArgOffB, B0);
-                    take = B.tail_cap != 0 && __hip_atomic_load(B.tail_ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < B.tail_backlog_max;
+                    take = B.tail_cap != 0 && __hip_atomic_load(B.tail_ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < (over ? B.tail_backlog_budget : B.tail_backlog_max);
                     A.n_waits &= ~kAskTail;  // (it asks again when its wait is over and the class is still dry)
                 }
+                const bool asked = !over;
                 if (take) {
                     if (give_to_host(asked ? CUR_TAIL_DRY : 0)) { back_to_base(); have = false; }
                     else tail_denied = true;  // the ring is full: this read stays on the GPU
@@ -899,7 +909,11 @@ __global__ void __launch_bounds__(64, (LPR == 1 && NL) ? 1 : LPR == 2 ? 2 : MAPA
 #endif
 }
 
+// heavy_kernel (one wavefront per read) is compiled only into the -DMAPAD_HEAVY_KERNEL build (libmapad_amd.heavy.so, mapad_amd/build.py): measured in round 3 not to beat the
+// quad per pop, off the default path since round 5.  The default library's full-limit stage is the quad kernel itself (PASS 1) in the full-limit arenas.
+#if defined(MAPAD_HEAVY_KERNEL)
 #include "heavy_kernel.hpp"
+#endif
 
 // ---- a few words from device memory into page-locked host memory, by a one-wavefront kernel ---------------------------------------------------------------
 // What the host needs to read back between launches (a batch's cursors, its base count, the text kernel's pool cursors) is a hundred bytes — and a hipMemcpy of
@@ -1048,11 +1062,17 @@ struct DevBuf {
 uint32_t near_bytes(uint32_t lmax, uint32_t top = kTop) { return (top + 1) * 8 + ((2 * lmax + 15) & ~15u) + ((4 * lmax + 15) & ~15u); }
 constexpr uint32_t kMaxLdsReadLen = 256;  // longer reads keep their near data in the HBM arena instead of LDS
 
+// bytes of an arena's heap area for `heap_cap` logical entries: the physical entries the layout needs (heap_core.hpp: HeapLayout — subtree blocks take a third more than
+// the implicit array) + slack for the vector loads past the end.  kTop's layout serves every kernel of a build (pairs, MAPAD_KTOP2 = 31, need no more: their
+// blocks start earlier).
+uint64_t heap_bytes(uint32_t heap_cap) {
+    return ((uint64_t)std::max(HeapLayout<kTop>::phys_end(heap_cap), HeapLayout<MAPAD_KTOP2>::phys_end(heap_cap)) + 16) * sizeof(HeapEntry);
+}
 ArenaPool make_pool_layout(uint32_t heap_cap, uint32_t node_cap, uint32_t hit_ops_cap, uint32_t lmax) {
     ArenaPool ap{};
     auto align = [](uint64_t x) { return (x + 127) & ~127ull; };
     ap.heap_cap = heap_cap; ap.node_cap = node_cap; ap.hit_ops_cap = hit_ops_cap;
-    uint64_t o = align(((uint64_t)heap_cap + 16) * sizeof(HeapEntry));  // +1 shift, + slack for the vector loads past the end
+    uint64_t o = align(heap_bytes(heap_cap));
     ap.off_nodes = o; o = align(o + (uint64_t)node_cap * sizeof(Node));
     ap.off_hits = o; o = align(o + (uint64_t)kMaxHits * sizeof(HitRec));
     ap.off_hit_ops = o; o = align(o + (uint64_t)hit_ops_cap * 4);
@@ -1195,7 +1215,7 @@ struct BatchSlot {
     uint64_t gen = 0;                     // process-wide serial number of this slot's latest launch: a fetched result knows whether the slot still holds it
     // host tail of the slot's latest launch (host_tail.hpp)
     CoherentBuf tail_ring;  // [64-byte header: control word][records]
-    uint32_t tail_ring_stride = 0, tail_ring_dirty = 0;  // records whose `ready` word the last launch may have set
+    uint32_t tail_ring_stride = 0, tail_ring_gen = 0;  // record size the ring's `ready` words were last cleared for; number of the slot's latest launch in this ring (TailRecord::ready)
     const uint8_t* tail_ring_base = nullptr;
     std::shared_ptr<std::atomic<bool>> tail_launched;  // set once the launch's end event has been recorded (TailBatch::launch_done)
     bool tail_failed = false;  // the host tail of this slot's batch could not be merged: the batch's collect keeps failing (reads handed over would otherwise come back unmapped)
@@ -1315,6 +1335,23 @@ int sync_all_slots(mapad_ctx* c) {
     return MAPAD_OK;
 }
 
+int merge_tail(mapad_ctx* c, BatchSlot& S, uint32_t* cur);  // (below)
+// Before the arenas are laid out anew: the launches of all slots have ended (sync_all_slots), but reads they handed over WITH their state (TailState) keep their
+// grown arenas until a host worker has copied them (fetch_tail_state, which reads c->grow without a lock) — and at depth >= 2 another slot's batch may still be
+// uncollected.  Their host tails are finished and merged here, as the batch's collect would do it later (which then finds nothing left to merge).
+int finish_tails(mapad_ctx* c) {
+    for (auto& b : c->bs) {
+        if (!b.tail || !b.ev_valid) continue;
+        uint32_t cur[CUR_COUNT] = {0};
+        if (!b.h_small.resize(CUR_COUNT + 8)) return MAPAD_ERR_NOMEM;
+        int rc = read_back_words(b.stream, b.last.cursors, b.h_small, 0, CUR_COUNT);
+        if (rc) return rc;
+        std::memcpy(cur, b.h_small.data(), sizeof cur);
+        if ((rc = merge_tail(c, b, cur))) return rc;
+    }
+    return MAPAD_OK;
+}
+
 int upload_tables(mapad_ctx* c) {
     if (!c->tables_dirty) return MAPAD_OK;
     int rc;
@@ -1359,6 +1396,7 @@ int ensure_arenas(mapad_ctx* c, BatchSlot& S, uint32_t lmax, uint64_t n_reads) {
     int rc;
     if (c->pool[0].stride && lmax <= c->arena_lmax && n_reads <= c->arena_reads) return MAPAD_OK;  // layouts and pools stand
     if ((rc = sync_all_slots(c))) return rc;  // the layouts change: nothing may be in flight
+    if ((rc = finish_tails(c))) return rc;    // ... nor may a host worker still come for a grown arena
     for (auto& a : c->d_arena) a.release();
     n_reads = std::max<uint64_t>(n_reads, c->arena_reads);  // pools never shrink; a batch cannot use more arenas than it has reads
     { const uint32_t l = env_u32("MAPAD_LANES_PER_READ", 4); c->lpr = l == 1 ? 1 : l == 2 ? 2 : 4; }
@@ -1376,7 +1414,7 @@ int ensure_arenas(mapad_ctx* c, BatchSlot& S, uint32_t lmax, uint64_t n_reads) {
         {
             size_t free_b = 0, total_b = 0;
             if (hipMemGetInfo(&free_b, &total_b) == hipSuccess)
-                while (nodes > 16384 && (uint64_t)c->n_cu * 16 * 64 / c->lpr * ((uint64_t)nodes * 40 + 16384) > free_b / 4 * 3) nodes /= 2;  // base arenas take at most three quarters of what is free
+                while (nodes > 16384 && (uint64_t)c->n_cu * 16 * 64 / c->lpr * ((uint64_t)nodes * 32 + heap_bytes(nodes) + 16384) > free_b / 4 * 3) nodes /= 2;  // base arenas take at most three quarters of what is free
         }
         c->pool[0] = make_pool_layout((uint32_t)std::min<uint64_t>(nodes, stack_cap), (uint32_t)std::min<uint64_t>(nodes, tree_cap), hit_ops_cap, lm);
         const uint32_t cus_used = (uint32_t)(c->depth > 1 ? c->n_cu - c->reserved_cus : c->n_cu);  // (mapad_ctx_set_reserved_cus: the launches of a pipelined context leave CUs free)
@@ -1391,10 +1429,18 @@ int ensure_arenas(mapad_ctx* c, BatchSlot& S, uint32_t lmax, uint64_t n_reads) {
     }
     {   // last stage: full limits, one arena per heavy wavefront (owner word per arena, shared by all XCDs)
         c->pool[1] = make_pool_layout((uint32_t)stack_cap, (uint32_t)tree_cap, hit_ops_cap, lm);
+#if defined(MAPAD_HEAVY_KERNEL)
         n_sets[1] = std::max<uint32_t>(env_u32("MAPAD_LAST_PASS_ARENAS", 16), 1);
+#else
+        n_sets[1] = std::max<uint32_t>((env_u32("MAPAD_LAST_PASS_ARENAS", 16) + 15) / 16, 1);  // sets of a quad wavefront's 16 read slots
+#endif
     }
     for (int t = 0; t < kTiers; ++t) {
+#if defined(MAPAD_HEAVY_KERNEL)
         c->slots[t] = t == 0 ? n_sets[t] * rpw : n_sets[t];
+#else
+        c->slots[t] = t == 0 ? n_sets[t] * rpw : n_sets[t] * 16;  // the full-limit stage runs quads whatever the lanes per read of the growable stages
+#endif
         if ((rc = c->d_arena[t].ensure((size_t)c->slots[t] * c->pool[t].stride, true))) return rc;
         if ((rc = c->d_set_owner[t].ensure(n_sets[t]))) return rc;
         HIP_TRY(hipMemsetAsync(c->d_set_owner[t].p, 0, (size_t)n_sets[t] * 4, S.stream));
@@ -1419,7 +1465,11 @@ int ensure_arenas(mapad_ctx* c, BatchSlot& S, uint32_t lmax, uint64_t n_reads) {
         for (const char* q = e; *q && k < kClasses; ++k) { counts[k] = (uint32_t)std::strtoul(q, const_cast<char**>(&q), 10); if (*q == ',') ++q; }
     }
     // reads are handed to heavy wavefronts only on request (MAPAD_HEAVY=1) and only in batches of reads up to 1 024 bp (a heavy wavefront keeps the read's position data in LDS)
+#if defined(MAPAD_HEAVY_KERNEL)
     const bool heavy_possible = env_u32("MAPAD_HEAVY", 0) != 0 && lm <= 1024;
+#else
+    const bool heavy_possible = false;
+#endif
     uint64_t nodes = std::min<uint64_t>(c->pool[0].node_cap, env_u32("MAPAD_CLASS_ANCHOR_NODES", 8192));  // the ladder 16 K, 32 K, ... does not move with the base arena; classes the base arena already covers get no arenas
     GrowPools& g = c->grow;
     for (int k = 0; k < kClasses; ++k) {
@@ -1427,7 +1477,7 @@ int ensure_arenas(mapad_ctx* c, BatchSlot& S, uint32_t lmax, uint64_t n_reads) {
         g.heap_cap[k] = (uint32_t)std::min<uint64_t>(nodes, stack_cap);
         g.node_cap[k] = (uint32_t)std::min<uint64_t>(nodes, tree_cap);
         auto align = [](uint64_t x) { return (x + 127) & ~127ull; };
-        g.off_nodes[k] = align(((uint64_t)g.heap_cap[k] + 16) * sizeof(HeapEntry));
+        g.off_nodes[k] = align(heap_bytes(g.heap_cap[k]));
         g.off_hits[k] = align(g.off_nodes[k] + (uint64_t)g.node_cap[k] * sizeof(Node));  // hit staging of a suspended read (heavy_kernel.hpp): only if reads can be suspended
         g.off_hit_ops[k] = heavy_possible ? align(g.off_hits[k] + (uint64_t)kMaxHits * sizeof(HitRec)) : g.off_hits[k];
         g.off_scratch[k] = heavy_possible ? align(g.off_hit_ops[k] + (uint64_t)hit_ops_cap * 4) : g.off_hits[k];
@@ -1485,9 +1535,12 @@ int ensure_arenas(mapad_ctx* c, BatchSlot& S, uint32_t lmax, uint64_t n_reads) {
         auto align = [](uint64_t x) { return (x + 127) & ~127ull; };
         uint64_t nodes = (set_bytes - 4096) / (sizeof(HeapEntry) + sizeof(Node));
         nodes = std::min<uint64_t>(nodes & ~63ull, tree_cap);
+        // (subtree blocks: the heap area of `nodes` entries is 4/3 of the implicit array's when its last level pair is full and up to 8/3 when it has just begun —
+        //  heap_core.hpp: HeapLayout::phys_end —, so the capacity is stepped down until heap and nodes fit the set)
+        while (nodes > 64 && align(heap_bytes((uint32_t)std::min<uint64_t>(nodes, stack_cap))) + nodes * sizeof(Node) > set_bytes) nodes = (nodes - std::max<uint64_t>(64, nodes / 64)) & ~63ull;
         g.heap_cap[k] = (uint32_t)std::min<uint64_t>(nodes, stack_cap);
         g.node_cap[k] = (uint32_t)nodes;
-        g.off_nodes[k] = align(((uint64_t)g.heap_cap[k] + 16) * sizeof(HeapEntry));
+        g.off_nodes[k] = align(heap_bytes(g.heap_cap[k]));
         g.off_hits[k] = g.off_hit_ops[k] = g.off_scratch[k] = 0;
         g.stride[k] = set_bytes;
         g.base[k] = c->pool[0].base;
@@ -1551,6 +1604,8 @@ int create_slot_stream(mapad_ctx* c, hipStream_t* out) {
             const int bit = striped ? (c->n_cu - 1 - k) : (xcd * per_xcd + per_xcd - 1 - nth);
             if (bit >= 0 && bit < c->n_cu) mask[(size_t)bit / 32] &= ~(1u << (bit % 32));
         }
+        // (a CU-masked stream is created with default flags: it is a BLOCKING stream with respect to the NULL stream, unlike the hipStreamNonBlocking streams of the
+        //  path below — a context that reserves CUs must be given a stream of its own (mapad_ctx_set_stream), or its batches serialise behind the NULL stream's work)
         HIP_TRY(hipExtStreamCreateWithCUMask(out, (uint32_t)mask.size(), mask.data()));
         return MAPAD_OK;
     }
@@ -1623,8 +1678,8 @@ int ensure_batch_buffers(mapad_ctx* c, BatchSlot& S, uint64_t n_reads, uint64_t 
     return MAPAD_OK;
 }
 
-// A worker of the host tail takes over a read WITH its search (host_tail.hpp: TailState): heap slots [0, heap_len] (physical: logical i lives in slot i + 1; the
-// kernel has written levels 0-5 out of LDS) and nodes [0, tree_entries) of the grown arena `grown` come over PCIe into the worker's arena, then the arena is
+// A worker of the host tail takes over a read WITH its search (host_tail.hpp: TailState): the physical heap entries that hold logical slots [0, heap_len) (heap_core.hpp:
+// HeapLayout, the host's search step reads the same layout; the kernel has written levels 0-5 out of LDS into the shadow entries in front) and nodes [0, tree_entries) of the grown arena `grown` come over PCIe into the worker's arena, then the arena is
 // released on the device (its owner word cleared by a one-wavefront kernel: fits beside the searches).  Called from worker threads, several at a time.  The arena is released whether or not the copies worked; false = map the read from scratch.
 bool release_tail_arena(mapad_ctx* c, uint32_t grown, hipStream_t st) {
     const uint32_t cls = (grown >> kGrownShift) - 1, idx = grown & ((1u << kGrownShift) - 1);
@@ -1657,8 +1712,13 @@ bool fetch_tail_state(mapad_ctx* c, uint32_t grown, uint32_t heap_len, uint32_t 
     }
     if (!st) return false;
     const uint8_t* b = c->grow.base[cls] + (uint64_t)idx * c->grow.stride[cls];
+    if (!heap_phys || !nodes) {  // the worker cannot take the state over (no room, no memory): the arena is released all the same, the read is mapped from scratch
+        (void)release_tail_arena(c, grown, st);
+        (void)hipStreamSynchronize(st);
+        return false;
+    }
     bool ok = heap_len < c->grow.heap_cap[cls] + 8 && tree_entries <= c->grow.node_cap[cls];
-    ok = ok && hipMemcpyAsync(heap_phys, b, ((size_t)heap_len + 2) * sizeof(HeapEntry), hipMemcpyDeviceToHost, st) == hipSuccess;
+    ok = ok && hipMemcpyAsync(heap_phys, b, ((size_t)HeapLayout<kTop>::phys_end(heap_len) + 1) * sizeof(HeapEntry), hipMemcpyDeviceToHost, st) == hipSuccess;
     ok = ok && hipMemcpyAsync(nodes, b + c->grow.off_nodes[cls], (size_t)tree_entries * sizeof(Node), hipMemcpyDeviceToHost, st) == hipSuccess;
     const bool released = release_tail_arena(c, grown, st);
     ok = (hipStreamSynchronize(st) == hipSuccess) && ok && released;
@@ -1678,7 +1738,7 @@ void drop_tail(mapad_ctx* c, BatchSlot& S) {
     bool any = false;
     for (uint32_t k = 0; k < tb->cap; ++k) {
         const uint8_t* rec = tb->ring + (size_t)k * tb->stride;
-        if (reinterpret_cast<const host::TailRecord*>(rec)->ready != 1u || tb->fetched[k]) continue;
+        if (reinterpret_cast<const host::TailRecord*>(rec)->ready != tb->gen || tb->fetched[k]) continue;
         const host::TailState* ts = reinterpret_cast<const host::TailState*>(rec + host::tail_state_offset(tb->lmax));
         if (ts->grown) any = release_tail_arena(c, ts->grown, c->tail_stream) || any;
     }
@@ -1714,7 +1774,7 @@ int launch_batch(mapad_ctx* c, BatchSlot& S, const uint8_t* d_seqs, const uint8_
     B.prof = c->d_prof.p;
 #endif
     B.tail_ring = nullptr; B.tail_stride = 0; B.tail_cap = 0; B.tail_lmax = 0; B.tail_pops = 0xFFFFFFFFu;
-    B.tail_ctl = nullptr; B.tail_backlog_max = 0; B.tail_min_class = (uint32_t)kClasses; B.tail_continue = 0;
+    B.tail_ctl = nullptr; B.tail_backlog_max = 0; B.tail_min_class = (uint32_t)kClasses; B.tail_continue = 0; B.tail_gen = 1; B.tail_backlog_budget = 0; B.tail_ask_mask = 0;
     drop_tail(c, S);
     for (auto& x : S.tail_info) x = 0;
     S.tail_failed = false;
@@ -1728,17 +1788,26 @@ int launch_batch(mapad_ctx* c, BatchSlot& S, const uint8_t* d_seqs, const uint8_
         uint8_t* ring = S.tail_ring.p + kRingHeader;
         uint32_t* ctl = reinterpret_cast<uint32_t*>(S.tail_ring.p);
         *ctl = host::TailWorkers::instance().pending();
-        // (`ready` words: all of them after a (re)allocation or a change of the record size, else those the slot's previous launch can have set — page-locked coherent
-        //  memory is slow to write from the host, and 65 536 stores in front of every launch were 10 ms of the submitting thread's time)
-        const uint32_t dirty = (S.tail_ring_stride == stride && S.tail_ring_base == S.tail_ring.p) ? std::min<uint32_t>(S.tail_ring_dirty, cap) : cap;
-        for (uint32_t k = 0; k < dirty; ++k) reinterpret_cast<host::TailRecord*>(ring + (size_t)k * stride)->ready = 0;
-        S.tail_ring_stride = stride; S.tail_ring_base = S.tail_ring.p; S.tail_ring_dirty = cap;  // until the launch's count of hand-overs is known (merge_tail)
+        // `ready` words: a record is ready when its word holds THIS launch's number (BatchDev::tail_gen), so nothing is cleared between launches (round 5 cleared
+        // the records the previous launch could have set, and lost track of them when a small batch came between two large ones: ADVICE r5; page-locked coherent
+        // memory is slow to write from the host).  After a (re)allocation or a change of the record size — the words then sit elsewhere, and what lies there is old
+        // payload — every record the buffer can hold is cleared once and the numbering starts again.
+        if (S.tail_ring_stride != stride || S.tail_ring_base != S.tail_ring.p) {
+            const size_t holds = (S.tail_ring.cap - kRingHeader) / stride;
+            for (size_t k = 0; k < holds; ++k) reinterpret_cast<host::TailRecord*>(ring + k * stride)->ready = 0;
+            S.tail_ring_stride = stride; S.tail_ring_base = S.tail_ring.p; S.tail_ring_gen = 0;
+        }
+        if (++S.tail_ring_gen == 0) {  // (wrapped: 2^32 launches of one slot)
+            const size_t holds = (S.tail_ring.cap - kRingHeader) / stride;
+            for (size_t k = 0; k < holds; ++k) reinterpret_cast<host::TailRecord*>(ring + k * stride)->ready = 0;
+            S.tail_ring_gen = 1;
+        }
         auto tb = std::make_shared<host::TailBatch>();
         tb->ix = c->index->ix.view();
         tb->tables = c->tables_snap;
         tb->P = c->dprm;
         tb->P.sdm_table = tb->tables->sdm.data(); tb->P.table_base = tb->tables->table_base.data(); tb->P.reject_thr = tb->tables->reject_thr.data();
-        tb->ring = ring; tb->stride = stride; tb->cap = cap; tb->lmax = tl; tb->ctl = ctl;
+        tb->ring = ring; tb->stride = stride; tb->cap = cap; tb->lmax = tl; tb->ctl = ctl; tb->gen = S.tail_ring_gen;
         {   // "has this launch ended?" for the dispatcher's count of hand-overs that arrive during the launch: the event is recorded at the end of this function
             auto launched = std::make_shared<std::atomic<bool>>(false);
             S.tail_launched = launched;
@@ -1748,10 +1817,10 @@ int launch_batch(mapad_ctx* c, BatchSlot& S, const uint8_t* d_seqs, const uint8_
         // continuation: a read handed over with its state (TailState) — a worker copies its heap and nodes out of the grown arena and releases the arena
         B.tail_continue = env_u32("MAPAD_TAIL_CONTINUE", 1) && c->grow.heavy_min_class >= (uint32_t)kClasses ? 1u : 0u;
         tb->fetched.assign(cap, 0);
-        if (B.tail_continue) tb->fetch_state = [c](uint32_t grown, uint32_t heap_len, uint32_t tree_entries, HeapEntry* heap_phys, Node* nodes) { return fetch_tail_state(c, grown, heap_len, tree_entries, heap_phys, nodes); };
+        if (B.tail_continue) tb->fetch_state = [c](uint32_t grown, uint32_t heap_len, uint32_t tree_entries, HeapEntry* heap_phys, Node* nodes) { return fetch_tail_state(c, grown, heap_len, tree_entries, heap_phys, nodes); };  // (heap_phys == nullptr: release only)
         host::tail_start(tb);
         S.tail = tb;
-        B.tail_ring = ring; B.tail_stride = stride; B.tail_cap = cap; B.tail_lmax = tl; B.tail_pops = c->tail_pops;
+        B.tail_ring = ring; B.tail_stride = stride; B.tail_cap = cap; B.tail_lmax = tl; B.tail_pops = c->tail_pops; B.tail_gen = S.tail_ring_gen;
         // Hand-over on a dry arena class (DeviceGrow::acquire): classes from MAPAD_TAIL_MIN_CLASS up (default 4: the classes whose arena counts are absolute numbers,
         // not a share of the resident read slots), while the host has fewer than MAPAD_TAIL_BACKLOG reads waiting or running (default: half the worker threads — such a
         // read is handed over only when the reads past the pop budget leave threads idle.  1 M reads of the C5 mix on 3 Gbp, 16 threads: limit 32 / 16 / 8 ->
@@ -1759,6 +1828,10 @@ int launch_batch(mapad_ctx* c, BatchSlot& S, const uint8_t* d_seqs, const uint8_
         B.tail_ctl = ctl;
         B.tail_min_class = env_u32("MAPAD_TAIL_MIN_CLASS", 4);
         B.tail_backlog_max = env_u32("MAPAD_TAIL_BACKLOG", std::max(1u, host::TailWorkers::instance().size() / 2));
+        // Past the budget: a worker finishes such a read ~15 x faster than its quad would, so the host is the better place while fewer than ~15 reads per worker wait
+        // in front of it; MAPAD_TAIL_BACKLOG_BUDGET (default 8 per worker; 0xFFFFFFFF = round 5's unconditional hand-over).  Asked again every 1/8 budget.
+        B.tail_backlog_budget = env_u32("MAPAD_TAIL_BACKLOG_BUDGET", 8u * std::max(1u, host::TailWorkers::instance().size()));
+        { uint32_t m = 64; while (2 * m <= c->tail_pops / 8) m *= 2; B.tail_ask_mask = m - 1; }
     }
     S.last = B; S.last_total_bases = total_bases; S.last_lmax = lmax; S.compacted = false;
     // A process-wide launch number, not a per-slot count: a result of a destroyed context must not pass for the batch of a new context that happens to sit at
@@ -1810,9 +1883,14 @@ int launch_batch(mapad_ctx* c, BatchSlot& S, const uint8_t* d_seqs, const uint8_
     }
     const bool cont = c->dprm.bound_kind == BOUND_CONTINUOUS;
     const bool heavy_on = c->grow.heavy_min_class < (uint32_t)kClasses;
+    (void)heavy_on;
+#if defined(MAPAD_HEAVY_KERNEL)
 #define MAPAD_LAUNCH(L, C, P, N)                                                                                                                                   \
     if (heavy_on && L == 4) hipLaunchKernelGGL((search_kernel<L, C, P, N, (L == 4)>), dim3(grid), dim3(64), lds, S.stream, c->dix, c->dprm, B, ap, c->d_grow.p, near_stride, near_lmax, stage); \
     else hipLaunchKernelGGL((search_kernel<L, C, P, N, false>), dim3(grid), dim3(64), lds, S.stream, c->dix, c->dprm, B, ap, c->d_grow.p, near_stride, near_lmax, stage)
+#else
+#define MAPAD_LAUNCH(L, C, P, N) hipLaunchKernelGGL((search_kernel<L, C, P, N, false>), dim3(grid), dim3(64), lds, S.stream, c->dix, c->dprm, B, ap, c->d_grow.p, near_stride, near_lmax, stage)
+#endif
 #define MAPAD_LAUNCH_PASS(P)                                                                                      \
     if (c->lpr == 2 && near_stride) { if (!cont) { MAPAD_LAUNCH(2, false, P, true); } else { MAPAD_LAUNCH(2, true, P, true); } }   \
     else if (c->lpr == 2) { if (!cont) { MAPAD_LAUNCH(2, false, P, false); } else { MAPAD_LAUNCH(2, true, P, false); } }          \
@@ -1837,6 +1915,7 @@ int launch_batch(mapad_ctx* c, BatchSlot& S, const uint8_t* d_seqs, const uint8_
     }
     const uint32_t full_waves = c->resident_waves, shared_waves = std::max<uint32_t>(1, std::min<uint32_t>(full_waves, env_u32("MAPAD_SHARED_WAVES_PER_CU", 8) * (uint32_t)(c->depth > 1 ? c->n_cu - c->reserved_cus : c->n_cu)));
     const uint32_t grid_s = warm ? 1u : (uint32_t)std::min<uint64_t>((n_reads + rpw - 1) / rpw, others_running ? shared_waves : full_waves);
+#if defined(MAPAD_HEAVY_KERNEL)
     // heavy wavefronts: as many as the chip holds (LDS: heap levels 0-9 + the read's position data); a wavefront that finds no work exits at once
     const uint32_t heavy_lds = heavy_lds_bytes(near_lmax);
     const uint32_t heavy_per_cu = std::max<uint32_t>(1, std::min<uint32_t>(env_u32("MAPAD_HEAVY_WAVES_PER_CU", 8), (160u * 1024u) / heavy_lds));
@@ -1844,14 +1923,18 @@ int launch_batch(mapad_ctx* c, BatchSlot& S, const uint8_t* d_seqs, const uint8_
 #define MAPAD_LAUNCH_HEAVY(M, R, GRID, AP, TIER)                                                                                                                      \
     if (!cont) hipLaunchKernelGGL((heavy_kernel<false, M, R>), dim3(GRID), dim3(64), heavy_lds, S.stream, c->dix, c->dprm, B, AP, c->d_grow.p, near_lmax, TIER);   \
     else hipLaunchKernelGGL((heavy_kernel<true, M, R>), dim3(GRID), dim3(64), heavy_lds, S.stream, c->dix, c->dprm, B, AP, c->d_grow.p, near_lmax, TIER);
+#endif
     for (int stage = 0; stage + 1 < kStages; ++stage) {  // Q0 + H0: every read; Q1 + H1: the reads that gave up waiting (normally none: the launches exit at once)
         const uint32_t grid = grid_s;
         const ArenaPool ap = c->pool[0];
         if (stage == 0) { MAPAD_LAUNCH_PASS(0) } else { MAPAD_LAUNCH_PASS(2) }  // PASS 2 = PASS 0 under its own symbol, so that profiles keep the passes apart
+#if defined(MAPAD_HEAVY_KERNEL)
         if ((heavy_on || warm) && near_lmax <= kHeavyMaxLdsReadLen) { MAPAD_LAUNCH_HEAVY(0, true, grid_h, ap, stage) }
+#endif
         HIP_TRY(hipGetLastError());
     }
     if (!warm) HIP_TRY(hipEventRecord(S.ev[2], S.stream));
+#if defined(MAPAD_HEAVY_KERNEL)
     {   // leftovers with the reference's full limits: heavy wavefronts from scratch
         const uint32_t grid = warm ? 1u : (uint32_t)std::min<uint64_t>(n_reads, c->slots[1]);
         const ArenaPool ap = c->pool[1];
@@ -1859,6 +1942,18 @@ int launch_batch(mapad_ctx* c, BatchSlot& S, const uint8_t* d_seqs, const uint8_
         HIP_TRY(hipGetLastError());
     }
 #undef MAPAD_LAUNCH_HEAVY
+#else
+    {   // leftovers with the reference's full limits (only when the host tail is off or its ring was full): quads from scratch in the full-limit arenas, no growing (PASS 1)
+        const uint32_t grid = warm ? 1u : (uint32_t)std::min<uint64_t>((n_reads + 15) / 16, c->pool[1].n_sets);
+        const ArenaPool ap = c->pool[1];
+        const int stage = kStages - 1;
+        const uint32_t near_stride = (near_lmax <= kMaxLdsReadLen && env_u32("MAPAD_NEAR_LDS", 1)) ? near_bytes(near_lmax, kTop) : 0;
+        const size_t lds = (size_t)near_stride * 16;
+        if (near_stride) { if (!cont) { MAPAD_LAUNCH(4, false, 1, true); } else { MAPAD_LAUNCH(4, true, 1, true); } }
+        else { if (!cont) { MAPAD_LAUNCH(4, false, 1, false); } else { MAPAD_LAUNCH(4, true, 1, false); } }
+        HIP_TRY(hipGetLastError());
+    }
+#endif
 #undef MAPAD_LAUNCH_PASS
 #undef MAPAD_LAUNCH
     if (warm) return MAPAD_OK;
@@ -1877,7 +1972,6 @@ int merge_tail(mapad_ctx* c, BatchSlot& S, uint32_t* cur) {
     std::shared_ptr<host::TailBatch> tb = S.tail;
     S.tail.reset();
     S.tail_failed = true;  // until the results are on the device: a failure below leaves reads marked ST_TAIL, and the batch's collect must go on failing (compact_last)
-    S.tail_ring_dirty = std::min<uint32_t>(cur[CUR_TAIL], tb->cap);  // the launch has ended: this many records were written
     const bool ok = host::tail_finish(tb, cur[CUR_TAIL]);
     if (!ok) { std::fprintf(stderr, "mapad_amd: a read of the host tail could not be mapped (out of host memory?)\n"); return MAPAD_ERR_NOMEM; }
     std::vector<host::TailResult>& res = tb->results;
@@ -2156,6 +2250,7 @@ int mapad_ctx_set_tail_pops(mapad_ctx_t* ctx, uint32_t pops) {
     ctx->tail_pops = pops;
     return MAPAD_OK;
 }
+uint32_t mapad_tail_set_local_world(uint32_t local_world) { return host::TailWorkers::instance().set_local_world(local_world); }
 int mapad_last_tail_info(mapad_ctx_t* ctx, uint64_t out[16]) {
     if (!ctx || !out) return MAPAD_ERR_INVALID;
     std::memcpy(out, ctx->bs[ctx->view].tail_info, sizeof ctx->bs[ctx->view].tail_info);

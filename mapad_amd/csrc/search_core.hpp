@@ -398,7 +398,7 @@ MAPAD_HD bool search_step(const DevIndex& ix, const DevParams& P, const ReadInT<
         const bool l_near = li < (uint32_t)TOP;
         const HeapEntry ln = load_entry(A.top + (l_near ? li : 0u));
         HeapEntry lg = HeapEntry{0.0f, 0u};
-        if (!l_near) lg = load_entry(A.heap + li);
+        if (!l_near) lg = load_entry(A.heap + HeapLayout<TOP>::slot(li));
         last.score = l_near ? ln.score : lg.score; last.node = l_near ? ln.node : lg.node;
     }
 

@@ -108,6 +108,11 @@ def lib():
             "mo_hit_bam_fields": (i32, [vp, vp, u64, u64, i32, u64, i32, C.c_char_p, C.c_char_p, C.POINTER(i32)]),
             "mo_records_tsv": (vp, [vp, vp, PP, vp, vp, vp, vp, u64]),
             "mo_free": (None, [vp]),
+            "mo_records_from_hits": (vp, [vp, PP, vp, vp, vp, vp, vp, vp, vp, vp, vp, u64, u64, i32]),
+            "mo_hit_records_text_bytes": (u64, [vp]),
+            "mo_hit_records_error": (C.c_char_p, [vp]),
+            "mo_hit_records_export": (None, [vp, vp, vp]),
+            "mo_hit_records_free": (None, [vp]),
             "mo_prrange": (i64, [u64, u64, u64, vp, u64]),
             "mo_prrange_count": (i32, [u64, u64, u64, u64, C.POINTER(u64), C.POINTER(u64)]),
             "mo_tree_script": (i32, [vp, i32, vp]),
@@ -214,11 +219,41 @@ class OracleIndex:
         qual = np.ascontiguousarray(qual, dtype=np.uint8)
         return lib().mo_d_array_get(self.h, C.byref(params), seq, _ptr(qual), len(seq), split, k, l)
 
+    def records_from_hits(self, params, hit_begin, intervals, scores, op_begin, ops, seqs, quals, offsets, flags=None, first_read_index=0, n_threads=1):
+        """intervals_to_record (mapping.rs:402-718 restated) over hits found elsewhere, given per read in BinaryHeap array order: hit_begin u64[n + 1], intervals
+        u64[n_hits, 3], scores f32[n_hits], op_begin u64[n_hits + 1] into the packed edit operations `ops`.  The index needs its sampled suffix array and contigs
+        (set_sampled_sa / sample_sa, add_contig).  Returns (records: MO_RECORD_DTYPE[n], text: uint8 — [CIGAR][MD][XA] of the mapped reads in read order)."""
+        a = lambda x, t: np.ascontiguousarray(x, dtype=t)  # noqa: E731
+        hit_begin, intervals, scores, op_begin, ops = a(hit_begin, np.uint64), a(intervals, np.uint64).reshape(-1, 3), a(scores, np.float32), a(op_begin, np.uint64), a(ops, np.uint32)
+        seqs, quals, offsets = a(seqs, np.uint8), a(quals, np.uint8), a(offsets, np.uint64)
+        n = offsets.size - 1
+        assert hit_begin.size == n + 1 and op_begin.size == int(hit_begin[-1]) + 1 and intervals.shape[0] == int(hit_begin[-1]) == scores.size
+        fl = a(flags, np.uint16) if flags is not None else None
+        pad = lambda x: x if x.size else np.zeros(1, x.dtype)  # noqa: E731
+        h = lib().mo_records_from_hits(self.h, C.byref(params), _ptr(hit_begin), _ptr(pad(intervals.reshape(-1))), _ptr(pad(scores)), _ptr(op_begin), _ptr(pad(ops)),
+                                       _ptr(pad(seqs)), _ptr(pad(quals)), _ptr(offsets), _ptr(fl) if fl is not None else None, n, int(first_read_index), int(n_threads))
+        try:
+            err = lib().mo_hit_records_error(h)
+            if err:
+                raise RuntimeError("oracle intervals_to_record: " + err.decode())
+            recs = np.zeros(max(n, 1), MO_RECORD_DTYPE)
+            text = np.zeros(max(int(lib().mo_hit_records_text_bytes(h)), 1), np.uint8)
+            lib().mo_hit_records_export(h, _ptr(recs), _ptr(text))
+            return recs[:n], text[:int(lib().mo_hit_records_text_bytes(h))]
+        finally:
+            lib().mo_hit_records_free(h)
+
     def map_batch(self, params, reads, quals, n_threads=1, keep_d=False):
         """reads: list[bytes]; quals: list[array-like u8] -> OracleResult"""
         seqs, qs, offsets = pack_reads(reads, quals)
         r = lib().mo_map_batch(self.h, C.byref(params), _ptr(seqs), _ptr(qs), _ptr(offsets), len(reads), n_threads, int(keep_d))
         return OracleResult(self, r, params, seqs, qs, offsets)
+
+
+# capi.cpp: MoRecord (64 bytes)
+MO_RECORD_DTYPE = np.dtype({"names": ["pos", "tid", "as_bits", "xs_bits", "nm", "x0", "x1", "cigar_len", "md_len", "xa_len", "flags", "mapq", "mapped", "reverse", "has_xs", "xt", "text_off"],
+                            "formats": ["<i8", "<i4", "<u4", "<u4", "<i4", "<i4", "<i4", "<u4", "<u4", "<u4", "<u2", "u1", "u1", "u1", "u1", "u1", "<u8"],
+                            "offsets": [0, 8, 12, 16, 20, 24, 28, 32, 36, 40, 44, 46, 47, 48, 49, 50, 56], "itemsize": 64})
 
 
 def pack_reads(reads, quals):

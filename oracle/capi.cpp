@@ -276,6 +276,82 @@ char* mo_records_tsv(void* h, void* r, const mo_params* p, const uint8_t* seqs, 
 }
 void mo_free(void* p) { std::free(p); }
 
+// ---- post-processing of hits handed over from outside (round 6: the record-level audit at n > 2^32, profiles/audit_c4.py --records) ----
+// intervals_to_record (src/map/mapping.rs:402-718, record.rs:269-449 restated in mapad_oracle.hpp) over hits that were found elsewhere — the product's, proven
+// identical to this oracle's own search results read by read — given per read in BinaryHeap array order: hit_begin[n + 1]; per hit intervals[3], score,
+// op_begin[n_hits + 1] into the packed edit operations.  Read i draws the stand-ins for rand::rng() of read first_read_index + i (seed_for), as mo_records_tsv does.
+// Output: one fixed record per read + a text pool ([CIGAR][MD][XA] per mapped read, in read order), fetched with mo_hit_records_export.
+struct MoRecord {
+    int64_t pos; int32_t tid; uint32_t as_bits, xs_bits; int32_t nm, x0, x1; uint32_t cigar_len, md_len, xa_len;
+    uint16_t flags; uint8_t mapq, mapped, reverse, has_xs, xt, pad;
+    uint64_t text_off;
+};
+static_assert(sizeof(MoRecord) == 64, "oracle record layout (oracle/binding.py: MO_RECORD_DTYPE)");
+struct HitRecords { std::vector<MoRecord> recs; std::string text; std::string error; };
+void* mo_records_from_hits(void* h, const mo_params* p, const uint64_t* hit_begin, const uint64_t* intervals, const float* scores, const uint64_t* op_begin,
+                           const uint32_t* ops, const uint8_t* seqs, const uint8_t* quals, const uint64_t* offsets, const uint16_t* flags, uint64_t n,
+                           uint64_t first_read_index, int n_threads) {
+    auto idx = (Index*)h;
+    auto out = new HitRecords();
+    out->recs.resize(n);
+    const int T = std::max(1, n_threads);
+    std::vector<std::string> texts((size_t)T);
+    std::vector<std::string> errors((size_t)T);
+    auto worker = [&](int t) {
+        auto m = make_models(*p);
+        const uint64_t lo = n * (uint64_t)t / (uint64_t)T, hi = n * (uint64_t)(t + 1) / (uint64_t)T;
+        std::string& text = texts[(size_t)t];
+        try {
+            for (uint64_t i = lo; i < hi; ++i) {
+                InRecord in;
+                in.flags = flags ? flags[i] : 4;
+                in.seq.assign(seqs + offsets[i], seqs + offsets[i + 1]);
+                in.qual.assign(quals + offsets[i], quals + offsets[i + 1]);
+                HitHeap heap;
+                for (uint64_t k = hit_begin[i]; k < hit_begin[i + 1]; ++k) {
+                    HitInterval hv;
+                    hv.interval = RtBiInterval{intervals[3 * k], intervals[3 * k + 1], intervals[3 * k + 2]};
+                    hv.alignment_score = scores[k];
+                    for (uint64_t o = op_begin[k]; o < op_begin[k + 1]; ++o)
+                        hv.edit_operations.push_back(EditOperation{(OpKind)(ops[o] >> 24), (uint16_t)(ops[o] & 0xFFFFu), (uint8_t)((ops[o] >> 16) & 0xFFu)});
+                    heap.data.push_back(std::move(hv));  // array order as given: the heap is not re-built
+                }
+                uint32_t call = 0;
+                const OutRecord rec = intervals_to_record(in, std::move(heap), idx->ssa, idx->idmap, idx->orig, *m.mb, [&]() { return seed_for(first_read_index + i, call++); });
+                MoRecord r{};
+                r.pos = rec.pos; r.tid = rec.tid; r.flags = rec.flags; r.mapq = rec.mapq; r.mapped = rec.mapped; r.reverse = rec.reverse;
+                if (rec.mapped) {
+                    std::memcpy(&r.as_bits, &rec.as, 4); std::memcpy(&r.xs_bits, &rec.xs, 4);
+                    r.nm = rec.nm; r.x0 = rec.x0; r.x1 = rec.x1; r.has_xs = rec.has_xs; r.xt = (uint8_t)rec.xt;
+                    r.cigar_len = (uint32_t)rec.cigar.size(); r.md_len = (uint32_t)rec.md.size(); r.xa_len = (uint32_t)rec.xa.size();
+                    r.text_off = text.size();  // relative to this thread's piece; rebased below
+                    text += rec.cigar; text += rec.md; text += rec.xa;
+                }
+                out->recs[i] = r;
+            }
+        } catch (const std::exception& e) { errors[(size_t)t] = e.what(); }
+    };
+    if (T == 1) worker(0);
+    else { std::vector<std::thread> ts; for (int t = 0; t < T; ++t) ts.emplace_back(worker, t); for (auto& t : ts) t.join(); }
+    uint64_t base = 0;
+    for (int t = 0; t < T; ++t) {
+        const uint64_t lo = n * (uint64_t)t / (uint64_t)T, hi = n * (uint64_t)(t + 1) / (uint64_t)T;
+        for (uint64_t i = lo; i < hi; ++i) if (out->recs[i].mapped) out->recs[i].text_off += base;
+        base += texts[(size_t)t].size();
+        out->text += texts[(size_t)t];
+        if (!errors[(size_t)t].empty()) out->error = errors[(size_t)t];
+    }
+    return out;
+}
+uint64_t mo_hit_records_text_bytes(void* r) { return ((HitRecords*)r)->text.size(); }
+const char* mo_hit_records_error(void* r) { return ((HitRecords*)r)->error.c_str(); }
+void mo_hit_records_export(void* r, void* recs, char* text) {
+    auto hr = (HitRecords*)r;
+    std::memcpy(recs, hr->recs.data(), hr->recs.size() * sizeof(MoRecord));
+    std::memcpy(text, hr->text.data(), hr->text.size());
+}
+void mo_hit_records_free(void* r) { delete (HitRecords*)r; }
+
 // ---- PrRange ----
 int64_t mo_prrange(uint64_t start, uint64_t end, uint64_t seed, uint64_t* out, uint64_t max_out) {
     auto pr = PrRange::try_new(start, end, seed);

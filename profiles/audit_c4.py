@@ -20,6 +20,55 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
+def records_audit(args, ctx, index, genome, rp, res, seqs, quals, offsets):
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from oracle import binding as ob
+    from parity_util import canonical_records, check_ungapped_records_against_the_text, compare_records, oracle_records_from_product_hits, oracle_threads, records_digest
+    n_reads = len(offsets) - 1
+    t0 = time.time()
+    recs, text = ctx.hits_to_records(res, seqs, quals, offsets, seed=0, as_arrays=True)
+    t_dev = time.time() - t0
+    t0 = time.time()
+    oidx = ob.OracleIndex.from_bwt(index.bwt(), "$ACGTX", 128)
+    sample, er, ev = index.sampled_sa()
+    oidx.set_sampled_sa(sample, 32, er, ev)  # the oracle walks its own byte BWT / Occ from the product's samples (which test_gpu_index.py checks against the text and the host SA-IS)
+    for name, s, e in index.contigs():
+        oidx.add_contig(s, e, name)
+    t_struct = time.time() - t0
+    op = ob.make_params(rp)
+    h_dev, h_ora = hashlib.sha256(), hashlib.sha256()
+    bad, first_bad, per_field_total, t_ora = 0, [], {}, 0.0
+    for lo in range(0, n_reads, args.chunk):
+        hi = min(lo + args.chunk, n_reads)
+        t = time.time()
+        orecs, otext = oracle_records_from_product_hits(oidx, op, res, seqs, quals, offsets, lo, hi, n_threads=oracle_threads())
+        t_ora += time.time() - t
+        cd, co = canonical_records(recs[lo:hi], text, oracle_side=False), canonical_records(orecs, otext, oracle_side=True)
+        h_dev.update(records_digest(cd).encode()); h_ora.update(records_digest(co).encode())
+        nb, fb, pf = compare_records(cd, co)
+        bad += nb
+        first_bad += [lo + i for i in fb][:max(0, 10 - len(first_bad))]
+        for k, v in pf.items():
+            per_field_total[k] = per_field_total.get(k, 0) + v
+        print(f"  records [{lo}, {hi}): {nb} differ; oracle {t_ora:.0f} s so far", file=sys.stderr, flush=True)
+    t0 = time.time()
+    checked, failed = check_ungapped_records_against_the_text(genome, recs, text, seqs, offsets)
+    mapped = recs["mapped"] != 0
+    out = {"config": f"C4: synthetic genome ({args.genome_bp} bp, n = {len(index)} BWT rows), {n_reads} x 50 bp reads (the batch of bench.py --config c4), -p 0.03, no-damage model",
+           "what": "device-built records (mapad_hits_to_records_gpu: records_kernel, text_kernel, locate_kernel; MAPQ and flags on the host) of every read vs the oracle's intervals_to_record "
+                   "(oracle/mapad_oracle.hpp restating mapping.rs:402-718, record.rs:269-449) over the same hits with the same per-read stand-ins for rand::rng() (seed 0)",
+           "compared": "per read: flags, tid, POS, strand, MAPQ, AS bits, XS bits / presence, NM, X0, X1, XT, CIGAR, MD, XA",
+           "reads": n_reads, "mapped": int(mapped.sum()), "reverse_strand (suffix positions >= 2^32 in the 6e9-row text)": int((recs["reverse"][mapped] != 0).sum()),
+           "with_XA": int((recs["xa_len"][mapped] > 0).sum()), "X0_above_1": int((recs["x0"][mapped] > 1).sum()), "mapq_histogram": {str(k): int(v) for k, v in zip(*np.unique(recs["mapq"][mapped], return_counts=True))},
+           "reads_that_differ": bad, "first_reads_that_differ": first_bad, "per_field_differences": {k: v for k, v in per_field_total.items() if v},
+           "sha256_device": h_dev.hexdigest(), "sha256_oracle": h_ora.hexdigest(), "digests_equal": h_dev.hexdigest() == h_ora.hexdigest(),
+           "ungapped_records_checked_against_the_text": checked, "of_them_NM_or_POS_or_strand_wrong": failed,
+           "device_records_s": round(t_dev, 2), "oracle_structures_s": round(t_struct, 1), "oracle_records_s": round(t_ora, 1), "text_check_s": round(time.time() - t0, 1)}
+    os.makedirs(os.path.dirname(args.records) or ".", exist_ok=True)
+    json.dump(out, open(args.records, "w"), indent=1)
+    print(json.dumps(out), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reads", type=int, default=10_000_000)
@@ -28,6 +77,11 @@ def main():
     ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r04", "c4_full_parity.json"))
     ap.add_argument("--against", default=None, help="a committed audit of the same batch (e.g. profiles/r04/c4_full_parity.json): map on the GPU only and compare the digest of the "
                                                     "results with that audit's ORACLE digest (same arrays, same chunking) — a minute instead of the oracle's 25")
+    ap.add_argument("--records", default=None, metavar="OUT.json",
+                    help="record-level audit (round 6): the device-built records of ALL reads (mapad_hits_to_records_gpu: records_kernel / text_kernel / locate_kernel, MAPQ and flags "
+                         "on the host) against the oracle's intervals_to_record (mapping.rs:402-718, record.rs:269-449 restated) run over the same hits with the same per-read "
+                         "stand-ins for rand::rng() — flags, tid, POS, strand, MAPQ, AS / XS bits, NM, X0, X1, XT, CIGAR, MD, XA —, digests of both sides, and every ungapped "
+                         "record against the text itself.  Combine with --against: the hits are then shown identical to the oracle's by that audit's digest")
     args = ap.parse_args()
 
     import mapad_amd
@@ -48,8 +102,10 @@ def main():
     res = ctx.map_batch(seqs, quals, offsets)
     t_gpu = time.time() - t1
     tail = ctx.tail_info()
-    ctx.close()
     print(f"index {t_index:.1f} s, GPU mapped {args.reads} reads in {t_gpu:.1f} s ({res.n_hits} hits)", file=sys.stderr, flush=True)
+    if args.records:
+        records_audit(args, ctx, index, genome, rp, res, seqs, quals, offsets)
+    ctx.close()
 
     if args.against:
         prior = json.load(open(args.against))

@@ -12,7 +12,7 @@ cd /tmp; export TMPDIR=/tmp
 B="--no-cpu-baseline --no-extras"
 timeout 900 rocprofv3 --kernel-trace --stats -d "$OUT/stats" -o out --output-format csv -- python3 "$ROOT/bench.py" --steps ${COLLECT_STEPS:-5} --warmup 1 $B "$@" > "$OUT/stats.log" 2>&1; echo "stats rc=$?"
 timeout 900 rocprofv3 --kernel-trace --stats -d "$OUT/stats_d1" -o out --output-format csv -- python3 "$ROOT/bench.py" --steps 3 --warmup 1 --depth 1 $B "$@" > "$OUT/stats_d1.log" 2>&1; echo "stats_d1 rc=$?"
-for grp in "fetch:FETCH_SIZE" "write:WRITE_SIZE" "tcc:TCC_HIT_sum TCC_MISS_sum"; do
+for grp in "fetch:FETCH_SIZE" "write:WRITE_SIZE" "tcc:TCC_HIT_sum TCC_MISS_sum" "ea:TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum"; do
   name=${grp%%:*}; ctrs=${grp#*:}
   timeout 900 rocprofv3 --pmc $ctrs --kernel-trace -d "$OUT/pmc_$name" -o out --output-format csv -- python3 "$ROOT/bench.py" --steps 1 --warmup 0 --depth 1 $B "$@" > "$OUT/pmc_$name.log" 2>&1; echo "$name rc=$?"
 done

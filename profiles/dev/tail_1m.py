@@ -26,6 +26,9 @@ def main():
     ap.add_argument("--genome-bp", type=int, default=3_000_000_000)
     ap.add_argument("--log", default=os.path.join(ROOT, "gpurun_out", "tail_reads.log"))
     ap.add_argument("--budgets", default="", help="comma-separated pop budgets (mapad_ctx_set_tail_pops) to map the batch with, one after the other; default: the library's")
+    ap.add_argument("--ranks", default="", help="comma-separated LOCAL_WORLD[:BACKLOG_BUDGET[:BUDGET_POPS]] settings to map the batch with, one after the other: this process as one rank "
+                                                "of LOCAL_WORLD on its node (mapad_tail_set_local_world: its share of the host tail's workers), MAPAD_TAIL_BACKLOG_BUDGET (`u` = unconditional "
+                                                "hand-over past the budget, round 5's behaviour; empty = the default, 8 per worker), pop budget; e.g. 8,8:u,4,1")
     args = ap.parse_args()
     os.makedirs(os.path.dirname(args.log), exist_ok=True)
     import mapad_amd
@@ -37,8 +40,20 @@ def main():
     print(f"genome + index {time.time() - t0:.1f} s", flush=True)
     seqs, quals, offsets = synth.reads(genome, args.reads, 50, seed=4321 + 5, qual_range=(20, 40), damage=dict(f=0.5, t=0.5, d=0.02, s=1.0), len_range=(35, 100), indel_frac=0.05)
     import hashlib
-    for budget in ([int(b) for b in args.budgets.split(",")] if args.budgets else [None]):
-        log_path = args.log + (f".{budget}" if budget is not None else "")
+    runs = [(int(b), None, None) for b in args.budgets.split(",")] if args.budgets else [(None, None, None)]
+    if args.ranks:
+        runs = []
+        for spec in args.ranks.split(","):
+            f = (spec.split(":") + ["", ""])[:3]
+            runs.append((int(f[2]) if f[2] else None, int(f[0]), f[1]))
+    for budget, lw, backlog in runs:
+        if lw is not None:
+            workers = mapad_amd.lib().mapad_tail_set_local_world(lw)
+            os.environ.pop("MAPAD_TAIL_BACKLOG_BUDGET", None)
+            if backlog:
+                os.environ["MAPAD_TAIL_BACKLOG_BUDGET"] = "4294967295" if backlog == "u" else backlog
+            print(f"--- one rank of {lw}: {workers} host workers, backlog limit past the budget: {backlog or 'default (8 per worker)'}", flush=True)
+        log_path = args.log + (f".{budget}" if budget is not None else "") + (f".lw{lw}_{backlog or 'd'}" if lw is not None else "")
         if os.path.exists(log_path):
             os.remove(log_path)
         os.environ["MAPAD_TAIL_LOG"] = log_path

@@ -69,7 +69,7 @@ if tr:
                "kernels": overlap, "depth1": solo}, open(os.path.join(ROOT, "profiles", f"{tag}_kernel_overlap.json"), "w"), indent=1)
 counters = collections.defaultdict(lambda: collections.defaultdict(float))
 launches = collections.defaultdict(lambda: collections.defaultdict(set))
-for d in ("pmc_fetch", "pmc_write", "pmc_tcc"):
+for d in ("pmc_fetch", "pmc_write", "pmc_tcc", "pmc_ea"):
     for f in glob.glob(os.path.join(out, d, "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
             k = short(r["Kernel_Name"])
@@ -93,6 +93,12 @@ for k, c in counters.items():
         # requests the L2 sent to memory (FETCH_SIZE and WRITE_SIZE are request counts x 64 B on gfx950, whatever a request's size): the path's accesses are
         # random, and what such a path saturates is the rate of requests, not bytes (profiles/calib/fetch_calib.hip; bench.py: roofline.random_access)
         traffic[k + "_hbm_requests"] = int((per["FETCH_SIZE"] + per["WRITE_SIZE"]) * 1024 / 64)
+        traffic[k + "_hbm_read_requests"] = int(per["FETCH_SIZE"] * 1024 / 64)           # every one a 128-byte line (profiles/r05/calib_ea_request_sizes.txt)
+        traffic[k + "_hbm_write_64B_units"] = int(per["WRITE_SIZE"] * 1024 / 64)        # bytes written / 64
+    if "TCC_EA0_WRREQ_sum" in per:  # the memory side's own request counts (round 6): a write request is 32 or 64 bytes, so there are more of them than WRITE_SIZE / 64
+        traffic[k + "_ea_rdreq"] = int(per.get("TCC_EA0_RDREQ_sum", 0))
+        traffic[k + "_ea_wrreq"] = int(per["TCC_EA0_WRREQ_sum"])
+        traffic[k + "_ea_wrreq_64B"] = int(per.get("TCC_EA0_WRREQ_64B_sum", 0))
 summary["traffic_bytes_per_batch"] = traffic
 json.dump(summary, open(os.path.join(ROOT, "profiles", f"{tag}_pmc_summary.json"), "w"), indent=1)
 tp = os.path.join(ROOT, "profiles", "traffic.json")

@@ -13,17 +13,19 @@ _SRC = os.path.join(_HERE, "emu", "emu.cpp")
 _libs = {}
 
 
-def lib(heap_variant=0):
-    """heap_variant: the reading of the frontier heap's tie rules the emulation is compiled with (csrc/heap_core.hpp: MAPAD_HEAP_VARIANT)."""
-    _lib = _libs.get(heap_variant)
-    _OUT = os.path.join(_HERE, "emu", "_build", "libmapad_emu.so" if not heap_variant else f"libmapad_emu.hv{heap_variant}.so")
+def lib(heap_variant=0, subtree=0):
+    """heap_variant: the reading of the frontier heap's tie rules the emulation is compiled with (csrc/heap_core.hpp: MAPAD_HEAP_VARIANT); subtree: MAPAD_SUBTREE_HEAP
+    (the arena's heap levels in subtree blocks: profiles/request_attribution.py models both layouts)."""
+    key = (heap_variant, subtree)
+    _lib = _libs.get(key)
+    _OUT = os.path.join(_HERE, "emu", "_build", "libmapad_emu" + (f".hv{heap_variant}" if heap_variant else "") + (".sub" if subtree else "") + ".so")
     if _lib is None:
         deps = [_SRC] + [os.path.join(_HERE, "..", "mapad_amd", "csrc", f) for f in os.listdir(os.path.join(_HERE, "..", "mapad_amd", "csrc")) if f.endswith((".hpp", ".hip"))]
         if not os.path.exists(_OUT) or any(os.path.getmtime(d) > os.path.getmtime(_OUT) for d in deps):
             os.makedirs(os.path.dirname(_OUT), exist_ok=True)
             subprocess.check_call(["g++", "-O2", "-g", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math", "-fno-builtin-log2f", "-fno-builtin-powf",
                                    "-fno-builtin-expf", "-fno-builtin-exp2f", "-fno-builtin-log10f", "-Wall",
-                                   "-Wno-unused-function", "-Wno-unknown-pragmas", f"-DMAPAD_HEAP_VARIANT={int(heap_variant)}", "-o", _OUT + f".tmp{os.getpid()}", _SRC])
+                                   "-Wno-unused-function", "-Wno-unknown-pragmas", f"-DMAPAD_HEAP_VARIANT={int(heap_variant)}", f"-DMAPAD_SUBTREE_HEAP={int(subtree)}", "-o", _OUT + f".tmp{os.getpid()}", _SRC])
             os.replace(_OUT + f".tmp{os.getpid()}", _OUT)  # atomically: the two ranks of test_distributed may both find the library stale
         L = C.CDLL(_OUT)
         L.emu_map_batch.restype = C.POINTER(mb.BatchResultC)
@@ -35,20 +37,46 @@ def lib(heap_variant=0):
         L.emu_block_pos_selftest.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32]
         L.emu_par_commit_selftest.restype = C.c_uint64
         L.emu_par_commit_selftest.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32]
-        _libs[heap_variant] = _lib = L
+        _libs[key] = _lib = L
     return _lib
 
 
-def map_batch(index, params, seqs, quals, offsets, node_cap=4096, heap_cap=4096, heap_variant=0):
+def map_batch(index, params, seqs, quals, offsets, node_cap=4096, heap_cap=4096, heap_variant=0, subtree=0):
     """Runs the kernels' per-read logic on the host over the product's device-layout index."""
     blocks, nb, less, sent = index.device_view()
     seqs = np.ascontiguousarray(seqs, dtype=np.uint8)
     quals = np.ascontiguousarray(quals, dtype=np.uint8)
     offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
-    r = lib(heap_variant).emu_map_batch(blocks, nb, len(index), less.ctypes.data_as(C.c_void_p), sent.ctypes.data_as(C.c_void_p), C.byref(params),
+    r = lib(heap_variant, subtree).emu_map_batch(blocks, nb, len(index), less.ctypes.data_as(C.c_void_p), sent.ctypes.data_as(C.c_void_p), C.byref(params),
                             seqs.ctypes.data_as(C.c_void_p), quals.ctypes.data_as(C.c_void_p), offsets.ctypes.data_as(C.c_void_p),
                             offsets.size - 1, node_cap, heap_cap)
-    return mb.BatchResult(r, lib(heap_variant).emu_result_free)
+    return mb.BatchResult(r, lib(heap_variant, subtree).emu_result_free)
+
+
+_HS_SRC = os.path.join(_HERE, "emu", "heap_selftest.cpp")
+_hs = {}
+
+
+def heap_selftest_lib(subtree=1, heap_variant=0):
+    """tests/emu/heap_selftest.cpp: the product's min-max heap in the build's physical layout (csrc/heap_core.hpp: HeapLayout; subtree=0: the implicit array) against
+    the oracle's MinMaxHeap."""
+    key = (int(subtree), int(heap_variant))
+    if key not in _hs:
+        out = os.path.join(_HERE, "emu", "_build", f"libheap_selftest.s{key[0]}.hv{key[1]}.so")
+        csrc = os.path.join(_HERE, "..", "mapad_amd", "csrc")
+        deps = [_HS_SRC, os.path.join(_HERE, "..", "oracle", "mapad_oracle.hpp")] + [os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith(".hpp")]
+        if not os.path.exists(out) or any(os.path.getmtime(d) > os.path.getmtime(out) for d in deps):
+            os.makedirs(os.path.dirname(out), exist_ok=True)
+            subprocess.check_call(["g++", "-O2", "-g", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math", "-Wall", "-Wno-unused-function", "-Wno-unknown-pragmas", "-Wno-misleading-indentation",
+                                   f"-DMAPAD_SUBTREE_HEAP={key[0]}", f"-DMAPAD_HEAP_VARIANT={key[1]}", "-o", out + f".tmp{os.getpid()}", _HS_SRC])
+            os.replace(out + f".tmp{os.getpid()}", out)
+        L = C.CDLL(out)
+        L.heap_layout_properties.restype = C.c_uint64
+        L.heap_layout_properties.argtypes = [C.c_uint32]
+        L.heap_random_ops_selftest.restype = C.c_uint64
+        L.heap_random_ops_selftest.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]
+        _hs[key] = L
+    return _hs[key]
 
 
 _TB_SRC = os.path.join(_HERE, "emu", "tail_bench.cpp")

@@ -100,13 +100,13 @@ def test_two_rank_sharding_and_gather_matches_single_process(tmp_path):
     assert hb[-1] > 50
 
 
-def _fake_records(n, seed):
+def _fake_records(n, seed, p_unmapped=0.2):
     """n record structs in the layout of csrc/text_core.hpp: DevRecord (22 words) with their text and pair pools, as a rank's mapad_records_device leaves them."""
     rng = np.random.default_rng(seed)
     recs = np.zeros((n, 22), np.int32)
     text, pairs = bytearray(), []
     for i in range(n):
-        if rng.random() < 0.2:
+        if rng.random() < p_unmapped:
             recs[i, 0:2] = -1; recs[i, 2] = -1  # unmapped: pos -1, tid -1, offsets 0
             continue
         cig, md, xa = b"%dM" % rng.integers(30, 100), b"%d" % rng.integers(30, 100), (b"chr1,+%d,50M,50,0,1,-1.50;" % rng.integers(1, 10 ** 6)) if rng.random() < 0.3 else b""
@@ -182,6 +182,63 @@ def test_two_rank_gather_of_compact_records(tmp_path):
     assert records_digest(r2, np.frombuffer(bytes(t2), np.uint8).view(np.int32), np.array(p2, np.float32).view(np.int32)) == records_digest(recs, text, pairs)
     r2[5, 0] ^= 1
     assert records_digest(r2, np.frombuffer(bytes(t2), np.uint8).view(np.int32), np.array(p2, np.float32).view(np.int32)) != records_digest(recs, text, pairs)
+
+
+# world size 8 — the node north_star names — with the shards an 8-way split really produces: empty shards (a chunk of fewer reads than ranks: shard_bounds(5, 8, r)), a
+# one-read shard, a shard none of whose reads mapped (no text, no pairs: its two pool buffers are EMPTY tensors, which are never sent), and ordinary ones.
+_SHARDS8 = {"ragged": [(300, 0.2), (0, 0.2), (5, 0.2), (317, 0.2), (1, 0.0), (0, 0.2), (40, 1.0), (64, 0.2)],
+            "fewer_reads_than_ranks": [(1 if r < 5 else 0, 0.0) for r in range(8)]}  # = shard_bounds(5, 8, r), checked by the workers
+
+
+def _records_worker8(rank, world, port, out_path, case):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sys.path.insert(0, ROOT)
+    from mapad_amd.distributed import gather_hit_records, merge_gathered_records, records_digest, shard_bounds
+    n, p_un = _SHARDS8[case][rank]
+    if case == "fewer_reads_than_ranks":
+        lo, hi = shard_bounds(5, world, rank)
+        assert hi - lo == n
+    own = _fake_records(n, seed=50 + rank, p_unmapped=p_un)
+    own_digest = records_digest(*own)
+    meta = dist.new_group(backend="gloo")
+    parts = gather_hit_records(torch.from_numpy(own[0].reshape(-1)), torch.from_numpy(own[1]), torch.from_numpy(own[2]), rank, world, meta_group=meta)
+    digests = [None] * world
+    dist.all_gather_object(digests, own_digest)
+    if rank == 0:
+        assert len(parts) == world
+        recs, text, pairs, per_rank = merge_gathered_records(parts)
+        assert per_rank == digests  # every shard — the empty ones too — arrived as the rank's own
+        np.savez(out_path, recs=recs, text=text, pairs=pairs)
+    else:
+        assert parts is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("case", ["ragged", "fewer_reads_than_ranks"])
+def test_eight_rank_gather_with_empty_and_unmapped_shards(tmp_path, case):
+    """N = 8 without the node (the `nccl` backend needs eight GPUs; RCCL refuses duplicate devices, so there is no one-GPU dry run of it): gather_hit_records +
+    merge_gathered_records at world size 8 over gloo.  Reference return path: src/distributed/dispatcher.rs:223-247 (results of all workers merged in task order)."""
+    out = str(tmp_path / f"records8_{case}.npz")
+    mp.spawn(_records_worker8, args=(8, _free_port(), out, case), nprocs=8, join=True)
+    got = np.load(out)
+    shards = [_fake_records(n, seed=50 + r, p_unmapped=p) for r, (n, p) in enumerate(_SHARDS8[case])]
+    total = sum(n for n, _ in _SHARDS8[case])
+    assert got["recs"].shape == (total, 22) and total == (727 if case == "ragged" else 5)
+    base = 0
+    for recs, text, pairs in shards:
+        tb, pf = text.view(np.uint8), pairs.view(np.float32)
+        for i in range(recs.shape[0]):
+            g = got["recs"][base + i]
+            assert np.array_equal(np.delete(g, [12, 18]), np.delete(recs[i], [12, 18]))
+            if recs[i, 3]:
+                assert _text_of(got["recs"], got["text"], base + i) == _text_of(recs, tb, i)
+                k = int(recs[i, 19])
+                assert np.array_equal(got["pairs"][2 * int(g[18]):2 * int(g[18]) + 2 * k], pf[2 * int(recs[i, 18]):2 * int(recs[i, 18]) + 2 * k])
+        base += recs.shape[0]
+    if case == "ragged":
+        assert not got["recs"][300 + 5 + 317 + 1:300 + 5 + 317 + 1 + 40, 3].any()  # the all-unmapped shard sits where rank 6's reads belong
 
 
 @pytest.mark.gpu

@@ -22,7 +22,9 @@ from oracle import binding as ob
 from kat_util import resolve_params
 from parity_util import CONTINUOUS, DAMAGE, NO_DAMAGE, assert_same_as_oracle, split_reads
 v = build.selected_variant()
-assert v == int(sys.argv[1]) and os.path.basename(build.lib_path(v)) == f"libmapad_amd.hv{v}.so"
+flavour = os.environ.get("MAPAD_TEST_FLAVOUR")  # a build flavour of reading 0 (mapad_amd/build.py: FLAVOURS), loaded through MAPAD_AMD_LIB
+assert v == int(sys.argv[1]) and (flavour or os.path.basename(build.lib_path(v)) == f"libmapad_amd.hv{v}.so")
+assert not flavour or (v == 0 and os.path.basename(os.environ["MAPAD_AMD_LIB"]) == f"libmapad_amd.{flavour}.so")
 g = synth.genome(300_000, seed=99)
 pidx = mapad_amd.Index.build([("chr1", g)])
 oidx = ob.OracleIndex.from_bwt(pidx.bwt(), "$ACGTX", 128)
@@ -58,7 +60,7 @@ for name, prm, kw, n, env, tail in (
     o0 = oidx.map_batch(ob.make_params(rp), reads, qs, n_threads=8)
     differs += int((o0.counters != ores.counters).any(axis=1).sum())
     print(name, "ok", flush=True)
-assert differs > 0  # this reading is not reading 0
+assert differs > 0 or flavour  # this reading is not reading 0
 print("variant", v, "identical to the matching oracle reading;", differs, "reads differ from reading 0 in their event counters")
 '''
 
@@ -76,3 +78,19 @@ def test_product_reading_equals_the_matching_oracle_reading_on_the_gpu(variant, 
     pr = subprocess.run([sys.executable, str(script), str(variant)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
     assert pr.returncode == 0, pr.stdout[-3000:]
     assert f"variant {variant} identical" in pr.stdout
+
+
+def test_subtree_block_heap_layout_build_equals_the_oracle_on_the_gpu(tmp_path):
+    """csrc/heap_core.hpp: MAPAD_SUBTREE_HEAP=1 — the arena's heap levels in subtree-contiguous 64-byte blocks (libmapad_amd.sub.so; measured slower than the implicit
+    array and therefore not the default: profiles/r06/ab_layout.txt).  A logical -> physical slot change under the same min-max heap: the same batches as above —
+    quad kernel, speculative sift, lane-parallel commit, arena growth and migrations, host tail with continuation from the arena, limits — bit for bit against the oracle."""
+    sys.path.insert(0, ROOT)
+    from mapad_amd import build
+    if not os.path.exists(build.lib_path(flavour="sub")):
+        build.build(flavour="sub")
+    script = tmp_path / "child.py"
+    script.write_text(_CHILD)
+    env = dict(os.environ, MAPAD_HEAP_VARIANT="0", MAPAD_ROOT=ROOT, MAPAD_AMD_LIB=build.lib_path(flavour="sub"), MAPAD_TEST_FLAVOUR="sub")
+    pr = subprocess.run([sys.executable, str(script), "0"], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
+    assert pr.returncode == 0, pr.stdout[-3000:]
+    assert "variant 0 identical" in pr.stdout

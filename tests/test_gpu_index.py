@@ -12,7 +12,8 @@ from mapad_amd import synth
 from oracle import binding as ob
 
 from kat_util import resolve_params
-from parity_util import oracle_threads, DAMAGE, NO_DAMAGE, assert_same_as_oracle, split_reads
+from parity_util import (DAMAGE, NO_DAMAGE, assert_same_as_oracle, canonical_records, check_ungapped_records_against_the_text, compare_records,
+                         oracle_records_from_product_hits, oracle_threads, split_reads)
 
 pytestmark = pytest.mark.gpu
 
@@ -105,6 +106,12 @@ def test_index_beyond_2_pow_32_rows_maps_like_the_oracle(monkeypatch):
     G = int(os.environ.get("MAPAD_TEST_BIG_GENOME", 3_000_000_000))
     t0 = time.time()
     g = synth.genome(G, seed=1234)
+    # a random text has no repeats, and without them no read maps to several rows (X0 > 1, XA entries, low MAPQ, rows drawn by PrRange): 64 stretches of 300 bp are
+    # copied 20 Mbp further on, and their reverse complements 10 Mbp further on, spread over the whole text (reads from them are added to the first batch below)
+    rep_src = [1_000 + k * (G // 70) for k in range(64)] if G >= 100_000_000 else []
+    for a in rep_src:
+        g[a + 20_000_000:a + 20_000_300] = g[a:a + 300]
+        g[a + 10_000_000:a + 10_000_300] = synth.revcomp(g[a:a + 300])
     t1 = time.time()
     pidx = mapad_amd.Index.build([("chr1", g)], device=0)
     t2 = time.time()
@@ -134,7 +141,11 @@ def test_index_beyond_2_pow_32_rows_maps_like_the_oracle(monkeypatch):
     # reads vs the oracle
     n_reads = int(os.environ.get("MAPAD_TEST_BIG_READS", 100_000))
     half = n_reads // 2
-    batches = [(NO_DAMAGE, synth.reads(g, half, 50, seed=4325, qual=40)),
+    first = synth.reads(g, half, 50, seed=4325, qual=40)
+    for k, a in enumerate(rep_src):  # 30 reads from every repeated stretch
+        r = synth.reads(g[a:a + 300], 30, 50, seed=5000 + k, qual=40, exo_frac=0.0)
+        first = (np.concatenate([first[0], r[0]]), np.concatenate([first[1], r[1]]), np.concatenate([first[2], r[2][1:] + first[2][-1]]))
+    batches = [(NO_DAMAGE, first),
                (DAMAGE, synth.reads(g, n_reads - half, 50, seed=4326, qual_range=(20, 40), damage=dict(f=0.5, t=0.5, d=0.02, s=1.0)))]
     # C5's read mix (BASELINE.json configs[4]: 35-100 bp, 5 % of the reads with a 1-2 bp indel, damage model, Phred 20-40) on the 3 Gbp index.  The
     # reference's limits are scaled down 10x (STACK_LIMIT / EDIT_TREE_LIMIT, mapping.rs:52-54: the recovery code is the same and the heaviest
@@ -145,13 +156,41 @@ def test_index_beyond_2_pow_32_rows_maps_like_the_oracle(monkeypatch):
     c5 = synth.reads(g, n_c5, 50, seed=4327, qual_range=(20, 40), damage=dict(f=0.5, t=0.5, d=0.02, s=1.0), len_range=(35, 100), indel_frac=0.05)
     t3 = time.time()
     oidx = ob.OracleIndex.from_bwt(pidx.bwt(), "$ACGTX", 128)
+    # for the record-level comparison (round 6): the oracle's SampledSuffixArray::get walks ITS byte BWT / Occ from the product's samples (the samples themselves are
+    # checked against the text above and in test_gpu_index_equals_host_index_100mbp), and its contig table is the text's one contig
+    oidx.set_sampled_sa(pidx.sampled_sa()[0], 32, *pidx.sampled_sa()[1:])
+    oidx.add_contig(0, G - 1, "chr1")
     t4 = time.time()
-    print(f"oracle structures (byte BWT + Occ k=128) {t4 - t3:.1f} s")
+    print(f"oracle structures (byte BWT + Occ k=128, sampled SA) {t4 - t3:.1f} s")
     ctx.close()
+
+    def check_records(ctx, rp, res, seqs, quals, offsets, what):
+        """Device-built records (records_kernel / text_kernel / locate_kernel + host MAPQ and flags: mapad_hits_to_records_gpu) of a batch on this index against the
+        oracle's intervals_to_record (mapping.rs:402-718, record.rs:269-449 restated) over the same hits with the same per-read stand-ins for rand::rng(), field by
+        field, and the ungapped ones against the text itself."""
+        t = time.time()
+        recs, text = ctx.hits_to_records(res, seqs, quals, offsets, seed=0, as_arrays=True)
+        t_dev = time.time() - t
+        orecs, otext = oracle_records_from_product_hits(oidx, ob.make_params(rp), res, seqs, quals, offsets, n_threads=oracle_threads())
+        n_bad, first, per_field = compare_records(canonical_records(recs, text, oracle_side=False), canonical_records(orecs, otext, oracle_side=True))
+        checked, failed = check_ungapped_records_against_the_text(g, recs, text, seqs, offsets)
+        mapped = recs["mapped"] != 0
+        stats = dict(reads=len(recs), mapped=int(mapped.sum()), reverse=int((recs["reverse"][mapped] != 0).sum()), with_xa=int((recs["xa_len"][mapped] > 0).sum()),
+                     multi_row=int((recs["x0"][mapped] > 1).sum()), gapped=int(mapped.sum()) - checked, differ=n_bad, text_check=(checked, failed))
+        print(f"records [{what}]: device {t_dev:.2f} s, oracle {time.time() - t - t_dev:.1f} s: {stats}")
+        assert n_bad == 0, (first, per_field)
+        assert failed == 0 and checked > 0.5 * mapped.sum()
+        if n > 2 ** 32 and len(recs) >= 20_000:
+            assert stats["reverse"] > 0.3 * stats["mapped"]  # reverse-strand hits: suffix positions in the second half of the text, >= 2^32
+        return stats
+
     for prm, (seqs, quals, offsets) in batches:
         rp = resolve_params(prm)
         ctx = mapad_amd.Context(pidx, mapad_amd.make_params(rp), 0)
         res = ctx.map_batch(seqs, quals, offsets)
+        rstats = check_records(ctx, rp, res, seqs, quals, offsets, "50 bp, " + ("no damage" if prm is NO_DAMAGE else "damage model"))
+        if prm is NO_DAMAGE and rep_src:
+            assert rstats["with_xa"] > 1000 and rstats["multi_row"] > 1000  # the reads from the repeated stretches: three rows each, XA entries, rows drawn by PrRange
         ctx.close()
         reads, qs = split_reads(seqs, quals, offsets)
         t5 = time.time()
@@ -194,6 +233,8 @@ def test_index_beyond_2_pow_32_rows_maps_like_the_oracle(monkeypatch):
         res = ctx.map_batch(seqs, quals, offsets)
         info = ctx.tail_info()
         t6 = time.time()
+        c5_stats = check_records(ctx, rp, res, seqs, quals, offsets, "C5 mix at the real limits")  # (the hits of the heaviest reads are compared with the oracle's below)
+        assert c5_stats["gapped"] > 0.01 * c5_stats["mapped"] or n_pre < 20_000  # reads with indels took part
         pops = res.counters["n_pop"].astype(np.int64)
         heavy = np.sort(np.argsort(pops)[-n_heavy:])
         lens = np.diff(offsets.astype(np.int64))

@@ -16,6 +16,13 @@ from parity_util import CONTINUOUS, DAMAGE, NO_DAMAGE, assert_same_as_oracle, sp
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True)
+def _hand_over_whatever_the_backlog(monkeypatch):
+    """These tests are about the hand-over itself (which reads leave, what the host makes of them): every read past the budget leaves, whatever the host has waiting —
+    round 5's behaviour.  The gate of round 6 (a read past the budget stays on the GPU while the host's backlog is long) has its own test below."""
+    monkeypatch.setenv("MAPAD_TAIL_BACKLOG_BUDGET", "4294967295")
+
+
 def _map(index, params, seqs, quals, offsets, tail_pops):
     ctx = mapad_amd.Context(index, params, 0)
     try:
@@ -54,6 +61,29 @@ def test_reads_finished_on_the_host_equal_the_oracle(name, prm, kw, n):
     off, info_off = _map(pidx, params, seqs, quals, offsets, tail_pops=0)
     assert info_off["reads"] == 0
     _same(res, off)
+
+
+def test_reads_past_the_budget_stay_on_the_gpu_while_the_host_is_busy(monkeypatch):
+    """Round 6: every hand-over trigger looks at the host's backlog (the word the launch's dispatcher keeps current).  With room for ONE waiting read
+    (MAPAD_TAIL_BACKLOG_BUDGET=1) most reads past the budget are refused, go on on the GPU, ask again every 64 pops and mostly finish there; some are taken.  Nothing
+    of that shows in the results."""
+    g = synth.genome(300_000, seed=77)
+    seqs, quals, offsets = synth.reads(g, 3000, 50, seed=12, qual_range=(20, 40), damage=dict(f=0.5, t=0.5, d=0.02, s=1.0))
+    rp = resolve_params(DAMAGE)
+    pidx = mapad_amd.Index.build([("chr1", g)])
+    oidx = ob.OracleIndex.from_bwt(pidx.bwt(), "$ACGTX", 128)
+    params = mapad_amd.make_params(rp)
+    reads, qs = split_reads(seqs, quals, offsets)
+    ores = oidx.map_batch(ob.make_params(rp), reads, qs, n_threads=8, keep_d=True)
+    past = int((ores.counters[:, 3] > 64).sum())
+    every, info_every = _map(pidx, params, seqs, quals, offsets, tail_pops=64)
+    assert info_every["reads"] == past > 500
+    monkeypatch.setenv("MAPAD_TAIL_BACKLOG_BUDGET", "1")
+    res, info = _map(pidx, params, seqs, quals, offsets, tail_pops=64)
+    assert 0 < info["reads"] < past // 2, (info["reads"], past)
+    assert_same_as_oracle(ores, res, offsets)
+    _same(res, every)
+    assert (res.status & 16).sum() == 0
 
 
 def test_limit_recovery_and_abort_on_the_host():

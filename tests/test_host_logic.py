@@ -271,6 +271,22 @@ def test_kernel_logic_heap_variants_follow_the_matching_oracle_variant(variant, 
     assert differs > 0  # the readings are not the same algorithm: the switch does something
 
 
+@pytest.mark.parametrize("subtree", [0, 1])
+def test_kernel_logic_with_the_heap_levels_in_subtree_blocks(subtree):
+    """csrc/heap_core.hpp: MAPAD_SUBTREE_HEAP — the host build of the step with the arena's heap levels in either physical layout: deep heaps (35-100 bp reads with
+    indels), arena migrations (physical ranges copied: HeapLayout::phys_end) and the overflow recovery's pop_min sifts, against the oracle."""
+    g = synth.genome(150_000, seed=99)
+    seqs, quals, offsets = synth.reads(g, 250, 50, seed=19, qual_range=(20, 40), damage=dict(f=0.5, t=0.5, d=0.02, s=1.0), len_range=(35, 100), indel_frac=0.05)
+    reads, qs = split_reads(seqs, quals, offsets)
+    pidx = mapad_amd.Index.build([("chr1", g)])
+    oidx = ob.OracleIndex.from_bwt(pidx.bwt(), "$ACGTX", 128)
+    for rp, caps in ((resolve_params(DAMAGE), dict(node_cap=64, heap_cap=64)), (dict(resolve_params(DAMAGE), stack_limit=300, edit_tree_limit=100000), {})):
+        res = emu_util.map_batch(pidx, mapad_amd.make_params(rp), seqs, quals, offsets, subtree=subtree, **caps)
+        ores = oidx.map_batch(ob.make_params(rp), reads, qs, n_threads=8, keep_d=True)
+        assert ores.counters[:, 3].max() > 2000 and (not caps or res.n_second_pass > 50)
+        assert_same_as_oracle(ores, res, offsets)
+
+
 @pytest.mark.parametrize("step", ["lane_parallel_commit", "payload_cache"])
 def test_kernel_logic_second_pass_and_limit_recovery(step, monkeypatch):
     monkeypatch.setenv("MAPAD_EMU_PAYLOAD_CACHE", "1" if step == "payload_cache" else "0")
@@ -350,6 +366,25 @@ def test_lane_parallel_commit_equals_sequential_pushes_on_random_heaps(max_n, le
     (ties everywhere, like the no-damage model), many (like the damage model), heaps that straddle the near / arena boundary (63 slots) and level boundaries."""
     for seed in range(4):
         assert emu_util.lib().emu_par_commit_selftest(seed + 17 * levels, 4000, max_n, levels) == 0
+
+
+@pytest.mark.parametrize("subtree", [1, 0])
+def test_heap_layout_is_a_bijection_with_aligned_pairs_and_one_block_per_stride(subtree):
+    """heap_core.hpp: HeapLayout — where a logical slot of the arena's heap levels lives.  For every slot below 2^21 of the quads' (63 near slots) and the pairs' (31)
+    layouts: physical entries are distinct, never inside the shadow of the near levels, covered by what an arena migration copies (phys_end, monotone), sibling pairs
+    are 16-byte aligned neighbours, and (subtree blocks) a max-level entry's children and grandchildren share one 64-byte block."""
+    assert emu_util.heap_selftest_lib(subtree).heap_layout_properties(1 << 21) == 0
+
+
+@pytest.mark.parametrize("subtree,variant", [(1, 0), (0, 0), (1, 3)])
+@pytest.mark.parametrize("max_n,levels", [(100, 3), (3000, 2), (3000, 500), (200_000, 6), (1_200_000, 40)])
+def test_heap_in_its_physical_layout_equals_the_oracles_heap_under_random_operations(subtree, variant, max_n, levels):
+    """The layout is a logical -> physical slot change: under random pushes, pop_max and pop_min (sifts from the root through the arena levels — the search's
+    evictions) the product's heap equals the oracle's plain-vector min-max heap entry for entry, up to 2^20 entries (heap level 20), for the default and the last
+    reading of the tie rules."""
+    L = emu_util.heap_selftest_lib(subtree, variant)
+    ops = min(6 * max_n, 3_000_000)
+    assert L.heap_random_ops_selftest(11 + levels, ops, max_n, levels, max(ops // 7, 1)) == 0
 
 
 @pytest.mark.parametrize("bits", [20, 33, 40, 47])
@@ -434,6 +469,51 @@ def test_postproc_matches_oracle_on_multicontig_genome():
             assert g_["tid"] == int(o["tid"]) and g_["pos"] == int(o["pos"]) and (g_["xa"] or "*") == o["xa"], (i, o, g_)
         n_multi += int(o["x0"]) > 1
     assert n_multi > 10
+
+
+def test_records_equal_the_oracles_intervals_to_record_over_the_same_hits_and_the_text_itself():
+    """The record-level audit's machinery (profiles/audit_c4.py --records, tests/test_gpu_index.py at n > 2^32) on a small multi-contig text with repeats: every field of
+    every record the product builds (host path here) — flags, tid, POS, MAPQ, strand, AS / XS bits, NM, X0, X1, XT, CIGAR, MD, XA — equals the oracle's
+    intervals_to_record run over the product's hits with the same per-read stand-ins for rand::rng() (seed 0), incl. the rows drawn from >= 3-row intervals;
+    and the ungapped records agree with the text itself (NM = mismatches at POS on the reported strand)."""
+    from parity_util import canonical_records, check_ungapped_records_against_the_text, compare_records, oracle_records_from_product_hits, records_digest
+    g = synth.genome(150_000, seed=41)
+    g[60_000:60_300] = g[5_000:5_300]
+    g[110_000:110_300] = g[5_000:5_300]
+    g[130_000:130_200] = synth.revcomp(g[5_050:5_250])  # the same stretch on the other strand
+    contigs = [("c1", g[:70_000]), ("c2", g[70_000:120_000]), ("c3", g[120_000:])]
+    pidx = mapad_amd.Index.build(contigs)
+    oidx = ob.OracleIndex.from_text(g.tobytes(), "$ACGTX", 128)
+    starts, s0 = [], 0
+    for nme, c in contigs:
+        oidx.add_contig(s0, s0 + len(c) - 1, nme)
+        starts.append(s0)
+        s0 += len(c)
+    sample, er, ev = pidx.sampled_sa()
+    oidx.set_sampled_sa(sample, 32, er, ev)  # the product's samples under the oracle's own LF walk, as at 3 Gbp
+    seqs, quals, offsets = synth.reads(g, 1500, 50, seed=79, qual_range=(20, 40), len_range=(35, 80), indel_frac=0.05)
+    rep = synth.reads(g[5_000:5_300], 300, 50, seed=80, exo_frac=0.0)
+    seqs = np.concatenate([seqs, rep[0]]); quals = np.concatenate([quals, rep[1]])
+    offsets = np.concatenate([offsets, rep[2][1:] + offsets[-1]])
+    rp = resolve_params(NO_DAMAGE)
+    params = mapad_amd.make_params(rp)
+    res = emu_util.map_batch(pidx, params, seqs, quals, offsets)
+    recs, text = mapad_amd.hits_to_records(pidx, params, res, seqs, quals, offsets, seed=0, as_arrays=True)
+    prod = canonical_records(recs, text, oracle_side=False)
+    n = len(offsets) - 1
+    ora_parts = [oracle_records_from_product_hits(oidx, ob.make_params(rp), res, seqs, quals, offsets, lo, hi, n_threads=3) for lo, hi in ((0, 700), (700, n))]  # chunked like the audit
+    for (lo, hi), (orecs, otext) in zip(((0, 700), (700, n)), ora_parts):
+        sub = canonical_records(recs[lo:hi], text, oracle_side=False)
+        n_bad, first, per_field = compare_records(sub, canonical_records(orecs, otext, oracle_side=True))
+        assert n_bad == 0, (first, per_field)
+    assert records_digest(prod) == records_digest(canonical_records(recs.copy(), text.copy(), oracle_side=False))
+    f = prod[0]
+    assert (f["x0"] >= 3).sum() > 100 and (prod[1][2][0] > 0).sum() > 100 and f["reverse"].sum() > 300  # multi-row intervals, XA entries and both strands took part
+    checked, failed = check_ungapped_records_against_the_text(g, recs, text, seqs, offsets, contig_starts=starts)
+    assert checked > 1200 and failed == 0
+    bad = recs.copy()
+    bad["pos"][np.flatnonzero(recs["mapped"])[0]] += 1
+    assert compare_records(canonical_records(bad[:700], text, False), canonical_records(*ora_parts[0], True))[0] == 1
 
 
 def test_postproc_thread_count_does_not_change_records(monkeypatch):
