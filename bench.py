@@ -779,6 +779,9 @@ def main():
             cli = {"reads_per_s": round(n_cli / float(m.group(5)), 1), "reads": n_cli, "mapping_s": float(m.group(5)), "index_load_and_contexts_s": float(m.group(4)),
                    "process_wall_s": round(t_map, 2), "mapped": int(m.group(2)), "bam_bytes": os.path.getsize(bam), "index_files_s": round(t_idx, 2), "index_files": idx_how,
                    "index_files_bytes": index_bytes,
+                   "steady_state": (lambda mm: {"reads_per_s": float(mm.group(3)), "reads": int(mm.group(1)), "s": float(mm.group(2)), "pipeline_fill_s": float(mm.group(4)),
+                                                "what": "the run without its fill: reads behind the first chunk / time from the first chunk's records written to the last chunk's"} if mm else None)(
+                       re.search(r"steady state: (\d+) reads in ([0-9.]+) s behind the first chunk \((\d+) reads/s\); pipeline fill ([0-9.]+) s", pr.stderr)),
                    "stage_busy_s": (lambda mm: {"reader": float(mm.group(1)), "device_worker": float(mm.group(2)), "writer": float(mm.group(3))} if mm else None)(
                        re.search(r"reader ([0-9.]+) s, device worker 0 ([0-9.]+) s, writer ([0-9.]+) s", pr.stderr)),
                    "what": "mapad-amd map: FASTQ -> BAM, --batch_size 250000 (the reference's default; on a 3 Gbp index four chunks go to the device as one launch), up to 4 launches in flight on one GPU; reader, MAPQ and BGZF on host threads, coordinates and record text on the GPU"}

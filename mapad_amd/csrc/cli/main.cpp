@@ -478,6 +478,7 @@ int cmd_map(const Args& a, uint64_t seed, const std::vector<int>& devices, const
 
     // ---- writer ----
     uint64_t n_total = 0, n_mapped = 0;
+    uint64_t first_chunk_reads = 0, t_first_chunk_us = 0, t_last_chunk_us = 0;  // for the steady-state rate: everything behind the pipeline's fill (the first chunk's way through reader, device and writer)
     std::thread writer([&] {
         try {
             ChunkPtr c;
@@ -510,6 +511,8 @@ int cmd_map(const Args& a, uint64_t seed, const std::vector<int>& devices, const
                 for (unsigned t = 0; t < host_threads; ++t) { out.write_compressed(comp[t]); n_mapped += mapped[t]; }
                 n_total += n;
                 for (auto& sl : c->slices) { mapad_records_free(sl.recs); mapad_batch_result_free(sl.res); sl.recs = nullptr; sl.res = nullptr; }
+                t_last_chunk_us = now_us();
+                if (!t_first_chunk_us) { t_first_chunk_us = t_last_chunk_us; first_chunk_reads = n; }
                 us_writer += now_us() - t_w0;
             }
         } catch (const std::exception& e) { fail(e.what()); }
@@ -526,6 +529,10 @@ int cmd_map(const Args& a, uint64_t seed, const std::vector<int>& devices, const
     const double t_all = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
     std::fprintf(stderr, "mapad-amd: %llu reads, %llu mapped; %zu device(s); index + contexts %.2f s, mapping %.2f s (%.0f reads/s)\n", (unsigned long long)n_total,
                  (unsigned long long)n_mapped, n_dev, t_load, t_all - t_load, (double)n_total / std::max(t_all - t_load, 1e-9));
+    if (n_total > first_chunk_reads && t_last_chunk_us > t_first_chunk_us)  // the run without its fill: from the first chunk's records on disk to the last chunk's
+        std::fprintf(stderr, "mapad-amd: steady state: %llu reads in %.2f s behind the first chunk (%.0f reads/s); pipeline fill %.2f s\n", (unsigned long long)(n_total - first_chunk_reads),
+                     (t_last_chunk_us - t_first_chunk_us) * 1e-6, (double)(n_total - first_chunk_reads) / ((t_last_chunk_us - t_first_chunk_us) * 1e-6),
+                     t_all - t_load - (t_last_chunk_us - t_first_chunk_us) * 1e-6);
     std::fprintf(stderr, "mapad-amd: stage busy time: reader %.2f s, device worker 0 %.2f s, writer %.2f s\n", us_reader.load() * 1e-6, us_device.load() * 1e-6, us_writer.load() * 1e-6);
     std::fprintf(stderr, "mapad-amd: device worker 0: submit %.2f s, fetch (incl. waiting for the GPU) %.2f s, coordinates %.2f s; records thread (strings, MAPQ) %.2f s\n",
                  us_submit.load() * 1e-6, us_fetch.load() * 1e-6, us_records.load() * 1e-6, us_text.load() * 1e-6);

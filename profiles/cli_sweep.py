@@ -49,6 +49,6 @@ for bs, fl, env in cases:
     m = re.search(r"mapping ([0-9.]+) s \((\d+) reads/s\)", pr.stderr)
     b = re.search(r"reader ([0-9.]+) s, device worker 0 ([0-9.]+) s, writer ([0-9.]+) s", pr.stderr)
     w = re.search(r"submit ([0-9.]+) s, fetch \(incl. waiting for the GPU\) ([0-9.]+) s, coordinates ([0-9.]+) s; records thread \(strings, MAPQ\) ([0-9.]+) s", pr.stderr)
-    hp = re.search(r"host pools.*", pr.stderr)
+    hp = re.search(r"steady state.*", pr.stderr)
     print("   worker:", w.groups() if w else None, "|", hp.group(0) if hp else "")
     print(bs, fl, env, m.group(1) if m else pr.stderr[-300:], m.group(2) if m else "", b.groups() if b else "", flush=True)
