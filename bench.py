@@ -659,30 +659,39 @@ def main():
             n5 = int(os.environ.get("MAPAD_BENCH_C5_READS", "200000"))
             s5, q5, o5 = make_reads(synth, genome, n5, 4321 + 5, qual_range=(20, 40), damage=dict(f=0.5, t=0.5, d=0.02, s=1.0), len_range=(35, 100), indel_frac=0.05)
             rp5 = resolve_params(DAMAGE)
-            ctx5 = mapad_amd.Context(index, mapad_amd.make_params(rp5), local_rank)
-            ctx5.set_fetch_d_arrays(False)
-            ctx5.prepare_lengths(sorted(set(np.diff(o5.astype(np.int64)).tolist())))
-            t1 = time.perf_counter()
-            res5 = ctx5.map_batch(s5, q5, o5)
-            dt5 = time.perf_counter() - t1
-            ti5 = ctx5.tail_info()
-            k5 = [float(x) for x in ctx5.kernel_ms()]
-            c5 = [int(x) for x in ctx5.last_counters()]
-            ctx5.close()
-            pops_all = c5[3]
-            ev = {"E_search": c5[0] - ti5["host_e_search"], "N_push": c5[2] - ti5["host_n_push"], "N_pop": c5[3] - ti5["host_pops"], "N_node": c5[4] - ti5["host_n_node"]}
-            b5 = 256 * ev["E_search"] + 40 * (ev["N_push"] + ev["N_pop"]) + 8 * ev["N_node"]
-            leg = {"reads_per_s": round(n5 / dt5, 1), "wall_s": round(dt5, 3), "reads": n5, "steps": 1,
-                   "workload": f"C5 read mix: {n5} x 35-100 bp reads, 5 % with an indel, ss 50% deamination model, Phred 20-40, -p 0.03, on the {genome_bp} bp index of this run; "
-                               "STACK_LIMIT / EDIT_TREE_LIMIT at the reference's values (2 000 000 / 10 000 000); one mapad_map_batch call (H2D, D arrays, search stages, host tail, collect, D2H)",
-                   "pops_per_read": round(pops_all / n5, 1),
-                   "roofline": {"kernel": "search_kernel", "kernel_ms": round(k5[1], 2), "algorithmic_bytes_per_launch": b5, "achieved": round(b5 / (k5[1] * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBPS,
-                                "unit": "GB/s", "frac": round(b5 / (k5[1] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5), "traffic": None,
-                                "note": "events of the reads the host finished are not the kernel's and are left out; the launch lasts as long as its slowest read (a serial chain at ~5.5 us per pop)"},
-                   "tail": {"reads": ti5["reads"], "pops_share": round(ti5["host_pops"] / max(pops_all, 1), 5), "gpu_pops_before_hand_over": ti5["gpu_pops"], "host_s_per_step": round(ti5["host_us"] / 1e6, 3),
-                            "host_thread_s_per_step": round(ti5["host_thread_us"] / 1e6, 3), "threads": ti5["threads"], "budget_pops": ti5["budget"], "reads_dry_class": ti5["reads_dry_class"],
-                            "reads_full_limit": ti5["reads_full_limit"], "seen_while_launch_ran": ti5["seen_live"]},
-                   "arena_migrations": res5.n_second_pass}
+
+            def c5_run(local_world):
+                """one mapad_map_batch of the C5 batch; local_world: this process as one rank of that many on its node (its share of the host tail's workers)"""
+                workers = mb.lib().mapad_tail_set_local_world(local_world)
+                ctx5 = mapad_amd.Context(index, mapad_amd.make_params(rp5), local_rank)
+                try:
+                    ctx5.set_fetch_d_arrays(False)
+                    ctx5.prepare_lengths(sorted(set(np.diff(o5.astype(np.int64)).tolist())))
+                    t1 = time.perf_counter()
+                    res5 = ctx5.map_batch(s5, q5, o5)
+                    dt5 = time.perf_counter() - t1
+                    ti5 = ctx5.tail_info()
+                    k5 = [float(x) for x in ctx5.kernel_ms()]
+                    c5 = [int(x) for x in ctx5.last_counters()]
+                finally:
+                    ctx5.close()
+                pops_all = c5[3]
+                ev = {"E_search": c5[0] - ti5["host_e_search"], "N_push": c5[2] - ti5["host_n_push"], "N_pop": c5[3] - ti5["host_pops"], "N_node": c5[4] - ti5["host_n_node"]}
+                b5 = 256 * ev["E_search"] + 40 * (ev["N_push"] + ev["N_pop"]) + 8 * ev["N_node"]
+                leg = {"reads_per_s": round(n5 / dt5, 1), "wall_s": round(dt5, 3), "reads": n5, "steps": 1, "host_tail_workers": int(workers),
+                       "workload": f"C5 read mix: {n5} x 35-100 bp reads, 5 % with an indel, ss 50% deamination model, Phred 20-40, -p 0.03, on the {genome_bp} bp index of this run; "
+                                   "STACK_LIMIT / EDIT_TREE_LIMIT at the reference's values (2 000 000 / 10 000 000); one mapad_map_batch call (H2D, D arrays, search stages, host tail, collect, D2H)",
+                       "pops_per_read": round(pops_all / n5, 1),
+                       "roofline": {"kernel": "search_kernel", "kernel_ms": round(k5[1], 2), "algorithmic_bytes_per_launch": b5, "achieved": round(b5 / (k5[1] * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBPS,
+                                    "unit": "GB/s", "frac": round(b5 / (k5[1] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5), "traffic": None,
+                                    "note": "events of the reads the host finished are not the kernel's and are left out; the launch lasts as long as its slowest read (a serial chain at ~5.5 us per pop)"},
+                       "tail": {"reads": ti5["reads"], "pops_share": round(ti5["host_pops"] / max(pops_all, 1), 5), "gpu_pops_before_hand_over": ti5["gpu_pops"], "host_s_per_step": round(ti5["host_us"] / 1e6, 3),
+                                "host_thread_s_per_step": round(ti5["host_thread_us"] / 1e6, 3), "threads": ti5["threads"], "budget_pops": ti5["budget"], "reads_dry_class": ti5["reads_dry_class"],
+                                "reads_full_limit": ti5["reads_full_limit"], "seen_while_launch_ran": ti5["seen_live"], "continued_from_gpu_state": ti5["continued"]},
+                       "arena_migrations": res5.n_second_pass}
+                return leg, res5
+
+            leg, res5 = c5_run(0)
             if not args.no_cpu_baseline:
                 reads5 = [s5[int(o5[i]):int(o5[i + 1])].tobytes() for i in range(n5)]
                 quals5 = [q5[int(o5[i]):int(o5[i + 1])] for i in range(n5)]
@@ -707,9 +716,25 @@ def main():
                                  "heaviest_read_checked_pops": int(o5r.counters[:, 3].max()), "status_words_clean": bool(((st5 & 16) == 0).all())}
                 if not (ok5 and leg["parity"]["identical_event_counters"]):
                     log("PARITY FAILURE (C5 leg): GPU + host-tail hits differ from the oracle on the sample")
-            del res5
             leg["wall_s_leg"] = round(time.perf_counter() - t, 1)
             secondary["c5"] = leg
+            # The same batch as ONE RANK OF EIGHT sees it (round-5 verdict): eight ranks of a node share its CPUs, so this rank's host tail gets an eighth of the workers
+            # (mapad_tail_set_local_world(8): 2 of a 16-CPU box's 14).  Every hand-over trigger looks at the host's backlog, so what the two workers cannot take stays on the GPU.
+            try:
+                t = time.perf_counter()
+                leg8, res8 = c5_run(8)
+                same = all(np.array_equal(a, b) for a, b in ((res8.hit_begin, res5.hit_begin), (res8.hits_arr, res5.hits_arr), (res8.ops, res5.ops), (res8.status, res5.status), (res8.counters, res5.counters)))
+                leg8["parity"] = {"identical_to_secondary_c5": bool(same), "what": "hit offsets, hit records, edit tracks, status words and the six event counters of all reads equal the c5 leg's (which carries the oracle sample)"}
+                if not same:
+                    log("PARITY FAILURE (C5 rank-of-8 leg): results differ from the c5 leg's")
+                leg8["wall_s_leg"] = round(time.perf_counter() - t, 1)
+                secondary["c5_rank_of_8"] = leg8
+                del res8
+            except Exception as e:
+                secondary["c5_rank_of_8"] = {"skipped": f"{type(e).__name__}: {e}"}
+            finally:
+                mb.lib().mapad_tail_set_local_world(0)
+            del res5
         except Exception as e:
             secondary["c5"] = {"skipped": f"{type(e).__name__}: {e}"}
         try:

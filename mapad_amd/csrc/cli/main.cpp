@@ -5,7 +5,7 @@
 //   mapad-amd [--seed N] [--devices K] index -g ref.fa
 //   mapad-amd [--devices K] worker --host H [--port 3130] [--dry_run]
 //   mapad-amd [--seed N] [--devices 0-7 | 0,1,...] map -r reads.{bam,cram,fastq,fastq.gz} -g ref.fa -o out.bam -l single_stranded|double_stranded
-//             -p 0.03 | (-c CUTOFF [-e EXP]) -f F -t T -d D -s S [-D 0.02] -i I [-x 1.0] [--batch_size 250000] [--coalesce 1 (4 on a text of >= 2^31 rows)] [--in_flight 4] [--ignore_base_quality]
+//             -p 0.03 | (-c CUTOFF [-e EXP]) -f F -t T -d D -s S [-D 0.02] -i I [-x 1.0] [--batch_size 250000] [--coalesce 1 (4 on a text of >= 2^31 rows)] [--coalesce_steady N (= --coalesce)] [--in_flight 4] [--ignore_base_quality]
 //             [--gap_dist_ends 5] [--max_num_gaps_open 2] [--no_search_limit_recovery] [--force_overwrite] [-R ID]
 #include <atomic>
 #include <chrono>
@@ -247,7 +247,13 @@ int cmd_map(const Args& a, uint64_t seed, const std::vector<int>& devices, const
     // granularity does (chunk wall time / reads, mapping.rs:912-918).
     const bool big_text = mapad_index_text_len(idx) >= (1ull << 31);
     const uint64_t coalesce = std::max<uint64_t>(1, std::min<uint64_t>(std::strtoull(a.get("coalesce", big_text ? "4" : "1").c_str(), nullptr, 10), 64));
-    const uint64_t chunk_reads = prm.chunk_size * coalesce;
+    // --coalesce_steady N (round 6): launches behind the first `in_flight` ones take N chunks.  Bigger launches from the start map faster once the pipeline is full (3 Gbp,
+    // same box, profiles/r06/cli_sweep_c4.txt: 3.03 M reads/s behind the first chunk with 1 M-read launches, 3.25 M with 2.5 M, 3.59 M with 5 M) but fill it slower
+    // (2.1 / 5.3 / 8.2 s until the first chunk is on disk).  Starting small and growing was measured and is NOT the default: on the same 24 M reads the run that goes on
+    // with 2 M-read launches is slower throughout (2.65 M reads/s behind the first chunk against 2.97 M, 11.0 s against 9.9 s; profiles/r06/cli_sweep_ramp_c4.txt) —
+    // four 2 M-read batches in flight on top of the first four leave the device worker waiting longer per fetch than they save per launch.
+    const uint64_t coalesce_steady = std::max<uint64_t>(coalesce, std::min<uint64_t>(std::strtoull(a.get("coalesce_steady", "0").c_str(), nullptr, 10), 64));
+    const uint64_t chunk_reads_first = prm.chunk_size * coalesce, chunk_reads_max = prm.chunk_size * coalesce_steady;
     const char* in_flight_default = "4";
     const int in_flight = std::max(1, std::min(std::atoi(a.get("in_flight", in_flight_default).c_str()), 16));
     const size_t n_dev = devices.size();
@@ -256,7 +262,7 @@ int cmd_map(const Args& a, uint64_t seed, const std::vector<int>& devices, const
         check(mapad_ctx_create(idx, &prm, devices[d], &ctxs[d]), "mapad_ctx_create");
         check(mapad_ctx_set_fetch_d_arrays(ctxs[d], 0), "mapad_ctx_set_fetch_d_arrays");
         check(mapad_ctx_set_pipeline_depth(ctxs[d], in_flight), "mapad_ctx_set_pipeline_depth");
-        const uint64_t per_dev = (chunk_reads + n_dev - 1) / n_dev;  // both batch slots' buffers up front (typical short reads; longer ones grow them)
+        const uint64_t per_dev = (chunk_reads_max + n_dev - 1) / n_dev;  // both batch slots' buffers up front (typical short reads; longer ones grow them)
         check(mapad_ctx_reserve(ctxs[d], per_dev, per_dev * 64, 128, 1), "mapad_ctx_reserve");
     }
     const double t_load = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
@@ -304,6 +310,7 @@ int cmd_map(const Args& a, uint64_t seed, const std::vector<int>& devices, const
             while (more && !failed) {
                 const uint64_t t_r0 = now_us();
                 auto c = std::make_shared<Chunk>();
+                const uint64_t chunk_reads = chunk_no < (uint64_t)in_flight * n_dev ? chunk_reads_first : chunk_reads_max;
                 c->no = chunk_no;
                 c->first_read = reads_so_far;
                 c->offsets.assign(1, 0);

@@ -247,6 +247,9 @@ __device__ __forceinline__ HeapPair load_pair(const MAPAD_LDS HeapEntry* p) {
 #if !defined(MAPAD_SUBTREE_HEAP)
 #define MAPAD_SUBTREE_HEAP 0
 #endif
+#if !defined(MAPAD_MAX_SIFT_ARENA_ONLY)
+#define MAPAD_MAX_SIFT_ARENA_ONLY 1  // (mm_trickle_down; 0 for A/B runs)
+#endif
 #if defined(MAPAD_HEAVY_KERNEL) && MAPAD_SUBTREE_HEAP != 0
 #error "heavy_kernel's wavefront-wide strides address the implicit heap array"
 #endif
@@ -523,6 +526,12 @@ MAPAD_HD void mm_trickle_down(const ArenaT<NL, TOP>& A, uint32_t n, uint32_t pos
         }
 #endif
         HeapPair c, ga, gb;  // a level is entirely near or entirely in the arena
+        // A pop_max sift starts at slot 1 or 2 and every stride takes it two levels down: with an even number of near levels (TOP = 63: levels 0-5) the strides above
+        // have used up the near levels exactly, and every stride of this loop reads arena levels only — no near reads, no selects (round 6: 3 ds_read_b128, their
+        // clamped addresses and 12 v_cndmask per arena stride were spent on values that were never taken).
+        if constexpr (MAX && MAPAD_MAX_SIFT_ARENA_ONLY && TOP >= 31 && (HeapLayout<TOP>::kT % 2) == 0 && MAPAD_SUBTREE_HEAP == 0) {
+            c = load_pair(A.heap + c1); ga = load_pair(A.heap + g1); gb = load_pair(A.heap + g1 + 2);
+        } else
         {   // near reads for every slot (clamped), arena loads predicated and back to back: one wait per level for the whole wavefront
             const bool c_near = c1 < (uint32_t)TOP, g_near = g1 + 3 < (uint32_t)TOP;
             const uint32_t kc = c_near ? c1 : 1u, kg = g_near ? g1 : 3u;  // clamped indices keep the 16-byte alignment of a pair (odd logical index)

@@ -105,8 +105,8 @@ struct BatchDev {
     const uint32_t* tail_ctl;
     uint32_t tail_backlog_max, tail_min_class;
     // ... and (round 6) a read past the pop budget leaves only while the host has fewer than tail_backlog_budget reads waiting or running; refused, it goes on on the GPU
-    // and asks again every tail_ask_mask + 1 pops (a power of two)
-    uint32_t tail_backlog_budget, tail_ask_mask;
+    // and asks again whenever its excess over the budget has doubled
+    uint32_t tail_backlog_budget;
     uint32_t tail_continue;   // 1: a read in a grown arena is handed over WITH its state (host_tail.hpp: TailState), the arena stays the read's until a host thread has copied it
     uint32_t tail_gen;        // what the kernel writes into a record's `ready` word: this launch's number in its ring (never 0) — words left by earlier launches do not match it
 };
@@ -685,6 +685,13 @@ __device__ __forceinline__ void hand_to_host(const BatchDev& B, const ReadInT<NL
 // hold, arenas with the reference's full limits.
 // NL: the near data (heap top, position data) of every read slot is in LDS and addressed with ds_* instructions; otherwise it
 // lives in the slot's HBM arena (reads longer than kMaxLdsReadLen, lanes-per-read 1).
+// MAPAD_OPAQUE_LANE=1: the lane's index inside its group, the stage number and the uniform conditions on the parameters are made opaque once per trip of the search
+// loop, so that the compiler recomputes `w == 0`, `nq == 1`, ... (one v_cmp / s_cmp) instead of hoisting them as 64-bit masks and spilling those into VGPR lanes:
+// SGPR spills of the shipped kernel 34 -> 29, VGPRs 168 -> 156 — and 1.6 % SLOWER on all three workloads, same box (profiles/r06/ab_opaque_lane.txt: C3 2.59 -> 2.55 M
+// reads/s, C2 6.05 -> 5.94 M, C4 3.10 -> 3.05 M): a v_readlane of a spilled mask is cheaper than the compare that rebuilds it.  Off.
+#if !defined(MAPAD_OPAQUE_LANE)
+#define MAPAD_OPAQUE_LANE 0
+#endif
 #if !defined(MAPAD_MIN_WAVES)
 #define MAPAD_MIN_WAVES 3  // 12 wavefronts per CU: 168 VGPRs (no SGPR spills into VGPR lanes) and 853 B of LDS per read slot (heap levels 0-5)
 #endif
@@ -721,9 +728,9 @@ __device__ __forceinline__ T kernarg_reload(size_t off, const T& by_value) {
 template <int LPR> struct top_of { static constexpr int value = LPR == 2 ? MAPAD_KTOP2 : kTop; };
 template <int LPR, bool CONT, int PASS, bool NL, bool HEAVY>
 __global__ void __launch_bounds__(64, (LPR == 1 && NL) ? 1 : LPR == 2 ? 2 : MAPAD_MIN_WAVES) search_kernel(DevIndex ix, DevParams P, BatchDev B0, ArenaPool AP0, const GrowPools* GP, uint32_t near_stride, uint32_t near_lmax, int stage) {
-    const int lane = threadIdx.x & 63, w = lane & (LPR - 1);
-    const int tier = stage;
-    const uint32_t n_items = tier == 0 ? B0.n_reads : B0.cursors[CUR_OVF + 2 * (tier - 1)];
+    const int lane = threadIdx.x & 63, w0 = lane & (LPR - 1);
+    const int tier0 = stage;
+    const uint32_t n_items = tier0 == 0 ? B0.n_reads : B0.cursors[CUR_OVF + 2 * (tier0 - 1)];
     if (n_items == 0) return;  // retry / full-limit stages normally have nothing to do
     uint32_t* const cursors = B0.cursors;
     const uint32_t set = acquire_set(AP0);
@@ -740,12 +747,12 @@ __global__ void __launch_bounds__(64, (LPR == 1 && NL) ? 1 : LPR == 2 ? 2 : MAPA
     A.top = (typename near_ptr<HeapEntry, NL>::type)near + 1;
     const NearBytes near_qc = near + (TOPK + 1) * sizeof(HeapEntry);
     const typename near_ptr<float, NL>::type near_d = (typename near_ptr<float, NL>::type)(near_qc + ((2 * near_lmax + 15) & ~15u));
-    uint32_t* work = &cursors[CUR_WORK + 2 * tier];
+    uint32_t* work = &cursors[CUR_WORK + 2 * tier0];
     // reads of the first stages give up after kMaxWaits fruitless waits for an arena and are restarted by the next stage, when the
     // pools are quiet; the last growable stage waits as long as it takes
-    const DeviceGrow<LPR, NL, TOPK> grow{GP, &cursors[CUR_GROWN], slot, w, stage + 2 < kStages || HEAVY, false, B0.tail_min_class};
+    const DeviceGrow<LPR, NL, TOPK> grow{GP, &cursors[CUR_GROWN], slot, w0, stage + 2 < kStages || HEAVY, false, B0.tail_min_class};
     const uint32_t wide_copy_nodes = GP->wide_copy_nodes;
-    const uint32_t tail_pops = B0.tail_pops, tail_ask_mask = B0.tail_ask_mask;
+    const uint32_t tail_pops = B0.tail_pops;
     bool tail_denied = false;  // the ring was full when this read asked: it stays on the GPU
     bool drained = false;      // the launch's own list of reads is exhausted (this quad has seen its end)
 #if defined(MAPAD_PROFILE_SECTIONS)
@@ -755,11 +762,16 @@ __global__ void __launch_bounds__(64, (LPR == 1 && NL) ? 1 : LPR == 2 ? 2 : MAPA
 #endif
     bool have = false, done = false;
     ReadInT<NL> rd{near_qc, near_d, 0, 0.0f, 0};
-    if constexpr (LPR == 4) rd.lane_less = w == 0 ? ix.less[1] : w == 1 ? ix.less[2] : w == 2 ? ix.less[3] : ix.less[4];
-    if constexpr (LPR == 2) { rd.lane_less = w == 0 ? ix.less[1] : ix.less[3]; rd.lane_less1 = w == 0 ? ix.less[2] : ix.less[4]; }
+    if constexpr (LPR == 4) rd.lane_less = w0 == 0 ? ix.less[1] : w0 == 1 ? ix.less[2] : w0 == 2 ? ix.less[3] : ix.less[4];
+    if constexpr (LPR == 2) { rd.lane_less = w0 == 0 ? ix.less[1] : ix.less[3]; rd.lane_less1 = w0 == 0 ? ix.less[2] : ix.less[4]; }
     SearchState st;
     uint32_t read = 0;
     for (;;) {
+        int w = w0, tier = tier0;  // (MAPAD_OPAQUE_LANE, above)
+#if MAPAD_OPAQUE_LANE
+        asm volatile("" : "+v"(w));
+        asm volatile("" : "+s"(tier));
+#endif
         MAPAD_MARK(PROF_LOOP);
         if (!have && !done) {
             uint32_t item = 0;
@@ -824,8 +836,12 @@ __global__ void __launch_bounds__(64, (LPR == 1 && NL) ? 1 : LPR == 2 ? 2 : MAPA
         }
         if (have) {
             bool cont;
-            if constexpr (PASS != 1) cont = search_step<LPR, CONT, NL>(ix, P, rd, A, st, w, grow);
-            else cont = search_step<LPR, CONT, NL>(ix, P, rd, A, st, w, NoGrow());
+            DevParams Ps = P;  // (the same for the uniform conditions on the parameters — `nq == 1`, `bound_kind == 2`, `gap_dist_ends > 0`, ...: 64-bit masks when hoisted, one s_cmp when not)
+#if MAPAD_OPAQUE_LANE
+            asm volatile("" : "+s"(Ps.nq), "+s"(Ps.bound_kind), "+s"(Ps.gap_dist_ends), "+s"(Ps.max_num_gaps_open), "+s"(Ps.start_at_end), "+s"(Ps.stack_limit_abort));
+#endif
+            if constexpr (PASS != 1) cont = search_step<LPR, CONT, NL>(ix, Ps, rd, A, st, w, grow);
+            else cont = search_step<LPR, CONT, NL>(ix, Ps, rd, A, st, w, NoGrow());
             MAPAD_MARK(PROF_TAIL);
             // the read leaves this quad for a host thread (host_tail.hpp), which maps it from scratch: a record of the batch's ring, if one is left
             auto give_to_host = [&](int why) -> bool {
@@ -867,12 +883,12 @@ __global__ void __launch_bounds__(64, (LPR == 1 && NL) ? 1 : LPR == 2 ? 2 : MAPA
                 have = false;
                 drain_memory();
                 MAPAD_MARK(PROF_FINALIZE);
-            } else if (MAPAD_UNLIKELY((((st.c_pop >= tail_pops) & (((st.c_pop - tail_pops) & tail_ask_mask) == 0u)) | (A.n_waits >= kAskTail)) & !tail_denied)) {
+            } else if (MAPAD_UNLIKELY((((st.c_pop >= tail_pops) & (((st.c_pop - tail_pops) & (st.c_pop - tail_pops - 1u)) == 0u)) | (A.n_waits >= kAskTail)) & !tail_denied)) {
                 // past the pop budget, or queuing for an arena class that is dry (DeviceGrow::acquire): a host thread takes this read over, the quad takes its next read —
                 // while the host's workers keep up with what they have.  Round 5 handed a read past the budget over whatever the host's backlog (only the dry-class
                 // trigger looked at it): a rank of eight on a 16-CPU box has two workers, and the reads the GPU gave up queued behind them for minutes while its quads
                 // idled.  Every trigger looks at the backlog word now; a read that is refused goes on on the GPU (a quad's pop is 15 x a worker's, but thousands of quads
-                // run side by side) and asks again tail_ask_mask + 1 pops later.
+                // run side by side) and asks again when its excess over the budget has doubled (at 0, 1, 2, 4, 8, ... pops past it: no state, no register).
                 const bool over = st.c_pop >= tail_pops;
                 bool take;
                 {
@@ -1774,7 +1790,7 @@ int launch_batch(mapad_ctx* c, BatchSlot& S, const uint8_t* d_seqs, const uint8_
     B.prof = c->d_prof.p;
 #endif
     B.tail_ring = nullptr; B.tail_stride = 0; B.tail_cap = 0; B.tail_lmax = 0; B.tail_pops = 0xFFFFFFFFu;
-    B.tail_ctl = nullptr; B.tail_backlog_max = 0; B.tail_min_class = (uint32_t)kClasses; B.tail_continue = 0; B.tail_gen = 1; B.tail_backlog_budget = 0; B.tail_ask_mask = 0;
+    B.tail_ctl = nullptr; B.tail_backlog_max = 0; B.tail_min_class = (uint32_t)kClasses; B.tail_continue = 0; B.tail_gen = 1; B.tail_backlog_budget = 0;
     drop_tail(c, S);
     for (auto& x : S.tail_info) x = 0;
     S.tail_failed = false;
@@ -1829,9 +1845,8 @@ int launch_batch(mapad_ctx* c, BatchSlot& S, const uint8_t* d_seqs, const uint8_
         B.tail_min_class = env_u32("MAPAD_TAIL_MIN_CLASS", 4);
         B.tail_backlog_max = env_u32("MAPAD_TAIL_BACKLOG", std::max(1u, host::TailWorkers::instance().size() / 2));
         // Past the budget: a worker finishes such a read ~15 x faster than its quad would, so the host is the better place while fewer than ~15 reads per worker wait
-        // in front of it; MAPAD_TAIL_BACKLOG_BUDGET (default 8 per worker; 0xFFFFFFFF = round 5's unconditional hand-over).  Asked again every 1/8 budget.
+        // in front of it; MAPAD_TAIL_BACKLOG_BUDGET (default 8 per worker; 0xFFFFFFFF = round 5's unconditional hand-over).
         B.tail_backlog_budget = env_u32("MAPAD_TAIL_BACKLOG_BUDGET", 8u * std::max(1u, host::TailWorkers::instance().size()));
-        { uint32_t m = 64; while (2 * m <= c->tail_pops / 8) m *= 2; B.tail_ask_mask = m - 1; }
     }
     S.last = B; S.last_total_bases = total_bases; S.last_lmax = lmax; S.compacted = false;
     // A process-wide launch number, not a per-slot count: a result of a destroyed context must not pass for the batch of a new context that happens to sit at

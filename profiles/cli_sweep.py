@@ -40,7 +40,7 @@ for bs, fl, env in cases:
     cmd = base + ["--batch_size", str(bs), "--in_flight", str(fl)]
     if env.get("exe"):  # another build of the command (e.g. exe=profiles/dev/r04_bin/mapad-amd: round 4's, with its own library beside it)
         cmd[0] = os.path.abspath(env.pop("exe"))
-    for opt in ("coalesce", "parse_threads", "encode_threads"):
+    for opt in ("coalesce", "coalesce_steady", "parse_threads", "encode_threads"):
         if opt in env:
             cmd += ["--" + opt, env.pop(opt)]
     if env.pop("ROCPROF", None):  # kernel statistics of the run: the summary lands in gpurun_out/prof_cli

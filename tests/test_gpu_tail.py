@@ -64,9 +64,9 @@ def test_reads_finished_on_the_host_equal_the_oracle(name, prm, kw, n):
 
 
 def test_reads_past_the_budget_stay_on_the_gpu_while_the_host_is_busy(monkeypatch):
-    """Round 6: every hand-over trigger looks at the host's backlog (the word the launch's dispatcher keeps current).  With room for ONE waiting read
-    (MAPAD_TAIL_BACKLOG_BUDGET=1) most reads past the budget are refused, go on on the GPU, ask again every 64 pops and mostly finish there; some are taken.  Nothing
-    of that shows in the results."""
+    """Round 6: every hand-over trigger looks at the host's backlog (the word the launch's dispatcher keeps current).  With no room at all
+    (MAPAD_TAIL_BACKLOG_BUDGET=0) every read past the budget is refused, goes on on the GPU, asks again whenever its excess has doubled and finishes there; with the
+    default (8 waiting reads per worker) any number between none and all of them leave, as the host's pace has it.  Nothing of that shows in the results."""
     g = synth.genome(300_000, seed=77)
     seqs, quals, offsets = synth.reads(g, 3000, 50, seed=12, qual_range=(20, 40), damage=dict(f=0.5, t=0.5, d=0.02, s=1.0))
     rp = resolve_params(DAMAGE)
@@ -78,12 +78,16 @@ def test_reads_past_the_budget_stay_on_the_gpu_while_the_host_is_busy(monkeypatc
     past = int((ores.counters[:, 3] > 64).sum())
     every, info_every = _map(pidx, params, seqs, quals, offsets, tail_pops=64)
     assert info_every["reads"] == past > 500
-    monkeypatch.setenv("MAPAD_TAIL_BACKLOG_BUDGET", "1")
+    monkeypatch.setenv("MAPAD_TAIL_BACKLOG_BUDGET", "0")
     res, info = _map(pidx, params, seqs, quals, offsets, tail_pops=64)
-    assert 0 < info["reads"] < past // 2, (info["reads"], past)
+    assert info["reads"] == 0, info
     assert_same_as_oracle(ores, res, offsets)
     _same(res, every)
     assert (res.status & 16).sum() == 0
+    monkeypatch.delenv("MAPAD_TAIL_BACKLOG_BUDGET")
+    res, info = _map(pidx, params, seqs, quals, offsets, tail_pops=64)
+    assert 0 <= info["reads"] <= past
+    _same(res, every)
 
 
 def test_limit_recovery_and_abort_on_the_host():
