@@ -3,7 +3,7 @@
 #   bash profiles/dev/ab_pmc.sh "cfg..." LIB LIB ...     LIB = default | NAME (mapad_amd/variant_NAME.so)
 # Per (variant, config): two rocprofv3 --pmc passes (FETCH_SIZE; WRITE_SIZE — counters in their own runs, --kernel-trace only) of one launch alone on the chip
 # (`bench.py --steps 1 --warmup 0 --depth 1`).  Read requests = FETCH_SIZE KiB * 1024 / 64 (gfx950 tallies a 128-byte request as 64 bytes), write requests =
-# WRITE_SIZE KiB * 1024 / 64; pops from the bench line's event counters.  One line per (variant, config) on stdout, JSON.
+# WRITE_SIZE KiB * 1024 / 64, mean over the process's real launches; pops from the bench line's event counters.  One line per (variant, config) on stdout, JSON.
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 CFGS=$1; shift
 OUT=$ROOT/gpurun_out/ab_pmc
@@ -22,11 +22,15 @@ import csv, glob, json, os, sys
 out, v, cfg = sys.argv[1:4]
 res = {"variant": v, "config": cfg}
 for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
-    tot, ms = 0.0, []
+    per_dispatch, ms = {}, []
     for f in glob.glob(os.path.join(out, f"{v}_{cfg}_{ctr}", "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
             if "search_kernel<4, false, 0" in r["Kernel_Name"] and r["Counter_Name"] == ctr:
-                tot += float(r["Counter_Value"])
+                per_dispatch[r["Dispatch_Id"]] = per_dispatch.get(r["Dispatch_Id"], 0.0) + float(r["Counter_Value"])
+    # `bench.py --steps 1 --warmup 0` maps the batch twice (the timed step and the solo launch): the mean over the real launches (the empty warm-up launches dropped)
+    real = [x for x in per_dispatch.values() if x > 0.01 * max(per_dispatch.values())] if per_dispatch else []
+    tot = sum(real) / len(real) if real else 0.0
+    res["launches_" + ctr] = len(real)
     for f in glob.glob(os.path.join(out, f"{v}_{cfg}_{ctr}", "**", "*kernel_trace.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
             if "search_kernel<4, false, 0" in r["Kernel_Name"]:
