@@ -247,6 +247,9 @@ __device__ __forceinline__ HeapPair load_pair(const MAPAD_LDS HeapEntry* p) {
 #if !defined(MAPAD_SUBTREE_HEAP)
 #define MAPAD_SUBTREE_HEAP 0
 #endif
+#if !defined(MAPAD_UNIFORM_SIFT_STORES)
+#define MAPAD_UNIFORM_SIFT_STORES 0  // (mm_trickle_down: arena strides store to the arena without hp_set's per-lane near / arena branch; measured +-0 on C2 / C3 / C4, profiles/r06/ab_lds_pad_and_uniform_stores.txt: off)
+#endif
 #if !defined(MAPAD_MAX_SIFT_ARENA_ONLY)
 #define MAPAD_MAX_SIFT_ARENA_ONLY 1  // (mm_trickle_down; 0 for A/B runs)
 #endif
@@ -493,6 +496,11 @@ MAPAD_HD void mm_trickle_down(const ArenaT<NL, TOP>& A, uint32_t n, uint32_t pos
     };
     auto set_near = [&](uint32_t i, const HeapEntry e) { store_entry(A.top + i, e); };
     auto set_any = [&](uint32_t i, const HeapEntry e) { hp_set(A, i, e); };
+    auto set_arena = [&](uint32_t i, const HeapEntry e) { store_entry(A.heap + HeapLayout<TOP>::slot(i), e); };
+    // (MAX sifts from slot 1 or 2, even number of near levels: see the loads below) the hole of the general loop's FIRST stride sits on the last near level, its
+    // children and everything any later stride stores to are arena slots: only that first stride needs the per-lane near / arena choice of hp_set
+    constexpr bool kArenaOnly = MAX && MAPAD_MAX_SIFT_ARENA_ONLY && TOP >= 31 && (HeapLayout<TOP>::kT % 2) == 0 && MAPAD_SUBTREE_HEAP == 0;
+    bool first_general = true;
     if constexpr (TOP >= 31) {
         constexpr int kNearStrides = TOP >= 1023 ? 4 : TOP >= 255 ? 3 : TOP >= 63 ? 2 : 1;  // strides that stay inside the near levels when the sift starts at slot 1 or 2
 #pragma unroll
@@ -529,7 +537,7 @@ MAPAD_HD void mm_trickle_down(const ArenaT<NL, TOP>& A, uint32_t n, uint32_t pos
         // A pop_max sift starts at slot 1 or 2 and every stride takes it two levels down: with an even number of near levels (TOP = 63: levels 0-5) the strides above
         // have used up the near levels exactly, and every stride of this loop reads arena levels only — no near reads, no selects (round 6: 3 ds_read_b128, their
         // clamped addresses and 12 v_cndmask per arena stride were spent on values that were never taken).
-        if constexpr (MAX && MAPAD_MAX_SIFT_ARENA_ONLY && TOP >= 31 && (HeapLayout<TOP>::kT % 2) == 0 && MAPAD_SUBTREE_HEAP == 0) {
+        if constexpr (kArenaOnly) {
             c = load_pair(A.heap + c1); ga = load_pair(A.heap + g1); gb = load_pair(A.heap + g1 + 2);
         } else
         {   // near reads for every slot (clamped), arena loads predicated and back to back: one wait per level for the whole wavefront
@@ -570,7 +578,9 @@ MAPAD_HD void mm_trickle_down(const ArenaT<NL, TOP>& A, uint32_t n, uint32_t pos
             if (spec & (sc1 < n)) sc = load_pair(A.heap + ss);
             if (spec & (sg1 < n)) { sga = load_pair(A.heap + sg1); sgb = load_pair(A.heap + sg1 + 2); }
 #endif
-            going = stride(c, ga, gb, c1, g1, set_any);
+            if (kArenaOnly && MAPAD_UNIFORM_SIFT_STORES && !first_general) going = stride(c, ga, gb, c1, g1, set_arena);
+            else going = stride(c, ga, gb, c1, g1, set_any);
+            first_general = false;
             if (spec & going & (2 * pos + 1 < n)) {  // the hole went to grandchild pos = g1 + k: lane k holds the next stride's candidates
                 const int src = (int)((threadIdx.x & ~3u) + (pos - g1)) << 2;
                 auto take = [&](const HeapPair& p) {
@@ -581,12 +591,15 @@ MAPAD_HD void mm_trickle_down(const ArenaT<NL, TOP>& A, uint32_t n, uint32_t pos
                 };
                 const HeapPair c2 = take(sc), ga2 = take(sga), gb2 = take(sgb);
                 const uint32_t c1b = 2 * pos + 1;
-                going = stride(c2, ga2, gb2, c1b, 2 * c1b + 1, set_any);
+                if (kArenaOnly && MAPAD_UNIFORM_SIFT_STORES) going = stride(c2, ga2, gb2, c1b, 2 * c1b + 1, set_arena);
+                else going = stride(c2, ga2, gb2, c1b, 2 * c1b + 1, set_any);
             }
             continue;
         }
 #endif
-        going = stride(c, ga, gb, c1, g1, set_any);
+        if (kArenaOnly && MAPAD_UNIFORM_SIFT_STORES && !first_general) going = stride(c, ga, gb, c1, g1, set_arena);
+        else going = stride(c, ga, gb, c1, g1, set_any);
+        first_general = false;
     }
     hp_set(A, pos, elt);
 }

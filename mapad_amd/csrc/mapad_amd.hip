@@ -1075,7 +1075,16 @@ struct DevBuf {
 
 // bytes of "near" data per read slot: heap top (32 physical slots), 2 bytes + 4 bytes per read position
 // (+ 64 bytes for the payload cache of heap slots 1 and 2 where the kernel keeps one: quads with their near data in LDS)
-uint32_t near_bytes(uint32_t lmax, uint32_t top = kTop) { return (top + 1) * 8 + ((2 * lmax + 15) & ~15u) + ((4 * lmax + 15) & ~15u); }
+// MAPAD_NEAR_PAD=1 (round 6): padded to an ODD number of 16-byte units.  The read slots of a wavefront run in lockstep and ask for the same slot-relative address at
+// once (heap slot 1, the D array's entry j, ...): with the 50 bp stride of 832 bytes = 208 dwords = 16 (mod 32 banks) the sixteen quads of a wavefront fall onto two
+// groups of four banks — an 8-way conflict on every 16-byte read of a near level —; an odd number of 16-byte units spreads them over all 32 banks.  Measured: no
+// difference on C2 / C3 / C4 (profiles/r06/ab_lds_pad_and_uniform_stores.txt) — the LDS is idle 95 % of the time and its reads are not what the chain waits for.  Off.
+uint32_t near_bytes(uint32_t lmax, uint32_t top = kTop) {
+    uint32_t b = (top + 1) * 8 + ((2 * lmax + 15) & ~15u) + ((4 * lmax + 15) & ~15u);
+    static const bool pad = [] { const char* e = std::getenv("MAPAD_NEAR_PAD"); return e && e[0] == '1'; }();
+    if (pad && ((b / 16) & 1u) == 0) b += 16;
+    return b;
+}
 constexpr uint32_t kMaxLdsReadLen = 256;  // longer reads keep their near data in the HBM arena instead of LDS
 
 // bytes of an arena's heap area for `heap_cap` logical entries: the physical entries the layout needs (heap_core.hpp: HeapLayout — subtree blocks take a third more than
