@@ -692,6 +692,9 @@ __device__ __forceinline__ void hand_to_host(const BatchDev& B, const ReadInT<NL
 #if !defined(MAPAD_OPAQUE_LANE)
 #define MAPAD_OPAQUE_LANE 0
 #endif
+#if !defined(MAPAD_NODE_PREFETCH)
+#define MAPAD_NODE_PREFETCH 0  // (search_core.hpp: NodePrefetch — measured +-0 on C3 / C4, -0.8 % on C2, same box: profiles/r06/ab_node_prefetch.txt; off)
+#endif
 #if !defined(MAPAD_MIN_WAVES)
 #define MAPAD_MIN_WAVES 3  // 12 wavefronts per CU: 168 VGPRs (no SGPR spills into VGPR lanes) and 853 B of LDS per read slot (heap levels 0-5)
 #endif
@@ -765,6 +768,9 @@ __global__ void __launch_bounds__(64, (LPR == 1 && NL) ? 1 : LPR == 2 ? 2 : MAPA
     if constexpr (LPR == 4) rd.lane_less = w0 == 0 ? ix.less[1] : w0 == 1 ? ix.less[2] : w0 == 2 ? ix.less[3] : ix.less[4];
     if constexpr (LPR == 2) { rd.lane_less = w0 == 0 ? ix.less[1] : ix.less[3]; rd.lane_less1 = w0 == 0 ? ix.less[2] : ix.less[4]; }
     SearchState st;
+#if MAPAD_NODE_PREFETCH
+    NodePrefetch node_pf;  // (search_core.hpp; quads with their near data in LDS)
+#endif
     uint32_t read = 0;
     for (;;) {
         int w = w0, tier = tier0;  // (MAPAD_OPAQUE_LANE, above)
@@ -821,6 +827,9 @@ __global__ void __launch_bounds__(64, (LPR == 1 && NL) ? 1 : LPR == 2 ? 2 : MAPA
                     A.n_waits = again != ~0u ? kRestarted : 0u;
                     search_init(kernarg_reload(0, ix).n, alignment_start_of(P, rd.L), rd, A, tmp);
                     st = tmp;
+#if MAPAD_NODE_PREFETCH
+                    node_pf.ok = false;
+#endif
                     have = true;
                     tail_denied = false;
                 }
@@ -839,6 +848,10 @@ __global__ void __launch_bounds__(64, (LPR == 1 && NL) ? 1 : LPR == 2 ? 2 : MAPA
             DevParams Ps = P;  // (the same for the uniform conditions on the parameters — `nq == 1`, `bound_kind == 2`, `gap_dist_ends > 0`, ...: 64-bit masks when hoisted, one s_cmp when not)
 #if MAPAD_OPAQUE_LANE
             asm volatile("" : "+s"(Ps.nq), "+s"(Ps.bound_kind), "+s"(Ps.gap_dist_ends), "+s"(Ps.max_num_gaps_open), "+s"(Ps.start_at_end), "+s"(Ps.stack_limit_abort));
+#endif
+#if MAPAD_NODE_PREFETCH
+            if constexpr (PASS != 1 && LPR == 4 && NL) cont = search_step_pf<LPR, CONT, NL, false>(ix, Ps, rd, A, st, w, grow, node_pf);
+            else
 #endif
             if constexpr (PASS != 1) cont = search_step<LPR, CONT, NL>(ix, Ps, rd, A, st, w, grow);
             else cont = search_step<LPR, CONT, NL>(ix, Ps, rd, A, st, w, NoGrow());

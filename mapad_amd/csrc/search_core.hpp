@@ -324,11 +324,38 @@ MAPAD_HD void pc_clear(const ArenaT<NL, TOP>& A) { A.pc[0] = 0; A.pc[4] = 0; }
 #define MAPAD_PAR_COMMIT 1
 #endif
 // MAPAD_SPEC_SIFT=1: the pop's sift fetches two strides per trip to the arena (heap_core.hpp: mm_trickle_down<.., SPEC>).  Quads with near data in LDS only.
+// (Round 6, measured and removed — commit c63a3b5..: profiles/r06/ab_quad_movers.txt.  The movers of a commit round decided by the whole quad from registers — static DPP
+//  broadcasts of the mover's element and ancestors, every lane patching its own ancestors with what the mover wrote — instead of each by its own lane behind a reload from
+//  memory: no trip to memory between movers, parity-green, and 7-8 % SLOWER on C3 and C2.  Like round 4's forwarding (-3 %): the movers' cost is their instructions, and
+//  four unrolled decisions per round are more instructions than the reloads they replace.)
+#if !defined(MAPAD_LAZY_GAP_NODES)
+#define MAPAD_LAZY_GAP_NODES 0  // (measured +-0: profiles/r06/ab_lazy_gap_nodes.txt — the compiler sinks the packing into the predicated stores by itself)
+#endif
 #if !defined(MAPAD_SPEC_SIFT)
 #define MAPAD_SPEC_SIFT 1
 #endif
+// NodePrefetch (device quads, MAPAD_NODE_PREFETCH): the node of the frame the NEXT step will pop, requested at the end of this step.  Between the end of a step and the
+// node load of the next lie the step's tail, the kernel loop's hand-over and grow checks and the next step's prologue — a tenth of a wave's time (section profile: loop
+// head + step tail + read setup), during which nothing is in flight for this read; the frontier does not change in between (an arena migration copies the nodes
+// unchanged), so the next step's `find max` names the same node and takes the payload from these registers.  A new read starts with `ok = false`.
+// Built and parity-green in round 6, and NEUTRAL (profiles/r06/ab_node_prefetch.txt: C3 2.64 / 2.64 M reads/s, C4 3.10 / 3.10 M, C2 6.08 / 6.13 M with / without): like
+// the payload cache and the early ancestors of round 4, taking a trip out of the step's chain does not shorten the step.  Off by default (MAPAD_NODE_PREFETCH=1).
+struct NodePrefetch {
+    static constexpr bool on = true;
+    uint64_t w1 = 0, w2 = 0, w3 = 0;
+    uint32_t id = 0;
+    bool ok = false;
+};
+struct NoPrefetch { static constexpr bool on = false; };
+template <int LPR, bool CONT, bool NL, bool PC = false, class Grow = NoGrow, int TOP = kTop, bool NLR = NL, class PFT = NoPrefetch>
+MAPAD_HD bool search_step_pf(const DevIndex& ix, const DevParams& P, const ReadInT<NLR>& rd, ArenaT<NL, TOP>& A, SearchState& st, int w, const Grow& grow, PFT& pf);
 template <int LPR, bool CONT, bool NL, bool PC = false, class Grow = NoGrow, int TOP = kTop, bool NLR = NL>
 MAPAD_HD bool search_step(const DevIndex& ix, const DevParams& P, const ReadInT<NLR>& rd, ArenaT<NL, TOP>& A, SearchState& st, int w, const Grow& grow) {
+    NoPrefetch np;
+    return search_step_pf<LPR, CONT, NL, PC>(ix, P, rd, A, st, w, grow, np);
+}
+template <int LPR, bool CONT, bool NL, bool PC, class Grow, int TOP, bool NLR, class PFT>
+MAPAD_HD bool search_step_pf(const DevIndex& ix, const DevParams& P, const ReadInT<NLR>& rd, ArenaT<NL, TOP>& A, SearchState& st, int w, const Grow& grow, PFT& pf) {
     if (st.heap_len == 0 || st.status != ST_OK) return false;
     if (MAPAD_UNLIKELY(st.tree_len + kStepNodes > A.node_cap || st.heap_len + kStepNodes > A.heap_cap)) {
         MAPAD_MARK(PROF_LOOP);
@@ -367,6 +394,15 @@ MAPAD_HD bool search_step(const DevIndex& ix, const DevParams& P, const ReadInT<
             drain_memory();
         }
         top_node.w0 = 0; top_node.w1 = hit ? c1 : g1; top_node.w2 = hit ? c2 : g2; top_node.w3 = hit ? c3 : g3;
+    } else if constexpr (PFT::on) {
+        const bool hit = pf.ok & (pf.id == top.node);
+        uint64_t g1 = 0, g2 = 0, g3 = 0;
+        if (MAPAD_UNLIKELY(!hit)) {  // the first step of a read: the usual trip, waited for here so that the common path carries no wait of its own (drain_memory)
+            const Node g = A.nodes[top.node];
+            g1 = g.w1; g2 = g.w2; g3 = g.w3;
+            drain_memory();
+        }
+        top_node.w0 = 0; top_node.w1 = hit ? pf.w1 : g1; top_node.w2 = hit ? pf.w2 : g2; top_node.w3 = hit ? pf.w3 : g3;
     } else {
         MAPAD_TOUCH(&A.nodes[top.node], sizeof(Node), false);
         top_node = A.nodes[top.node];
@@ -515,12 +551,15 @@ MAPAD_HD bool search_step(const DevIndex& ix, const DevParams& P, const ReadInT<
         return pack_node(op, top.node, c);
     };
     Node nd_ins{}, nd_del[kBases] = {}, nd_mm[kBases] = {};
-    if constexpr (kLaneKids) {  // every lane packs the two children of its base(s) once; the commit loop below only selects and stores
-        nd_ins = make_child(0, 0, 0, 0, 0);
+    if constexpr (kLaneKids) {  // every lane packs the children of its base(s) once; the commit loop below only selects and stores
+        // Round 6 (MAPAD_LAZY_GAP_NODES): the insertion and deletion children only where a gate let one through (`cand` is quad-uniform and only loses bits from here
+        // on).  At -p 0.03 that is 0.2 % of the pops — a few per cent of the wavefront steps —, and their ~30 pack instructions used to run in every step.
+        const bool gap_kids = !MAPAD_LAZY_GAP_NODES || (cand & 0xABu) != 0u;  // bit 0 = Ins, bits 1, 3, 5, 7 = Del
+        if (gap_kids) nd_ins = make_child(0, 0, 0, 0, 0);
 #pragma unroll
         for (int b = 0; b < kBases; ++b) {
             const int k = kBases * w + b;
-            nd_del[b] = make_child(1 + 2 * (3 - k), k, my_lower[b], my_lower_rev[b], my_size[b]);
+            if (gap_kids) nd_del[b] = make_child(1 + 2 * (3 - k), k, my_lower[b], my_lower_rev[b], my_size[b]);
             nd_mm[b] = make_child(2 + 2 * (3 - k), k, my_lower[b], my_lower_rev[b], my_size[b]);
         }
     }
@@ -788,6 +827,15 @@ MAPAD_HD bool search_step(const DevIndex& ix, const DevParams& P, const ReadInT<
         if constexpr (PC) pc_clear(A);  // slots 1 and 2 may hold other entries now, and the freed node ids will be reused
         drain_memory();
         st = tmp;
+    }
+    if constexpr (PFT::on) {  // the next step's node (NodePrefetch): the loads stay in flight across the kernel's loop head
+        pf.ok = false;
+        if (st.heap_len > 0) {
+            uint32_t ni;
+            const HeapEntry nt = mm_find_max(A, st.heap_len, ni);
+            const Node g = A.nodes[nt.node];
+            pf.w1 = g.w1; pf.w2 = g.w2; pf.w3 = g.w3; pf.id = nt.node; pf.ok = true;
+        }
     }
     return st.heap_len > 0;
 }

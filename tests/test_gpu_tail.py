@@ -296,3 +296,57 @@ def test_arenas_of_reads_nobody_came_for_are_released(monkeypatch):
     ores = oidx.map_batch(ob.make_params(rp), reads, qs, n_threads=8, keep_d=True)
     assert_same_as_oracle(ores, res, b[2])
     assert info["handed_over_with_state"] > 0 and res.n_second_pass > 500  # reads still find grown arenas: nothing leaked
+
+
+def test_an_arena_relayout_waits_for_the_host_tails_of_uncollected_batches(monkeypatch):
+    """a batch with more reads than the arenas were laid out for makes the context free and re-allocate its pools.  Reads of ANOTHER slot's uncollected batch
+    that were handed over with their state still own grown arenas in those pools until a host worker has copied them (and the workers read the pool descriptors
+    unlocked): the re-layout first finishes and merges the host tails of every slot (finish_tails), and the earlier batch's results — collected afterwards — are
+    still the oracle's."""
+    monkeypatch.setenv("MAPAD_TIER0_NODES", "32")
+    g = synth.genome(300_000, seed=77)
+    rp = resolve_params(DAMAGE)
+    pidx = mapad_amd.Index.build([("chr1", g)])
+    oidx = ob.OracleIndex.from_bwt(pidx.bwt(), "$ACGTX", 128)
+    small = synth.reads(g, 1500, 50, seed=61, qual_range=(20, 40), damage=dict(f=0.5, t=0.5, d=0.02, s=1.0))
+    big = synth.reads(g, 12_000, 50, seed=62, qual=40, subst_rate=0.0, exo_frac=0.0)  # (exact reads: a few dozen pops each, nothing for the host — the re-layout is what this batch is for)
+    ctx = mapad_amd.Context(pidx, mapad_amd.make_params(rp), 0)
+    try:
+        ctx.set_pipeline_depth(2)
+        ctx.set_tail_pops(150)
+        ctx.submit_batch(*small)   # reads go to the host with their state; nobody collects yet
+        ctx.submit_batch(*big)     # more reads than the pools were sized for: the arenas are laid out anew
+        ctx.select_batch(1)
+        first, info = ctx.fetch(), ctx.tail_info()
+        ctx.select_batch(0)
+        second = ctx.fetch()
+    finally:
+        ctx.close()
+    assert info["handed_over_with_state"] > 50, info
+    for b, res in ((small, first), (big, second)):
+        reads, qs = split_reads(*b)
+        ores = oidx.map_batch(ob.make_params(rp), reads, qs, n_threads=8, keep_d=True)
+        assert_same_as_oracle(ores, res, b[2])
+
+
+def test_hand_over_ring_is_not_fooled_by_records_of_earlier_launches():
+    """the ring's `ready` words used to be cleared by count, and a small batch between two large ones left records of the first large batch marked ready when
+    the third ran — the dispatcher would have taken a stale record for a new one.  A record is ready when its word holds THIS launch's number now.  Same context, same
+    slot: 2 000 hand-overs, then a batch of 100 reads (ring of 100 records), then another large batch — every batch equals the oracle and hands over exactly its own reads."""
+    g = synth.genome(300_000, seed=77)
+    rp = resolve_params(NO_DAMAGE)
+    pidx = mapad_amd.Index.build([("chr1", g)])
+    oidx = ob.OracleIndex.from_bwt(pidx.bwt(), "$ACGTX", 128)
+    ctx = mapad_amd.Context(pidx, mapad_amd.make_params(rp), 0)
+    try:
+        ctx.set_tail_pops(48)
+        for n, seed in ((3000, 71), (100, 72), (3000, 73), (100, 74), (2500, 75)):
+            b = synth.reads(g, n, 50, seed=seed, qual=40)
+            res = ctx.map_batch(*b)
+            info = ctx.tail_info()
+            reads, qs = split_reads(*b)
+            ores = oidx.map_batch(ob.make_params(rp), reads, qs, n_threads=8, keep_d=True)
+            assert_same_as_oracle(ores, res, b[2])
+            assert info["reads"] == int((ores.counters[:, 3] > 48).sum()) and (res.status & 16).sum() == 0
+    finally:
+        ctx.close()
