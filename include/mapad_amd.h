@@ -128,7 +128,8 @@ int mapad_ctx_set_stream(mapad_ctx_t* ctx, void* hip_stream);
 int mapad_ctx_set_reserved_cus(mapad_ctx_t* ctx, int n_cus);
 /* The heavy tail.  The reference absorbs the reads that run into STACK_LIMIT / EDIT_TREE_LIMIT (src/map/mapping.rs:52-54,1358-1380) on its rayon threads; here a
  * read is handed — by the kernel, while it runs, through host-coherent page-locked memory — to the library's host threads when (a) it has made `pops` pops on the
- * GPU (default 2^19; MAPAD_TAIL_POPS; 0 = the host tail is off), (b) it needs a grown arena of a class the GPU has few of and every one is taken, while the host
+ * GPU while the host threads keep up (default 2^20; MAPAD_TAIL_POPS; 0 = the host tail is off; MAPAD_TAIL_BACKLOG_BUDGET) — or MAPAD_TAIL_POPS_IDLE pops while a host
+ * thread is idle —, (b) it needs a grown arena of a class the GPU has few of and every one is taken, while the host
  * threads have little waiting (MAPAD_TAIL_MIN_CLASS, MAPAD_TAIL_BACKLOG), or (c) no growable arena can hold it (the reads the full-limit stage would restart).
  * The host threads map it from scratch with the kernel's own search step compiled for the host (csrc/host_tail.hpp; MAPAD_TAIL_THREADS threads, default this
  * process's share of the CPUs, divided by LOCAL_WORLD_SIZE when several ranks share a node).  Their results join the batch before its order-preserving collect:
@@ -142,7 +143,7 @@ uint32_t mapad_tail_set_local_world(uint32_t local_world);
 /* the batch selected by mapad_ctx_select_batch, after its collect / fetch: {reads finished on the host, pops the GPU had spent on them, pops on the host,
  * host wall-clock microseconds from the first hand-over to the last result, host threads, pop budget, and the host reads' E_search, N_push, N_node sums
  * (SURVEY 8d events the kernel did not execute), microseconds the host threads spent inside these reads, summed over the threads,
- * [10] hand-overs the host saw while the launch was still running, [11] reads handed over for reason (b), [12] for reason (c), [13] smallest class of (b),
+ * [10] hand-overs the host saw while the launch was still running, [11] reads handed over for reason (b), [12] for reason (c), [13] smallest class of (b) | reads handed over below `pops` because a host thread was idle << 32,
  * [14] reads a host thread CONTINUED from the GPU's state (heap and nodes copied out of the read's grown arena) instead of mapping them from scratch, [15] reads
  * the kernel handed over with their state.  For continued reads the pop / event figures above count the host's share only.} */
 int mapad_last_tail_info(mapad_ctx_t* ctx, uint64_t out[16]);

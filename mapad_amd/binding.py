@@ -441,8 +441,11 @@ class Context:
         """{reads, gpu_pops, host_pops, host_us (wall), threads, budget, ..., host_thread_us (summed over the threads)} of the selected batch's host tail (after its collect / fetch)."""
         out = np.zeros(16, np.uint64)
         _check(lib().mapad_last_tail_info(self.h, _ptr(out)), "mapad_last_tail_info")
-        return dict(zip(("reads", "gpu_pops", "host_pops", "host_us", "threads", "budget", "host_e_search", "host_n_push", "host_n_node", "host_thread_us",
-                         "seen_live", "reads_dry_class", "reads_full_limit", "min_class", "continued", "handed_over_with_state"), (int(x) for x in out)))
+        d = dict(zip(("reads", "gpu_pops", "host_pops", "host_us", "threads", "budget", "host_e_search", "host_n_push", "host_n_node", "host_thread_us",
+                      "seen_live", "reads_dry_class", "reads_full_limit", "min_class", "continued", "handed_over_with_state"), (int(x) for x in out)))
+        d["reads_idle_tier"] = d["min_class"] >> 32  # word 13: dry-class threshold | reads handed over below the budget because a worker was idle << 32
+        d["min_class"] &= 0xFFFFFFFF
+        return d
 
     def launch_info(self):
         out = np.zeros(8, np.uint32)

@@ -244,7 +244,7 @@ struct TailBatch {
     const uint8_t* ring = nullptr;  // records in host-coherent page-locked memory
     uint32_t stride = 0, cap = 0, lmax = 0;
     uint32_t gen = 1;               // a record of this launch is ready when its `ready` word holds this number
-    uint32_t* ctl = nullptr;        // word the kernel reads before a hand-over it could do without (dry arena class): tasks the workers have waiting or running
+    uint32_t* ctl = nullptr;        // two words the kernel reads before a hand-over: [0] tasks the workers have waiting or running, [1] records of this launch the dispatcher has picked up
     std::function<bool()> launch_done;  // has the launch that writes this ring ended? (set by the library; counts the hand-overs that arrive while it runs)
     uint32_t seen_live = 0;         // records the dispatcher saw while the launch was still running
     // continuation (TailState): copies heap slots [0, heap_len] (physical, shifted by one) and nodes [0, tree_entries) of the grown arena into the worker's arena and
@@ -382,8 +382,11 @@ inline void tail_start(const std::shared_ptr<TailBatch>& tb) {
                         tb->seen_live += live ? 1u : 0u;
                     }
                     TailWorkers::instance().submit([tb, rec] { tail_map_read(tb, rec); }, rec->pops);
-                    if (tb->ctl) __atomic_store_n(tb->ctl, TailWorkers::instance().pending(), __ATOMIC_RELAXED);
                     next += 1;
+                    if (tb->ctl) {  // the count first: a record is then never in neither word (the kernel adds the records beyond ctl[1] to ctl[0])
+                        __atomic_store_n(tb->ctl, TailWorkers::instance().pending(), __ATOMIC_RELEASE);
+                        __atomic_store_n(tb->ctl + 1, next, __ATOMIC_RELEASE);
+                    }
                     idle = 0;
                     continue;
                 }

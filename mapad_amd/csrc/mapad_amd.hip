@@ -62,6 +62,14 @@ enum : uint32_t { ST_POOL_OVERFLOW = 4, ST_NO_TABLE = 8, ST_TAIL = 16 /* handed 
 #if !defined(MAPAD_DEFAULT_TAIL_POPS)
 #define MAPAD_DEFAULT_TAIL_POPS (1u << 20)
 #endif
+// ... and the pop count from which a read leaves while a host worker is IDLE (MAPAD_TAIL_POPS_IDLE; 0 = only the budget counts).  Round 6, C5 mix on 3 Gbp, 14 workers,
+// same box, default / 2^17 (profiles/r06/c5_idle_tier.txt): 200 K reads, four interleaved repetitions: search launch 11.2-12.5 s -> 8.5-8.7 s, last host read done
+// 12.6-14.8 s -> 8.5-10.5 s after the first hand-over, call 14.1-20.8 s -> 14.5-16.5 s (the workers' share of the pops 5.7 % -> 10 %; reads queuing for a dry arena class
+// 290-330 -> 55-60); 1 M reads: launch 36.7 -> 32.1 s, call 40.9 -> 39.7 s (there the workers are busy 61 % of the time without this tier, 93 % with it); 2^16 and 2^18
+// are no better.  Results identical (sha256).
+#if !defined(MAPAD_DEFAULT_TAIL_POPS_IDLE)
+#define MAPAD_DEFAULT_TAIL_POPS_IDLE (1u << 17)
+#endif
 constexpr int kTiers = 2;   // arena pools: growable base arenas, full-limit arenas
 constexpr int kStages = 3;  // hand-over lists: Q0 -> Q1 -> F
 constexpr int kClasses = 10;  // grown arenas: 2x steps above the base arena (16 Ki nodes -> 32 Ki ... ), the last one with the full limits
@@ -71,7 +79,8 @@ constexpr int kKeyBins = kMaxReadLen + 2;
 // overflow, not wrap around.
 enum { CUR_HITS = 0, CUR_OPS = 2, CUR_POOL_OVF = 4, CUR_ERR = 5, CUR_WORK = 6, CUR_OVF = 7, CUR_GROWN = 6 + 2 * kStages, CUR_HEAVY_N = CUR_GROWN + 4 /* per quad stage */, CUR_HEAVY_WORK = CUR_GROWN + 6 /* per heavy stage */,
        CUR_HEAVY_POPS = CUR_GROWN + 8 /* 64-bit */, CUR_HPROF = CUR_GROWN + 10 /* 8 x 64-bit, -DMAPAD_HEAVY_PROF */, CUR_TAIL = CUR_GROWN + 26 /* reads handed to the host tail */, CUR_TAIL_DRY = CUR_GROWN + 27 /* ... of them because an arena class was dry */,
-       CUR_TAIL_F = CUR_GROWN + 28 /* ... instead of going to the full-limit stage */, CUR_TAIL_STATE = CUR_GROWN + 29 /* ... handed over with their state */, CUR_COUNT = CUR_GROWN + 31 };
+       CUR_TAIL_F = CUR_GROWN + 28 /* ... instead of going to the full-limit stage */, CUR_TAIL_STATE = CUR_GROWN + 29 /* ... handed over with their state */,
+       CUR_TAIL_IDLE = CUR_GROWN + 30 /* ... below the pop budget, because host workers were idle */, CUR_COUNT = CUR_GROWN + 31 };
 inline uint64_t cur64(const uint32_t* cur, int k) { return (uint64_t)cur[k] | ((uint64_t)cur[k + 1] << 32); }
 
 struct BatchDev {
@@ -109,6 +118,9 @@ struct BatchDev {
     uint32_t tail_backlog_budget;
     uint32_t tail_continue;   // 1: a read in a grown arena is handed over WITH its state (host_tail.hpp: TailState), the arena stays the read's until a host thread has copied it
     uint32_t tail_gen;        // what the kernel writes into a record's `ready` word: this launch's number in its ring (never 0) — words left by earlier launches do not match it
+    // ... and a read that has made tail_pops_idle pops (<= tail_pops; == tail_pops: this tier is off) leaves while the host has fewer than tail_backlog_idle reads waiting
+    // or running, i.e. while a worker is idle: a worker's pop is 15 x a quad's, and a launch lasts as long as its slowest read
+    uint32_t tail_pops_idle, tail_backlog_idle;
 };
 
 // A read that has outgrown its base arena, as the quad stage leaves it: everything else (heap, nodes, hit staging) is in the grown arena.
@@ -480,6 +492,7 @@ __device__ __forceinline__ void copy_units(MAPAD_GLOBAL uint4* dst, const MAPAD_
 }
 
 constexpr uint32_t kRestarted = 0x40000000u;  // in ArenaT::n_waits: this read gave up waiting for an arena once already (taken from the restart list): it waits as long as it takes now
+constexpr uint32_t kTailAskEvery = 0x3FFFu;  // a read past its hand-over threshold asks every 16 384 pops (mask)
 constexpr uint32_t kAskTail = 0x80000000u;  // in ArenaT::n_waits: the read's last request found its arena class dry and the class is one the host tail takes reads of
 template <int LPR, bool NL, int TOP = kTop, bool HITS = false>
 struct DeviceGrow {
@@ -755,7 +768,7 @@ __global__ void __launch_bounds__(64, (LPR == 1 && NL) ? 1 : LPR == 2 ? 2 : MAPA
     // pools are quiet; the last growable stage waits as long as it takes
     const DeviceGrow<LPR, NL, TOPK> grow{GP, &cursors[CUR_GROWN], slot, w0, stage + 2 < kStages || HEAVY, false, B0.tail_min_class};
     const uint32_t wide_copy_nodes = GP->wide_copy_nodes;
-    const uint32_t tail_pops = B0.tail_pops;
+    const uint32_t tail_lo = B0.tail_pops_idle;  // first pop count at which a read asks for the host tail (<= B.tail_pops; the ask itself sorts out which rule applies)
     bool tail_denied = false;  // the ring was full when this read asked: it stays on the GPU
     bool drained = false;      // the launch's own list of reads is exhausted (this quad has seen its end)
 #if defined(MAPAD_PROFILE_SECTIONS)
@@ -857,13 +870,31 @@ __global__ void __launch_bounds__(64, (LPR == 1 && NL) ? 1 : LPR == 2 ? 2 : MAPA
             else cont = search_step<LPR, CONT, NL>(ix, Ps, rd, A, st, w, NoGrow());
             MAPAD_MARK(PROF_TAIL);
             // the read leaves this quad for a host thread (host_tail.hpp), which maps it from scratch: a record of the batch's ring, if one is left
-            auto give_to_host = [&](int why) -> bool {
+            // `limit`: the hand-over happens only while the host has fewer reads than that waiting or running — the dispatcher's count (tail_ctl[0]) plus the records of
+            // this launch it has not picked up yet (this launch's ring cursor, exact, less tail_ctl[1]); the ring slot is claimed by CAS under that test, so a crowd of
+            // quads that ask in the same microsecond cannot overrun the limit (the host's word alone is a millisecond old).  0xFFFFFFFF: whatever the backlog.
+            // Returns 0 = handed over, 1 = refused (backlog), 2 = the ring is full.
+            auto give_to_host = [&](int why, uint32_t limit) -> int {
                 const BatchDev B = kernarg_reload(kArgOffB, B0);
-                if (B.tail_cap == 0) return false;
-                uint32_t k = 0;
-                if (w == 0) k = atomicAdd(&cursors[CUR_TAIL], 1u);
+                if (B.tail_cap == 0) return 2;
+                uint32_t k = 0xFFFFFFFEu;  // refused
+                if (w == 0) {
+                    if (limit == 0xFFFFFFFFu) k = atomicAdd(&cursors[CUR_TAIL], 1u);
+                    else {
+                        const uint32_t seen = __hip_atomic_load(B.tail_ctl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                        const uint32_t pend = __hip_atomic_load(B.tail_ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                        uint32_t cur = __hip_atomic_load(&cursors[CUR_TAIL], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        for (;;) {
+                            if (cur >= B.tail_cap) { k = 0xFFFFFFFFu; break; }
+                            if ((uint64_t)pend + (cur > seen ? cur - seen : 0u) >= limit) break;
+                            const uint32_t old = atomicCAS(&cursors[CUR_TAIL], cur, cur + 1u);
+                            if (old == cur) { k = cur; break; }
+                            cur = old;
+                        }
+                    }
+                }
                 k = group_bcast<LPR>(k);
-                if (k >= B.tail_cap) return false;
+                if (k >= B.tail_cap) return k == 0xFFFFFFFEu ? 1 : 2;
                 // with its state if it sits in a grown arena and has found nothing yet (hit staging stays in the slot's base arena): the arena then belongs to the
                 // read until a host thread has copied it and releases it (TailBatch::fetch_state) — this quad just lets go of it
                 // (quads only: the host's step reads the arena's heap levels in kTop's layout — heap_core.hpp: HeapLayout —, a pair kernel's blocks start one level earlier)
@@ -875,7 +906,7 @@ __global__ void __launch_bounds__(64, (LPR == 1 && NL) ? 1 : LPR == 2 ? 2 : MAPA
                     const ArenaT<NL, TOPK> base = carve<NL, TOPK>(kernarg_reload(kArgOffAP, AP0), slot);
                     A.heap = base.heap; A.nodes = base.nodes; A.heap_cap = base.heap_cap; A.node_cap = base.node_cap; A.grown = 0;
                 }
-                return true;
+                return 0;
             };
             auto back_to_base = [&]() {  // give the grown arena back; the next read starts in the base arena again
                 if (PASS != 1 && A.grown) {
@@ -890,30 +921,31 @@ __global__ void __launch_bounds__(64, (LPR == 1 && NL) ? 1 : LPR == 2 ? 2 : MAPA
                 // pop budget; only a full ring leaves it to the GPU's last stage.
                 bool handed = false;
                 const int tier_r = tier + ((A.n_waits & kRestarted) ? 1 : 0);  // a read taken from the restart list is a read of the next stage
-                if (PASS != 1 && tier_r + 2 == kStages) { if (MAPAD_UNLIKELY(st.status == ST_ARENA_OVERFLOW)) handed = give_to_host(CUR_TAIL_F); }
+                if (PASS != 1 && tier_r + 2 == kStages) { if (MAPAD_UNLIKELY(st.status == ST_ARENA_OVERFLOW)) handed = give_to_host(CUR_TAIL_F, 0xFFFFFFFFu) == 0; }
                 if (!handed) finalize_read<LPR>(kernarg_reload(kArgOffB, B0), rd, A, st, read, w, tier_r);
                 back_to_base();
                 have = false;
                 drain_memory();
                 MAPAD_MARK(PROF_FINALIZE);
-            } else if (MAPAD_UNLIKELY((((st.c_pop >= tail_pops) & (((st.c_pop - tail_pops) & (st.c_pop - tail_pops - 1u)) == 0u)) | (A.n_waits >= kAskTail)) & !tail_denied)) {
-                // past the pop budget, or queuing for an arena class that is dry (DeviceGrow::acquire): a host thread takes this read over, the quad takes its next read —
-                // while the host's workers keep up with what they have.  Round 5 handed a read past the budget over whatever the host's backlog (only the dry-class
-                // trigger looked at it): a rank of eight on a 16-CPU box has two workers, and the reads the GPU gave up queued behind them for minutes while its quads
-                // idled.  Every trigger looks at the backlog word now; a read that is refused goes on on the GPU (a quad's pop is 15 x a worker's, but thousands of quads
-                // run side by side) and asks again when its excess over the budget has doubled (at 0, 1, 2, 4, 8, ... pops past it: no state, no register).
-                const bool over = st.c_pop >= tail_pops;
-                bool take;
-                {
-                    const BatchDev B = kernarg_reload(kArgOffB, B0);
-                    take = B.tail_cap != 0 && __hip_atomic_load(B.tail_ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < (over ? B.tail_backlog_budget : B.tail_backlog_max);
-                    A.n_waits &= ~kAskTail;  // (it asks again when its wait is over and the class is still dry)
-                }
-                const bool asked = !over;
-                if (take) {
-                    if (give_to_host(asked ? CUR_TAIL_DRY : 0)) { back_to_base(); have = false; }
-                    else tail_denied = true;  // the ring is full: this read stays on the GPU
-                }
+            } else if (MAPAD_UNLIKELY((((st.c_pop >= tail_lo) & (((st.c_pop - tail_lo) & kTailAskEvery) == 0u)) | (A.n_waits >= kAskTail)) & !tail_denied)) {
+                // A host thread could take this read over and the quad its next read — while the host's workers keep up with what they have (every rule looks at the
+                // backlog: a rank of eight on a 16-CPU box has two workers, and in round 5 the reads the GPU gave up queued behind them for minutes while its quads idled).
+                //   past the pop budget (tail_pops): while fewer than tail_backlog_budget reads wait or run (8 per worker: a worker's pop is 15 x a quad's);
+                //   past tail_pops_idle: while fewer than tail_backlog_idle do (one per worker: a worker is idle) — a launch lasts as long as its slowest read, and until
+                //     the first reads reach the budget (1 M pops: 5.8 s) the workers had nothing to do;
+                //   queuing for an arena class that is dry (DeviceGrow::acquire): while fewer than tail_backlog_max do (half the workers).
+                // A read that is refused goes on on the GPU (thousands of quads run side by side) and asks again every kTailAskEvery + 1 pops (90 ms; an ask is two
+                // reads of host memory: a pop's time).
+                const BatchDev B = kernarg_reload(kArgOffB, B0);
+                const bool dry = A.n_waits >= kAskTail, over = st.c_pop >= B.tail_pops, at_ask = (st.c_pop >= tail_lo) & (((st.c_pop - tail_lo) & kTailAskEvery) == 0u);
+                A.n_waits &= ~kAskTail;  // (it asks again when its wait is over and the class is still dry)
+                uint32_t limit = dry ? B.tail_backlog_max : 0u;
+                int why = CUR_TAIL_DRY;
+                if (at_ask & !over & (B.tail_backlog_idle > limit)) { limit = B.tail_backlog_idle; why = CUR_TAIL_IDLE; }
+                if (at_ask & over) { limit = B.tail_backlog_budget; why = 0; }
+                const int rc = give_to_host(why, limit);
+                if (rc == 0) { back_to_base(); have = false; }
+                else if (rc == 2) tail_denied = true;  // the ring is full: this read stays on the GPU
                 drain_memory();
             } else if constexpr (HEAVY) { if (MAPAD_UNLIKELY(A.grown != 0)) {
                 // The read has outgrown its base arena: it is heavy.  Its state goes into the grown arena (heap top from the near array, hit staging
@@ -1813,6 +1845,7 @@ int launch_batch(mapad_ctx* c, BatchSlot& S, const uint8_t* d_seqs, const uint8_
 #endif
     B.tail_ring = nullptr; B.tail_stride = 0; B.tail_cap = 0; B.tail_lmax = 0; B.tail_pops = 0xFFFFFFFFu;
     B.tail_ctl = nullptr; B.tail_backlog_max = 0; B.tail_min_class = (uint32_t)kClasses; B.tail_continue = 0; B.tail_gen = 1; B.tail_backlog_budget = 0;
+    B.tail_pops_idle = 0xFFFFFFFFu; B.tail_backlog_idle = 0;
     drop_tail(c, S);
     for (auto& x : S.tail_info) x = 0;
     S.tail_failed = false;
@@ -1825,7 +1858,7 @@ int launch_batch(mapad_ctx* c, BatchSlot& S, const uint8_t* d_seqs, const uint8_
         if (!S.tail_ring.ensure(kRingHeader + (size_t)cap * stride)) return MAPAD_ERR_NOMEM;
         uint8_t* ring = S.tail_ring.p + kRingHeader;
         uint32_t* ctl = reinterpret_cast<uint32_t*>(S.tail_ring.p);
-        *ctl = host::TailWorkers::instance().pending();
+        ctl[0] = host::TailWorkers::instance().pending(); ctl[1] = 0;  // reads the workers have waiting or running (all launches); records of THIS launch the dispatcher has picked up
         // `ready` words: a record is ready when its word holds THIS launch's number (BatchDev::tail_gen), so nothing is cleared between launches (round 5 cleared
         // the records the previous launch could have set, and lost track of them when a small batch came between two large ones: ADVICE r5; page-locked coherent
         // memory is slow to write from the host).  After a (re)allocation or a change of the record size — the words then sit elsewhere, and what lies there is old
@@ -1869,6 +1902,13 @@ int launch_batch(mapad_ctx* c, BatchSlot& S, const uint8_t* d_seqs, const uint8_
         // Past the budget: a worker finishes such a read ~15 x faster than its quad would, so the host is the better place while fewer than ~15 reads per worker wait
         // in front of it; MAPAD_TAIL_BACKLOG_BUDGET (default 8 per worker; 0xFFFFFFFF = round 5's unconditional hand-over).
         B.tail_backlog_budget = env_u32("MAPAD_TAIL_BACKLOG_BUDGET", 8u * std::max(1u, host::TailWorkers::instance().size()));
+        // Below the budget, from MAPAD_TAIL_POPS_IDLE pops on (0 = this tier is off): while a worker is idle — fewer reads waiting or running than MAPAD_TAIL_BACKLOG_IDLE
+        // (default: the workers).  The budget is what a loaded host should be spared (a million pops are 5.8 s of a quad and 0.4 s of a worker); but until the first
+        // reads of a launch reach it the workers have nothing to do, and afterwards they idle whenever the reads past the budget are few — while the launch waits for
+        // reads that are a few hundred thousand pops from their end.
+        const uint32_t idle_pops = env_u32("MAPAD_TAIL_POPS_IDLE", MAPAD_DEFAULT_TAIL_POPS_IDLE);
+        B.tail_pops_idle = idle_pops ? std::min(idle_pops, c->tail_pops) : c->tail_pops;
+        B.tail_backlog_idle = env_u32("MAPAD_TAIL_BACKLOG_IDLE", std::max(1u, host::TailWorkers::instance().size()));
     }
     S.last = B; S.last_total_bases = total_bases; S.last_lmax = lmax; S.compacted = false;
     // A process-wide launch number, not a per-slot count: a result of a destroyed context must not pass for the batch of a new context that happens to sit at
@@ -2016,7 +2056,7 @@ int merge_tail(mapad_ctx* c, BatchSlot& S, uint32_t* cur) {
     S.tail_info[3] = res.empty() ? 0 : (uint64_t)(std::max(tb->t_last - tb->t_first, 0.0) * 1e6); S.tail_info[4] = host::TailWorkers::instance().size(); S.tail_info[5] = c->tail_pops;
     for (const auto& r : res) { S.tail_info[6] += r.e_search - r.gpu_e_search; S.tail_info[7] += r.n_push - r.gpu_n_push; S.tail_info[8] += r.n_node - r.gpu_n_node; }  // what the host threads did themselves
     S.tail_info[9] = (uint64_t)(tb->host_thread_s * 1e6);
-    S.tail_info[10] = tb->seen_live; S.tail_info[11] = cur[CUR_TAIL_DRY]; S.tail_info[12] = cur[CUR_TAIL_F]; S.tail_info[13] = S.last.tail_min_class;
+    S.tail_info[10] = tb->seen_live; S.tail_info[11] = cur[CUR_TAIL_DRY]; S.tail_info[12] = cur[CUR_TAIL_F]; S.tail_info[13] = S.last.tail_min_class | ((uint64_t)cur[CUR_TAIL_IDLE] << 32);
     S.tail_info[14] = tb->continued; S.tail_info[15] = cur[CUR_TAIL_STATE];
     if (res.empty()) { S.tail_failed = false; return MAPAD_OK; }
     std::sort(res.begin(), res.end(), [](const host::TailResult& a, const host::TailResult& b) { return a.read < b.read; });

@@ -26,9 +26,10 @@ def main():
     ap.add_argument("--genome-bp", type=int, default=3_000_000_000)
     ap.add_argument("--log", default=os.path.join(ROOT, "gpurun_out", "tail_reads.log"))
     ap.add_argument("--budgets", default="", help="comma-separated pop budgets (mapad_ctx_set_tail_pops) to map the batch with, one after the other; default: the library's")
-    ap.add_argument("--ranks", default="", help="comma-separated LOCAL_WORLD[:BACKLOG_BUDGET[:BUDGET_POPS]] settings to map the batch with, one after the other: this process as one rank "
+    ap.add_argument("--ranks", default="", help="comma-separated LOCAL_WORLD[:BACKLOG_BUDGET[:BUDGET_POPS[:IDLE_POPS]]] settings to map the batch with, one after the other: this process as one rank "
                                                 "of LOCAL_WORLD on its node (mapad_tail_set_local_world: its share of the host tail's workers), MAPAD_TAIL_BACKLOG_BUDGET (`u` = unconditional "
-                                                "hand-over past the budget, round 5's behaviour; empty = the default, 8 per worker), pop budget; e.g. 8,8:u,4,1")
+                                                "hand-over past the budget, round 5's behaviour; empty = the default, 8 per worker), pop budget, MAPAD_TAIL_POPS_IDLE (pops from which a read leaves while a "
+                                                "worker is idle; 0 = off); e.g. 8,8:u,4,1,1:::131072")
     args = ap.parse_args()
     os.makedirs(os.path.dirname(args.log), exist_ok=True)
     import mapad_amd
@@ -44,16 +45,20 @@ def main():
     if args.ranks:
         runs = []
         for spec in args.ranks.split(","):
-            f = (spec.split(":") + ["", ""])[:3]
-            runs.append((int(f[2]) if f[2] else None, int(f[0]), f[1]))
-    for budget, lw, backlog in runs:
+            f = (spec.split(":") + ["", "", ""])[:4]
+            runs.append((int(f[2]) if f[2] else None, int(f[0]), f[1], f[3]))
+    runs = [(r + (None,))[:4] for r in runs]
+    for budget, lw, backlog, idle in runs:
         if lw is not None:
             workers = mapad_amd.lib().mapad_tail_set_local_world(lw)
             os.environ.pop("MAPAD_TAIL_BACKLOG_BUDGET", None)
             if backlog:
                 os.environ["MAPAD_TAIL_BACKLOG_BUDGET"] = "4294967295" if backlog == "u" else backlog
-            print(f"--- one rank of {lw}: {workers} host workers, backlog limit past the budget: {backlog or 'default (8 per worker)'}", flush=True)
-        log_path = args.log + (f".{budget}" if budget is not None else "") + (f".lw{lw}_{backlog or 'd'}" if lw is not None else "")
+            os.environ.pop("MAPAD_TAIL_POPS_IDLE", None)
+            if idle:
+                os.environ["MAPAD_TAIL_POPS_IDLE"] = idle
+            print(f"--- one rank of {lw}: {workers} host workers, backlog limit past the budget: {backlog or 'default (8 per worker)'}, idle-worker threshold: {idle or 'default'} pops", flush=True)
+        log_path = args.log + (f".{budget}" if budget is not None else "") + (f".lw{lw}_{backlog or 'd'}_{idle or 'd'}" if lw is not None else "")
         if os.path.exists(log_path):
             os.remove(log_path)
         os.environ["MAPAD_TAIL_LOG"] = log_path

@@ -65,7 +65,7 @@ def test_reads_finished_on_the_host_equal_the_oracle(name, prm, kw, n):
 
 def test_reads_past_the_budget_stay_on_the_gpu_while_the_host_is_busy(monkeypatch):
     """Round 6: every hand-over trigger looks at the host's backlog (the word the launch's dispatcher keeps current).  With no room at all
-    (MAPAD_TAIL_BACKLOG_BUDGET=0) every read past the budget is refused, goes on on the GPU, asks again whenever its excess has doubled and finishes there; with the
+    (MAPAD_TAIL_BACKLOG_BUDGET=0) every read past the budget is refused, goes on on the GPU, asks again every 16 384 pops and finishes there; with the
     default (8 waiting reads per worker) any number between none and all of them leave, as the host's pace has it.  Nothing of that shows in the results."""
     g = synth.genome(300_000, seed=77)
     seqs, quals, offsets = synth.reads(g, 3000, 50, seed=12, qual_range=(20, 40), damage=dict(f=0.5, t=0.5, d=0.02, s=1.0))
@@ -88,6 +88,34 @@ def test_reads_past_the_budget_stay_on_the_gpu_while_the_host_is_busy(monkeypatc
     res, info = _map(pidx, params, seqs, quals, offsets, tail_pops=64)
     assert 0 <= info["reads"] <= past
     _same(res, every)
+
+
+def test_reads_below_the_budget_leave_while_a_worker_is_idle(monkeypatch):
+    """Round 6: from MAPAD_TAIL_POPS_IDLE pops on a read leaves although it is short of the budget — while fewer reads than MAPAD_TAIL_BACKLOG_IDLE (default: the workers)
+    wait or run on the host, i.e. while a worker is idle; the ring slot is claimed under that test (the kernel counts the records the dispatcher has not picked up yet
+    itself), so the hundreds of reads that ask in the same microsecond cannot overrun it.  With no room (0) nobody leaves.  Nothing of that shows in the results."""
+    g = synth.genome(300_000, seed=77)
+    seqs, quals, offsets = synth.reads(g, 3000, 50, seed=12, qual_range=(20, 40), damage=dict(f=0.5, t=0.5, d=0.02, s=1.0))
+    rp = resolve_params(DAMAGE)
+    pidx = mapad_amd.Index.build([("chr1", g)])
+    params = mapad_amd.make_params(rp)
+    off, info_off = _map(pidx, params, seqs, quals, offsets, tail_pops=0)
+    past = int((off.counters["n_pop"] > 64).sum())
+    assert info_off["reads"] == 0 and past > 500
+    monkeypatch.setenv("MAPAD_TAIL_POPS_IDLE", "64")
+    res, info = _map(pidx, params, seqs, quals, offsets, tail_pops=1 << 20)  # a budget no read of this batch reaches
+    assert 0 < info["reads"] == info["reads_idle_tier"] <= past, info
+    assert info["gpu_pops"] >= 64 * info["reads"]
+    _same(res, off)
+    assert (res.status & 16).sum() == 0
+    monkeypatch.setenv("MAPAD_TAIL_BACKLOG_IDLE", "0")
+    res, info = _map(pidx, params, seqs, quals, offsets, tail_pops=1 << 20)
+    assert info["reads"] == 0, info
+    _same(res, off)
+    monkeypatch.setenv("MAPAD_TAIL_BACKLOG_IDLE", "4294967295")  # whatever the backlog: every read past 64 pops
+    res, info = _map(pidx, params, seqs, quals, offsets, tail_pops=1 << 20)
+    assert info["reads"] == info["reads_idle_tier"] == past and info["gpu_pops"] == 64 * past, (info, past)  # each left at its first ask
+    _same(res, off)
 
 
 def test_limit_recovery_and_abort_on_the_host():
