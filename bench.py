@@ -686,7 +686,7 @@ def main():
                                     "unit": "GB/s", "frac": round(b5 / (k5[1] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5), "traffic": None,
                                     "note": "events of the reads the host finished are not the kernel's and are left out; the launch lasts as long as its slowest read (a serial chain at ~5.5 us per pop)"},
                        "tail": {"reads": ti5["reads"], "pops_share": round(ti5["host_pops"] / max(pops_all, 1), 5), "gpu_pops_before_hand_over": ti5["gpu_pops"], "host_s_per_step": round(ti5["host_us"] / 1e6, 3),
-                                "host_thread_s_per_step": round(ti5["host_thread_us"] / 1e6, 3), "threads": ti5["threads"], "budget_pops": ti5["budget"], "reads_dry_class": ti5["reads_dry_class"],
+                                "host_thread_s_per_step": round(ti5["host_thread_us"] / 1e6, 3), "threads": ti5["threads"], "budget_pops": ti5["budget"], "reads_below_budget_idle_worker": ti5.get("reads_idle_tier", 0), "reads_dry_class": ti5["reads_dry_class"],
                                 "reads_full_limit": ti5["reads_full_limit"], "seen_while_launch_ran": ti5["seen_live"], "continued_from_gpu_state": ti5["continued"]},
                        "arena_migrations": res5.n_second_pass}
                 return leg, res5
@@ -837,7 +837,8 @@ def main():
                      "host_s_per_step": round(sum(t["host_us"] for t in tail_timed) / max(len(tail_timed), 1) / 1e6, 3),
                      # thread-seconds inside the reads: far below host_s x threads = the host waited for the GPU's hand-overs; close to it = the host's CPUs set the pace
                      "host_thread_s_per_step": round(sum(t.get("host_thread_us", 0) for t in tail_timed) / max(len(tail_timed), 1) / 1e6, 3), "budget_pops": tail_last["budget"],
-                     # why reads went to the host: past the pop budget; their arena class was dry while the host had room (round 5); no growable arena could hold them
+                     # why reads went to the host: past the pop budget; below it while a worker was idle (round 6); their arena class was dry while the host had room (round 5); no growable arena could hold them
+                     "reads_below_budget_idle_worker": int(sum(t.get("reads_idle_tier", 0) for t in tail_timed)),
                      "reads_dry_class": int(sum(t.get("reads_dry_class", 0) for t in tail_timed)), "reads_full_limit": int(sum(t.get("reads_full_limit", 0) for t in tail_timed)),
                      "seen_while_launch_ran": int(sum(t.get("seen_live", 0) for t in tail_timed)),
                      "where": f"{tail_last['threads']} host threads, search_core.hpp compiled for the host (the kernel's source; reads handed over from a grown arena continue from the GPU's state, others start over), overlapped with the GPU's bulk" if tail_last["budget"] else "off"},

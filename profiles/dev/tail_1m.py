@@ -26,7 +26,7 @@ def main():
     ap.add_argument("--genome-bp", type=int, default=3_000_000_000)
     ap.add_argument("--log", default=os.path.join(ROOT, "gpurun_out", "tail_reads.log"))
     ap.add_argument("--budgets", default="", help="comma-separated pop budgets (mapad_ctx_set_tail_pops) to map the batch with, one after the other; default: the library's")
-    ap.add_argument("--ranks", default="", help="comma-separated LOCAL_WORLD[:BACKLOG_BUDGET[:BUDGET_POPS[:IDLE_POPS]]] settings to map the batch with, one after the other: this process as one rank "
+    ap.add_argument("--ranks", default="", help="comma-separated LOCAL_WORLD[:BACKLOG_BUDGET[:BUDGET_POPS[:IDLE_POPS[:ENV=VAL;ENV=VAL...]]]] settings to map the batch with, one after the other: this process as one rank "
                                                 "of LOCAL_WORLD on its node (mapad_tail_set_local_world: its share of the host tail's workers), MAPAD_TAIL_BACKLOG_BUDGET (`u` = unconditional "
                                                 "hand-over past the budget, round 5's behaviour; empty = the default, 8 per worker), pop budget, MAPAD_TAIL_POPS_IDLE (pops from which a read leaves while a "
                                                 "worker is idle; 0 = off); e.g. 8,8:u,4,1,1:::131072")
@@ -45,10 +45,21 @@ def main():
     if args.ranks:
         runs = []
         for spec in args.ranks.split(","):
-            f = (spec.split(":") + ["", "", ""])[:4]
-            runs.append((int(f[2]) if f[2] else None, int(f[0]), f[1], f[3]))
-    runs = [(r + (None,))[:4] for r in runs]
-    for budget, lw, backlog, idle in runs:
+            f = (spec.split(":") + ["", "", "", ""])[:5]
+            runs.append((int(f[2]) if f[2] else None, int(f[0]), f[1], f[3], f[4]))
+    runs = [(r + (None, None))[:5] for r in runs]
+    extra_set = []
+    for budget, lw, backlog, idle, extra in runs:
+        for k in extra_set:
+            os.environ.pop(k, None)
+        extra_set = []
+        for kv in (extra or "").split(";"):
+            if "=" in kv:
+                k, v = kv.split("=", 1)
+                os.environ[k] = v
+                extra_set.append(k)
+        if extra:
+            print(f"--- environment: {extra}", flush=True)
         if lw is not None:
             workers = mapad_amd.lib().mapad_tail_set_local_world(lw)
             os.environ.pop("MAPAD_TAIL_BACKLOG_BUDGET", None)
@@ -58,7 +69,7 @@ def main():
             if idle:
                 os.environ["MAPAD_TAIL_POPS_IDLE"] = idle
             print(f"--- one rank of {lw}: {workers} host workers, backlog limit past the budget: {backlog or 'default (8 per worker)'}, idle-worker threshold: {idle or 'default'} pops", flush=True)
-        log_path = args.log + (f".{budget}" if budget is not None else "") + (f".lw{lw}_{backlog or 'd'}_{idle or 'd'}" if lw is not None else "")
+        log_path = args.log + (f".{budget}" if budget is not None else "") + (f".lw{lw}_{backlog or 'd'}_{idle or 'd'}" if lw is not None else "") + (("." + "".join(c if c.isalnum() else "_" for c in extra)) if extra else "")
         if os.path.exists(log_path):
             os.remove(log_path)
         os.environ["MAPAD_TAIL_LOG"] = log_path
