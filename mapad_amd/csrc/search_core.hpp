@@ -120,13 +120,60 @@ MAPAD_RARE uint32_t extract_ops_general(NP nodes, uint32_t end_node, int alignme
     }
     return m;
 }
+#if !defined(MAPAD_QUAD_WALK)
+#define MAPAD_QUAD_WALK 1  // (0 for A/B runs)
+#endif
+#if defined(__HIP_DEVICE_COMPILE__)
+// The dense walk by a quad (round 6).  A leaf-to-root walk is a chain of ~L dependent loads — 0.6 us each on the loaded chip, ~30 us per hit, during which the other
+// 15 read slots of the wavefront idle (section profile: 3.4 % of the wave time at C4, 4.6 % at C2).  But a search that runs straight down a matching stretch pops the
+// child it has just pushed, and that child's children take the slab's next keys: along such stretches parent = child - 1 ... child - 9 (dense slab: keys only grow,
+// a parent's key is below its child's).  So lane w of the quad loads the words of nodes s - w, s - w - 4, s - w - 8, s - w - 12 — one trip for the 16 nodes below
+// s —, and the walk hops through registers (a quad broadcast per hop) until it leaves that window.  Same writes, same order, same `in_order` test as the loop above.
+template <class NP, class OP>
+__device__ __forceinline__ uint32_t extract_ops_quad(NP nodes, uint32_t end_node, int alignment_start, OP out, uint32_t out_cap, int w, bool& in_order) {
+    uint32_t m = 0, prev = 0, s = end_node;
+    in_order = true;
+    while (s != 0) {
+        const uint32_t top = s, b = s - (uint32_t)w;  // (b is only used where s >= w + 4 i)
+        uint64_t w0 = 0, w1 = 0, w2 = 0, w3 = 0;
+        if (top >= (uint32_t)w) w0 = nodes[b].w0;
+        if (top >= (uint32_t)w + 4u) w1 = nodes[b - 4u].w0;
+        if (top >= (uint32_t)w + 8u) w2 = nodes[b - 8u].w0;
+        if (top >= (uint32_t)w + 12u) w3 = nodes[b - 12u].w0;
+        do {
+            const uint32_t d = top - s;  // 0 .. 15, quad-uniform
+            const uint32_t i = d >> 2;
+            const uint64_t mine = i == 0 ? w0 : i == 1 ? w1 : i == 2 ? w2 : w3;
+            const uint64_t x = quad_pick64(mine, (int)(d & 3u));
+            const uint32_t op = (uint32_t)x, p = op & 0xFFFFu;
+            in_order = in_order && p >= prev && (int)p < alignment_start;
+            prev = p;
+            if (m < out_cap) out[m] = op;
+            m += 1;
+            s = (uint32_t)(x >> 32);
+        } while (s != 0 && top - s < 16u);
+    }
+    return m;
+}
+#endif
+
 // The walk is a chain of dependent loads (one arena round trip per edit operation) during which the other read slots of the wavefront
 // idle, so it is done once where that is enough: with the production model the alignment starts at the 3' end (every position is left of
 // the alignment start) and the search only moves backward, so positions do not decrease from leaf to root and the bucket order of
 // record.rs:491-496 IS the walk order.  The walk checks exactly that while it writes; anything else (the bidirectional test models)
 // falls back to the counting sort.  `dense`: the slab has no vacant entries, so the occupancy word of a node need not be loaded.
 template <class NP, class SP, class OP>
-MAPAD_RARE uint32_t extract_ops(NP nodes, uint32_t end_node, int alignment_start, int L, SP scratch, OP out, uint32_t out_cap, bool dense) {
+MAPAD_RARE uint32_t extract_ops(NP nodes, uint32_t end_node, int alignment_start, int L, SP scratch, OP out, uint32_t out_cap, bool dense, int quad_lane = -1) {
+#if defined(__HIP_DEVICE_COMPILE__) && MAPAD_QUAD_WALK
+    if (dense && quad_lane >= 0) {
+        bool in_order;
+        const uint32_t m = extract_ops_quad(nodes, end_node, alignment_start, out, out_cap, quad_lane, in_order);
+        if (m > out_cap) return 0xFFFFFFFFu;
+        if (in_order) return m;
+        dense = false;  // (the bidirectional test models: the counting sort below)
+    }
+#endif
+    (void)quad_lane;
     if (dense) {
         uint32_t m = 0, prev = 0;
         bool in_order = true;
@@ -203,12 +250,12 @@ MAPAD_HD int alignment_start_of(const DevParams& P, int L) { return P.start_at_e
 // The `len == pattern.len()` branch of check_and_push_stack_frame (mapping.rs:973-984): a finished alignment becomes a hit.
 template <bool NLR, bool NL, int TOP>
 MAPAD_RARE void record_hit(const ReadInT<NLR> rd, const ArenaT<NL, TOP> A, SearchState& st, int alignment_start, uint64_t lower, uint64_t lower_rev, uint64_t size,
-                           float score, uint32_t id) {
+                           float score, uint32_t id, int quad_lane = -1) {
     if (st.n_hits >= (uint32_t)kMaxHits) { st.status = ST_ARENA_OVERFLOW; return; }
     HitRec h;
     h.lower = lower; h.lower_rev = lower_rev; h.size = size; h.score = score; h.pad = 0;
     h.ops_off = st.hit_ops_used;
-    const uint32_t m = extract_ops(A.nodes, id, alignment_start, rd.L, A.scratch, A.hit_ops + st.hit_ops_used, A.hit_ops_cap - st.hit_ops_used, st.tree_len == st.tree_entries);
+    const uint32_t m = extract_ops(A.nodes, id, alignment_start, rd.L, A.scratch, A.hit_ops + st.hit_ops_used, A.hit_ops_cap - st.hit_ops_used, st.tree_len == st.tree_entries, quad_lane);
     if (m == 0xFFFFFFFFu) { st.status = ST_ARENA_OVERFLOW; return; }
     h.n_ops = m;
     st.hit_ops_used += m;
@@ -254,7 +301,11 @@ MAPAD_HD void commit_child(const DevParams& P, const ReadInT<NLR>& rd, ArenaT<NL
         const Frame c = unpack_frame(u);
         SearchState tmp = st;
         MAPAD_MARK(PROF_COMMIT);
-        record_hit(rd, A, tmp, alignment_start, c.lower, c.lower_rev, c.size, score, id);
+        int quad_lane = -1;  // quads walk the hit's path with a window of 16 nodes per trip (extract_ops_quad)
+#if defined(__HIP_DEVICE_COMPILE__)
+        if (LPR == 4) quad_lane = (int)(threadIdx.x & 3u);
+#endif
+        record_hit(rd, A, tmp, alignment_start, c.lower, c.lower_rev, c.size, score, id, quad_lane);
         drain_memory();
         MAPAD_MARK(PROF_HIT);
         st = tmp;
