@@ -48,7 +48,8 @@ enum : uint32_t { ST_POOL_OVERFLOW = 4, ST_NO_TABLE = 8, ST_TAIL = 16 /* handed 
 // Launches over a batch (all on the batch's stream):
 //   Q0  search_kernel, every read: one quad per read, a per-slot base arena that GROWS on demand (size classes and idle sets of base arenas, below).  A quad that
 //       has run out of reads takes over reads of this launch that gave up waiting for an arena (the restart list).  With the host tail on (the default) a read
-//       leaves for a host thread when it passes the pop budget, queues for a scarce arena class while the host has room, or fits no growable arena.
+//       leaves for a host thread when it passes the pop budget (or an eighth of it while a host worker is idle), queues for a scarce arena class while the host has
+//       room, or fits no growable arena — each rule only while the host's backlog is short (search_kernel: give_to_host).
 //       (MAPAD_HEAVY=1 only: a read that has outgrown its base arena is suspended (HeavyItem) and H0 — heavy_kernel, one WAVEFRONT per read — continues it.)
 //   Q1  search_kernel again over what is left of the restart list (normally nothing: the launch exits at once); these reads wait for arenas as long as it takes.
 //   F   heavy_kernel from scratch, with arenas that hold the reference's full limits (STACK_LIMIT / EDIT_TREE_LIMIT, mapping.rs:52-54), for the reads that no
